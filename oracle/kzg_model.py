@@ -1,0 +1,779 @@
+"""
+ORACLE (test infrastructure, NOT product code) -- pure-Python big-integer restatement of the
+proxima-one/kzg commit/open hot path.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+The product path (kzg_amd/ + libkzg_mi355x.so) never does.
+
+PARITY STATUS
+  * Fr-polynomial layer: PINNED by the reference's own literal known-answer tests
+    (src/polynomial.rs:494-690), restated in tests/test_oracle_reference_vectors.py.
+  * NTT: property-pinned by the reference's tests (src/ft.rs:411-479: fft_mul == naive mul,
+    ifft(fft(x)) == x) -- restated likewise.
+  * G1 layer: "parity unpinned" by the reference: no reference test holds a literal G1 value and the
+    arithmetic lives in third-party crates absent from /root/reference
+    (blstrs git rev b98fc83 -> supranational blst; pairing 0.21.0 -> group/ff; Cargo.toml:23,27).
+    The published BLS12-381 definition is restated here (curve y^2 = x^3 + 4 over Fq, standard
+    generator, zcash serialisation) and pinned by: generator-on-curve, r*G = infinity, the well
+    known compressed generator encoding 97f1d3a7...c6bb, and the known-tau identities
+    commit(p) == [p(tau)]G etc..
+
+Every function cites the reference file:line it follows.  Scalars are python ints in [0, r).
+G1 points are affine tuples (x, y) of ints in [0, q) or None for the identity.
+"""
+
+# --------------------------------------------------------------------------------------
+# BLS12-381 constants (public definition; validated in selfcheck())
+# --------------------------------------------------------------------------------------
+Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+BLS_Z = -0xd201000000010000
+CURVE_B = 4
+G1_X = 0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb
+G1_Y = 0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1
+G1 = (G1_X, G1_Y)
+
+# ff::PrimeField constants of blstrs::Scalar (src/ft.rs:67,73,89 use S, root_of_unity(),
+# multiplicative_generator()).
+FR_S = 32
+FR_GENERATOR = 7
+FR_ROOT_OF_UNITY = pow(FR_GENERATOR, (R - 1) >> FR_S, R)
+
+FR_MONT_R = (1 << 256) % R
+FQ_MONT_R = (1 << 384) % Q
+
+
+# --------------------------------------------------------------------------------------
+# Fr helpers
+# --------------------------------------------------------------------------------------
+def fr_inv(a):
+    a %= R
+    if a == 0:
+        raise ZeroDivisionError("Scalar::invert() of zero (the reference unwrap()s -> panic)")
+    return pow(a, R - 2, R)
+
+
+def fr_neg(a):
+    return (-a) % R
+
+
+# --------------------------------------------------------------------------------------
+# G1 arithmetic (stands in for blstrs::G1Projective / G1Affine -- external, see header)
+# --------------------------------------------------------------------------------------
+def g1_is_on_curve(P):
+    if P is None:
+        return True
+    x, y = P
+    return (y * y - x * x * x - CURVE_B) % Q == 0
+
+
+def g1_neg(P):
+    if P is None:
+        return None
+    return (P[0], (-P[1]) % Q)
+
+
+def _jac_double(P):
+    X, Y, Z = P
+    if Z == 0 or Y == 0:
+        return (1, 1, 0)
+    A = X * X % Q
+    B = Y * Y % Q
+    C = B * B % Q
+    D = 2 * ((X + B) * (X + B) - A - C) % Q
+    E = 3 * A % Q
+    F = E * E % Q
+    X3 = (F - 2 * D) % Q
+    Y3 = (E * (D - X3) - 8 * C) % Q
+    Z3 = 2 * Y * Z % Q
+    return (X3, Y3, Z3)
+
+
+def _jac_add(P, Qp):
+    X1, Y1, Z1 = P
+    X2, Y2, Z2 = Qp
+    if Z1 == 0:
+        return Qp
+    if Z2 == 0:
+        return P
+    Z1Z1 = Z1 * Z1 % Q
+    Z2Z2 = Z2 * Z2 % Q
+    U1 = X1 * Z2Z2 % Q
+    U2 = X2 * Z1Z1 % Q
+    S1 = Y1 * Z2 * Z2Z2 % Q
+    S2 = Y2 * Z1 * Z1Z1 % Q
+    if U1 == U2:
+        if S1 == S2:
+            return _jac_double(P)
+        return (1, 1, 0)
+    H = (U2 - U1) % Q
+    Rr = (S2 - S1) % Q
+    HH = H * H % Q
+    HHH = H * HH % Q
+    V = U1 * HH % Q
+    X3 = (Rr * Rr - HHH - 2 * V) % Q
+    Y3 = (Rr * (V - X3) - S1 * HHH) % Q
+    Z3 = Z1 * Z2 * H % Q
+    return (X3, Y3, Z3)
+
+
+def _to_jac(P):
+    return (1, 1, 0) if P is None else (P[0], P[1], 1)
+
+
+def _from_jac(P):
+    X, Y, Z = P
+    if Z == 0:
+        return None
+    zi = pow(Z, Q - 2, Q)
+    zi2 = zi * zi % Q
+    return (X * zi2 % Q, Y * zi2 * zi % Q)
+
+
+def g1_add(P, Qp):
+    return _from_jac(_jac_add(_to_jac(P), _to_jac(Qp)))
+
+
+def g1_mul(P, k):
+    """[k]P; k is reduced mod r first (Scalar semantics)."""
+    k %= R
+    acc = (1, 1, 0)
+    base = _to_jac(P)
+    while k:
+        if k & 1:
+            acc = _jac_add(acc, base)
+        base = _jac_double(base)
+        k >>= 1
+    return _from_jac(acc)
+
+
+def g1_multi_exp(points, scalars):
+    """G1Projective::multi_exp(points, scalars) followed by to_affine()
+    (call sites src/coeff_form.rs:61,78,102; src/eval_form.rs:118,136).
+    Mathematical definition: sum_i scalars[i] * points[i].  Naive double-and-add; tiny sizes only."""
+    assert len(points) == len(scalars)
+    acc = (1, 1, 0)
+    for P, s in zip(points, scalars):
+        if P is None or s % R == 0:
+            continue
+        acc = _jac_add(acc, _to_jac(g1_mul(P, s)))
+    return _from_jac(acc)
+
+
+# --------------------------------------------------------------------------------------
+# Serialisation (zcash / blst canonical encodings)
+# --------------------------------------------------------------------------------------
+def fr_to_le(a):
+    return (a % R).to_bytes(32, "little")
+
+
+def fr_from_le(b):
+    v = int.from_bytes(b, "little")
+    assert v < R
+    return v
+
+
+def fr_to_mont_le(a):
+    """blst_fr layout: 4 x u64 little-endian limbs of a*2^256 mod r [upstream-memory]."""
+    return ((a % R) * FR_MONT_R % R).to_bytes(32, "little")
+
+
+def g1_to_uncompressed(P):
+    if P is None:
+        return bytes([0x40]) + bytes(95)
+    return P[0].to_bytes(48, "big") + P[1].to_bytes(48, "big")
+
+
+def g1_from_uncompressed(b):
+    assert len(b) == 96
+    if b[0] & 0x40:
+        return None
+    x = int.from_bytes(b[:48], "big")
+    y = int.from_bytes(b[48:], "big")
+    return (x, y)
+
+
+def g1_to_compressed(P):
+    if P is None:
+        return bytes([0xC0]) + bytes(47)
+    x, y = P
+    out = bytearray(x.to_bytes(48, "big"))
+    out[0] |= 0x80
+    if y > (Q - 1) // 2:
+        out[0] |= 0x20
+    return bytes(out)
+
+
+def g1_from_compressed(b):
+    assert len(b) == 48 and (b[0] & 0x80)
+    if b[0] & 0x40:
+        return None
+    sign = bool(b[0] & 0x20)
+    x = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:], "big")
+    y2 = (x * x * x + CURVE_B) % Q
+    y = pow(y2, (Q + 1) // 4, Q)
+    assert y * y % Q == y2, "not on curve"
+    if (y > (Q - 1) // 2) != sign:
+        y = Q - y
+    return (x, y)
+
+
+def g1_to_affine_mont(P):
+    """blst_p1_affine layout: x,y as 6 x u64 LE limbs in Montgomery form; identity = all zero
+    [upstream-memory]."""
+    if P is None:
+        return bytes(96)
+    return (P[0] * FQ_MONT_R % Q).to_bytes(48, "little") + (P[1] * FQ_MONT_R % Q).to_bytes(48, "little")
+
+
+def g1_to_jacobian_mont(P):
+    """blst_p1 layout: X,Y,Z Montgomery LE limbs; identity has Z = 0 [upstream-memory]."""
+    if P is None:
+        return bytes(144)
+    one = FQ_MONT_R.to_bytes(48, "little")
+    return g1_to_affine_mont(P) + one
+
+
+# --------------------------------------------------------------------------------------
+# src/lib.rs:38-55  setup()
+# --------------------------------------------------------------------------------------
+def setup_g1(s, num_coeffs):
+    """gs[i] = gs[i-1] * s  (src/lib.rs:39-46).  G2 powers (hs) are out of scope."""
+    gs = [G1]
+    for _ in range(1, num_coeffs):
+        gs.append(g1_mul(gs[-1], s))
+    return gs[:num_coeffs] if num_coeffs > 0 else []
+
+
+def setup_g1_fast(s, num_coeffs):
+    """Same group elements as setup_g1: gs[i] = [s^i]G (one scalar-mul each)."""
+    out, e = [], 1
+    for _ in range(num_coeffs):
+        out.append(g1_mul(G1, e))
+        e = e * s % R
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# src/polynomial.rs  Polynomial
+# --------------------------------------------------------------------------------------
+def _vec_resize(v, n):
+    """Vec::resize(n, Scalar::zero()): truncate or zero-extend to exactly n."""
+    v = list(v)
+    return v[:n] if len(v) >= n else v + [0] * (n - len(v))
+
+
+class Polynomial:
+    """Dense polynomial with an explicit `degree` field (src/polynomial.rs:24-27)."""
+
+    def __init__(self, coeffs, degree=None):
+        coeffs = [c % R for c in coeffs]
+        if degree is None:  # Polynomial::new  (src/polynomial.rs:83-87)
+            degree = Polynomial.compute_degree(coeffs, len(coeffs) - 1)
+        self.coeffs = coeffs
+        self.degree = degree
+
+    @staticmethod
+    def new_from_coeffs(coeffs, degree):  # src/polynomial.rs:89-92
+        return Polynomial(coeffs, degree)
+
+    @staticmethod
+    def compute_degree(coeffs, upper_bound):  # src/polynomial.rs:94-105
+        i = upper_bound
+        while True:
+            if i == 0:
+                return 0
+            if coeffs[i] != 0:
+                return i
+            i -= 1
+
+    @staticmethod
+    def new_zero():  # :49-54
+        return Polynomial([0], 0)
+
+    @staticmethod
+    def new_zero_with_size(cap):  # :76-81
+        return Polynomial([0] * cap, 0)
+
+    @staticmethod
+    def new_monic_of_degree(degree):  # :63-68 (all-ones, as in the reference)
+        return Polynomial([1] * (degree + 1), degree)
+
+    def clone(self):
+        return Polynomial(list(self.coeffs), self.degree)
+
+    def is_zero(self):  # :45-47
+        return self.degree == 0 and self.coeffs[0] == 0
+
+    def shrink_degree(self):  # :117-120
+        self.degree = Polynomial.compute_degree(self.coeffs, self.degree)
+
+    def fixup_degree(self):  # :122-125
+        self.degree = Polynomial.compute_degree(self.coeffs, len(self.coeffs) - 1)
+
+    def lead(self):  # :127-129
+        return self.coeffs[self.degree]
+
+    def num_coeffs(self):  # :135-137
+        return self.degree + 1
+
+    def slice_coeffs(self):  # :148-150
+        return self.coeffs[: self.num_coeffs()]
+
+    def __eq__(self, other):  # :29-40
+        if self.degree != other.degree:
+            return False
+        return all(l == r for l, r in zip(self.coeffs, other.coeffs))
+
+    def eval(self, x):  # Horner, :156-165
+        res = self.coeffs[self.degree]
+        for i in range(self.degree - 1, -1, -1):
+            res = (res * x + self.coeffs[i]) % R
+        return res
+
+    def mul_naive(self, rhs):  # impl Mul, :473-487
+        res = Polynomial.new_zero_with_size(self.degree + rhs.degree + 1)
+        for i in range(self.num_coeffs()):
+            for j in range(rhs.num_coeffs()):
+                res.coeffs[i + j] = (res.coeffs[i + j] + self.coeffs[i] * rhs.coeffs[j]) % R
+        res.degree = self.degree + rhs.degree
+        return res
+
+    def fft_mul(self, other):  # :167-183
+        n, k = self.num_coeffs(), other.num_coeffs()
+        lhs = _vec_resize(self.coeffs, n + k)
+        rhs = _vec_resize(other.coeffs, n + k)
+        L = EvaluationDomain.from_coeffs(lhs)
+        Rr = EvaluationDomain.from_coeffs(rhs)
+        L.fft()
+        Rr.fft()
+        L.mul_assign(Rr)
+        L.ifft()
+        return Polynomial(L.coeffs)  # From<EvaluationDomain> = Polynomial::new, src/ft.rs:27-31
+
+    FFT_MUL_THRESHOLD = 128  # :13
+
+    def best_mul(self, other):  # :185-191
+        if self.degree < Polynomial.FFT_MUL_THRESHOLD or other.degree < Polynomial.FFT_MUL_THRESHOLD:
+            return self.mul_naive(other)
+        return self.fft_mul(other)
+
+    def long_division(self, divisor):  # :193-227
+        if self.is_zero():
+            return Polynomial.new_zero(), None
+        if divisor.is_zero():
+            raise ZeroDivisionError("divisor must not be zero!")
+        if self.degree < divisor.degree:
+            return Polynomial.new_zero(), self.clone()
+        remainder = self.clone()
+        quotient = Polynomial([0] * (self.degree - divisor.degree + 1), self.degree - divisor.degree)
+        lead_inverse = fr_inv(divisor.lead())
+        dco = divisor.slice_coeffs()
+        while (not remainder.is_zero()) and remainder.degree >= divisor.degree:
+            factor = remainder.lead() * lead_inverse % R
+            i = remainder.degree - divisor.degree
+            quotient.coeffs[i] = factor
+            for j, c in enumerate(dco):
+                remainder.coeffs[i + j] = (remainder.coeffs[i + j] - c * factor) % R
+            remainder.shrink_degree()
+        if remainder.is_zero():
+            return quotient, None
+        return quotient, remainder
+
+    def multi_eval(self, xs):  # :229-233
+        assert len(xs) > self.degree
+        tree = SubProductTree.new_from_points(xs)
+        return tree.eval(xs, self)
+
+    @staticmethod
+    def lagrange_interpolation_with_tree(xs, ys, tree):  # :237-264
+        assert len(xs) == len(ys)
+        if len(xs) == 1:
+            return Polynomial([(ys[0] - xs[0]) % R, 1], 1)  # quirk: X + (y - x), SURVEY 9.2
+        m_prime = tree.product.clone()
+        for i in range(1, m_prime.num_coeffs()):
+            m_prime.coeffs[i] = m_prime.coeffs[i] * i % R
+        m_prime.coeffs.pop(0)
+        m_prime.degree -= 1
+        cs = [ys[i] * fr_inv(c) % R for i, c in enumerate(m_prime.multi_eval(xs))]
+        return tree.linear_mod_combination(cs)
+
+    @staticmethod
+    def lagrange_interpolation(xs, ys):  # :266-293
+        assert len(xs) == len(ys)
+        if len(xs) == 1:
+            return Polynomial([(ys[0] - xs[0]) % R, 1], 1)
+        tree = SubProductTree.new_from_points(xs)
+        return Polynomial.lagrange_interpolation_with_tree(xs, ys, tree)
+
+    def scalar_multiplication(self, rhs):  # :295-300
+        p = self.clone()
+        for i in range(p.num_coeffs()):
+            p.coeffs[i] = p.coeffs[i] * rhs % R
+        return p
+
+    def add_owned(self, rhs):  # impl Add for Polynomial (by value), :412-428
+        res, shorter = (rhs.clone(), self) if rhs.degree > self.degree else (self.clone(), rhs)
+        for i in range(shorter.num_coeffs()):
+            res.coeffs[i] = (res.coeffs[i] + shorter.coeffs[i]) % R
+        return res
+
+    def add_ref(self, rhs):  # impl Add for &Polynomial, :394-410 (off-by-one quirk)
+        res, shorter = (rhs.clone(), self) if rhs.degree > self.degree else (self.clone(), rhs)
+        for i in range(shorter.degree):
+            res.coeffs[i] = (res.coeffs[i] + shorter.coeffs[i]) % R
+        return res
+
+    def sub_ref(self, rhs):  # impl Sub for &Polynomial, :443-460
+        res = self.clone()
+        if rhs.num_coeffs() > self.num_coeffs():
+            res.coeffs = _vec_resize(res.coeffs, rhs.num_coeffs())
+            res.degree = rhs.degree
+        for i in range(rhs.num_coeffs()):
+            res.coeffs[i] = (res.coeffs[i] - rhs.coeffs[i]) % R
+        res.shrink_degree()
+        return res
+
+
+class SubProductTree:  # src/polynomial.rs:303-365
+    def __init__(self, product, left, right):
+        self.product, self.left, self.right = product, left, right
+
+    @staticmethod
+    def new_from_points(xs):  # :310-327
+        n = len(xs)
+        if n == 1:
+            return SubProductTree(Polynomial([fr_neg(xs[0]), 1], 1), None, None)
+        left = SubProductTree.new_from_points(xs[: n // 2])
+        right = SubProductTree.new_from_points(xs[n // 2:])
+        return SubProductTree(left.product.best_mul(right.product), left, right)
+
+    def eval(self, xs, f):  # :329-348
+        n = len(xs)
+        if n == 1:
+            return [f.eval(xs[0])]
+        _, r0 = f.long_division(self.left.product)
+        _, r1 = f.long_division(self.right.product)
+        if r0 is None or r1 is None:
+            raise RuntimeError("called `Option::unwrap()` on a `None` value (src/polynomial.rs:342-343)")
+        l0 = self.left.eval(xs[: n // 2], r0)
+        l1 = self.right.eval(xs[n // 2:], r1)
+        return l0 + l1
+
+    def linear_mod_combination(self, cs):  # :350-364
+        n = len(cs)
+        if n == 1:
+            return Polynomial([cs[0]], 0)
+        l = self.left.linear_mod_combination(cs[: n // 2])
+        r = self.right.linear_mod_combination(cs[n // 2:])
+        return self.right.product.best_mul(l).add_owned(self.left.product.best_mul(r))
+
+
+def op_tree(size, get_elem, op):  # src/polynomial.rs:367-392
+    def inner(left, size):
+        assert size > 0
+        if size == 1:
+            return get_elem(left)
+        if size == 2:
+            return op(get_elem(left), get_elem(left + 1))
+        mid = left + size // 2
+        return op(inner(left, size // 2), inner(mid, size - size // 2))
+
+    return inner(0, size)
+
+
+# --------------------------------------------------------------------------------------
+# src/ft.rs  EvaluationDomain + best_fft / serial_fft
+# --------------------------------------------------------------------------------------
+class PolynomialDegreeTooLarge(Exception):  # KZGError::PolynomialDegreeTooLarge, src/lib.rs:34-35
+    pass
+
+
+class PointNotOnPolynomial(Exception):  # KZGError::PointNotOnPolynomial, src/lib.rs:30-31
+    pass
+
+
+def compute_omega(d):  # src/ft.rs:55-76
+    m, exp = 1, 0
+    while m < d:
+        m *= 2
+        exp += 1
+        if exp >= FR_S:
+            raise PolynomialDegreeTooLarge()
+    omega = pow(FR_ROOT_OF_UNITY, 1 << (FR_S - exp), R)
+    return m, exp, omega
+
+
+def _bitreverse(n, l):  # src/ft.rs:292-299
+    r = 0
+    for _ in range(l):
+        r = (r << 1) | (n & 1)
+        n >>= 1
+    return r
+
+
+def serial_fft(a, omega, log_n):  # src/ft.rs:291-333 (in place, natural order in/out)
+    n = len(a)
+    assert n == 1 << log_n
+    for k in range(n):
+        rk = _bitreverse(k, log_n)
+        if k < rk:
+            a[rk], a[k] = a[k], a[rk]
+    m = 1
+    for _ in range(log_n):
+        w_m = pow(omega, n // (2 * m), R)
+        k = 0
+        while k < n:
+            w = 1
+            for j in range(m):
+                t = a[k + j + m] * w % R
+                a[k + j + m] = (a[k + j] - t) % R
+                a[k + j] = (a[k + j] + t) % R
+                w = w * w_m % R
+            k += 2 * m
+        m *= 2
+
+
+def best_fft(a, omega, log_n):  # src/ft.rs:274-288 (parallel_fft is output-identical; :336-387)
+    serial_fft(a, omega, log_n)
+
+
+class EvaluationDomain:  # src/ft.rs:17-25
+    def __init__(self, coeffs, d, exp, omega):  # EvaluationDomain::new, :82-92
+        self.coeffs = [c % R for c in coeffs]
+        self.d, self.exp, self.omega = d, exp, omega
+        self.omegainv = fr_inv(omega)
+        self.geninv = fr_inv(FR_GENERATOR)
+        self.minv = fr_inv(d)
+
+    @staticmethod
+    def from_coeffs(coeffs):  # :94-109
+        m, exp, omega = compute_omega(len(coeffs))
+        coeffs = list(coeffs) + [0] * (m - len(coeffs))
+        return EvaluationDomain(coeffs, m, exp, omega)
+
+    def clone(self):
+        return EvaluationDomain(list(self.coeffs), self.d, self.exp, self.omega)
+
+    def clone_with_different_coeffs(self, coeffs):  # :78-80
+        return EvaluationDomain(list(coeffs), self.d, self.exp, self.omega)
+
+    def __len__(self):  # :49-51
+        return len(self.coeffs)
+
+    def fft(self):  # :111-113
+        best_fft(self.coeffs, self.omega, self.exp)
+
+    def ifft(self):  # :115-140
+        best_fft(self.coeffs, self.omegainv, self.exp)
+        self.coeffs = [v * self.minv % R for v in self.coeffs]
+
+    def distribute_powers(self, g):  # :142-166  (v[i] *= g^i)
+        self.coeffs = [v * pow(g, i, R) % R for i, v in enumerate(self.coeffs)]
+
+    def coset_fft(self):  # :168-171
+        self.distribute_powers(FR_GENERATOR)
+        self.fft()
+
+    def icoset_fft(self):  # :173-178
+        self.ifft()
+        self.distribute_powers(self.geninv)
+
+    def z(self, tau):  # :182-187
+        return (pow(tau, len(self.coeffs), R) - 1) % R
+
+    def divide_by_z_on_coset(self):  # :192-217
+        i = fr_inv(self.z(FR_GENERATOR))
+        self.coeffs = [v * i % R for v in self.coeffs]
+
+    def mul_assign(self, other):  # :220-244
+        assert len(self.coeffs) == len(other.coeffs)
+        self.coeffs = [a * b % R for a, b in zip(self.coeffs, other.coeffs)]
+
+    def sub_assign(self, other):  # :247-271
+        assert len(self.coeffs) == len(other.coeffs)
+        self.coeffs = [(a - b) % R for a, b in zip(self.coeffs, other.coeffs)]
+
+    def to_polynomial(self):  # impl From<EvaluationDomain> for Polynomial, :27-31
+        return Polynomial(self.coeffs)
+
+
+# --------------------------------------------------------------------------------------
+# src/coeff_form.rs  KZGProver
+# --------------------------------------------------------------------------------------
+class KZGParams:  # src/lib.rs:14-19 (G1 half only)
+    def __init__(self, gs):
+        self.gs = gs
+
+
+def setup(s, num_coeffs):
+    return KZGParams(setup_g1_fast(s, num_coeffs))
+
+
+class KZGProver:  # src/coeff_form.rs:37-112
+    def __init__(self, parameters):
+        self.parameters = parameters
+
+    def commit(self, polynomial):  # :59-64
+        n = polynomial.num_coeffs()
+        assert n <= len(self.parameters.gs), "slice index out of range (reference panics)"
+        return g1_multi_exp(self.parameters.gs[:n], polynomial.slice_coeffs())
+
+    def create_witness(self, polynomial, point):  # :66-81
+        x, y = point
+        dividend = polynomial.clone()
+        dividend.coeffs[0] = (dividend.coeffs[0] - y) % R
+        divisor = Polynomial([fr_neg(x), 1], 1)
+        psi, rem = dividend.long_division(divisor)
+        if rem is not None:
+            raise PointNotOnPolynomial()
+        if psi.num_coeffs() == 1:
+            return g1_mul(self.parameters.gs[0], psi.coeffs[0])
+        return g1_multi_exp(self.parameters.gs[: psi.num_coeffs()], psi.slice_coeffs())
+
+    def create_witness_batched(self, polynomial, xs, ys):  # :83-111 -> (r: Polynomial, w: G1Affine)
+        tree = SubProductTree.new_from_points(xs)
+        interpolation = Polynomial.lagrange_interpolation_with_tree(xs, ys, tree)
+        numerator = polynomial.sub_ref(interpolation)
+        psi, rem = numerator.long_division(tree.product)
+        if rem is not None:
+            raise PointNotOnPolynomial()
+        if psi.num_coeffs() == 1:
+            w = g1_mul(self.parameters.gs[0], psi.coeffs[0])
+        else:
+            w = g1_multi_exp(self.parameters.gs[: psi.num_coeffs()], psi.slice_coeffs())
+        return interpolation, w
+
+    def verify_poly(self, commitment, polynomial):  # KZGVerifier::verify_poly, :119-124
+        return self.commit(polynomial) == commitment
+
+
+# --------------------------------------------------------------------------------------
+# src/eval_form.rs  KZGProverEvalForm
+# --------------------------------------------------------------------------------------
+def div_by_omega_i(evals, m):  # src/eval_form.rs:58-84 (literal restatement; O(d) inversions)
+    d = evals.d
+    omega_m = pow(evals.omega, m, R)
+    out = []
+    for j, f in enumerate(evals.coeffs):
+        if j == m:
+            qm = 0
+            am = d * fr_inv(omega_m) % R
+            for i in range(d):
+                if i == m:
+                    continue
+                omega_i = pow(evals.omega, i, R)
+                ai = d * fr_inv(omega_i) % R
+                term = evals.coeffs[i] * (am * fr_inv(ai) % R) % R
+                term = term * fr_inv(omega_m - omega_i) % R
+                qm = (qm + term) % R
+            out.append(qm)
+        else:
+            omega_j = pow(evals.omega, j, R)
+            out.append(f * fr_inv(omega_j - omega_m) % R)
+    return evals.clone_with_different_coeffs(out)
+
+
+def div_by_omega_i_fast(evals, m):
+    """Closed form of div_by_omega_i: q_j = f_j/(w^j - w^m), q_m = -sum_{i!=m} q_i w^(i-m).
+    Same field elements as div_by_omega_i; used for sizes where the literal version is too slow."""
+    d, w = evals.d, evals.omega
+    pw = [1] * d
+    for i in range(1, d):
+        pw[i] = pw[i - 1] * w % R
+    out = [0] * d
+    qm = 0
+    for j, f in enumerate(evals.coeffs):
+        if j == m:
+            continue
+        q = f * fr_inv(pw[j] - pw[m]) % R
+        out[j] = q
+        qm = (qm - q * pw[(j - m) % d]) % R
+    out[m] = qm
+    return evals.clone_with_different_coeffs(out)
+
+
+class KZGProverEvalForm:  # src/eval_form.rs:39-147
+    def __init__(self, parameters, lagrange_basis_g):  # :88-100
+        self.parameters = parameters
+        self.lagrange_basis_g = lagrange_basis_g
+        self.d, self.exp, self.omega = compute_omega(len(parameters.gs))
+
+    def commit(self, evals):  # :114-122
+        assert self.d == evals.d
+        return g1_multi_exp(self.lagrange_basis_g[: len(evals)], evals.coeffs)
+
+    def create_witness(self, evals, i, fast=True):  # :124-140
+        y = evals.coeffs[i]
+        numerator = evals.clone_with_different_coeffs([(c - y) % R for c in evals.coeffs])
+        q = div_by_omega_i_fast(numerator, i) if fast else div_by_omega_i(numerator, i)
+        if len(q.coeffs) == 1:
+            return g1_mul(self.lagrange_basis_g[0], q.coeffs[0])
+        return g1_multi_exp(self.lagrange_basis_g[: len(q)], q.coeffs)
+
+    def create_witness_all(self):  # :142-146
+        return None
+
+    def verify_poly(self, commitment, evals):  # KZGVerifierEvalForm::verify_poly, :162-171
+        e = evals.clone()
+        e.ifft()
+        p = e.to_polynomial()
+        return g1_multi_exp(self.parameters.gs[: p.num_coeffs()], p.slice_coeffs()) == commitment
+
+
+def compute_lagrange_basis_g1(params):
+    """src/eval_form.rs:254-280 restated literally (O(d^3); tiny d only), G1 half."""
+    d0 = len(params.gs)
+    assert d0 & (d0 - 1) == 0
+    d, _, omega = compute_omega(d0)
+    gs = []
+    for i in range(d):
+        xi = pow(omega, i, R)
+        l = Polynomial.new_monic_of_degree(0)
+        for j in range(d):
+            if j == i:
+                continue
+            xj = pow(omega, j, R)
+            l = l.best_mul(Polynomial([fr_neg(xj), 1]))
+            l = l.scalar_multiplication(fr_inv(xi - xj))
+        coeffs = l.slice_coeffs()
+        gs.append(g1_multi_exp(params.gs[: len(coeffs)], coeffs))
+    return gs
+
+
+def lagrange_basis_g1_known_tau(tau, d):
+    """L_i(tau) G with L_i(tau) = (tau^d - 1) w^i / (d (tau - w^i))  (SURVEY 8a row a14).
+    Identical group elements to compute_lagrange_basis_g1 when gs = setup(tau, d)."""
+    _, _, omega = compute_omega(d)
+    zt = (pow(tau, d, R) - 1) % R
+    out = []
+    for i in range(d):
+        wi = pow(omega, i, R)
+        if (tau - wi) % R == 0:
+            li = 1
+        else:
+            li = zt * wi % R * fr_inv(d * (tau - wi)) % R
+        out.append(g1_mul(G1, li))
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# selfcheck: validates the constants above (run by tests/test_oracle_model.py)
+# --------------------------------------------------------------------------------------
+def selfcheck():
+    z = BLS_Z
+    assert R == z ** 4 - z ** 2 + 1
+    assert Q == ((z - 1) ** 2 * R) // 3 + z and ((z - 1) ** 2 * R) % 3 == 0
+    assert Q % 4 == 3
+    assert (R - 1) % (1 << FR_S) == 0 and ((R - 1) >> FR_S) & 1 == 1
+    assert pow(FR_GENERATOR, (R - 1) // 2, R) == R - 1  # 7 is a non-residue
+    assert FR_ROOT_OF_UNITY == 0x16a2a19edfe81f20d09b681922c813b4b63683508c2280b93829971f439f0d2b
+    assert pow(FR_ROOT_OF_UNITY, 1 << 32, R) == 1 and pow(FR_ROOT_OF_UNITY, 1 << 31, R) == R - 1
+    assert compute_omega(1 << 20)[2] == 0x03e1c54bcb947035a57a6e07cb98de4a2f69e02d265e09d9fece7e0e39898d4b
+    assert g1_is_on_curve(G1)
+    assert g1_mul(G1, R - 1) == g1_neg(G1)
+    assert _from_jac(_jac_add(_to_jac(g1_mul(G1, R - 1)), _to_jac(G1))) is None  # r*G = O
+    assert g1_to_compressed(G1).hex().startswith("97f1d3a7") and g1_to_compressed(G1).hex().endswith("c6bb")
+    assert g1_from_compressed(g1_to_compressed(G1)) == G1
+    assert FR_MONT_R == 0x1824b159acc5056f998c4fefecbc4ff55884b7fa0003480200000001fffffffe
+    return True
