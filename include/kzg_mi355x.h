@@ -1,0 +1,180 @@
+/*
+ * kzg_mi355x.h -- C ABI of the MI355X-native (gfx950) KZG commit/open engine.
+ *
+ * This is the drop-in boundary for the hot path of proxima-one/kzg (crate kzg 0.8.0-beta.1).  The
+ * reference has no FFI of its own (it is pure Rust calling blstrs); the entry points below are the
+ * ones a `kzg-mi355x-sys` binding would splice in at the reference's call sites, cited per function
+ * as (reference file:line).  INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++ exceptions or callbacks cross the ABI.
+ *   - every call returns a kzg_status; 0 = ok, >0 = the reference's own error conditions,
+ *     <0 = runtime failure (HIP).  kzg_last_error(ctx) gives a human-readable string.
+ *   - a kzg_ctx is bound to one GPU and is thread-safe (calls on one ctx serialise on an internal
+ *     mutex; use one ctx per host thread for concurrency).  There is NO CPU fallback: without a
+ *     usable HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
+ *   - `flags` says where buffers live: scalars/points in host memory (default) or already resident
+ *     in this GPU's HBM (KZG_IN_DEVICE), result written to host (default) or device (KZG_OUT_DEVICE).
+ *
+ * Data formats (all little-endian unless "ZCASH")
+ *   KZG_FR_MONT_LE_32        4 x u64 limbs of a*2^256 mod r      (= blst_fr = blstrs::Scalar in memory)
+ *   KZG_FR_CANONICAL_LE_32   32 bytes of a < r                    (= Scalar::to_bytes_le)
+ *   KZG_G1_AFFINE_MONT_96    x,y: 6 x u64 Montgomery limbs each; identity = all zero (= blst_p1_affine)
+ *   KZG_G1_JACOBIAN_MONT_144 X,Y,Z Montgomery limbs; identity has Z = 0 (= blst_p1 = G1Projective)
+ *   KZG_G1_ZCASH_UNCOMPRESSED_96 / KZG_G1_ZCASH_COMPRESSED_48   big-endian canonical with flag bits
+ *                            (bit7 compressed, bit6 infinity, bit5 y-sign) = G1Affine::to_uncompressed
+ *                            / to_compressed
+ */
+#ifndef KZG_MI355X_H
+#define KZG_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kzg_ctx kzg_ctx;
+typedef struct kzg_srs kzg_srs;
+
+typedef enum {
+    KZG_OK = 0,
+    KZG_ERR_POINT_NOT_ON_POLY = 1,  /* KZGError::PointNotOnPolynomial      (src/lib.rs:30-31) */
+    KZG_ERR_DEGREE_TOO_LARGE = 2,   /* KZGError::PolynomialDegreeTooLarge  (src/lib.rs:34-35) */
+    KZG_ERR_SHAPE = 3,              /* a condition on which the reference panics (slice OOB,
+                                       assert!(d == evals.d), index out of range, ...) */
+    KZG_ERR_BAD_POINT = 4,          /* input point failed to decode / not on the curve */
+    KZG_ERR_HIP = -1,
+    KZG_ERR_NO_DEVICE = -2,
+    KZG_ERR_ALLOC = -3,
+    KZG_ERR_INTERNAL = -4
+} kzg_status;
+
+enum { KZG_FR_MONT_LE_32 = 0, KZG_FR_CANONICAL_LE_32 = 1 };
+enum {
+    KZG_G1_AFFINE_MONT_96 = 0,
+    KZG_G1_JACOBIAN_MONT_144 = 1,
+    KZG_G1_ZCASH_UNCOMPRESSED_96 = 2,
+    KZG_G1_ZCASH_COMPRESSED_48 = 3
+};
+enum { KZG_IN_DEVICE = 1, KZG_OUT_DEVICE = 2 };
+
+/* ---- context ------------------------------------------------------------------------------- */
+const char *kzg_version(void);
+/* device: HIP device ordinal.  Fails with KZG_ERR_NO_DEVICE if no gfx950-class device is usable. */
+int kzg_ctx_create(int device, kzg_ctx **out);
+void kzg_ctx_destroy(kzg_ctx *ctx);
+const char *kzg_last_error(kzg_ctx *ctx);
+int kzg_sync(kzg_ctx *ctx);
+/* tunables: "window_bits" (0 = auto), "streams" (batch pipelining depth) */
+int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value);
+
+/* ---- SRS (KZGParams.gs, src/lib.rs:14-19; lagrange_basis_g, src/eval_form.rs:40-46) --------- */
+/* Upload n G1 points once; they stay resident in HBM in the engine's internal layout
+ * (affine Montgomery + per-window precomputed multiples).  Caller keeps ownership of `pts`. */
+int kzg_srs_upload_g1(kzg_ctx *ctx, const void *pts, size_t n, int pfmt, kzg_srs **out);
+/* setup(s, n), G1 half (src/lib.rs:38-47): gs[i] = [s^i]G, generated on the GPU. */
+int kzg_srs_setup_g1(kzg_ctx *ctx, const void *s, int sfmt, size_t n, kzg_srs **out);
+/* Lagrange-basis SRS for a known secret: L_i(s) G, i < d, d a power of two.  Same group elements
+ * as compute_lagrange_basis(&setup(s, d)).0 (src/eval_form.rs:254-280), in O(d) not O(d^3). */
+int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *s, int sfmt, size_t d, kzg_srs **out);
+/* compute_lagrange_basis (src/eval_form.rs:254-280), G1 half, from the monomial SRS alone
+ * (no secret): inverse group-NTT of gs.  gs length must be a power of two. */
+int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *monomial, kzg_srs **out);
+int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, size_t n, void *out, int pfmt);
+size_t kzg_srs_len(const kzg_srs *srs);
+void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs);
+
+/* ---- MSM: G1Projective::multi_exp(&gs[offset..offset+n], scalars) --------------------------- */
+/* (call sites src/coeff_form.rs:61,78,102; src/eval_form.rs:118,136).  n may be 0 (-> identity). */
+int kzg_msm_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, int sfmt,
+               int flags, void *out, int ofmt);
+/* `batch` scalar vectors (each n scalars, contiguous, stride n*32 B) against one SRS; out gets
+ * `batch` points.  Throughput mode: independent MSMs are pipelined on several HIP streams. */
+int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n,
+                     size_t batch, int sfmt, int flags, void *out, int ofmt);
+/* sum of `count` G1 points (multi-GPU combine of per-rank partial MSMs). points in pfmt. */
+int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pfmt, int flags, void *out, int ofmt);
+
+/* ---- NTT: EvaluationDomain::fft / ifft (src/ft.rs:111-140; best_fft :274-288) --------------- */
+/* EvaluationDomain::compute_omega (src/ft.rs:55-76): m = next pow2 >= d, exp = log2 m, omega.
+ * Returns KZG_ERR_DEGREE_TOO_LARGE if exp >= 32.  Host-only helper; omega written in sfmt. */
+int kzg_compute_omega(size_t d, size_t *m, uint32_t *exp, void *omega, int sfmt);
+/* In place, natural order in and out: out[i] = sum_j a[j] w^(ij); inverse uses w^-1 and scales by
+ * d^-1.  The transform is linear, so data may be in either Fr format (it is preserved). */
+int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int flags);
+/* coset_fft / icoset_fft (src/ft.rs:168-178): distribute_powers(g = 7) then fft; ifft then g^-i. */
+int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int sfmt, int flags);
+
+/* ---- coefficient form (src/coeff_form.rs) ---------------------------------------------------- */
+/* KZGProver::commit (:59-64).  coeffs[0..n) = polynomial.slice_coeffs(); KZG_ERR_SHAPE if n > SRS. */
+int kzg_commit_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, int sfmt, int flags,
+                     void *out, int ofmt);
+/* KZGProver::create_witness (:66-81): [(p - y)/(X - x)]_1; KZG_ERR_POINT_NOT_ON_POLY iff p(x) != y.
+ * x, y are host scalars in sfmt.  n = polynomial.num_coeffs() >= 1. */
+int kzg_witness_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *x,
+                      const void *y, int sfmt, int flags, void *out, int ofmt);
+/* KZGProver::create_witness_batched (:83-111): w = [(p - I)/Z]_1 and r = I (the interpolant through
+ * (xs, ys)).  xs, ys: k host scalars.  out_r receives *out_r_len scalars (host, sfmt): k normally,
+ * 2 for k == 1 (the reference returns X + (y - x), src/polynomial.rs:244-247).
+ * KZG_ERR_POINT_NOT_ON_POLY iff some p(xs[i]) != ys[i]. */
+int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n,
+                              const void *xs, const void *ys, size_t k, int sfmt, int flags, void *out_w,
+                              int ofmt, void *out_r, size_t *out_r_len);
+/* KZGVerifier::verify_poly (:119-124): *ok = (commit(coeffs) == commitment). */
+int kzg_verify_poly_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *commitment, int pfmt,
+                          const void *coeffs, size_t n, int sfmt, int flags, int *ok);
+
+/* ---- evaluation form (src/eval_form.rs) ------------------------------------------------------ */
+/* KZGProverEvalForm::commit (:114-122): MSM against the Lagrange SRS.  KZG_ERR_SHAPE unless
+ * d == kzg_srs_len(lagrange) (assert!(self.d == evals.d)). */
+int kzg_commit_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, int sfmt, int flags,
+                    void *out, int ofmt);
+/* KZGProverEvalForm::create_witness (:124-140) incl. div_by_omega_i (:58-84).  KZG_ERR_SHAPE if
+ * i >= d (the reference panics on the index). */
+int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, size_t i, int sfmt,
+                     int flags, void *out, int ofmt);
+/* KZGVerifierEvalForm::verify_poly (:162-171): ifft then monomial MSM, compare. */
+int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const void *commitment, int pfmt,
+                         const void *evals, size_t d, int sfmt, int flags, int *ok);
+
+/* ---- Fr polynomial helpers on the path (device) ---------------------------------------------- */
+/* Polynomial::eval (src/polynomial.rs:156-165) at one point. */
+int kzg_poly_eval(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, int sfmt, int flags, void *y_out);
+/* quotient of create_witness without the MSM: q = (p - y)/(X - x), n-1 scalars, in place allowed.
+ * Returns KZG_ERR_POINT_NOT_ON_POLY if the remainder is non-zero. */
+int kzg_quotient_linear(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, const void *y, int sfmt,
+                        int flags, void *q_out);
+/* div_by_omega_i (src/eval_form.rs:58-84) applied to (evals - evals[i]). */
+int kzg_quotient_eval(kzg_ctx *ctx, const void *evals, size_t d, size_t i, int sfmt, int flags, void *q_out);
+
+/* ---- device memory + measurement ------------------------------------------------------------- */
+int kzg_dev_alloc(kzg_ctx *ctx, size_t bytes, void **out);
+int kzg_dev_free(kzg_ctx *ctx, void *p);
+int kzg_dev_upload(kzg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int kzg_dev_download(kzg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+/* Fill n Fr elements with a counter-based generator (SplitMix64 of (seed, i), reduced mod r;
+ * `u64_valued` != 0 mirrors the reference benches' u64-valued coefficients,
+ * benches/commit_coeff_form.rs:16-21).  Output canonical or Montgomery per sfmt. */
+int kzg_fill_random_fr(kzg_ctx *ctx, void *dst_dev, size_t n, uint64_t seed, int u64_valued, int sfmt);
+/* Per-kernel HIP-event timing on the stream the kernels run on (for bench.py's roofline line). */
+int kzg_prof_enable(kzg_ctx *ctx, int on);
+int kzg_prof_reset(kzg_ctx *ctx);
+int kzg_prof_get(kzg_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
+/* comma-separated list of kernel names seen so far */
+int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen);
+/* number of window bits and windows the engine chose for this SRS (for G1-adds accounting) */
+int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows);
+
+/* ---- unit-test hooks (device arithmetic exercised directly; used by tests/ only) -------------- */
+int kzg_test_fr_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery */
+int kzg_test_fq_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery, 48 B */
+int kzg_test_fr_inv(kzg_ctx *ctx, const void *a, size_t n, void *out);
+int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* affine mont 96 */
+int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k_canonical, size_t n, void *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KZG_MI355X_H */

@@ -1,0 +1,12 @@
+"""kzg_amd -- MI355X-native (gfx950) engine for the KZG commit/open hot path of proxima-one/kzg.
+
+The product is the C-ABI shared library libkzg_mi355x.so (include/kzg_mi355x.h) built from the
+hand-written HIP sources in kzg_amd/csrc/.  This package is the thin host-side mirror of the
+reference's prover surface used by tests/ and bench.py.  There is no CPU fallback.
+"""
+from ._lib import (FR_CANONICAL, FR_MONT, G1_AFFINE_MONT, G1_JACOBIAN_MONT, G1_ZCASH_COMPRESSED,
+                   G1_ZCASH_UNCOMPRESSED, IN_DEVICE, OUT_DEVICE, SO_PATH, load)
+from .api import (DeviceBuffer, Engine, EngineError, EvaluationDomain, KZGBatchWitness, KZGError, KZGParams,
+                  KZGProver, KZGProverEvalForm, KZGVerifier, KZGVerifierEvalForm, PointNotOnPolynomial, Polynomial,
+                  PolynomialDegreeTooLarge, ReferencePanic, Srs, compute_lagrange_basis, compute_omega, pack_scalars,
+                  setup, setup_lagrange, splitmix_scalar, unpack_scalars)

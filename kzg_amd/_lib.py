@@ -1,0 +1,97 @@
+"""ctypes loader for libkzg_mi355x.so.  There is no CPU fallback: if the library is missing or no
+MI355X-class device is usable the import / context creation raises."""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(HERE, "libkzg_mi355x.so")
+
+KZG_OK = 0
+KZG_ERR_POINT_NOT_ON_POLY = 1
+KZG_ERR_DEGREE_TOO_LARGE = 2
+KZG_ERR_SHAPE = 3
+KZG_ERR_BAD_POINT = 4
+KZG_ERR_HIP = -1
+KZG_ERR_NO_DEVICE = -2
+KZG_ERR_ALLOC = -3
+KZG_ERR_INTERNAL = -4
+
+FR_MONT = 0
+FR_CANONICAL = 1
+G1_AFFINE_MONT = 0
+G1_JACOBIAN_MONT = 1
+G1_ZCASH_UNCOMPRESSED = 2
+G1_ZCASH_COMPRESSED = 3
+POINT_BYTES = {0: 96, 1: 144, 2: 96, 3: 48}
+IN_DEVICE = 1
+OUT_DEVICE = 2
+
+_lib = None
+
+c_void_pp = ctypes.POINTER(ctypes.c_void_p)
+
+
+def load():
+    """Load the shared library (building it in-tree first if hipcc is available and it is stale)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise ImportError(
+            f"{SO_PATH} not found: build it with `python -m kzg_amd.build` (hipcc --offload-arch=gfx950). "
+            "kzg_amd has no CPU fallback.")
+    L = ctypes.CDLL(SO_PATH)
+    sz, i32, u32, u64, vp = ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p
+    sig = {
+        "kzg_version": (ctypes.c_char_p, []),
+        "kzg_ctx_create": (i32, [i32, c_void_pp]),
+        "kzg_ctx_destroy": (None, [vp]),
+        "kzg_last_error": (ctypes.c_char_p, [vp]),
+        "kzg_sync": (i32, [vp]),
+        "kzg_ctx_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
+        "kzg_srs_upload_g1": (i32, [vp, vp, sz, i32, c_void_pp]),
+        "kzg_srs_setup_g1": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_setup_lagrange_g1": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_lagrange_from_monomial_g1": (i32, [vp, vp, c_void_pp]),
+        "kzg_srs_download_g1": (i32, [vp, vp, sz, sz, vp, i32]),
+        "kzg_srs_len": (sz, [vp]),
+        "kzg_srs_free": (None, [vp, vp]),
+        "kzg_srs_window_info": (i32, [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
+        "kzg_msm_g1": (i32, [vp, vp, sz, vp, sz, i32, i32, vp, i32]),
+        "kzg_msm_g1_batch": (i32, [vp, vp, sz, vp, sz, sz, i32, i32, vp, i32]),
+        "kzg_g1_sum": (i32, [vp, vp, sz, i32, i32, vp, i32]),
+        "kzg_compute_omega": (i32, [sz, ctypes.POINTER(sz), ctypes.POINTER(u32), vp, i32]),
+        "kzg_ntt_fr": (i32, [vp, vp, u32, i32, i32]),
+        "kzg_coset_ntt_fr": (i32, [vp, vp, u32, i32, i32, i32]),
+        "kzg_commit_coeff": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
+        "kzg_witness_coeff": (i32, [vp, vp, vp, sz, vp, vp, i32, i32, vp, i32]),
+        "kzg_witness_coeff_batched": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, vp, ctypes.POINTER(sz)]),
+        "kzg_verify_poly_coeff": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
+        "kzg_commit_eval": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
+        "kzg_witness_eval": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
+        "kzg_verify_poly_eval": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
+        "kzg_poly_eval": (i32, [vp, vp, sz, vp, i32, i32, vp]),
+        "kzg_quotient_linear": (i32, [vp, vp, sz, vp, vp, i32, i32, vp]),
+        "kzg_quotient_eval": (i32, [vp, vp, sz, sz, i32, i32, vp]),
+        "kzg_dev_alloc": (i32, [vp, sz, c_void_pp]),
+        "kzg_dev_free": (i32, [vp, vp]),
+        "kzg_dev_upload": (i32, [vp, vp, vp, sz]),
+        "kzg_dev_download": (i32, [vp, vp, vp, sz]),
+        "kzg_fill_random_fr": (i32, [vp, vp, sz, u64, i32, i32]),
+        "kzg_prof_enable": (i32, [vp, i32]),
+        "kzg_prof_reset": (i32, [vp]),
+        "kzg_prof_get": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double)]),
+        "kzg_prof_names": (i32, [vp, ctypes.c_char_p, sz]),
+        "kzg_test_fr_mul": (i32, [vp, vp, vp, sz, vp]),
+        "kzg_test_fq_mul": (i32, [vp, vp, vp, sz, vp]),
+        "kzg_test_fr_inv": (i32, [vp, vp, sz, vp]),
+        "kzg_test_g1_add": (i32, [vp, vp, vp, sz, vp]),
+        "kzg_test_g1_mul": (i32, [vp, vp, vp, sz, vp]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)  # raises AttributeError if the export is missing
+        f.restype = res
+        f.argtypes = args
+    L._kzg_signatures = sig
+    _lib = L
+    return L

@@ -1,0 +1,541 @@
+"""Host-side mirror of the reference's prover surface over the C ABI (include/kzg_mi355x.h).
+
+Names, argument meaning and error behaviour follow proxima-one/kzg:
+  setup / KZGParams                      src/lib.rs:14-55
+  Polynomial                             src/polynomial.rs:24-165
+  EvaluationDomain                       src/ft.rs:17-140
+  KZGProver / KZGVerifier.verify_poly    src/coeff_form.rs:37-124
+  KZGProverEvalForm / verify_poly        src/eval_form.rs:39-171
+Scalars cross this layer as python ints (canonical, < r) or as packed 32-byte little-endian blobs;
+G1 points as 96-byte affine-Montgomery blobs (`bytes`), identity = 96 zero bytes.  All arithmetic
+happens on the GPU in libkzg_mi355x.so; nothing here computes field or curve operations.
+"""
+import ctypes
+
+from . import _lib as L
+
+R_MODULUS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+
+
+class KZGError(Exception):
+    """src/lib.rs:26-36"""
+
+
+class PointNotOnPolynomial(KZGError):
+    pass
+
+
+class PolynomialDegreeTooLarge(KZGError):
+    pass
+
+
+class ReferencePanic(Exception):
+    """A condition on which the reference panics (slice out of range, failed assert!, ...)."""
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _raise(engine, rc):
+    msg = engine.last_error() if engine is not None else ""
+    if rc == L.KZG_ERR_POINT_NOT_ON_POLY:
+        raise PointNotOnPolynomial(msg or "point not on polynomial!")
+    if rc == L.KZG_ERR_DEGREE_TOO_LARGE:
+        raise PolynomialDegreeTooLarge(msg or "polynomial degree too large")
+    if rc == L.KZG_ERR_SHAPE:
+        raise ReferencePanic(msg)
+    raise EngineError(f"kzg_mi355x error {rc}: {msg}")
+
+
+def pack_scalars(xs):
+    """list of ints -> canonical LE blob; bytes-like passes through."""
+    if isinstance(xs, (bytes, bytearray, memoryview)):
+        return bytes(xs)
+    return b"".join((int(x) % R_MODULUS).to_bytes(32, "little") for x in xs)
+
+
+def unpack_scalars(b):
+    return [int.from_bytes(b[i:i + 32], "little") for i in range(0, len(b), 32)]
+
+
+class DeviceBuffer:
+    """Scalars resident in HBM (n x 32 B), owned by an Engine."""
+
+    def __init__(self, engine, n, sfmt=L.FR_CANONICAL):
+        self.engine, self.n, self.sfmt = engine, n, sfmt
+        p = ctypes.c_void_p()
+        rc = engine.lib.kzg_dev_alloc(engine.ctx, n * 32, ctypes.byref(p))
+        if rc:
+            _raise(engine, rc)
+        self.ptr = p
+
+    def upload(self, blob):
+        assert len(blob) == self.n * 32
+        rc = self.engine.lib.kzg_dev_upload(self.engine.ctx, self.ptr, blob, len(blob))
+        if rc:
+            _raise(self.engine, rc)
+        return self
+
+    def download(self, n=None, offset=0):
+        n = self.n - offset if n is None else n
+        out = ctypes.create_string_buffer(n * 32)
+        src = ctypes.c_void_p(self.ptr.value + offset * 32)
+        rc = self.engine.lib.kzg_dev_download(self.engine.ctx, out, src, n * 32)
+        if rc:
+            _raise(self.engine, rc)
+        return out.raw
+
+    def fill_random(self, seed, u64_valued=False):
+        rc = self.engine.lib.kzg_fill_random_fr(self.engine.ctx, self.ptr, self.n, seed, 1 if u64_valued else 0, self.sfmt)
+        if rc:
+            _raise(self.engine, rc)
+        return self
+
+    def free(self):
+        if self.ptr:
+            self.engine.lib.kzg_dev_free(self.engine.ctx, self.ptr)
+            self.ptr = None
+
+
+def splitmix_scalar(seed, i, u64_valued=False):
+    """The element kzg_fill_random_fr writes at index i (definition in include/kzg_mi355x.h)."""
+    M = (1 << 64) - 1
+
+    def sm(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    v = 0
+    for k in range(1 if u64_valued else 4):
+        v |= sm((seed + 4 * i + k) & M) << (64 * k)
+    return v % R_MODULUS
+
+
+class Engine:
+    """One kzg_ctx bound to one GPU."""
+
+    def __init__(self, device=0):
+        self.lib = L.load()
+        ctx = ctypes.c_void_p()
+        rc = self.lib.kzg_ctx_create(device, ctypes.byref(ctx))
+        if rc:
+            raise EngineError(f"kzg_ctx_create(device={device}) failed with {rc}: no usable HIP device "
+                              "(kzg_amd has no CPU fallback)")
+        self.ctx = ctx
+        self.device = device
+
+    def close(self):
+        if self.ctx:
+            self.lib.kzg_ctx_destroy(self.ctx)
+            self.ctx = None
+
+    def last_error(self):
+        return (self.lib.kzg_last_error(self.ctx) or b"").decode()
+
+    def set_option(self, key, value):
+        rc = self.lib.kzg_ctx_set_option(self.ctx, key.encode(), value)
+        if rc:
+            _raise(self, rc)
+
+    def sync(self):
+        rc = self.lib.kzg_sync(self.ctx)
+        if rc:
+            _raise(self, rc)
+
+    def alloc_scalars(self, n, sfmt=L.FR_CANONICAL):
+        return DeviceBuffer(self, n, sfmt)
+
+    # --- profiling ---
+    def prof_enable(self, on=True):
+        self.lib.kzg_prof_enable(self.ctx, 1 if on else 0)
+
+    def prof_reset(self):
+        self.lib.kzg_prof_reset(self.ctx)
+
+    def prof_get(self, name):
+        n, ms = ctypes.c_uint64(), ctypes.c_double()
+        self.lib.kzg_prof_get(self.ctx, name.encode(), ctypes.byref(n), ctypes.byref(ms))
+        return n.value, ms.value
+
+    def prof_all(self):
+        buf = ctypes.create_string_buffer(8192)
+        self.lib.kzg_prof_names(self.ctx, buf, 8192)
+        names = [s for s in buf.value.decode().split(",") if s]
+        return {k: self.prof_get(k) for k in names}
+
+    # --- raw operations used by the classes below and by bench.py ---
+    def _scalars_arg(self, scalars):
+        if isinstance(scalars, DeviceBuffer):
+            return scalars.ptr, scalars.n, scalars.sfmt, L.IN_DEVICE, None
+        blob = pack_scalars(scalars)
+        return blob, len(blob) // 32, L.FR_CANONICAL, 0, blob
+
+    def msm(self, srs, scalars, n=None, offset=0, ofmt=L.G1_AFFINE_MONT):
+        ptr, nn, sfmt, flags, _keep = self._scalars_arg(scalars)
+        n = nn if n is None else n
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rc = self.lib.kzg_msm_g1(self.ctx, srs.handle, offset, ptr, n, sfmt, flags, out, ofmt)
+        if rc:
+            _raise(self, rc)
+        return out.raw
+
+    def msm_batch(self, srs, scalars, n, batch, offset=0, ofmt=L.G1_AFFINE_MONT):
+        ptr, nn, sfmt, flags, _keep = self._scalars_arg(scalars)
+        assert nn >= n * batch
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt] * batch)
+        rc = self.lib.kzg_msm_g1_batch(self.ctx, srs.handle, offset, ptr, n, batch, sfmt, flags, out, ofmt)
+        if rc:
+            _raise(self, rc)
+        psz = L.POINT_BYTES[ofmt]
+        return [out.raw[i * psz:(i + 1) * psz] for i in range(batch)]
+
+    def g1_sum(self, blobs, pfmt=L.G1_AFFINE_MONT, ofmt=L.G1_AFFINE_MONT):
+        raw = b"".join(blobs)
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rc = self.lib.kzg_g1_sum(self.ctx, raw, len(blobs), pfmt, 0, out, ofmt)
+        if rc:
+            _raise(self, rc)
+        return out.raw
+
+    def ntt(self, data, log_n, inverse=False):
+        """data: DeviceBuffer (in place) or ints/blob (returns list of ints)."""
+        if isinstance(data, DeviceBuffer):
+            rc = self.lib.kzg_ntt_fr(self.ctx, data.ptr, log_n, 1 if inverse else 0, L.IN_DEVICE)
+            if rc:
+                _raise(self, rc)
+            return data
+        blob = pack_scalars(data)
+        assert len(blob) == 32 << log_n
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        rc = self.lib.kzg_ntt_fr(self.ctx, buf, log_n, 1 if inverse else 0, 0)
+        if rc:
+            _raise(self, rc)
+        return unpack_scalars(buf.raw)
+
+    def coset_ntt(self, data, log_n, inverse=False):
+        blob = pack_scalars(data)
+        buf = ctypes.create_string_buffer(blob, len(blob))
+        rc = self.lib.kzg_coset_ntt_fr(self.ctx, buf, log_n, 1 if inverse else 0, L.FR_CANONICAL, 0)
+        if rc:
+            _raise(self, rc)
+        return unpack_scalars(buf.raw)
+
+    def poly_eval(self, coeffs, x, n=None):
+        ptr, nn, sfmt, flags, _keep = self._scalars_arg(coeffs)
+        n = nn if n is None else n
+        out = ctypes.create_string_buffer(32)
+        xb = self._host_scalar(x, sfmt)
+        rc = self.lib.kzg_poly_eval(self.ctx, ptr, n, xb, sfmt, flags, out)
+        if rc:
+            _raise(self, rc)
+        return self._scalar_from(out.raw, sfmt)
+
+    def quotient_linear(self, coeffs, x, y):
+        blob = pack_scalars(coeffs)
+        n = len(blob) // 32
+        out = ctypes.create_string_buffer(max(1, n - 1) * 32)
+        rc = self.lib.kzg_quotient_linear(self.ctx, blob, n, (x % R_MODULUS).to_bytes(32, "little"),
+                                          (y % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, 0, out)
+        if rc:
+            _raise(self, rc)
+        return unpack_scalars(out.raw[: (n - 1) * 32])
+
+    def quotient_eval(self, evals, i):
+        blob = pack_scalars(evals)
+        d = len(blob) // 32
+        out = ctypes.create_string_buffer(d * 32)
+        rc = self.lib.kzg_quotient_eval(self.ctx, blob, d, i, L.FR_CANONICAL, 0, out)
+        if rc:
+            _raise(self, rc)
+        return unpack_scalars(out.raw)
+
+    _MONT_R = (1 << 256) % R_MODULUS
+
+    def _host_scalar(self, x, sfmt):
+        x %= R_MODULUS
+        if sfmt == L.FR_MONT:
+            x = x * self._MONT_R % R_MODULUS
+        return x.to_bytes(32, "little")
+
+    def _scalar_from(self, b, sfmt):
+        v = int.from_bytes(b, "little")
+        if sfmt == L.FR_MONT:
+            v = v * pow(self._MONT_R, -1, R_MODULUS) % R_MODULUS
+        return v
+
+
+def compute_omega(d):
+    """EvaluationDomain::compute_omega (src/ft.rs:55-76) -> (m, exp, omega)."""
+    lib = L.load()
+    m, exp, w = ctypes.c_size_t(), ctypes.c_uint32(), ctypes.create_string_buffer(32)
+    rc = lib.kzg_compute_omega(d, ctypes.byref(m), ctypes.byref(exp), w, L.FR_CANONICAL)
+    if rc:
+        _raise(None, rc)
+    return m.value, exp.value, int.from_bytes(w.raw, "little")
+
+
+class Srs:
+    """A resident G1 SRS (kzg_srs)."""
+
+    def __init__(self, engine, handle):
+        self.engine, self.handle = engine, handle
+
+    def __len__(self):
+        return self.engine.lib.kzg_srs_len(self.handle)
+
+    def window_info(self):
+        c, w = ctypes.c_int(), ctypes.c_int()
+        self.engine.lib.kzg_srs_window_info(self.handle, ctypes.byref(c), ctypes.byref(w))
+        return c.value, w.value
+
+    def download(self, offset=0, n=None):
+        n = len(self) - offset if n is None else n
+        out = ctypes.create_string_buffer(96 * max(n, 1))
+        rc = self.engine.lib.kzg_srs_download_g1(self.engine.ctx, self.handle, offset, n, out, L.G1_AFFINE_MONT)
+        if rc:
+            _raise(self.engine, rc)
+        return out.raw[: 96 * n]
+
+    def free(self):
+        if self.handle:
+            self.engine.lib.kzg_srs_free(self.engine.ctx, self.handle)
+            self.handle = None
+
+    @staticmethod
+    def upload(engine, blob, n, pfmt=L.G1_AFFINE_MONT):
+        h = ctypes.c_void_p()
+        assert len(blob) == n * L.POINT_BYTES[pfmt]
+        rc = engine.lib.kzg_srs_upload_g1(engine.ctx, blob, n, pfmt, ctypes.byref(h))
+        if rc:
+            _raise(engine, rc)
+        return Srs(engine, h)
+
+
+class KZGParams:
+    """src/lib.rs:14-19 (G1 half; `hs` and pairings stay on the CPU side of the reference)."""
+
+    def __init__(self, gs):
+        self.gs = gs
+
+
+def setup(engine, s, num_coeffs):
+    """setup(s, num_coeffs) (src/lib.rs:38-55): gs[i] = [s^i]G, generated on the GPU."""
+    h = ctypes.c_void_p()
+    rc = engine.lib.kzg_srs_setup_g1(engine.ctx, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, num_coeffs,
+                                     ctypes.byref(h))
+    if rc:
+        _raise(engine, rc)
+    return KZGParams(Srs(engine, h))
+
+
+def setup_lagrange(engine, s, d):
+    """lagrange_basis_g for a known secret: same elements as compute_lagrange_basis(&setup(s, d)).0."""
+    h = ctypes.c_void_p()
+    rc = engine.lib.kzg_srs_setup_lagrange_g1(engine.ctx, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, d,
+                                              ctypes.byref(h))
+    if rc:
+        _raise(engine, rc)
+    return Srs(engine, h)
+
+
+def compute_lagrange_basis(params):
+    """compute_lagrange_basis (src/eval_form.rs:254-280), G1 half, from the monomial SRS."""
+    e = params.gs.engine
+    h = ctypes.c_void_p()
+    rc = e.lib.kzg_srs_lagrange_from_monomial_g1(e.ctx, params.gs.handle, ctypes.byref(h))
+    if rc:
+        _raise(e, rc)
+    return Srs(e, h)
+
+
+class Polynomial:
+    """src/polynomial.rs:24-27: dense coefficients + explicit degree."""
+
+    def __init__(self, coeffs, degree=None):
+        self.coeffs = [int(c) % R_MODULUS for c in coeffs]
+        if degree is None:  # Polynomial::new (:83-87) via compute_degree (:94-105)
+            degree = len(self.coeffs) - 1
+            while degree > 0 and self.coeffs[degree] == 0:
+                degree -= 1
+        self.degree = degree
+
+    @staticmethod
+    def new_from_coeffs(coeffs, degree):
+        return Polynomial(coeffs, degree)
+
+    def num_coeffs(self):  # :135-137
+        return self.degree + 1
+
+    def slice_coeffs(self):  # :148-150
+        return self.coeffs[: self.num_coeffs()]
+
+    def eval(self, engine, x):  # :156-165
+        return engine.poly_eval(self.slice_coeffs(), x)
+
+    def __eq__(self, other):  # :29-40
+        return self.degree == other.degree and all(a == b for a, b in zip(self.coeffs, other.coeffs))
+
+
+class EvaluationDomain:
+    """src/ft.rs:17-25"""
+
+    def __init__(self, coeffs, d, exp, omega):
+        self.coeffs, self.d, self.exp, self.omega = [int(c) % R_MODULUS for c in coeffs], d, exp, omega
+
+    @staticmethod
+    def from_coeffs(coeffs):  # :94-109
+        m, exp, omega = compute_omega(len(coeffs))
+        coeffs = list(coeffs) + [0] * (m - len(coeffs))
+        return EvaluationDomain(coeffs, m, exp, omega)
+
+    def __len__(self):
+        return len(self.coeffs)
+
+    def fft(self, engine):  # :111-113
+        self.coeffs = engine.ntt(self.coeffs, self.exp, inverse=False)
+
+    def ifft(self, engine):  # :115-140
+        self.coeffs = engine.ntt(self.coeffs, self.exp, inverse=True)
+
+    def coset_fft(self, engine):  # :168-171
+        self.coeffs = engine.coset_ntt(self.coeffs, self.exp, inverse=False)
+
+    def icoset_fft(self, engine):  # :173-178
+        self.coeffs = engine.coset_ntt(self.coeffs, self.exp, inverse=True)
+
+
+class KZGBatchWitness:
+    """src/coeff_form.rs:12-35"""
+
+    def __init__(self, r, w):
+        self.r, self.w = r, w
+
+    def elem(self):
+        return self.w
+
+    def polynomial(self):
+        return self.r
+
+
+class KZGProver:
+    """src/coeff_form.rs:37-112"""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.engine = parameters.gs.engine
+
+    def commit(self, polynomial, ofmt=L.G1_AFFINE_MONT):  # :59-64
+        e = self.engine
+        blob = pack_scalars(polynomial.slice_coeffs())
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rc = e.lib.kzg_commit_coeff(e.ctx, self.parameters.gs.handle, blob, polynomial.num_coeffs(), L.FR_CANONICAL, 0,
+                                    out, ofmt)
+        if rc:
+            _raise(e, rc)
+        return out.raw
+
+    def create_witness(self, polynomial, point, ofmt=L.G1_AFFINE_MONT):  # :66-81
+        e = self.engine
+        x, y = point
+        blob = pack_scalars(polynomial.slice_coeffs())
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rc = e.lib.kzg_witness_coeff(e.ctx, self.parameters.gs.handle, blob, polynomial.num_coeffs(),
+                                     (x % R_MODULUS).to_bytes(32, "little"), (y % R_MODULUS).to_bytes(32, "little"),
+                                     L.FR_CANONICAL, 0, out, ofmt)
+        if rc:
+            _raise(e, rc)
+        return out.raw
+
+    def create_witness_batched(self, polynomial, xs, ys, ofmt=L.G1_AFFINE_MONT):  # :83-111
+        e = self.engine
+        assert len(xs) == len(ys)
+        k = len(xs)
+        blob = pack_scalars(polynomial.slice_coeffs())
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        r = ctypes.create_string_buffer(32 * max(k, 2))
+        rlen = ctypes.c_size_t()
+        rc = e.lib.kzg_witness_coeff_batched(e.ctx, self.parameters.gs.handle, blob, polynomial.num_coeffs(),
+                                             pack_scalars(xs), pack_scalars(ys), k, L.FR_CANONICAL, 0, out, ofmt, r,
+                                             ctypes.byref(rlen))
+        if rc:
+            _raise(e, rc)
+        coeffs = unpack_scalars(r.raw[: 32 * rlen.value])
+        return KZGBatchWitness(Polynomial.new_from_coeffs(coeffs, len(coeffs) - 1), out.raw)
+
+
+class KZGVerifier:
+    """src/coeff_form.rs:114-124 (verify_poly only; the pairing checks are outside the hot path)."""
+
+    def __init__(self, parameters):
+        self.parameters = parameters
+        self.engine = parameters.gs.engine
+
+    def verify_poly(self, commitment, polynomial, pfmt=L.G1_AFFINE_MONT):
+        e = self.engine
+        ok = ctypes.c_int()
+        rc = e.lib.kzg_verify_poly_coeff(e.ctx, self.parameters.gs.handle, commitment, pfmt,
+                                         pack_scalars(polynomial.slice_coeffs()), polynomial.num_coeffs(),
+                                         L.FR_CANONICAL, 0, ctypes.byref(ok))
+        if rc:
+            _raise(e, rc)
+        return bool(ok.value)
+
+
+class KZGProverEvalForm:
+    """src/eval_form.rs:39-147"""
+
+    def __init__(self, parameters, lagrange_basis_g):  # :88-100
+        self.parameters = parameters
+        self.lagrange_basis_g = lagrange_basis_g
+        self.engine = parameters.gs.engine
+        self.d, self.exp, self._omega = compute_omega(len(parameters.gs))
+
+    def degree(self):
+        return self.d
+
+    def omega(self):
+        return self._omega
+
+    def commit(self, evals, ofmt=L.G1_AFFINE_MONT):  # :114-122
+        e = self.engine
+        if self.d != evals.d:
+            raise ReferencePanic("assert!(self.d == evals.d) (src/eval_form.rs:115)")
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rc = e.lib.kzg_commit_eval(e.ctx, self.lagrange_basis_g.handle, pack_scalars(evals.coeffs), len(evals),
+                                   L.FR_CANONICAL, 0, out, ofmt)
+        if rc:
+            _raise(e, rc)
+        return out.raw
+
+    def create_witness(self, evals, i, ofmt=L.G1_AFFINE_MONT):  # :124-140
+        e = self.engine
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rc = e.lib.kzg_witness_eval(e.ctx, self.lagrange_basis_g.handle, pack_scalars(evals.coeffs), len(evals), i,
+                                    L.FR_CANONICAL, 0, out, ofmt)
+        if rc:
+            _raise(e, rc)
+        return out.raw
+
+    def create_witness_all(self):  # :142-146: identity
+        return bytes(96)
+
+
+class KZGVerifierEvalForm:
+    """src/eval_form.rs:149-171 (verify_poly only)."""
+
+    def __init__(self, parameters, lagrange_basis_g):
+        self.parameters = parameters
+        self.lagrange_basis_g = lagrange_basis_g
+        self.engine = parameters.gs.engine
+
+    def verify_poly(self, commitment, evals, pfmt=L.G1_AFFINE_MONT):
+        e = self.engine
+        ok = ctypes.c_int()
+        rc = e.lib.kzg_verify_poly_eval(e.ctx, self.parameters.gs.handle, commitment, pfmt, pack_scalars(evals.coeffs),
+                                        len(evals), L.FR_CANONICAL, 0, ctypes.byref(ok))
+        if rc:
+            _raise(e, rc)
+        return bool(ok.value)

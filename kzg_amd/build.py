@@ -1,0 +1,54 @@
+"""Builds libkzg_mi355x.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch involved."""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libkzg_mi355x.so")
+SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip"]
+HEADERS = ["field.h", "curve.h", "common.h"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "kzg_mi355x.h")]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _stale(obj, [src] + hdrs):
+            jobs.append([hipcc] + FLAGS + ["-c", src, "-o", obj])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed: " + " ".join(cmd))
+        if verbose and r.stderr.strip():
+            sys.stderr.write(r.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(run, jobs))
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
+    if force or jobs or _stale(OUT, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

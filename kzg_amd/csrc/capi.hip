@@ -1,0 +1,716 @@
+// capi.hip -- the extern "C" boundary declared in include/kzg_mi355x.h: context / lanes / profiling
+// and the entry points that mirror KZGProver / KZGProverEvalForm / EvaluationDomain method by method.
+#include <algorithm>
+
+#include "common.h"
+
+namespace kzg {
+
+// ---------------------------------------------------------------------------------------------
+// lanes
+// ---------------------------------------------------------------------------------------------
+int lane_reserve(kzg_ctx *ctx, int lane, size_t bytes) {
+    Lane &l = ctx->lanes[lane];
+    bytes = align_up(bytes + 4096, 1 << 20);
+    if (l.arena_bytes < bytes) {
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+        if (l.arena) KZG_HIP_CHECK(ctx, hipFree(l.arena));
+        l.arena = nullptr;
+        l.arena_bytes = 0;
+        hipError_t e = hipMalloc((void **)&l.arena, bytes);
+        if (e != hipSuccess) return fail(ctx, KZG_ERR_ALLOC, std::string("hipMalloc(workspace): ") + hipGetErrorString(e));
+        l.arena_bytes = bytes;
+    }
+    l.arena_used = 0;
+    return KZG_OK;
+}
+
+void *lane_alloc(kzg_ctx *ctx, int lane, size_t bytes) {
+    Lane &l = ctx->lanes[lane];
+    size_t off = align_up(l.arena_used, 256);
+    if (off + bytes > l.arena_bytes) return nullptr;
+    l.arena_used = off + bytes;
+    return l.arena + off;
+}
+
+int lane_pinned(kzg_ctx *ctx, int lane, size_t bytes) {
+    Lane &l = ctx->lanes[lane];
+    if (l.pinned_bytes >= bytes) return KZG_OK;
+    if (l.pinned) hipHostFree(l.pinned);
+    l.pinned = nullptr;
+    l.pinned_bytes = 0;
+    bytes = align_up(bytes, 4096);
+    KZG_HIP_CHECK(ctx, hipHostMalloc((void **)&l.pinned, bytes, hipHostMallocDefault));
+    l.pinned_bytes = bytes;
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// profiling: HIP events recorded on the stream each kernel is launched on
+// ---------------------------------------------------------------------------------------------
+static hipEvent_t get_event(kzg_ctx *ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+ProfScope::ProfScope(kzg_ctx *c, hipStream_t s, const char *n) : ctx(c), stream(s), name(n) {
+    if (!ctx->prof) return;
+    start = get_event(ctx);
+    stop = get_event(ctx);
+    hipEventRecord(start, stream);
+}
+
+ProfScope::~ProfScope() {
+    if (!start) return;
+    hipEventRecord(stop, stream);
+    ctx->prof_pending.push_back(PendingEvent{name, start, stop});
+}
+
+void prof_collect(kzg_ctx *ctx) {
+    for (auto &p : ctx->prof_pending) {
+        float ms = 0.f;
+        hipEventSynchronize(p.stop);
+        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
+            ProfEntry &e = ctx->prof_map[p.name];
+            e.launches++;
+            e.total_ms += ms;
+        }
+        ctx->event_pool.push_back(p.start);
+        ctx->event_pool.push_back(p.stop);
+    }
+    ctx->prof_pending.clear();
+}
+
+// ---------------------------------------------------------------------------------------------
+// helpers shared by the entry points
+// ---------------------------------------------------------------------------------------------
+struct Guard {
+    std::lock_guard<std::mutex> lk;
+    explicit Guard(kzg_ctx *c) : lk(c->mu) {}
+};
+
+static int host_scalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
+    Fr v;
+    memcpy(v.v, s, 32);
+    if (sfmt == KZG_FR_CANONICAL_LE_32) {
+        if (!is_canonical(v)) return fail(ctx, KZG_ERR_SHAPE, "scalar not canonical (>= r)");
+        v = to_mont(v);
+    } else if (sfmt != KZG_FR_MONT_LE_32) {
+        return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    }
+    *mont = v;
+    return KZG_OK;
+}
+
+static void scalar_out(const Fr &mont, int sfmt, void *dst) {
+    Fr v = sfmt == KZG_FR_CANONICAL_LE_32 ? from_mont(mont) : mont;
+    memcpy(dst, v.v, 32);
+}
+
+// bring `bytes` of input to the device (no-op for device-resident input)
+static int stage_in(kzg_ctx *ctx, int lane, const void *src, size_t bytes, int flags, const void **dptr) {
+    if (flags & KZG_IN_DEVICE) {
+        *dptr = src;
+        return KZG_OK;
+    }
+    void *d = lane_alloc(ctx, lane, bytes ? bytes : 16);
+    if (!d) return fail(ctx, KZG_ERR_ALLOC, "input staging not reserved");
+    if (bytes) KZG_HIP_CHECK(ctx, hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->lanes[lane].stream));
+    *dptr = d;
+    return KZG_OK;
+}
+
+static size_t stage_bytes(size_t bytes, int flags) { return (flags & KZG_IN_DEVICE) ? 0 : align_up(bytes + 256, 256); }
+
+// result point: XYZZ on device -> ofmt at `out` (host or device)
+static int finish_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_pt, void *out, int ofmt, int flags) {
+    size_t psz = point_format_bytes(ofmt);
+    if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    hipStream_t st = ctx->lanes[lane].stream;
+    if (flags & KZG_OUT_DEVICE) {
+        KZG_TRY(emit_point(ctx, lane, d_pt, out, ofmt));
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    } else {
+        void *d = lane_alloc(ctx, lane, 256);
+        if (!d) return fail(ctx, KZG_ERR_ALLOC, "output staging not reserved");
+        KZG_TRY(emit_point(ctx, lane, d_pt, d, ofmt));
+        KZG_TRY(lane_pinned(ctx, lane, 4096));
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned, d, psz, hipMemcpyDeviceToHost, st));
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        memcpy(out, ctx->lanes[lane].pinned, psz);
+    }
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
+static int check_sfmt(kzg_ctx *ctx, int sfmt) {
+    if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    return KZG_OK;
+}
+
+static bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+
+// ---------------------------------------------------------------------------------------------
+// device unit-test kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_test_fr_mul(const Fr *a, const Fr *b, size_t n, Fr *o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = mul(a[i], b[i]);
+}
+__global__ __launch_bounds__(256) void k_test_fq_mul(const Fq *a, const Fq *b, size_t n, Fq *o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = mul(a[i], b[i]);
+}
+__global__ __launch_bounds__(256) void k_test_fr_inv(const Fr *a, size_t n, Fr *o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = a[i].is_zero() ? Fr::zero() : inv(a[i]);
+}
+__global__ __launch_bounds__(256) void k_test_g1_add(const G1Affine *a, const G1Affine *b, size_t n, G1Affine *o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    // exercise both the mixed and the general addition on de-normalised operands
+    G1Xyzz p = g1_madd(G1Xyzz::from_affine(a[i]), b[i]);
+    G1Xyzz pa = g1_madd(g1_dbl(G1Xyzz::from_affine(a[i])), g1_neg(a[i]));
+    G1Xyzz pb = g1_madd(g1_dbl(G1Xyzz::from_affine(b[i])), g1_neg(b[i]));
+    G1Xyzz q = g1_add(pa, pb);
+    G1Affine r1 = g1_to_affine(p), r2 = g1_to_affine(q);
+    bool same = (r1.x == r2.x) && (r1.y == r2.y);
+    o[i] = same ? r1 : G1Affine{Fq::one(), Fq::one()};  // (1,1) is not on the curve: flags a mismatch
+}
+__global__ __launch_bounds__(256) void k_test_g1_mul(const G1Affine *p, const Fr *k, size_t n, G1Affine *o) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr kk = k[i];
+    o[i] = g1_to_affine(g1_scalar_mul(p[i], kk.v));
+}
+
+}  // namespace kzg
+
+using namespace kzg;
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" const char *kzg_version(void) { return "kzg-mi355x 0.1.0 (gfx950)"; }
+
+extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
+    if (!out) return KZG_ERR_SHAPE;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return KZG_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return KZG_ERR_NO_DEVICE;
+    kzg_ctx *ctx = new kzg_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    ctx->lanes.resize(1);
+    if (hipStreamCreateWithFlags(&ctx->lanes[0].stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return KZG_ERR_HIP;
+    }
+    *out = ctx;
+    return KZG_OK;
+}
+
+static int ensure_lanes(kzg_ctx *ctx, int want) {
+    while ((int)ctx->lanes.size() < want) {
+        Lane l;
+        KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        ctx->lanes.push_back(l);
+    }
+    return KZG_OK;
+}
+
+extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    for (auto &l : ctx->lanes) {
+        if (l.stream) hipStreamSynchronize(l.stream);
+        if (l.arena) hipFree(l.arena);
+        if (l.pinned) hipHostFree(l.pinned);
+        if (l.stream) hipStreamDestroy(l.stream);
+    }
+    for (auto e : ctx->event_pool) hipEventDestroy(e);
+    // cached tables (NTT plans, eval-domain tables, fixed-base table) are released with the process
+    delete ctx;
+}
+
+extern "C" const char *kzg_last_error(kzg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+extern "C" int kzg_sync(kzg_ctx *ctx) {
+    if (!ctx) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (auto &l : ctx->lanes) KZG_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+    return KZG_OK;
+}
+
+extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    std::string k(key);
+    if (k == "window_bits") {
+        if (value != 0 && (value < 4 || value > 16)) return fail(ctx, KZG_ERR_SHAPE, "window_bits must be 0 or 4..16");
+        ctx->opt_window_bits = (int)value;
+    } else if (k == "streams") {
+        if (value < 1 || value > 16) return fail(ctx, KZG_ERR_SHAPE, "streams must be 1..16");
+        ctx->opt_streams = (int)value;
+    } else {
+        return fail(ctx, KZG_ERR_SHAPE, "unknown option " + k);
+    }
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device memory + profiling
+// ---------------------------------------------------------------------------------------------
+extern "C" int kzg_dev_alloc(kzg_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(ctx, KZG_ERR_ALLOC, hipGetErrorString(e));
+    return KZG_OK;
+}
+extern "C" int kzg_dev_free(kzg_ctx *ctx, void *p) {
+    if (!ctx) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
+    if (p) KZG_HIP_CHECK(ctx, hipFree(p));
+    return KZG_OK;
+}
+extern "C" int kzg_dev_upload(kzg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
+    if (!ctx) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (bytes) KZG_HIP_CHECK(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
+    return KZG_OK;
+}
+extern "C" int kzg_dev_download(kzg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
+    if (!ctx) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
+    if (bytes) KZG_HIP_CHECK(ctx, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return KZG_OK;
+}
+
+extern "C" int kzg_prof_enable(kzg_ctx *ctx, int on) {
+    if (!ctx) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    ctx->prof = on != 0;
+    return KZG_OK;
+}
+extern "C" int kzg_prof_reset(kzg_ctx *ctx) {
+    if (!ctx) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    prof_collect(ctx);
+    ctx->prof_map.clear();
+    return KZG_OK;
+}
+extern "C" int kzg_prof_get(kzg_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms) {
+    if (!ctx || !kernel) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    prof_collect(ctx);
+    auto it = ctx->prof_map.find(kernel);
+    if (launches) *launches = it == ctx->prof_map.end() ? 0 : it->second.launches;
+    if (total_ms) *total_ms = it == ctx->prof_map.end() ? 0.0 : it->second.total_ms;
+    return KZG_OK;
+}
+extern "C" int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen) {
+    if (!ctx || !buf || !buflen) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    prof_collect(ctx);
+    std::string s;
+    for (auto &kv : ctx->prof_map) {
+        if (!s.empty()) s += ",";
+        s += kv.first;
+    }
+    snprintf(buf, buflen, "%s", s.c_str());
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// MSM
+// ---------------------------------------------------------------------------------------------
+static int msm_locked(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, int sfmt, int flags,
+                      void *out, int ofmt) {
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
+    const void *d_sc = nullptr;
+    KZG_TRY(stage_in(ctx, 0, scalars, n * 32, flags, &d_sc));
+    G1Xyzz *res = nullptr;
+    KZG_TRY(msm_run(ctx, 0, srs, offset, d_sc, n, sfmt, &res));
+    return finish_point(ctx, 0, res, out, ofmt, flags);
+}
+
+extern "C" int kzg_msm_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, int sfmt,
+                          int flags, void *out, int ofmt) {
+    if (!ctx || !srs || !out || (!scalars && n)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    return msm_locked(ctx, srs, offset, scalars, n, sfmt, flags, out, ofmt);
+}
+
+extern "C" int kzg_commit_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, int sfmt, int flags,
+                                void *out, int ofmt) {
+    return kzg_msm_g1(ctx, srs, 0, coeffs, n, sfmt, flags, out, ofmt);
+}
+
+extern "C" int kzg_commit_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, int sfmt, int flags,
+                               void *out, int ofmt) {
+    if (!ctx || !lagrange) return KZG_ERR_SHAPE;
+    if (d != lagrange->n) {
+        Guard g(ctx);
+        return fail(ctx, KZG_ERR_SHAPE, "assert!(self.d == evals.d) (src/eval_form.rs:115)");
+    }
+    return kzg_msm_g1(ctx, lagrange, 0, evals, d, sfmt, flags, out, ofmt);
+}
+
+extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n,
+                                size_t batch, int sfmt, int flags, void *out, int ofmt) {
+    if (!ctx || !srs || !out || (!scalars && n && batch)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    size_t psz = point_format_bytes(ofmt);
+    if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
+    if (batch == 0) return KZG_OK;
+    int nl = (int)std::min<size_t>(batch, (size_t)ctx->opt_streams);
+    KZG_TRY(ensure_lanes(ctx, nl));
+    size_t per = msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192;
+    for (int l = 0; l < nl; l++) KZG_TRY(lane_reserve(ctx, l, per));
+    uint8_t *d_out = nullptr;
+    bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
+    if (out_dev) d_out = (uint8_t *)out;
+    else KZG_HIP_CHECK(ctx, hipMalloc((void **)&d_out, batch * psz + 256));
+    int rc = KZG_OK;
+    for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
+        int l = (int)(b % nl);
+        ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
+        const void *d_sc = nullptr;
+        rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
+        G1Xyzz *res = nullptr;
+        if (rc == KZG_OK) rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res);
+        if (rc == KZG_OK) rc = emit_point(ctx, l, res, d_out + b * psz, ofmt);
+    }
+    for (int l = 0; l < nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
+    if (rc == KZG_OK && !out_dev) {
+        hipError_t e = hipMemcpy(out, d_out, batch * psz, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
+    }
+    if (!out_dev) hipFree(d_out);
+    if (ctx->prof) prof_collect(ctx);
+    return rc;
+}
+
+extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pfmt, int flags, void *out, int ofmt) {
+    if (!ctx || !out || (!points && count)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t psz = point_format_bytes(pfmt);
+    if (!psz || !point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
+    size_t cnt = count ? count : 1;
+    size_t need = stage_bytes(cnt * psz, flags) + (cnt + 2 * sum_points_scratch_count(cnt) + 4) * sizeof(G1Xyzz) + 8192;
+    KZG_TRY(lane_reserve(ctx, 0, need));
+    hipStream_t st = ctx->lanes[0].stream;
+    G1Xyzz *pts = (G1Xyzz *)lane_alloc(ctx, 0, cnt * sizeof(G1Xyzz));
+    G1Xyzz *scratch = (G1Xyzz *)lane_alloc(ctx, 0, 2 * sum_points_scratch_count(cnt) * sizeof(G1Xyzz));
+    int *bad = (int *)lane_alloc(ctx, 0, 256);
+    if (!pts || !scratch || !bad) return fail(ctx, KZG_ERR_ALLOC, "sum workspace not reserved");
+    KZG_HIP_CHECK(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
+    G1Xyzz *res = pts;
+    if (count == 0) {
+        KZG_HIP_CHECK(ctx, hipMemsetAsync(pts, 0, sizeof(G1Xyzz), st));
+    } else {
+        const void *d_raw = nullptr;
+        KZG_TRY(stage_in(ctx, 0, points, count * psz, flags, &d_raw));
+        KZG_TRY(decode_points(ctx, st, d_raw, count, pfmt, pts, bad));
+        KZG_TRY(sum_points_run(ctx, 0, pts, count, scratch, &res));
+    }
+    int hbad = 0;
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    KZG_TRY(finish_point(ctx, 0, res, out, ofmt, flags));
+    if (hbad) return fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode or is not on the curve");
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NTT
+// ---------------------------------------------------------------------------------------------
+extern "C" int kzg_compute_omega(size_t d, size_t *m_out, uint32_t *exp_out, void *omega, int sfmt) {
+    // EvaluationDomain::compute_omega (src/ft.rs:55-76)
+    size_t m = 1;
+    uint32_t exp = 0;
+    while (m < d) {
+        m *= 2;
+        exp += 1;
+        if (exp >= FR_TWO_ADICITY) return KZG_ERR_DEGREE_TOO_LARGE;
+    }
+    if (m_out) *m_out = m;
+    if (exp_out) *exp_out = exp;
+    if (omega) scalar_out(host_omega(exp), sfmt, omega);
+    return KZG_OK;
+}
+
+extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int flags) {
+    if (!ctx || !data) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    size_t n = (size_t)1 << log_n;
+    KZG_TRY(lane_reserve(ctx, 0, n * 32 + stage_bytes(n * 32, flags) + 8192));
+    hipStream_t st = ctx->lanes[0].stream;
+    const void *d = nullptr;
+    KZG_TRY(stage_in(ctx, 0, data, n * 32, flags, &d));
+    KZG_TRY(ntt_run(ctx, 0, (Fr *)d, log_n, inverse));
+    if (!(flags & KZG_IN_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fr polynomial helpers
+// ---------------------------------------------------------------------------------------------
+extern "C" int kzg_poly_eval(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, int sfmt, int flags, void *y_out) {
+    if (!ctx || !coeffs || !x || !y_out || n == 0) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    Fr xm;
+    KZG_TRY(host_scalar(ctx, x, sfmt, &xm));
+    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(n * 32, flags) + (n / 2048 + 4) * 64 + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    const void *d = nullptr;
+    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
+    Fr *dy = (Fr *)lane_alloc(ctx, 0, 256);
+    if (!dy) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_TRY(poly_eval_run(ctx, 0, (const Fr *)d, n, xm, dy));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(y_out, dy, 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
+extern "C" int kzg_quotient_linear(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, const void *y, int sfmt,
+                                   int flags, void *q_out) {
+    if (!ctx || !coeffs || !x || !y || n == 0 || (!q_out && n > 1)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    Fr xm;
+    KZG_TRY(host_scalar(ctx, x, sfmt, &xm));
+    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(n * 32, flags) * 2 + (n / 2048 + 4) * 64 + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    const void *d = nullptr;
+    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
+    bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
+    Fr *dq = out_dev ? (Fr *)q_out : (Fr *)lane_alloc(ctx, 0, n * 32);
+    Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
+    if (!dq || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_TRY(quotient_linear_run(ctx, 0, (const Fr *)d, n, xm, dq, dpx));
+    Fr px;
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
+    if (!out_dev && n > 1) KZG_HIP_CHECK(ctx, hipMemcpyAsync(q_out, dq, (n - 1) * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    if (memcmp(px.v, y, 32) != 0) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
+    return KZG_OK;
+}
+
+extern "C" int kzg_quotient_eval(kzg_ctx *ctx, const void *evals, size_t d, size_t i, int sfmt, int flags, void *q_out) {
+    if (!ctx || !evals || !q_out) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
+    if (i >= d) return fail(ctx, KZG_ERR_SHAPE, "evaluation index out of range (reference: index panic)");
+    uint32_t log_d = (uint32_t)ilog2_ceil(d);
+    if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
+    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(d * 32, flags) * 2 + (d / 256 + 4) * 32 + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    const void *de = nullptr;
+    KZG_TRY(stage_in(ctx, 0, evals, d * 32, flags, &de));
+    bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
+    Fr *dq = out_dev ? (Fr *)q_out : (Fr *)lane_alloc(ctx, 0, d * 32);
+    if (!dq) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_TRY(quotient_eval_run(ctx, 0, (const Fr *)de, log_d, i, sfmt, dq));
+    if (!out_dev) KZG_HIP_CHECK(ctx, hipMemcpyAsync(q_out, dq, d * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// witnesses
+// ---------------------------------------------------------------------------------------------
+extern "C" int kzg_witness_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *x,
+                                 const void *y, int sfmt, int flags, void *out, int ofmt) {
+    // KZGProver::create_witness (src/coeff_form.rs:66-81)
+    if (!ctx || !srs || !coeffs || !x || !y || !out || n == 0) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (n - 1 > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
+    Fr xm;
+    KZG_TRY(host_scalar(ctx, x, sfmt, &xm));
+    size_t need = msm_workspace_bytes(srs, n - 1) + stage_bytes(n * 32, flags) + n * 32 + (n / 2048 + 4) * 64 + 65536;
+    KZG_TRY(lane_reserve(ctx, 0, need));
+    hipStream_t st = ctx->lanes[0].stream;
+    const void *d = nullptr;
+    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
+    Fr *dq = (Fr *)lane_alloc(ctx, 0, n * 32);
+    Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
+    if (!dq || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_TRY(quotient_linear_run(ctx, 0, (const Fr *)d, n, xm, dq, dpx));
+    Fr px;
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
+    G1Xyzz *res = nullptr;
+    KZG_TRY(msm_run(ctx, 0, srs, 0, dq, n - 1, sfmt, &res));
+    KZG_TRY(finish_point(ctx, 0, res, out, ofmt, flags));  // synchronises the stream
+    // remainder of (p - y)/(X - x) is p(x) - y: Some(_) => Err(PointNotOnPolynomial)
+    if (memcmp(px.v, y, 32) != 0) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
+    return KZG_OK;
+}
+
+extern "C" int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, size_t i, int sfmt,
+                                int flags, void *out, int ofmt) {
+    // KZGProverEvalForm::create_witness (src/eval_form.rs:124-140)
+    if (!ctx || !lagrange || !evals || !out) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
+    if (i >= d) return fail(ctx, KZG_ERR_SHAPE, "evaluation index out of range (reference: index panic)");
+    if (d > lagrange->n) return fail(ctx, KZG_ERR_SHAPE, "evaluations longer than the Lagrange SRS (reference: slice panic)");
+    uint32_t log_d = (uint32_t)ilog2_ceil(d);
+    if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
+    size_t need = msm_workspace_bytes(lagrange, d) + stage_bytes(d * 32, flags) + d * 32 + (d / 256 + 4) * 32 + 65536;
+    KZG_TRY(lane_reserve(ctx, 0, need));
+    const void *de = nullptr;
+    KZG_TRY(stage_in(ctx, 0, evals, d * 32, flags, &de));
+    Fr *dq = (Fr *)lane_alloc(ctx, 0, d * 32);
+    if (!dq) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_TRY(quotient_eval_run(ctx, 0, (const Fr *)de, log_d, i, sfmt, dq));
+    G1Xyzz *res = nullptr;
+    KZG_TRY(msm_run(ctx, 0, lagrange, 0, dq, d, sfmt, &res));
+    return finish_point(ctx, 0, res, out, ofmt, flags);
+}
+
+static int verify_against(kzg_ctx *ctx, const G1Xyzz *res, const void *commitment, int pfmt, int *ok) {
+    size_t psz = point_format_bytes(pfmt);
+    if (!psz || pfmt == KZG_G1_JACOBIAN_MONT_144)
+        return fail(ctx, KZG_ERR_SHAPE, "verify_poly takes the commitment in an affine format (KZGCommitment = G1Affine)");
+    uint8_t mine[96];
+    KZG_TRY(finish_point(ctx, 0, res, mine, pfmt, 0));
+    *ok = memcmp(mine, commitment, psz) == 0;
+    return KZG_OK;
+}
+
+extern "C" int kzg_verify_poly_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *commitment, int pfmt,
+                                     const void *coeffs, size_t n, int sfmt, int flags, int *ok) {
+    // KZGVerifier::verify_poly (src/coeff_form.rs:119-124)
+    if (!ctx || !srs || !commitment || !ok || (!coeffs && n)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "polynomial longer than the SRS (reference: slice index panic)");
+    KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
+    const void *d = nullptr;
+    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
+    G1Xyzz *res = nullptr;
+    KZG_TRY(msm_run(ctx, 0, srs, 0, d, n, sfmt, &res));
+    return verify_against(ctx, res, commitment, pfmt, ok);
+}
+
+extern "C" int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const void *commitment, int pfmt,
+                                    const void *evals, size_t d, int sfmt, int flags, int *ok) {
+    // KZGVerifierEvalForm::verify_poly (src/eval_form.rs:162-171): ifft, then the monomial-basis MSM
+    if (!ctx || !monomial || !commitment || !ok || !evals) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
+    if (d > monomial->n) return fail(ctx, KZG_ERR_SHAPE, "polynomial longer than the SRS (reference: slice index panic)");
+    uint32_t log_d = (uint32_t)ilog2_ceil(d);
+    if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
+    KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(monomial, d) + 3 * d * 32 + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    Fr *work = (Fr *)lane_alloc(ctx, 0, d * 32);
+    if (!work) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(work, evals, d * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    KZG_TRY(ntt_run(ctx, 0, work, log_d, 1));
+    G1Xyzz *res = nullptr;
+    KZG_TRY(msm_run(ctx, 0, monomial, 0, work, d, sfmt, &res));
+    return verify_against(ctx, res, commitment, pfmt, ok);
+}
+
+// ---------------------------------------------------------------------------------------------
+// test hooks
+// ---------------------------------------------------------------------------------------------
+template <class K, class... Args>
+static int run_test_kernel(kzg_ctx *ctx, const char *name, K kern, size_t n, size_t in_elem, int n_in, const void *a,
+                           const void *b, size_t in_elem_b, void *out, size_t out_elem) {
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(lane_reserve(ctx, 0, n * (in_elem + in_elem_b + out_elem) + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    void *da = lane_alloc(ctx, 0, n * in_elem + 16), *db = lane_alloc(ctx, 0, n * in_elem_b + 16),
+         *dout = lane_alloc(ctx, 0, n * out_elem + 16);
+    if (!da || !db || !dout) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(da, a, n * in_elem, hipMemcpyHostToDevice, st));
+    if (n_in > 1) KZG_HIP_CHECK(ctx, hipMemcpyAsync(db, b, n * in_elem_b, hipMemcpyHostToDevice, st));
+    kern(st, da, db, dout);
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, dout, n * out_elem, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    KZG_HIP_CHECK(ctx, hipGetLastError());
+    return KZG_OK;
+}
+
+extern "C" int kzg_test_fr_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out) {
+    if (!ctx || !n) return KZG_ERR_SHAPE;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    return run_test_kernel(ctx, "k_test_fr_mul", [&](hipStream_t st, void *da, void *db, void *dout) {
+        hipLaunchKernelGGL(k_test_fr_mul, dim3(grid), dim3(256), 0, st, (const Fr *)da, (const Fr *)db, n, (Fr *)dout);
+    }, n, 32, 2, a, b, 32, out, 32);
+}
+extern "C" int kzg_test_fq_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out) {
+    if (!ctx || !n) return KZG_ERR_SHAPE;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    return run_test_kernel(ctx, "k_test_fq_mul", [&](hipStream_t st, void *da, void *db, void *dout) {
+        hipLaunchKernelGGL(k_test_fq_mul, dim3(grid), dim3(256), 0, st, (const Fq *)da, (const Fq *)db, n, (Fq *)dout);
+    }, n, 48, 2, a, b, 48, out, 48);
+}
+extern "C" int kzg_test_fr_inv(kzg_ctx *ctx, const void *a, size_t n, void *out) {
+    if (!ctx || !n) return KZG_ERR_SHAPE;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    return run_test_kernel(ctx, "k_test_fr_inv", [&](hipStream_t st, void *da, void *, void *dout) {
+        hipLaunchKernelGGL(k_test_fr_inv, dim3(grid), dim3(256), 0, st, (const Fr *)da, n, (Fr *)dout);
+    }, n, 32, 1, a, nullptr, 0, out, 32);
+}
+extern "C" int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out) {
+    if (!ctx || !n) return KZG_ERR_SHAPE;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    return run_test_kernel(ctx, "k_test_g1_add", [&](hipStream_t st, void *da, void *db, void *dout) {
+        hipLaunchKernelGGL(k_test_g1_add, dim3(grid), dim3(256), 0, st, (const G1Affine *)da, (const G1Affine *)db, n,
+                           (G1Affine *)dout);
+    }, n, 96, 2, a, b, 96, out, 96);
+}
+extern "C" int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k, size_t n, void *out) {
+    if (!ctx || !n) return KZG_ERR_SHAPE;
+    unsigned grid = (unsigned)((n + 255) / 256);
+    return run_test_kernel(ctx, "k_test_g1_mul", [&](hipStream_t st, void *da, void *db, void *dout) {
+        hipLaunchKernelGGL(k_test_g1_mul, dim3(grid), dim3(256), 0, st, (const G1Affine *)da, (const Fr *)db, n,
+                           (G1Affine *)dout);
+    }, n, 96, 2, p, k, 32, out, 96);
+}

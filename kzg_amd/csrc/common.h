@@ -1,0 +1,161 @@
+// common.h -- context, workspace arena, error handling and profiled kernel launches shared by the
+// translation units of libkzg_mi355x.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/kzg_mi355x.h"
+#include "curve.h"
+
+namespace kzg {
+
+struct ProfEntry {
+    uint64_t launches = 0;
+    double total_ms = 0.0;
+};
+
+struct PendingEvent {
+    std::string name;
+    hipEvent_t start, stop;
+};
+
+// One independent execution lane: a HIP stream plus a bump-allocated scratch arena in HBM.
+// Single calls use lane 0; kzg_msm_g1_batch pipelines independent MSMs over several lanes.
+struct Lane {
+    hipStream_t stream = nullptr;
+    char *arena = nullptr;
+    size_t arena_bytes = 0;
+    size_t arena_used = 0;
+    char *pinned = nullptr;  // small pinned host staging buffer for results
+    size_t pinned_bytes = 0;
+};
+
+struct NttPlan;
+struct FixedBaseTable;
+struct EvalDomainTables;
+
+}  // namespace kzg
+
+struct kzg_ctx {
+    int device = 0;
+    std::mutex mu;
+    std::string err;
+    std::vector<kzg::Lane> lanes;
+    int opt_window_bits = 0;  // 0 = auto
+    int opt_streams = 4;
+    int num_cus = 256;
+    // profiling
+    bool prof = false;
+    std::map<std::string, kzg::ProfEntry> prof_map;
+    std::vector<kzg::PendingEvent> prof_pending;
+    std::vector<hipEvent_t> event_pool;
+    // caches
+    std::map<uint32_t, kzg::NttPlan *> ntt_plans;          // key = log_n * 2 + inverse
+    std::map<uint32_t, kzg::EvalDomainTables *> eval_tabs;  // key = log_d
+    kzg::FixedBaseTable *fixed_base = nullptr;
+};
+
+struct kzg_srs {
+    size_t n = 0;        // points
+    size_t npad = 0;     // row stride (points)
+    int c = 0;           // window bits (signed digits, 2^(c-1) buckets)
+    int W = 0;           // windows = ceil(256 / c); table row w holds 2^(c*w) * P_i
+    kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
+    int device = 0;
+};
+
+namespace kzg {
+
+#define KZG_HIP_CHECK(ctx, expr)                                                                   \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess) {                                                                    \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
+            return KZG_ERR_HIP;                                                                    \
+        }                                                                                          \
+    } while (0)
+
+#define KZG_TRY(expr)                                                                              \
+    do {                                                                                           \
+        int _s = (expr);                                                                           \
+        if (_s != KZG_OK) return _s;                                                               \
+    } while (0)
+
+inline int fail(kzg_ctx *ctx, int code, const std::string &msg) {
+    ctx->err = msg;
+    return code;
+}
+
+// ---- arena ---------------------------------------------------------------------------------
+int lane_reserve(kzg_ctx *ctx, int lane, size_t bytes);  // ensure arena >= bytes and reset it
+void *lane_alloc(kzg_ctx *ctx, int lane, size_t bytes);  // 256-B aligned bump allocation (nullptr if exhausted)
+int lane_pinned(kzg_ctx *ctx, int lane, size_t bytes);   // ensure pinned staging >= bytes
+
+// ---- profiling -----------------------------------------------------------------------------
+struct ProfScope {
+    kzg_ctx *ctx;
+    hipStream_t stream;
+    hipEvent_t start = nullptr, stop = nullptr;
+    const char *name;
+    ProfScope(kzg_ctx *c, hipStream_t s, const char *n);
+    ~ProfScope();
+};
+void prof_collect(kzg_ctx *ctx);
+
+#define KZG_LAUNCH(ctx, stream, name, kern, grid, block, shmem, ...)                               \
+    do {                                                                                           \
+        kzg::ProfScope _ps((ctx), (stream), (name));                                               \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__);         \
+    } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+inline int ilog2_ceil(size_t x) {
+    int l = 0;
+    while (((size_t)1 << l) < x) l++;
+    return l;
+}
+
+// ---- cross-TU entry points -------------------------------------------------------------------
+// msm.hip
+size_t msm_workspace_bytes(const kzg_srs *srs, size_t n);
+// d_scalars: device pointer to n scalars (sfmt); result: device XYZZ point (192 B) in the lane arena
+int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
+            G1Xyzz **d_result);
+// d_points: count XYZZ points -> one XYZZ point (plain sum)
+int sum_points_run(kzg_ctx *ctx, int lane, G1Xyzz *d_points, size_t count, G1Xyzz *d_scratch, G1Xyzz **d_result);
+size_t sum_points_scratch_count(size_t count);
+// writes one point in `ofmt` (from XYZZ) to d_out (device); single thread incl. the Fq inversion
+int emit_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_point, void *d_out, int ofmt);
+size_t point_format_bytes(int fmt);
+
+// srs.hip
+int srs_choose_window(kzg_ctx *ctx, size_t n);
+int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out);
+int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz);  // batch-affine row 0 then precompute rows
+int srs_precompute(kzg_ctx *ctx, kzg_srs *srs);                              // rows 1..W-1 from row 0
+int batch_to_affine(kzg_ctx *ctx, hipStream_t stream, const G1Xyzz *d_in, G1Affine *d_out, size_t n);
+int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad);
+int fixed_base_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_scalars_mont, size_t n, G1Xyzz *d_out);
+
+// ntt.hip
+int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse);
+int pow_table(kzg_ctx *ctx, hipStream_t stream, const Fr &base_mont, const Fr &scale_mont, size_t count, Fr *d_out);
+Fr host_omega(uint32_t exp);  // Montgomery-form 2^exp-th root of unity per compute_omega (src/ft.rs:73)
+
+// poly.hip
+int fr_convert(kzg_ctx *ctx, hipStream_t stream, Fr *d_data, size_t n, int to_mont);  // in place
+int batch_inverse(kzg_ctx *ctx, hipStream_t stream, const Fr *d_in, Fr *d_out, size_t n);
+// Horner machinery: eval and linear quotient. d_coeffs in Montgomery or canonical form (linear ops:
+// the result is in the same form provided x_mont is Montgomery).
+int poly_eval_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_y_out);
+int quotient_linear_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_q_out,
+                        Fr *d_px_out);
+int quotient_eval_run(kzg_ctx *ctx, int lane, const Fr *d_evals, uint32_t log_d, size_t m, int sfmt, Fr *d_q_out);
+
+}  // namespace kzg

@@ -1,0 +1,530 @@
+// msm.hip -- Pippenger multi-scalar multiplication over BLS12-381 G1 for gfx950.
+//
+// Replaces G1Projective::multi_exp at the reference's call sites (src/coeff_form.rs:61,78,102;
+// src/eval_form.rs:118,136).  The result is the group element sum_i s_i * P_i; how it is computed
+// is free, so the structure below is chosen for the MI355X, not for the CPU the reference runs on:
+//
+//   * The SRS is resident in HBM as W = ceil(256/c) rows, row w holding the affine points
+//     2^(c*w) * P_i (built once at upload; 1.5 GiB for 2^20 points at c = 16 -- cheap in 288 GB).
+//     Every signed c-bit digit of every scalar therefore lands in ONE shared set of 2^(c-1)
+//     buckets: there is no per-window bucket reduction and no window-combine doubling chain.
+//   * Digits -> buckets by a one-pass counting sort whose 2^(c-1)-entry histogram / cursor array
+//     lives in LDS (128 KiB of the CU's 160 KiB at c = 16): k_hist, k_scan_*, k_scatter.
+//   * Bucket accumulation is cut into tasks of at most L1 = 64 sorted entries (k_accum_affine,
+//     XYZZ mixed adds, points gathered from the resident table), then partial sums are folded by
+//     key in rounds of fan-in LK (k_accum_xyzz) until every bucket holds one point.  No atomics, no
+//     unbounded per-thread chain, so adversarial inputs (all-equal scalars) stay bounded.
+//   * sum_b (b+1) * B_b by chunked running sums + small scalar-muls (k_bucket_reduce), a plain
+//     tree sum (k_sum_level), and one Fq inversion for the affine result (k_emit_point).
+//
+// Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
+#include "common.h"
+
+namespace kzg {
+
+constexpr int L1 = 64;  // sorted entries per round-1 task
+constexpr int LK = 4;   // fan-in of the later fold rounds
+constexpr int SUM_L = 4;  // fan-in of the plain tree sum
+constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
+constexpr int MAX_LEVELS = 24;
+
+struct MsmState {
+    uint32_t M;            // sorted entries
+    uint32_t ntasks;       // tasks of the level being run
+    uint32_t done;         // every bucket holds <= 1 partial
+    uint32_t final_level;  // index of the start[] array describing the final partial list
+    uint32_t final_buf;    // which ping-pong buffer holds it
+    uint32_t max_cnt;
+    uint32_t pad[2];
+};
+
+// ---------------------------------------------------------------------------------------------
+// scalar -> signed digits
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sel8(const uint32_t s[8], int idx) {
+    uint32_t r = s[0];
+    r = idx == 1 ? s[1] : r;
+    r = idx == 2 ? s[2] : r;
+    r = idx == 3 ? s[3] : r;
+    r = idx == 4 ? s[4] : r;
+    r = idx == 5 ? s[5] : r;
+    r = idx == 6 ? s[6] : r;
+    r = idx == 7 ? s[7] : r;
+    return r;
+}
+
+__device__ __forceinline__ void load_scalar(const Fr *scalars, size_t i, int sfmt, uint32_t s[8]) {
+    Fr v = scalars[i];
+    if (sfmt == KZG_FR_MONT_LE_32) v = from_mont(v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = v.v[k];
+}
+
+// calls f(w, magnitude in [1, 2^(c-1)], negative) for every non-zero signed digit
+template <class F>
+__device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W, F f) {
+    uint32_t carry = 0;
+    const uint32_t mask = (1u << c) - 1u;
+    const uint32_t half = 1u << (c - 1);
+    for (int w = 0; w < W; w++) {
+        int o = w * c;
+        int limb = o >> 5, sh = o & 31;
+        uint32_t lo = sel8(s, limb);
+        uint32_t hi = (limb < 7) ? sel8(s, limb + 1) : 0u;
+        uint64_t both = ((uint64_t)hi << 32) | lo;
+        uint32_t raw = ((uint32_t)(both >> sh) & mask) + carry;
+        uint32_t neg = raw > half ? 1u : 0u;
+        uint32_t mag = neg ? ((1u << c) - raw) : raw;
+        carry = neg;
+        if (mag) f(w, mag, neg);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// counting sort by bucket, LDS histogram / cursors
+// ---------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
+
+__global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int sfmt, int c, int W, int B,
+                                               size_t per_block, uint32_t *blk_hist) {
+    for (int b = threadIdx.x; b < B; b += blockDim.x) lds_u32[b] = 0;
+    __syncthreads();
+    size_t i0 = (size_t)blockIdx.x * per_block;
+    size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint32_t s[8];
+        load_scalar(scalars, i, sfmt, s);
+        for_each_digit(s, c, W, [&](int, uint32_t mag, uint32_t) { atomicAdd(&lds_u32[mag - 1], 1u); });
+    }
+    __syncthreads();
+    uint32_t *dst = blk_hist + (size_t)blockIdx.x * B;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) dst[b] = lds_u32[b];
+}
+
+// per bucket: exclusive scan over sort blocks; total[b] = bucket size
+__global__ void k_scan_blocks(uint32_t *blk_hist, int G, int B, uint32_t *total) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    uint32_t run = 0;
+    for (int g = 0; g < G; g++) {
+        uint32_t t = blk_hist[(size_t)g * B + b];
+        blk_hist[(size_t)g * B + b] = run;
+        run += t;
+    }
+    total[b] = run;
+}
+
+// Single-block exclusive scan helper over `B` per-bucket values produced by f(b); writes out[0..B].
+template <class F>
+__device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *out, uint32_t *lds) {
+    const int T = blockDim.x;
+    int per = (B + T - 1) / T;
+    int b0 = threadIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
+    uint32_t local = 0;
+    for (int b = b0; b < b1; b++) local += f(b);
+    lds[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < T; off <<= 1) {  // Hillis-Steele inclusive scan
+        uint32_t v = threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
+        __syncthreads();
+        lds[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t run = lds[threadIdx.x] - local;
+    uint32_t total = lds[T - 1];
+    for (int b = b0; b < b1; b++) {
+        out[b] = run;
+        run += f(b);
+    }
+    if (threadIdx.x == 0) out[B] = total;
+    __syncthreads();
+    return total;
+}
+
+// bucket_start[] from total[]; task_start[] for round 1 (ceil(cnt / L1) tasks per bucket)
+__global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t *total, int B, uint32_t *bucket_start,
+                                                       uint32_t *task_start, MsmState *st) {
+    __shared__ uint32_t lds[1024];
+    uint32_t M = block_exclusive_scan(B, [&](int b) { return total[b]; }, bucket_start, lds);
+    uint32_t T = block_exclusive_scan(B, [&](int b) { return (total[b] + L1 - 1) / L1; }, task_start, lds);
+    if (threadIdx.x == 0) {
+        st->M = M;
+        st->ntasks = T;
+        st->done = 0;
+        st->final_level = 0;
+        st->final_buf = 0;
+        st->max_cnt = 0;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, int sfmt, int c, int W, int B,
+                                                  size_t per_block, const uint32_t *blk_off,
+                                                  const uint32_t *bucket_start, uint32_t row_stride,
+                                                  uint32_t idx_base, uint32_t *entries) {
+    const uint32_t *off = blk_off + (size_t)blockIdx.x * B;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) lds_u32[b] = bucket_start[b] + off[b];
+    __syncthreads();
+    size_t i0 = (size_t)blockIdx.x * per_block;
+    size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint32_t s[8];
+        load_scalar(scalars, i, sfmt, s);
+        for_each_digit(s, c, W, [&](int w, uint32_t mag, uint32_t neg) {
+            uint32_t pos = atomicAdd(&lds_u32[mag - 1], 1u);
+            entries[pos] = ((uint32_t)w * row_stride + idx_base + (uint32_t)i) | (neg << 31);
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// accumulation rounds
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void find_task(const uint32_t *task_start, int B, uint32_t t, uint32_t &b, uint32_t &j) {
+    uint32_t lo = 0, hi = (uint32_t)B;  // task_start[lo] <= t < task_start[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (task_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    b = lo;
+    j = t - task_start[lo];
+}
+
+__device__ __forceinline__ G1Affine load_entry_point(const G1Affine *table, uint32_t ent) {
+    G1Affine p = table[ent & 0x7fffffffu];
+    if (ent >> 31) p.y = neg(p.y);
+    return p;
+}
+
+// round 1: each task folds <= L1 table points (gathered by sorted entry) into one XYZZ partial
+__global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
+                                                      const uint32_t *task_start, int B, const G1Affine *table,
+                                                      G1Xyzz *out, const MsmState *st) {
+    const uint32_t T = st->ntasks;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        uint32_t b, j;
+        find_task(task_start, B, t, b, j);
+        uint32_t s = bucket_start[b] + j * L1;
+        uint32_t e = bucket_start[b + 1];
+        e = s + L1 < e ? s + L1 : e;
+        G1Affine cur = load_entry_point(table, entries[s]);
+        G1Xyzz acc = G1Xyzz::from_affine(cur);
+        if (s + 1 < e) cur = load_entry_point(table, entries[s + 1]);
+        for (uint32_t k = s + 1; k < e; k++) {
+            G1Affine nxt = cur;
+            if (k + 1 < e) nxt = load_entry_point(table, entries[k + 1]);  // prefetch under the add
+            acc = g1_madd(acc, cur);
+            cur = nxt;
+        }
+        out[t] = acc;
+    }
+}
+
+// per-level task layout: ntask[b] = ceil(cnt[b] / L); also detects "every bucket <= 1 partial"
+__global__ __launch_bounds__(1024) void k_level_scan(const uint32_t *in_start, uint32_t *out_task_start, int B,
+                                                     int L, MsmState *st, uint32_t level, uint32_t in_buf) {
+    __shared__ uint32_t lds[1024];
+    __shared__ uint32_t smax;
+    if (st->done) return;
+    if (threadIdx.x == 0) smax = 0;
+    __syncthreads();
+    uint32_t mx = 0;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        uint32_t cnt = in_start[b + 1] - in_start[b];
+        mx = cnt > mx ? cnt : mx;
+    }
+    atomicMax(&smax, mx);
+    __syncthreads();
+    if (smax <= 1) {
+        if (threadIdx.x == 0) {
+            st->done = 1;
+            st->final_level = level;
+            st->final_buf = in_buf;
+            st->max_cnt = smax;
+        }
+        return;
+    }
+    uint32_t T = block_exclusive_scan(
+        B, [&](int b) { return (in_start[b + 1] - in_start[b] + L - 1) / L; }, out_task_start, lds);
+    if (threadIdx.x == 0) {
+        st->ntasks = T;
+        st->max_cnt = smax;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_accum_xyzz(const G1Xyzz *in, const uint32_t *in_start,
+                                                    const uint32_t *task_start, int B, int L, G1Xyzz *out,
+                                                    const MsmState *st) {
+    if (st->done) return;
+    const uint32_t T = st->ntasks;
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
+        uint32_t b, j;
+        find_task(task_start, B, t, b, j);
+        uint32_t s = in_start[b] + j * L;
+        uint32_t e = in_start[b + 1];
+        e = s + L < e ? s + L : e;
+        G1Xyzz acc = in[s];
+        for (uint32_t k = s + 1; k < e; k++) acc = g1_add(acc, in[k]);
+        out[t] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// sum_b (b + 1) * bucket[b]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_bucket_reduce(const G1Xyzz *buf0, const G1Xyzz *buf1,
+                                                      const uint32_t *starts, int B, int CH, G1Xyzz *out,
+                                                      const MsmState *st) {
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    int nchunks = B / CH;
+    if (t >= nchunks) return;
+    const uint32_t *start = starts + (size_t)st->final_level * (B + 1);
+    const G1Xyzz *buf = st->final_buf ? buf1 : buf0;
+    int lo = t * CH;
+    G1Xyzz run = G1Xyzz::inf(), acc = G1Xyzz::inf();
+    for (int b = lo + CH - 1; b >= lo; b--) {
+        uint32_t s = start[b];
+        if (start[b + 1] > s) run = g1_add(run, buf[s]);
+        acc = g1_add(acc, run);
+    }
+    // acc = sum (b - lo + 1) B_b ; add lo * run
+    if (lo != 0 && !run.is_inf()) {
+        G1Xyzz m = G1Xyzz::inf();
+        for (int bit = 30; bit >= 0; bit--) {
+            m = g1_dbl(m);
+            if ((lo >> bit) & 1) m = g1_add(m, run);
+        }
+        acc = g1_add(acc, m);
+    }
+    out[t] = acc;
+}
+
+__global__ __launch_bounds__(64) void k_sum_level(const G1Xyzz *in, uint32_t count, int L, G1Xyzz *out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nout = (count + L - 1) / L;
+    if (t >= nout) return;
+    uint32_t s = t * L, e = s + L < count ? s + L : count;
+    G1Xyzz acc = in[s];
+    for (uint32_t k = s + 1; k < e; k++) acc = g1_add(acc, in[k]);
+    out[t] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// output formatting (Curve::to_affine + serialisation), one thread per point
+// ---------------------------------------------------------------------------------------------
+__device__ void write_be48(uint8_t *dst, const Fq &canon) {
+    for (int i = 0; i < 48; i++) dst[47 - i] = (uint8_t)(canon.v[i >> 2] >> (8 * (i & 3)));
+}
+
+__device__ bool fq_lexicographically_largest(const Fq &canon) {  // y > (q-1)/2
+    // (q-1)/2
+    constexpr uint32_t H[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
+                                0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};
+    for (int i = 11; i >= 0; i--) {
+        if (canon.v[i] > H[i]) return true;
+        if (canon.v[i] < H[i]) return false;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(64) void k_emit_points(const G1Xyzz *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const G1Xyzz p = pts[i * stride_pts];
+    if (fmt == KZG_G1_JACOBIAN_MONT_144) {
+        G1Jacobian j = g1_to_jacobian(p);
+        *reinterpret_cast<G1Jacobian *>(out + i * 144) = j;
+        return;
+    }
+    G1Affine a = g1_to_affine(p);
+    if (fmt == KZG_G1_AFFINE_MONT_96) {
+        *reinterpret_cast<G1Affine *>(out + i * 96) = a;
+        return;
+    }
+    Fq x = from_mont(a.x), y = from_mont(a.y);
+    if (fmt == KZG_G1_ZCASH_UNCOMPRESSED_96) {
+        uint8_t *o = out + i * 96;
+        if (a.is_inf()) {
+            for (int k = 0; k < 96; k++) o[k] = 0;
+            o[0] = 0x40;
+        } else {
+            write_be48(o, x);
+            write_be48(o + 48, y);
+        }
+    } else {  // compressed
+        uint8_t *o = out + i * 48;
+        if (a.is_inf()) {
+            for (int k = 0; k < 48; k++) o[k] = 0;
+            o[0] = 0xC0;
+        } else {
+            write_be48(o, x);
+            o[0] |= 0x80;
+            if (fq_lexicographically_largest(y)) o[0] |= 0x20;
+        }
+    }
+}
+
+size_t point_format_bytes(int fmt) {
+    switch (fmt) {
+        case KZG_G1_AFFINE_MONT_96: return 96;
+        case KZG_G1_JACOBIAN_MONT_144: return 144;
+        case KZG_G1_ZCASH_UNCOMPRESSED_96: return 96;
+        case KZG_G1_ZCASH_COMPRESSED_48: return 48;
+        default: return 0;
+    }
+}
+
+int emit_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_point, void *d_out, int ofmt) {
+    if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    hipStream_t st = ctx->lanes[lane].stream;
+    KZG_LAUNCH(ctx, st, "k_emit_points", k_emit_points, 1, 64, 0, d_point, (size_t)1, (size_t)1, (uint8_t *)d_out,
+               ofmt);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+static int sort_blocks(size_t n) {
+    size_t g = (n + 2047) / 2048;
+    if (g < 1) g = 1;
+    if (g > 256) g = 256;
+    return (int)g;
+}
+
+static int worst_case_levels(size_t M) {  // fold rounds after round 1 until one partial per bucket
+    size_t c = (M + L1 - 1) / L1;
+    int lv = 0;
+    while (c > 1) {
+        c = (c + LK - 1) / LK;
+        lv++;
+    }
+    return lv;
+}
+
+size_t sum_points_scratch_count(size_t count) { return (count + SUM_L - 1) / SUM_L + 64; }
+
+struct MsmLayout {
+    int B, G, levels;
+    size_t M_max, T1_max;
+    size_t off_blk_hist, off_total, off_bucket_start, off_starts, off_state, off_entries, off_bufA, off_bufB,
+        off_chunks, off_sum, off_result, bytes;
+};
+
+static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
+    MsmLayout L;
+    L.B = 1 << (srs->c - 1);
+    L.G = sort_blocks(n);
+    L.M_max = n * (size_t)srs->W;
+    L.T1_max = L.M_max / L1 + L.B + 1;
+    L.levels = worst_case_levels(L.M_max);
+    if (L.levels > MAX_LEVELS) L.levels = MAX_LEVELS;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o = align_up(o + bytes, 256);
+        return r;
+    };
+    L.off_blk_hist = take((size_t)L.G * L.B * 4);
+    L.off_total = take((size_t)L.B * 4);
+    L.off_bucket_start = take((size_t)(L.B + 1) * 4);
+    L.off_starts = take((size_t)(L.levels + 2) * (L.B + 1) * 4);
+    L.off_state = take(sizeof(MsmState));
+    L.off_entries = take(L.M_max * 4 + 16);
+    L.off_bufA = take(L.T1_max * sizeof(G1Xyzz));
+    size_t t2 = L.T1_max / LK + L.B + 1;
+    L.off_bufB = take(t2 * sizeof(G1Xyzz));
+    int nchunks = L.B / (L.B < REDUCE_CH ? L.B : REDUCE_CH);
+    L.off_chunks = take((size_t)nchunks * sizeof(G1Xyzz));
+    L.off_sum = take(sum_points_scratch_count(nchunks) * 2 * sizeof(G1Xyzz));
+    L.off_result = take(sizeof(G1Xyzz));
+    L.bytes = o;
+    return L;
+}
+
+size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) { return msm_layout(srs, n ? n : 1).bytes; }
+
+int sum_points_run(kzg_ctx *ctx, int lane, G1Xyzz *d_points, size_t count, G1Xyzz *d_scratch, G1Xyzz **d_result) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    G1Xyzz *in = d_points;
+    G1Xyzz *bufs[2] = {d_scratch, d_scratch + sum_points_scratch_count(count)};
+    int which = 0;
+    while (count > 1) {
+        size_t nout = (count + SUM_L - 1) / SUM_L;
+        KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + 63) / 64), 64, 0, in, (uint32_t)count,
+                   SUM_L, bufs[which]);
+        in = bufs[which];
+        which ^= 1;
+        count = nout;
+    }
+    *d_result = in;
+    return KZG_OK;
+}
+
+static bool g_attr_set = false;
+
+int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
+            G1Xyzz **d_result) {
+    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
+    hipStream_t st = ctx->lanes[lane].stream;
+    MsmLayout L = msm_layout(srs, n ? n : 1);
+    char *base = (char *)lane_alloc(ctx, lane, L.bytes);
+    if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
+    G1Xyzz *result = (G1Xyzz *)(base + L.off_result);
+    *d_result = result;
+    if (n == 0) {
+        KZG_HIP_CHECK(ctx, hipMemsetAsync(result, 0, sizeof(G1Xyzz), st));
+        return KZG_OK;
+    }
+    if (!g_attr_set) {
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        g_attr_set = true;
+    }
+    const int B = L.B, G = L.G, c = srs->c, W = srs->W;
+    uint32_t *blk_hist = (uint32_t *)(base + L.off_blk_hist);
+    uint32_t *total = (uint32_t *)(base + L.off_total);
+    uint32_t *bucket_start = (uint32_t *)(base + L.off_bucket_start);
+    uint32_t *starts = (uint32_t *)(base + L.off_starts);
+    MsmState *state = (MsmState *)(base + L.off_state);
+    uint32_t *entries = (uint32_t *)(base + L.off_entries);
+    G1Xyzz *bufs[2] = {(G1Xyzz *)(base + L.off_bufA), (G1Xyzz *)(base + L.off_bufB)};
+    G1Xyzz *chunks = (G1Xyzz *)(base + L.off_chunks);
+    G1Xyzz *sum_scratch = (G1Xyzz *)(base + L.off_sum);
+    const Fr *sc = (const Fr *)d_scalars;
+    size_t per_block = (n + G - 1) / G;
+    size_t lds_bytes = (size_t)B * 4;
+    auto start_arr = [&](int level) { return starts + (size_t)level * (B + 1); };
+
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
+    KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
+    // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
+    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state);
+    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
+               bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
+    unsigned grid1 = (unsigned)((L.T1_max + 255) / 256);
+    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
+               srs->table, bufs[0], state);
+    // fold rounds: level k input list lives in bufs[(k-1)&1] with per-bucket starts start_arr(k-1)
+    size_t tmax = L.T1_max;
+    for (int lv = 1; lv <= L.levels + 1; lv++) {
+        int in_buf = (lv - 1) & 1;
+        KZG_LAUNCH(ctx, st, "k_level_scan", k_level_scan, 1, 1024, 0, start_arr(lv - 1), start_arr(lv), B, LK, state,
+                   (uint32_t)(lv - 1), (uint32_t)in_buf);
+        if (lv == L.levels + 1) break;  // the last scan only certifies done
+        tmax = tmax / LK + B + 1;
+        unsigned grid = (unsigned)((tmax + 255) / 256);
+        KZG_LAUNCH(ctx, st, "k_accum_xyzz", k_accum_xyzz, grid, 256, 0, bufs[in_buf], start_arr(lv - 1), start_arr(lv),
+                   B, LK, bufs[in_buf ^ 1], state);
+    }
+    int CH = B < REDUCE_CH ? B : REDUCE_CH;
+    int nchunks = B / CH;
+    KZG_LAUNCH(ctx, st, "k_bucket_reduce", k_bucket_reduce, (nchunks + 63) / 64, 64, 0, bufs[0], bufs[1], starts, B,
+               CH, chunks, state);
+    G1Xyzz *sum = nullptr;
+    KZG_TRY(sum_points_run(ctx, lane, chunks, nchunks, sum_scratch, &sum));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(result, sum, sizeof(G1Xyzz), hipMemcpyDeviceToDevice, st));
+    return KZG_OK;
+}
+
+}  // namespace kzg

@@ -1,0 +1,340 @@
+// poly.hip -- Fr vector kernels that feed the witness MSMs without leaving the device:
+//   * (p - y)/(X - x): the reference's long_division by a linear factor (src/polynomial.rs:193-227 as
+//     called from src/coeff_form.rs:71) is the Horner recurrence q_{i-1} = a_i + x q_i, restated as a
+//     three-kernel blocked suffix scan (block partials, carry scan, apply) -- 96 B/coefficient of HBM
+//     traffic instead of an n-step serial chain.  The remainder p(x) - y falls out of the carry scan.
+//   * div_by_omega_i (src/eval_form.rs:58-84) in closed form with per-domain tables
+//     w^t and 1/(w^t - 1) (one batch inversion per domain, not one inversion per element).
+//   * batch inversion, format conversion, Polynomial::eval (src/polynomial.rs:156-165), and the
+//     counter-based synthetic input generator used by bench.py.
+#include "common.h"
+
+namespace kzg {
+
+// ---------------------------------------------------------------------------------------------
+// format conversion and batch inversion
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fr_convert(Fr *data, size_t n, int to_m) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    data[i] = to_m ? to_mont(data[i]) : from_mont(data[i]);
+}
+
+int fr_convert(kzg_ctx *ctx, hipStream_t stream, Fr *d_data, size_t n, int to_m) {
+    if (!n) return KZG_OK;
+    KZG_LAUNCH(ctx, stream, "k_fr_convert", k_fr_convert, (unsigned)((n + 255) / 256), 256, 0, d_data, n, to_m);
+    return KZG_OK;
+}
+
+constexpr int BI_K = 16;
+
+// out[i] = 1/in[i] (Montgomery), zeros map to zero.  in != out.
+__global__ __launch_bounds__(256) void k_batch_inverse(const Fr *in, Fr *out, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i0 = t * BI_K;
+    if (i0 >= n) return;
+    size_t i1 = i0 + BI_K < n ? i0 + BI_K : n;
+    Fr prod = Fr::one();
+    for (size_t i = i0; i < i1; i++) {
+        out[i] = prod;
+        Fr v = in[i];
+        if (!v.is_zero()) prod = mul(prod, v);
+    }
+    Fr iv = inv(prod);
+    for (size_t i = i1; i-- > i0;) {
+        Fr v = in[i];
+        if (v.is_zero()) {
+            out[i] = Fr::zero();
+            continue;
+        }
+        Fr r = mul(iv, out[i]);
+        iv = mul(iv, v);
+        out[i] = r;
+    }
+}
+
+int batch_inverse(kzg_ctx *ctx, hipStream_t stream, const Fr *d_in, Fr *d_out, size_t n) {
+    if (!n) return KZG_OK;
+    size_t threads = (n + BI_K - 1) / BI_K;
+    KZG_LAUNCH(ctx, stream, "k_batch_inverse", k_batch_inverse, (unsigned)((threads + 255) / 256), 256, 0, d_in, d_out, n);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Horner as a blocked suffix scan
+// ---------------------------------------------------------------------------------------------
+constexpr int HT = 256;          // threads per block
+constexpr int HE = 8;            // coefficients per thread
+constexpr int HB = HT * HE;      // coefficients per block
+
+__device__ __forceinline__ Fr horner8(const Fr a[HE], const Fr &x) {
+    Fr v = a[HE - 1];
+#pragma unroll
+    for (int k = HE - 2; k >= 0; k--) v = add(mul(v, x), a[k]);
+    return v;
+}
+
+__device__ __forceinline__ void load8(const Fr *coeffs, size_t n, size_t i0, Fr a[HE]) {
+#pragma unroll
+    for (int k = 0; k < HE; k++) a[k] = (i0 + k < n) ? coeffs[i0 + k] : Fr::zero();
+}
+
+// S[b] = sum_{i in block b} a_i x^(i - start_b)
+__global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t n, Fr x, Fr x8, Fr *S) {
+    __shared__ Fr sh[HT];
+    int t = threadIdx.x;
+    size_t i0 = (size_t)blockIdx.x * HB + (size_t)t * HE;
+    Fr a[HE];
+    load8(coeffs, n, i0, a);
+    Fr v = horner8(a, x);
+    Fr m = x8;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < HT; off <<= 1) {
+        bool active = (t & (2 * off - 1)) == 0;
+        if (active) v = add(v, mul(sh[t + off], m));
+        __syncthreads();
+        if (active) sh[t] = v;
+        __syncthreads();
+        m = sqr(m);
+    }
+    if (t == 0) S[blockIdx.x] = v;
+}
+
+// H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block.
+constexpr int HS_T = 1024;
+__global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk, Fr X, Fr *H, Fr *px) {
+    __shared__ Fr sh[HS_T];
+    int t = threadIdx.x;
+    uint32_t g = (nblk + HS_T - 1) / HS_T;  // blocks per thread
+    uint32_t b0 = t * g;
+    // segment value v_t = sum_k S[b0+k] X^k
+    Fr v = Fr::zero();
+    for (uint32_t k = g; k-- > 0;) {
+        Fr s = (b0 + k < nblk) ? S[b0 + k] : Fr::zero();
+        v = add(mul(v, X), s);
+    }
+    Fr M = pow_u64(X, (uint64_t)g);
+    // inclusive suffix scan A_t = v_t + M A_{t+1}
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < HS_T; off <<= 1) {
+        Fr o = (t + off < HS_T) ? sh[t + off] : Fr::zero();
+        __syncthreads();
+        v = add(v, mul(o, M));
+        sh[t] = v;
+        __syncthreads();
+        M = sqr(M);
+    }
+    Fr carry = (t + 1 < HS_T) ? sh[t + 1] : Fr::zero();
+    for (uint32_t k = g; k-- > 0;) {
+        if (b0 + k < nblk) {
+            H[b0 + k] = carry;
+            carry = add(S[b0 + k], mul(carry, X));
+        }
+    }
+    if (t == 0) *px = carry;
+}
+
+// q_i = sum_{j > i} a_j x^(j-i-1) for i < n - 1.  coeffs may alias q.
+__global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t n, Fr x, Fr x8, const Fr *H, Fr *q) {
+    __shared__ Fr sh[HT];
+    int t = threadIdx.x;
+    size_t i0 = (size_t)blockIdx.x * HB + (size_t)t * HE;
+    Fr a[HE];
+    load8(coeffs, n, i0, a);
+    Fr v = horner8(a, x);
+    if (t == HT - 1) v = add(v, mul(x8, H[blockIdx.x]));  // fold the carry from higher blocks in
+    Fr M = x8;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = 1; off < HT; off <<= 1) {
+        Fr o = (t + off < HT) ? sh[t + off] : Fr::zero();
+        __syncthreads();
+        v = add(v, mul(o, M));
+        sh[t] = v;
+        __syncthreads();
+        M = sqr(M);
+    }
+    Fr carry = (t + 1 < HT) ? sh[t + 1] : H[blockIdx.x];
+#pragma unroll
+    for (int k = HE - 1; k >= 0; k--) {
+        if (i0 + k + 1 < n) q[i0 + k] = carry;
+        carry = add(a[k], mul(carry, x));
+    }
+}
+
+static int horner_common(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x, Fr **S, Fr **H, Fr **px,
+                         uint32_t *nblk_out, Fr *x8_out) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    uint32_t nblk = (uint32_t)((n + HB - 1) / HB);
+    *S = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
+    *H = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
+    *px = (Fr *)lane_alloc(ctx, lane, sizeof(Fr));
+    if (!*S || !*H || !*px) return fail(ctx, KZG_ERR_ALLOC, "Horner workspace not reserved");
+    Fr x8 = pow_u64(x, HE);
+    Fr X = pow_u64(x, HB);
+    KZG_LAUNCH(ctx, st, "k_horner_partials", k_horner_partials, nblk, HT, 0, d_coeffs, n, x, x8, *S);
+    KZG_LAUNCH(ctx, st, "k_horner_scan", k_horner_scan, 1, HS_T, 0, *S, nblk, X, *H, *px);
+    *nblk_out = nblk;
+    *x8_out = x8;
+    return KZG_OK;
+}
+
+int poly_eval_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_y_out) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    if (n == 0) return fail(ctx, KZG_ERR_SHAPE, "empty polynomial");
+    Fr *S, *H, *px, x8;
+    uint32_t nblk;
+    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &x8));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_y_out, px, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    return KZG_OK;
+}
+
+int quotient_linear_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_q_out,
+                        Fr *d_px_out) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    if (n == 0) return fail(ctx, KZG_ERR_SHAPE, "empty polynomial");
+    Fr *S, *H, *px, x8;
+    uint32_t nblk;
+    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &x8));
+    if (n > 1) KZG_LAUNCH(ctx, st, "k_quotient_apply", k_quotient_apply, nblk, HT, 0, d_coeffs, n, x_mont, x8, H, d_q_out);
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_px_out, px, sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// eval-form quotient (div_by_omega_i)
+// ---------------------------------------------------------------------------------------------
+struct EvalDomainTables {
+    size_t d = 0;
+    Fr *pw = nullptr;    // w^t
+    Fr *inv1 = nullptr;  // 1/(w^t - 1), inv1[0] = 0
+};
+
+__global__ __launch_bounds__(256) void k_sub_one(const Fr *in, Fr *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = sub(in[i], Fr::one());
+}
+
+static int eval_tables(kzg_ctx *ctx, hipStream_t st, uint32_t log_d, EvalDomainTables **out) {
+    auto it = ctx->eval_tabs.find(log_d);
+    if (it != ctx->eval_tabs.end()) {
+        *out = it->second;
+        return KZG_OK;
+    }
+    size_t d = (size_t)1 << log_d;
+    EvalDomainTables *t = new EvalDomainTables();
+    t->d = d;
+    Fr *tmp = nullptr;
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&t->pw, d * sizeof(Fr)));
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&t->inv1, d * sizeof(Fr)));
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&tmp, d * sizeof(Fr)));
+    KZG_TRY(pow_table(ctx, st, host_omega(log_d), Fr::one(), d, t->pw));
+    KZG_LAUNCH(ctx, st, "k_sub_one", k_sub_one, (unsigned)((d + 255) / 256), 256, 0, t->pw, tmp, d);
+    KZG_TRY(batch_inverse(ctx, st, tmp, t->inv1, d));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    KZG_HIP_CHECK(ctx, hipFree(tmp));
+    ctx->eval_tabs[log_d] = t;
+    *out = t;
+    return KZG_OK;
+}
+
+__device__ __forceinline__ Fr block_sum_fr(Fr v, Fr *sh) {
+    int t = threadIdx.x;
+    sh[t] = v;
+    __syncthreads();
+    for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+        if (t < off) sh[t] = add(sh[t], sh[t + off]);
+        __syncthreads();
+    }
+    Fr r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// q_j = (f_j - y) / (w^j - w^m) for j != m; partial[b] = sum_{j in block} q_j w^((j-m) mod d)
+__global__ __launch_bounds__(256) void k_eval_quotient(const Fr *evals, size_t d, size_t m, Fr wm_inv, const Fr *pw,
+                                                       const Fr *inv1, Fr *q, Fr *partial) {
+    __shared__ Fr sh[256];
+    size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    Fr contrib = Fr::zero();
+    if (j < d && j != m) {
+        Fr y = evals[m];
+        size_t t = (j + d - m) & (d - 1);
+        Fr qj = mul(sub(evals[j], y), mul(wm_inv, inv1[t]));
+        q[j] = qj;
+        contrib = mul(qj, pw[t]);
+    }
+    Fr s = block_sum_fr(contrib, sh);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// q_m = - sum partial
+__global__ __launch_bounds__(256) void k_eval_quotient_fix(const Fr *partial, uint32_t nblk, size_t m, Fr *q) {
+    __shared__ Fr sh[256];
+    Fr acc = Fr::zero();
+    for (uint32_t b = threadIdx.x; b < nblk; b += blockDim.x) acc = add(acc, partial[b]);
+    Fr s = block_sum_fr(acc, sh);
+    if (threadIdx.x == 0) q[m] = neg(s);
+}
+
+int quotient_eval_run(kzg_ctx *ctx, int lane, const Fr *d_evals, uint32_t log_d, size_t m, int sfmt, Fr *d_q_out) {
+    (void)sfmt;  // the map f -> q is linear with Montgomery-form constants: either input form is preserved
+    hipStream_t st = ctx->lanes[lane].stream;
+    size_t d = (size_t)1 << log_d;
+    if (m >= d) return fail(ctx, KZG_ERR_SHAPE, "evaluation index out of range (reference: index panic)");
+    EvalDomainTables *tab = nullptr;
+    KZG_TRY(eval_tables(ctx, st, log_d, &tab));
+    uint32_t nblk = (uint32_t)((d + 255) / 256);
+    Fr *partial = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
+    if (!partial) return fail(ctx, KZG_ERR_ALLOC, "eval quotient workspace not reserved");
+    Fr omega = host_omega(log_d);
+    Fr wm_inv = inv(pow_u64(omega, (uint64_t)m));
+    KZG_LAUNCH(ctx, st, "k_eval_quotient", k_eval_quotient, nblk, 256, 0, d_evals, d, m, wm_inv, tab->pw, tab->inv1,
+               d_q_out, partial);
+    KZG_LAUNCH(ctx, st, "k_eval_quotient_fix", k_eval_quotient_fix, 1, 256, 0, partial, nblk, m, d_q_out);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// synthetic inputs: element i = (SplitMix64(seed + 4i + k))_{k<4} as a 256-bit LE integer, mod r
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void k_fill_random(Fr *dst, size_t n, uint64_t seed, int u64_valued, int sfmt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = Fr::zero();
+    const int limbs = u64_valued ? 1 : 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint64_t w = k < limbs ? splitmix64(seed + 4ull * i + (uint64_t)k) : 0ull;
+        v.v[2 * k] = (uint32_t)w;
+        v.v[2 * k + 1] = (uint32_t)(w >> 32);
+    }
+    Fr m = mul(v, Fr::r2());  // v < 2^256: Montgomery form of (v mod r)
+    dst[i] = (sfmt == KZG_FR_MONT_LE_32) ? m : from_mont(m);
+}
+
+}  // namespace kzg
+
+using namespace kzg;
+
+extern "C" int kzg_fill_random_fr(kzg_ctx *ctx, void *dst_dev, size_t n, uint64_t seed, int u64_valued, int sfmt) {
+    if (!ctx || (!dst_dev && n)) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!n) return KZG_OK;
+    hipStream_t st = ctx->lanes[0].stream;
+    KZG_LAUNCH(ctx, st, "k_fill_random", k_fill_random, (unsigned)((n + 255) / 256), 256, 0, (Fr *)dst_dev, n, seed,
+               u64_valued, sfmt);
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return KZG_OK;
+}

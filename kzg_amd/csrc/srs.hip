@@ -1,0 +1,471 @@
+// srs.hip -- resident SRS objects: KZGParams.gs (src/lib.rs:14-19) and lagrange_basis_g
+// (src/eval_form.rs:40-46), decoded once into the engine's layout: W rows of affine Montgomery
+// points, row w = 2^(c*w) * P_i (see msm.hip for why).  Also the GPU versions of the untimed input
+// generators: setup() (src/lib.rs:38-47, G1 half) and the Lagrange basis for a known secret.
+#include "common.h"
+
+namespace kzg {
+
+// ---------------------------------------------------------------------------------------------
+// batch XYZZ -> affine (Montgomery trick: one Fq inversion per K points)
+// ---------------------------------------------------------------------------------------------
+constexpr int BA_K = 16;
+
+__global__ __launch_bounds__(256) void k_batch_affine(const G1Xyzz *in, G1Affine *out, size_t n) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i0 = t * BA_K;
+    if (i0 >= n) return;
+    size_t i1 = i0 + BA_K < n ? i0 + BA_K : n;
+    Fq prod = Fq::one();
+    for (size_t i = i0; i < i1; i++) {  // out[i].x temporarily holds the prefix product before i
+        out[i].x = prod;
+        Fq zzz = in[i].zzz;
+        if (!in[i].zz.is_zero()) prod = mul(prod, zzz);
+    }
+    Fq iv = inv(prod);
+    for (size_t i = i1; i-- > i0;) {
+        G1Xyzz p = in[i];
+        if (p.is_inf()) {
+            out[i] = G1Affine::inf();
+            continue;
+        }
+        Fq izzz = mul(iv, out[i].x);
+        iv = mul(iv, p.zzz);
+        out[i] = g1_to_affine_with_inv(p, izzz);
+    }
+}
+
+int batch_to_affine(kzg_ctx *ctx, hipStream_t stream, const G1Xyzz *d_in, G1Affine *d_out, size_t n) {
+    if (n == 0) return KZG_OK;
+    size_t threads = (n + BA_K - 1) / BA_K;
+    KZG_LAUNCH(ctx, stream, "k_batch_affine", k_batch_affine, (unsigned)((threads + 255) / 256), 256, 0, d_in, d_out, n);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-window precompute: row w = 2^c * row (w-1)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_dbl_c(const G1Affine *in, G1Xyzz *out, size_t n, int c) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    G1Xyzz p = G1Xyzz::from_affine(in[i]);
+    for (int k = 0; k < c; k++) p = g1_dbl(p);
+    out[i] = p;
+}
+
+int srs_choose_window(kzg_ctx *ctx, size_t n) {
+    int c = ctx->opt_window_bits;
+    if (c == 0) {
+        int l = ilog2_ceil(n ? n : 1);
+        c = l - 4;
+    }
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;  // 2^(c-1) u32 LDS counters must fit the CU's 160 KiB
+    return c;
+}
+
+int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
+    kzg_srs *s = new kzg_srs();
+    s->n = n;
+    s->npad = n ? n : 1;
+    s->c = srs_choose_window(ctx, n);
+    s->W = (256 + s->c - 1) / s->c;
+    s->device = ctx->device;
+    size_t bytes = (size_t)s->W * s->npad * sizeof(G1Affine);
+    hipError_t e = hipMalloc((void **)&s->table, bytes);
+    if (e != hipSuccess) {
+        delete s;
+        ctx->err = std::string("hipMalloc(SRS table): ") + hipGetErrorString(e);
+        return KZG_ERR_ALLOC;
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
+    if (srs->n == 0) return KZG_OK;
+    hipStream_t st = ctx->lanes[0].stream;
+    const size_t CHUNK = (size_t)1 << 20;
+    size_t chunk = srs->n < CHUNK ? srs->n : CHUNK;
+    G1Xyzz *tmp = nullptr;
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&tmp, chunk * sizeof(G1Xyzz)));
+    for (int w = 1; w < srs->W; w++) {
+        for (size_t o = 0; o < srs->n; o += chunk) {
+            size_t m = srs->n - o < chunk ? srs->n - o : chunk;
+            const G1Affine *src = srs->table + (size_t)(w - 1) * srs->npad + o;
+            G1Affine *dst = srs->table + (size_t)w * srs->npad + o;
+            KZG_LAUNCH(ctx, st, "k_dbl_c", k_dbl_c, (unsigned)((m + 255) / 256), 256, 0, src, tmp, m, srs->c);
+            KZG_TRY(batch_to_affine(ctx, st, tmp, dst, m));
+        }
+    }
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    KZG_HIP_CHECK(ctx, hipFree(tmp));
+    return KZG_OK;
+}
+
+int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz) {
+    hipStream_t st = ctx->lanes[0].stream;
+    KZG_TRY(batch_to_affine(ctx, st, d_row0_xyzz, srs->table, srs->n));
+    return srs_precompute(ctx, srs);
+}
+
+// ---------------------------------------------------------------------------------------------
+// decoding of the four input point formats into row 0
+// ---------------------------------------------------------------------------------------------
+__device__ Fq read_be48(const uint8_t *src, bool mask_flags) {
+    Fq r = Fq::zero();
+    for (int i = 0; i < 48; i++) {
+        uint32_t byte = src[47 - i];
+        if (mask_flags && i == 47) byte &= 0x1f;
+        r.v[i >> 2] |= byte << (8 * (i & 3));
+    }
+    return r;
+}
+
+// y = sqrt(a) = a^((q+1)/4) (q = 3 mod 4); caller checks y^2 == a
+__device__ Fq fq_sqrt_candidate(const Fq &a) {
+    // (q + 1) / 4
+    constexpr uint32_t E[12] = {0xffffeaabu, 0xee7fbfffu, 0xac54ffffu, 0x07aaffffu, 0x3dac3d89u, 0xd9cc34a8u,
+                                0x3ce144afu, 0xd91dd2e1u, 0x90d2eb35u, 0x92c6e9edu, 0x8e5ff9a6u, 0x0680447au};
+    Fq acc = Fq::one();
+    for (int i = 383; i >= 0; i--) {
+        acc = sqr(acc);
+        uint32_t limb = 0;
+#pragma unroll
+        for (int k = 0; k < 12; k++) limb = (k == (i >> 5)) ? E[k] : limb;
+        if ((limb >> (i & 31)) & 1) acc = mul(acc, a);
+    }
+    return acc;
+}
+
+__device__ bool fq_gt_half(const Fq &canon) {
+    constexpr uint32_t H[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
+                                0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};
+    for (int i = 11; i >= 0; i--) {
+        if (canon.v[i] > H[i]) return true;
+        if (canon.v[i] < H[i]) return false;
+    }
+    return false;
+}
+
+// any input point format -> XYZZ; *bad |= 1 on a decode / on-curve failure
+__global__ __launch_bounds__(256) void k_decode_points(const uint8_t *src, size_t n, int fmt, G1Xyzz *out, int *bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (fmt == KZG_G1_AFFINE_MONT_96) {
+        out[i] = G1Xyzz::from_affine(*reinterpret_cast<const G1Affine *>(src + i * 96));
+        return;
+    }
+    if (fmt == KZG_G1_JACOBIAN_MONT_144) {
+        G1Jacobian j = *reinterpret_cast<const G1Jacobian *>(src + i * 144);
+        out[i] = g1_from_jacobian(j);
+        return;
+    }
+    G1Affine a;
+    bool ok = true;
+    if (fmt == KZG_G1_ZCASH_UNCOMPRESSED_96) {
+        const uint8_t *p = src + i * 96;
+        if (p[0] & 0x80) ok = false;
+        if (p[0] & 0x40) {
+            a = G1Affine::inf();
+        } else {
+            Fq x = read_be48(p, true), y = read_be48(p + 48, false);
+            ok = ok && is_canonical(x) && is_canonical(y);
+            a.x = to_mont(x);
+            a.y = to_mont(y);
+            ok = ok && g1_on_curve(a);
+        }
+    } else {
+        const uint8_t *p = src + i * 48;
+        if (!(p[0] & 0x80)) ok = false;
+        if (p[0] & 0x40) {
+            a = G1Affine::inf();
+        } else {
+            Fq x = read_be48(p, true);
+            ok = ok && is_canonical(x);
+            a.x = to_mont(x);
+            Fq rhs = add(mul(sqr(a.x), a.x), from_u64<FqParams>(4));
+            Fq y = fq_sqrt_candidate(rhs);
+            ok = ok && (sqr(y) == rhs);
+            bool want_big = (p[0] & 0x20) != 0;
+            if (fq_gt_half(from_mont(y)) != want_big) y = neg(y);
+            a.y = y;
+        }
+    }
+    if (!ok) {
+        atomicOr(bad, 1);
+        a = G1Affine::inf();
+    }
+    out[i] = G1Xyzz::from_affine(a);
+}
+
+int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad) {
+    if (!n) return KZG_OK;
+    KZG_LAUNCH(ctx, st, "k_decode_points", k_decode_points, (unsigned)((n + 255) / 256), 256, 0, (const uint8_t *)d_raw, n,
+               fmt, d_out, d_bad);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// fixed-base multiplication [s]G with an 8-bit window table (32 x 255 affine points, built once)
+// ---------------------------------------------------------------------------------------------
+struct FixedBaseTable {
+    G1Affine *table = nullptr;  // [32][255]: (d) * 2^(8j) * G at [j*255 + d-1]
+};
+
+__global__ __launch_bounds__(64) void k_fb_build(G1Xyzz *out) {
+    int j = threadIdx.x;
+    if (j >= 32) return;
+    G1Xyzz base = G1Xyzz::from_affine(g1_generator());
+    for (int k = 0; k < 8 * j; k++) base = g1_dbl(base);
+    G1Xyzz acc = base;
+    for (int d = 1; d <= 255; d++) {
+        out[j * 255 + d - 1] = acc;
+        acc = g1_add(acc, base);
+    }
+}
+
+static int fixed_base_table(kzg_ctx *ctx, hipStream_t st, FixedBaseTable **out) {
+    if (!ctx->fixed_base) {
+        FixedBaseTable *t = new FixedBaseTable();
+        G1Xyzz *tmp = nullptr;
+        KZG_HIP_CHECK(ctx, hipMalloc((void **)&tmp, 32 * 255 * sizeof(G1Xyzz)));
+        KZG_HIP_CHECK(ctx, hipMalloc((void **)&t->table, 32 * 255 * sizeof(G1Affine)));
+        KZG_LAUNCH(ctx, st, "k_fb_build", k_fb_build, 1, 64, 0, tmp);
+        KZG_TRY(batch_to_affine(ctx, st, tmp, t->table, 32 * 255));
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        KZG_HIP_CHECK(ctx, hipFree(tmp));
+        ctx->fixed_base = t;
+    }
+    *out = ctx->fixed_base;
+    return KZG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_fixed_base_mul(const Fr *scalars_mont, size_t n, const G1Affine *table,
+                                                        G1Xyzz *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr s = from_mont(scalars_mont[i]);
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int j = 0; j < 32; j++) {
+        uint32_t limb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) limb = (k == (j >> 2)) ? s.v[k] : limb;
+        uint32_t byte = (limb >> (8 * (j & 3))) & 0xffu;
+        if (byte) acc = g1_madd(acc, table[j * 255 + byte - 1]);
+    }
+    out[i] = acc;
+}
+
+int fixed_base_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_scalars_mont, size_t n, G1Xyzz *d_out) {
+    FixedBaseTable *t = nullptr;
+    KZG_TRY(fixed_base_table(ctx, stream, &t));
+    if (n == 0) return KZG_OK;
+    KZG_LAUNCH(ctx, stream, "k_fixed_base_mul", k_fixed_base_mul, (unsigned)((n + 255) / 256), 256, 0, d_scalars_mont, n,
+               t->table, d_out);
+    return KZG_OK;
+}
+
+// scalars for setup(): s^i ; for the Lagrange basis: (s^d - 1) w^i / (d (s - w^i))
+__global__ __launch_bounds__(256) void k_powers(Fr base, size_t n, Fr *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = pow_u64(base, (uint64_t)i);
+}
+
+__global__ __launch_bounds__(256) void k_lagrange_den(Fr s, Fr omega, Fr d_mont, size_t d, Fr *den) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    den[i] = mul(d_mont, sub(s, pow_u64(omega, (uint64_t)i)));
+}
+
+__global__ __launch_bounds__(256) void k_lagrange_scalars(Fr zt, Fr omega, size_t d, const Fr *den, const Fr *den_inv,
+                                                          Fr *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d) return;
+    if (den[i].is_zero()) {  // s == w^i: L_i(s) = 1 (and zt = 0 makes every other L_j vanish)
+        out[i] = Fr::one();
+        return;
+    }
+    out[i] = mul(mul(zt, pow_u64(omega, (uint64_t)i)), den_inv[i]);
+}
+
+}  // namespace kzg
+
+using namespace kzg;
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: SRS objects
+// ---------------------------------------------------------------------------------------------
+static int load_host_scalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *out_mont) {
+    Fr v;
+    memcpy(v.v, s, 32);
+    if (sfmt == KZG_FR_CANONICAL_LE_32) {
+        if (!is_canonical(v)) return fail(ctx, KZG_ERR_SHAPE, "scalar not canonical");
+        v = to_mont(v);
+    } else if (sfmt != KZG_FR_MONT_LE_32) {
+        return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    }
+    *out_mont = v;
+    return KZG_OK;
+}
+
+extern "C" int kzg_srs_upload_g1(kzg_ctx *ctx, const void *pts, size_t n, int pfmt, kzg_srs **out) {
+    if (!ctx || !out || (!pts && n)) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t psz = point_format_bytes(pfmt);
+    if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
+    kzg_srs *s = nullptr;
+    KZG_TRY(srs_alloc(ctx, n, &s));
+    hipStream_t st = ctx->lanes[0].stream;
+    int rc = KZG_OK;
+    if (n) {
+        if (pfmt == KZG_G1_AFFINE_MONT_96) {
+            hipError_t e = hipMemcpyAsync(s->table, pts, n * 96, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
+            if (rc == KZG_OK) rc = srs_precompute(ctx, s);
+        } else {
+            uint8_t *raw = nullptr;
+            G1Xyzz *tmp = nullptr;
+            int *bad = nullptr;
+            int hbad = 0;
+            if (hipMalloc((void **)&raw, n * psz) != hipSuccess || hipMalloc((void **)&tmp, n * sizeof(G1Xyzz)) != hipSuccess ||
+                hipMalloc((void **)&bad, sizeof(int)) != hipSuccess) {
+                rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(decode staging)");
+            } else {
+                hipMemcpyAsync(raw, pts, n * psz, hipMemcpyHostToDevice, st);
+                hipMemsetAsync(bad, 0, sizeof(int), st);
+                KZG_LAUNCH(ctx, st, "k_decode_points", k_decode_points, (unsigned)((n + 255) / 256), 256, 0, raw, n, pfmt, tmp, bad);
+                hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+                hipStreamSynchronize(st);
+                if (hbad) rc = fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode or is not on the curve");
+                if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, tmp);
+            }
+            if (raw) hipFree(raw);
+            if (tmp) hipFree(tmp);
+            if (bad) hipFree(bad);
+        }
+    }
+    if (rc != KZG_OK) {
+        hipFree(s->table);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+static int srs_from_scalars(kzg_ctx *ctx, kzg_srs *s, Fr *d_scalars) {
+    hipStream_t st = ctx->lanes[0].stream;
+    G1Xyzz *tmp = nullptr;
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&tmp, s->n * sizeof(G1Xyzz)));
+    int rc = fixed_base_mul(ctx, st, d_scalars, s->n, tmp);
+    if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, tmp);
+    hipStreamSynchronize(st);
+    hipFree(tmp);
+    return rc;
+}
+
+extern "C" int kzg_srs_setup_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t n, kzg_srs **out) {
+    if (!ctx || !out || !sec) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    Fr tau;
+    KZG_TRY(load_host_scalar(ctx, sec, sfmt, &tau));
+    kzg_srs *s = nullptr;
+    KZG_TRY(srs_alloc(ctx, n, &s));
+    int rc = KZG_OK;
+    if (n) {
+        hipStream_t st = ctx->lanes[0].stream;
+        Fr *sc = nullptr;
+        if (hipMalloc((void **)&sc, n * sizeof(Fr)) != hipSuccess) rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(setup scalars)");
+        if (rc == KZG_OK) {
+            KZG_LAUNCH(ctx, st, "k_powers", k_powers, (unsigned)((n + 255) / 256), 256, 0, tau, n, sc);
+            rc = srs_from_scalars(ctx, s, sc);
+        }
+        if (sc) hipFree(sc);
+    }
+    if (rc != KZG_OK) {
+        hipFree(s->table);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+extern "C" int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t d, kzg_srs **out) {
+    if (!ctx || !out || !sec) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (d == 0 || (d & (d - 1))) return fail(ctx, KZG_ERR_SHAPE, "Lagrange basis needs a power-of-two size (src/eval_form.rs:255-256)");
+    uint32_t exp = (uint32_t)ilog2_ceil(d);
+    if (exp >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
+    Fr tau;
+    KZG_TRY(load_host_scalar(ctx, sec, sfmt, &tau));
+    Fr omega = host_omega(exp);
+    Fr zt = sub(pow_u64(tau, (uint64_t)d), Fr::one());
+    Fr dm = from_u64<FrParams>((uint64_t)d);
+    kzg_srs *s = nullptr;
+    KZG_TRY(srs_alloc(ctx, d, &s));
+    hipStream_t st = ctx->lanes[0].stream;
+    Fr *den = nullptr, *deni = nullptr, *sc = nullptr;
+    int rc = KZG_OK;
+    if (hipMalloc((void **)&den, d * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&deni, d * sizeof(Fr)) != hipSuccess ||
+        hipMalloc((void **)&sc, d * sizeof(Fr)) != hipSuccess)
+        rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange scalars)");
+    if (rc == KZG_OK) {
+        unsigned grid = (unsigned)((d + 255) / 256);
+        KZG_LAUNCH(ctx, st, "k_lagrange_den", k_lagrange_den, grid, 256, 0, tau, omega, dm, d, den);
+        rc = batch_inverse(ctx, st, den, deni, d);
+        if (rc == KZG_OK) {
+            KZG_LAUNCH(ctx, st, "k_lagrange_scalars", k_lagrange_scalars, grid, 256, 0, zt, omega, d, den, deni, sc);
+            rc = srs_from_scalars(ctx, s, sc);
+        }
+    }
+    hipStreamSynchronize(st);
+    if (den) hipFree(den);
+    if (deni) hipFree(deni);
+    if (sc) hipFree(sc);
+    if (rc != KZG_OK) {
+        hipFree(s->table);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
+}
+
+extern "C" int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, size_t n, void *out, int pfmt) {
+    if (!ctx || !srs || (!out && n)) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "SRS download range out of bounds");
+    if (n == 0) return KZG_OK;
+    if (pfmt != KZG_G1_AFFINE_MONT_96) return fail(ctx, KZG_ERR_SHAPE, "SRS download supports KZG_G1_AFFINE_MONT_96 only");
+    hipStream_t st = ctx->lanes[0].stream;
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, srs->table + offset, n * 96, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return KZG_OK;
+}
+
+extern "C" size_t kzg_srs_len(const kzg_srs *srs) { return srs ? srs->n : 0; }
+
+extern "C" int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows) {
+    if (!srs) return KZG_ERR_SHAPE;
+    if (window_bits) *window_bits = srs->c;
+    if (windows) *windows = srs->W;
+    return KZG_OK;
+}
+
+extern "C" void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs) {
+    if (!srs) return;
+    if (ctx) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        hipSetDevice(ctx->device);
+        for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
+    }
+    if (srs->table) hipFree(srs->table);
+    delete srs;
+}

@@ -1,0 +1,31 @@
+// Host build of kzg_amd/csrc/{field,curve}.h for CPU-side unit tests (tests/test_host_math.py).
+// The same headers are compiled by hipcc for gfx950; this exercises the identical arithmetic source.
+#include "../kzg_amd/csrc/curve.h"
+using namespace kzg;
+extern "C" {
+void hm_fq_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48); Fq z = mul(x, y); memcpy(o, z.v, 48); }
+void hm_fq_add(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48); Fq z = add(x, y); memcpy(o, z.v, 48); }
+void hm_fq_sub(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48); Fq z = sub(x, y); memcpy(o, z.v, 48); }
+void hm_fq_inv(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv(x); memcpy(o, z.v, 48); }
+void hm_fr_mul(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fr x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); Fr z = mul(x, y); memcpy(o, z.v, 32); }
+void hm_fr_add(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fr x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); Fr z = add(x, y); memcpy(o, z.v, 32); }
+void hm_fr_sub(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fr x, y; memcpy(x.v, a, 32); memcpy(y.v, b, 32); Fr z = sub(x, y); memcpy(o, z.v, 32); }
+void hm_fr_inv(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv(x); memcpy(o, z.v, 32); }
+void hm_fr_to_mont(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = to_mont(x); memcpy(o, z.v, 32); }
+void hm_fr_from_mont(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = from_mont(x); memcpy(o, z.v, 32); }
+void hm_fr_root_of_unity(uint32_t *o) { Fr z = from_mont(fr_root_of_unity()); memcpy(o, z.v, 32); }
+void hm_g1_generator(uint32_t *o) { G1Affine g = g1_generator(); memcpy(o, &g, 96); }
+// acc(affine a) + b via madd, then via add(xyzz,xyzz), then dbl; all returned affine
+void hm_g1_madd(const uint32_t *a, const uint32_t *b, uint32_t *o) { G1Affine x, y; memcpy(&x, a, 96); memcpy(&y, b, 96);
+    G1Affine r = g1_to_affine(g1_madd(G1Xyzz::from_affine(x), y)); memcpy(o, &r, 96); }
+void hm_g1_add(const uint32_t *a, const uint32_t *b, uint32_t *o) { G1Affine x, y; memcpy(&x, a, 96); memcpy(&y, b, 96);
+    // de-normalise both operands first so the general add sees non-trivial ZZ/ZZZ
+    G1Xyzz p = g1_dbl(G1Xyzz::from_affine(x)); p = g1_madd(p, g1_neg(x));
+    G1Xyzz q = g1_dbl(G1Xyzz::from_affine(y)); q = g1_madd(q, g1_neg(y));
+    G1Affine r = g1_to_affine(g1_add(p, q)); memcpy(o, &r, 96); }
+void hm_g1_mul(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1Affine x; memcpy(&x, a, 96);
+    G1Affine r = g1_to_affine(g1_scalar_mul(x, k)); memcpy(o, &r, 96); }
+void hm_g1_jac_roundtrip(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1Affine x; memcpy(&x, a, 96);
+    G1Xyzz p = g1_scalar_mul(x, k); G1Jacobian j = g1_to_jacobian(p); G1Affine r = g1_to_affine(g1_from_jacobian(j)); memcpy(o, &r, 96); }
+int hm_g1_on_curve(const uint32_t *a) { G1Affine x; memcpy(&x, a, 96); return g1_on_curve(x); }
+}

@@ -1,0 +1,177 @@
+"""MSM parity: kzg_msm_g1 / kzg_commit_coeff through the C ABI vs the oracle (C restatement + known-tau)."""
+import ctypes
+import random
+
+import pytest
+
+import kzg_amd
+from kzg_amd import _lib as L
+from oracle import c_oracle as C
+from oracle import kzg_model as M
+from tests.gpu_common import engine, rand_scalars  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+TAU = 0x1234567_89abcdef
+
+
+@pytest.fixture(scope="module")
+def srs_small(engine):
+    blob = C.setup_g1(TAU, 300)
+    s = kzg_amd.Srs.upload(engine, blob, 300)
+    yield s, blob
+    s.free()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 3, 16, 255, 300])
+def test_msm_small_sizes(engine, srs_small, n):
+    srs, blob = srs_small
+    rng = random.Random(100 + n)
+    sc = rand_scalars(rng, n)
+    got = engine.msm(srs, sc, n=n)
+    assert got == C.msm_g1(blob[: 96 * n], sc)
+
+
+def test_msm_edge_scalars(engine, srs_small):
+    """zero scalars, r-1, 1, all-equal scalars (every term in one bucket), u64-valued scalars."""
+    srs, blob = srs_small
+    rng = random.Random(7)
+    n = 200
+    cases = {
+        "zeros": [0] * n,
+        "ones": [1] * n,
+        "r_minus_1": [M.R - 1] * n,
+        "all_equal": [rng.randrange(M.R)] * n,
+        "mixed": [0, 1, M.R - 1, 2 ** 255 % M.R, (1 << 128) - 1] * (n // 5),
+        "u64": rand_scalars(rng, n, "u64"),
+        "half_boundary": [0x8000] * n,           # digit exactly 2^(c-1) for c = 16
+        "carry_chain": [int("7fff" * 15, 16)] * n,
+    }
+    for name, sc in cases.items():
+        assert engine.msm(srs, sc) == C.msm_g1(blob[: 96 * n], sc), name
+
+
+def test_msm_offset_and_formats(engine, srs_small):
+    srs, blob = srs_small
+    rng = random.Random(8)
+    n, off = 100, 37
+    sc = rand_scalars(rng, n)
+    want = C.msm_g1(blob[96 * off: 96 * (off + n)], sc)
+    assert engine.msm(srs, sc, offset=off) == want
+    P = C.blob_to_point(want)
+    assert engine.msm(srs, sc, offset=off, ofmt=L.G1_ZCASH_COMPRESSED) == M.g1_to_compressed(P)
+    assert engine.msm(srs, sc, offset=off, ofmt=L.G1_ZCASH_UNCOMPRESSED) == M.g1_to_uncompressed(P)
+    jac = engine.msm(srs, sc, offset=off, ofmt=L.G1_JACOBIAN_MONT)
+    rinv = pow(M.FQ_MONT_R, -1, M.Q)
+    X, Y, Z = (int.from_bytes(jac[48 * i:48 * i + 48], "little") * rinv % M.Q for i in range(3))
+    zi = pow(Z, -1, M.Q)
+    assert (X * zi * zi % M.Q, Y * zi * zi * zi % M.Q) == P
+    # identity result in every format
+    z = [0] * n
+    assert engine.msm(srs, z) == bytes(96)
+    assert engine.msm(srs, z, ofmt=L.G1_ZCASH_COMPRESSED) == M.g1_to_compressed(None)
+    assert engine.msm(srs, z, ofmt=L.G1_ZCASH_UNCOMPRESSED) == M.g1_to_uncompressed(None)
+    # montgomery-form scalars, device resident
+    buf = engine.alloc_scalars(n, sfmt=L.FR_MONT)
+    buf.upload(b"".join(M.fr_to_mont_le(s) for s in sc))
+    assert engine.msm(srs, buf, offset=off) == want
+    buf.free()
+    with pytest.raises(kzg_amd.ReferencePanic):
+        engine.msm(srs, sc, offset=250)  # 250 + 100 > 300: slice index panic in the reference
+
+
+def test_srs_with_identity_and_repeated_points(engine):
+    rng = random.Random(9)
+    G = C.g1_generator()
+    P = C.g1_mul(G, 777)
+    nP = C.point_to_blob(M.g1_neg(C.blob_to_point(P)))
+    pts = [P, P, nP, bytes(96), G, P, bytes(96), nP] * 8
+    n = len(pts)
+    blob = b"".join(pts)
+    srs = kzg_amd.Srs.upload(engine, blob, n)
+    for sc in ([5] * n, rand_scalars(rng, n), [1, 1, 2, 9, 0, M.R - 2, 3, 4] * 8):
+        assert engine.msm(srs, sc) == C.msm_g1(blob, sc)
+    srs.free()
+
+
+@pytest.mark.parametrize("pfmt", [L.G1_ZCASH_UNCOMPRESSED, L.G1_ZCASH_COMPRESSED, L.G1_JACOBIAN_MONT])
+def test_srs_upload_formats(engine, pfmt):
+    rng = random.Random(10)
+    n = 40
+    blob = C.setup_g1(TAU, n)
+    pts = [C.blob_to_point(blob[96 * i:96 * i + 96]) for i in range(n)]
+    pts[5] = None
+    if pfmt == L.G1_ZCASH_UNCOMPRESSED:
+        raw = b"".join(M.g1_to_uncompressed(p) for p in pts)
+    elif pfmt == L.G1_ZCASH_COMPRESSED:
+        raw = b"".join(M.g1_to_compressed(p) for p in pts)
+    else:
+        # non-trivial Z: (x z^2, y z^3, z)
+        out = []
+        for p in pts:
+            if p is None:
+                out.append(bytes(144)); continue
+            z = rng.randrange(1, M.Q)
+            c = [p[0] * z * z % M.Q, p[1] * z * z * z % M.Q, z]
+            out.append(b"".join((v * M.FQ_MONT_R % M.Q).to_bytes(48, "little") for v in c))
+        raw = b"".join(out)
+    srs = kzg_amd.Srs.upload(engine, raw, n, pfmt)
+    want = b"".join(M.g1_to_affine_mont(p) for p in pts)
+    assert srs.download() == want
+    sc = rand_scalars(rng, n)
+    assert engine.msm(srs, sc) == C.msm_g1(want, sc)
+    srs.free()
+    if pfmt != L.G1_JACOBIAN_MONT:
+        bad = bytearray(raw)
+        bad[L.POINT_BYTES[pfmt] - 1] ^= 1  # corrupt the first point
+        with pytest.raises(kzg_amd.EngineError):
+            kzg_amd.Srs.upload(engine, bytes(bad), n, pfmt)
+
+
+def test_setup_matches_reference_setup(engine):
+    """setup(s, n) (src/lib.rs:38-55) on the GPU == the oracle's chain gs[i] = gs[i-1]*s."""
+    params = kzg_amd.setup(engine, TAU, 130)
+    assert params.gs.download() == C.setup_g1(TAU, 130)
+    small = kzg_amd.setup(engine, TAU, 9)
+    assert small.gs.download() == b"".join(M.g1_to_affine_mont(p) for p in M.setup_g1(TAU, 9))
+    params.gs.free(); small.gs.free()
+
+
+@pytest.mark.parametrize("log_n,kind", [(10, "full"), (12, "u64"), (14, "full")])
+def test_commit_known_tau(engine, log_n, kind):
+    """commit(p) == [p(tau)]G  (SURVEY 8c), config-1 style at 2^10 and larger."""
+    n = 1 << log_n
+    rng = random.Random(log_n)
+    params = kzg_amd.setup(engine, TAU, n)
+    coeffs = rand_scalars(rng, n, kind)
+    prover = kzg_amd.KZGProver(params)
+    poly = kzg_amd.Polynomial(coeffs)
+    got = prover.commit(poly)
+    want = C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU))
+    assert got == want
+    if log_n <= 12:
+        assert got == C.msm_g1(params.gs.download(), coeffs)
+    assert kzg_amd.KZGVerifier(params).verify_poly(got, poly)
+    coeffs2 = list(coeffs); coeffs2[2] = (coeffs2[2] + 1) % M.R
+    assert not kzg_amd.KZGVerifier(params).verify_poly(got, kzg_amd.Polynomial(coeffs2))
+    with pytest.raises(kzg_amd.ReferencePanic):
+        prover.commit(kzg_amd.Polynomial(coeffs + [1]))  # longer than the SRS
+    params.gs.free()
+
+
+def test_msm_batch_and_sum(engine, srs_small):
+    srs, blob = srs_small
+    rng = random.Random(21)
+    n, batch = 128, 6
+    vecs = [rand_scalars(rng, n) for _ in range(batch)]
+    flat = [s for v in vecs for s in v]
+    got = engine.msm_batch(srs, flat, n, batch)
+    want = [C.msm_g1(blob[: 96 * n], v) for v in vecs]
+    assert got == want
+    total = engine.g1_sum(want)
+    acc = bytes(96)
+    for w in want:
+        acc = C.g1_add(acc, w)
+    assert total == acc
+    assert engine.g1_sum([]) == bytes(96)
+    assert engine.g1_sum([want[0], C.point_to_blob(M.g1_neg(C.blob_to_point(want[0])))]) == bytes(96)
