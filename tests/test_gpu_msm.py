@@ -122,10 +122,22 @@ def test_srs_upload_formats(engine, pfmt):
     assert engine.msm(srs, sc) == C.msm_g1(want, sc)
     srs.free()
     if pfmt != L.G1_JACOBIAN_MONT:
-        bad = bytearray(raw)
-        bad[L.POINT_BYTES[pfmt] - 1] ^= 1  # corrupt the first point
+        # an x with x^3 + 4 a non-residue (compressed) / a y off the curve (uncompressed) must be rejected
+        x = 5
+        while pow((x ** 3 + 4) % M.Q, (M.Q - 1) // 2, M.Q) == 1:
+            x += 1
+        if pfmt == L.G1_ZCASH_COMPRESSED:
+            bad_pt = bytearray(x.to_bytes(48, "big")); bad_pt[0] |= 0x80
+        else:
+            bad_pt = bytearray(M.g1_to_uncompressed(pts[0])); bad_pt[95] ^= 1
+        bad = bytes(bad_pt) + raw[L.POINT_BYTES[pfmt]:]
         with pytest.raises(kzg_amd.EngineError):
-            kzg_amd.Srs.upload(engine, bytes(bad), n, pfmt)
+            kzg_amd.Srs.upload(engine, bad, n, pfmt)
+        # x >= q is not a canonical encoding
+        big = bytearray((M.Q + 1).to_bytes(48, "big")); big[0] |= 0x80 if pfmt == L.G1_ZCASH_COMPRESSED else 0
+        bad = bytes(big) + raw[48:]
+        with pytest.raises(kzg_amd.EngineError):
+            kzg_amd.Srs.upload(engine, bad, n, pfmt)
 
 
 def test_setup_matches_reference_setup(engine):

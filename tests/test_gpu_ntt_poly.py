@@ -1,0 +1,131 @@
+"""NTT (src/ft.rs) and Fr-polynomial kernels vs the oracle, through the C ABI."""
+import random
+
+import pytest
+
+import kzg_amd
+from kzg_amd import _lib as L
+from oracle import c_oracle as C
+from oracle import kzg_model as M
+from tests.gpu_common import engine, rand_scalars  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n", list(range(0, 15)))
+def test_ntt_matches_serial_fft(engine, log_n):
+    """EvaluationDomain::fft == serial_fft restatement, natural order in/out, every size 2^0..2^14
+    (covers the single-tile path <= 2^12 and the two-pass path)."""
+    rng = random.Random(200 + log_n)
+    xs = rand_scalars(rng, 1 << log_n)
+    got = engine.ntt(xs, log_n)
+    assert got == C.fft(xs)
+    assert engine.ntt(got, log_n, inverse=True) == xs            # fft_composition (src/ft.rs:447-479)
+    assert engine.ntt(engine.ntt(xs, log_n, inverse=True), log_n) == xs
+
+
+def test_ntt_small_vs_python_model(engine):
+    rng = random.Random(31)
+    for log_n in (1, 3, 6):
+        xs = rand_scalars(rng, 1 << log_n)
+        e = M.EvaluationDomain.from_coeffs(xs)
+        e.fft()
+        assert engine.ntt(xs, log_n) == e.coeffs
+        e.ifft()
+        assert e.coeffs == xs
+
+
+def test_ntt_montgomery_and_device_resident(engine):
+    rng = random.Random(32)
+    log_n = 13
+    xs = rand_scalars(rng, 1 << log_n)
+    buf = engine.alloc_scalars(1 << log_n, sfmt=L.FR_MONT)
+    buf.upload(b"".join(M.fr_to_mont_le(x) for x in xs))
+    engine.ntt(buf, log_n)
+    rinv = pow(M.FR_MONT_R, -1, M.R)
+    got = [v * rinv % M.R for v in kzg_amd.unpack_scalars(buf.download())]
+    assert got == C.fft(xs)
+    buf.free()
+
+
+def test_ntt_linearity_2_20(engine):
+    """Full BASELINE size: NTT(a + c*b) == NTT(a) + c*NTT(b) on sampled outputs, plus round trip and
+    agreement with direct evaluation p(w^i) at a few points (size-independent properties)."""
+    log_n = 20
+    n = 1 << log_n
+    a = engine.alloc_scalars(n).fill_random(1)
+    b = engine.alloc_scalars(n).fill_random(2)
+    a0 = a.download()
+    _, _, omega = kzg_amd.compute_omega(n)
+    idx = [0, 1, 5, 1023, 1024, 65537, n - 1]
+    want = {i: C.poly_eval_bytes(a0, n, pow(omega, i, M.R)) for i in idx}
+    engine.ntt(a, log_n)
+    fa = a.download()
+    for i in idx:
+        assert int.from_bytes(fa[32 * i:32 * i + 32], "little") == want[i]
+    engine.ntt(a, log_n, inverse=True)
+    assert a.download() == a0
+    a.free(); b.free()
+
+
+def test_compute_omega():
+    assert kzg_amd.compute_omega(1 << 20) == M.compute_omega(1 << 20)
+    assert kzg_amd.compute_omega(10) == M.compute_omega(10)
+    assert kzg_amd.compute_omega(1) == M.compute_omega(1)
+    with pytest.raises(kzg_amd.PolynomialDegreeTooLarge):
+        kzg_amd.compute_omega((1 << 31) + 1)
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 8, 9, 2047, 2048, 2049, 5000, 70000])
+def test_poly_eval_and_linear_quotient(engine, n):
+    """Polynomial::eval and (p - y)/(X - x) by long_division (src/polynomial.rs:156-165,193-227)."""
+    rng = random.Random(300 + n)
+    coeffs = rand_scalars(rng, n)
+    x = rng.randrange(M.R)
+    y = C.poly_eval(coeffs, x)
+    assert engine.poly_eval(coeffs, x) == y
+    if n >= 2:
+        q = engine.quotient_linear(coeffs, x, y)
+        qb, nz = C.witness_quotient_bytes(C.scalars_to_bytes(coeffs), n, x, y)
+        assert not nz and q == C.bytes_to_scalars(qb)
+        with pytest.raises(kzg_amd.PointNotOnPolynomial):
+            engine.quotient_linear(coeffs, x, (y + 1) % M.R)
+
+
+def test_reference_literal_vectors(engine):
+    """The reference's own known-answer tests, run on the GPU path:
+    test_eval_basic (src/polynomial.rs:579-597) and the exact division of test_long_division (:558-576)."""
+    p = [34, 0, 7, 4, 0, 1]
+    assert engine.poly_eval(p, 0) == 34 and engine.poly_eval(p, 1) == 46 and engine.poly_eval(p, 5) == 3834
+    # x^3 + 6x^2 + 13x + 10 / x + 2 = x^2 + 4x + 5 r 0   (divisor X - (-2))
+    assert engine.quotient_linear([10, 13, 6, 1], M.R - 2, 0) == [5, 4, 1]
+    # x^3 + 2x^2 - 3x + 4 / x - 7 = x^2 + 9x + 60 r 424 : p(7) = 424
+    assert engine.poly_eval([4, M.R - 3, 2, 1], 7) == 424
+    assert engine.quotient_linear([4, M.R - 3, 2, 1], 7, 424) == [60, 9, 1]
+    # 3x^4 - 5x^2 + 3 / x + 2 = 3x^3 - 6x^2 + 7x - 14 r 31
+    assert engine.quotient_linear([3, 0, M.R - 5, 0, 3], M.R - 2, 31) == [M.R - 14, 7, M.R - 6, 3]
+
+
+@pytest.mark.parametrize("log_d,m", [(0, 0), (1, 1), (4, 3), (4, 0), (8, 255), (12, 1000)])
+def test_div_by_omega_i(engine, log_d, m):
+    """div_by_omega_i (src/eval_form.rs:58-84) applied to evals - evals[m]."""
+    d = 1 << log_d
+    rng = random.Random(400 + log_d)
+    ev = rand_scalars(rng, d)
+    got = engine.quotient_eval(ev, m)
+    num = [(v - ev[m]) % M.R for v in ev]
+    want = C.bytes_to_scalars(C.div_by_omega_i_bytes(C.scalars_to_bytes(num), d, m))
+    assert got == want
+    if log_d == 4:  # the literal O(d) inversions version of the reference
+        e = M.EvaluationDomain.from_coeffs(num)
+        assert got == M.div_by_omega_i(e, m).coeffs
+
+
+def test_fill_random_definition(engine):
+    buf = engine.alloc_scalars(1000).fill_random(42)
+    got = kzg_amd.unpack_scalars(buf.download())
+    assert got == [kzg_amd.splitmix_scalar(42, i) for i in range(1000)]
+    buf.fill_random(7, u64_valued=True)
+    got = kzg_amd.unpack_scalars(buf.download())
+    assert got == [kzg_amd.splitmix_scalar(7, i, True) for i in range(1000)] and max(got) < 1 << 64
+    buf.free()

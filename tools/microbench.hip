@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_madd(G1Xyzz *out, const G1Affine *pts, 
     out[i] = acc;
 }
 
-__global__ void k_init_points(G1Affine *pts, int n) {  // pts[i] = (i+1) * G via repeated madd in one thread
+__global__ __launch_bounds__(64) void k_init_points(G1Affine *pts, int n) {  // pts[i] = (i+1) * G via repeated madd in one thread
     if (threadIdx.x || blockIdx.x) return;
     G1Affine g = g1_generator();
     G1Xyzz acc = G1Xyzz::from_affine(g);
@@ -82,6 +82,7 @@ template <class K, class... A>
 double time_kernel(K kern, dim3 grid, dim3 block, int reps, A... args) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     hipLaunchKernelGGL(kern, grid, block, 0, 0, args...);
+    CHECK(hipGetLastError());
     CHECK(hipDeviceSynchronize());
     CHECK(hipEventRecord(e0));
     for (int r = 0; r < reps; r++) hipLaunchKernelGGL(kern, grid, block, 0, 0, args...);
@@ -91,6 +92,7 @@ double time_kernel(K kern, dim3 grid, dim3 block, int reps, A... args) {
 }
 
 int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     int cus = p.multiProcessorCount;
     printf("device %s, %d CUs, clock %d kHz\n", p.name, cus, p.clockRate);
@@ -121,8 +123,10 @@ int main() {
     CHECK(hipMalloc(&fr_in, (nthreads + 8) * sizeof(Fr))); CHECK(hipMalloc(&fr_out, nthreads * sizeof(Fr)));
     CHECK(hipMemset(fq_in, 0x5a, (nthreads + 8) * sizeof(Fq))); CHECK(hipMemset(fr_in, 0x3c, (nthreads + 8) * sizeof(Fr)));
     G1Affine *pts; G1Xyzz *pout; CHECK(hipMalloc(&pts, 4096 * sizeof(G1Affine))); CHECK(hipMalloc(&pout, nthreads * sizeof(G1Xyzz)));
-    hipLaunchKernelGGL(k_init_points, dim3(1), dim3(1), 0, 0, pts, 4096);
+    printf("init points...\n");
+    hipLaunchKernelGGL(k_init_points, dim3(1), dim3(64), 0, 0, pts, 4096);
     CHECK(hipDeviceSynchronize());
+    printf("init points done\n");
     for (int wps = 1; wps <= 8; wps *= 2) {
         dim3 grid(cus * wps), block(256);
         int it = 2000;
