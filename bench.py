@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's headline metric on MI355X: degree-2^20 coeff-form KZG commitments/sec
+(G1 Pippenger MSM, full-width uniform Fr scalars, SRS and scalars already resident in HBM).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N = 1 : workload = BASELINE configs[1] "degree-2^20 coeff_form commit (G1 Pippenger MSM) on 1xMI355X".
+        One step = one batch of `--batch` independent commitments pipelined on the engine's HIP
+        streams (kzg_msm_g1_batch); value = commitments / second.
+N > 1 : the SRS is sharded contiguously, 2^20 terms per rank (polynomial of N*2^20 coefficients, the
+        shape of configs[4]); each step every rank reduces its shard on its GPU, the 96-byte partials
+        are all-gathered over RCCL/xGMI and summed locally.  value = (terms processed by all ranks /
+        2^20) per second, i.e. degree-2^20-equivalent commitments/s (weak scaling, no work skipped).
+
+The JSON line also carries `roofline` for the dominant kernel (k_accum_affine; HIP-event time measured
+on the engine's stream inside this process) and `cpu_baseline` (the oracle's single-threaded C
+Pippenger on a bounded sample, rank 0, N = 1 only).  The oracle is never on the measured path.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = 20
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BYTES_PER_TERM = 128           # 32 B scalar + 96 B affine point per MSM term
+TAU = 0x5EED5EED5EED5EED       # known secret for the synthetic SRS (setup(s, n), src/lib.rs:38)
+
+
+def g1_adds_per_msm(n, c, W):
+    """algorithmic G1 additions, n*W bucket accumulations + bucket reduction."""
+    return n * W + 2 * (1 << (c - 1))
+
+
+def cpu_baseline(engine, params, log_sample=17):
+    """Oracle C Pippenger (single thread, like the reference's multi_exp) on the first 2^log_sample
+    terms of the same SRS / scalar distribution."""
+    from oracle import c_oracle as C
+    import kzg_amd
+    n = 1 << log_sample
+    pts = params.gs.download(0, n)
+    sc = b"".join(kzg_amd.splitmix_scalar(1, i).to_bytes(32, "little") for i in range(n))
+    t0 = time.perf_counter()
+    out = C.msm_g1_raw(pts, sc, n)
+    dt = time.perf_counter() - t0
+    buf = engine.alloc_scalars(n).upload(sc)
+    ok = engine.msm(params.gs, buf, n=n) == out   # the baseline run doubles as a parity check
+    buf.free()
+    terms_per_s = n / dt
+    return {"value": terms_per_s / (1 << LOG_N), "unit": "commitments/s (degree 2^20, extrapolated from sample)",
+            "cores": 1, "kind": "port",
+            "sample": f"one 2^{log_sample}-term MSM, same SRS and scalar distribution, {dt:.2f} s, "
+                      f"{terms_per_s:.0f} terms/s; matches GPU result: {ok}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4, help="commitments per step (N = 1)")
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n = 1 << args.log_n
+
+    import torch
+    import kzg_amd
+    from kzg_amd import _lib as L
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    engine = kzg_amd.Engine(local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- inputs, resident in HBM before the timed region -----------------------------------------
+    if world == 1:
+        params = kzg_amd.setup(engine, TAU, n)                       # gs[i] = [tau^i]G
+        srs = params.gs
+        scal = engine.alloc_scalars(n * args.batch).fill_random(1, u64_valued=args.u64)
+    else:
+        # rank r holds the contiguous shard gs[r*n .. (r+1)*n) = [tau^(r*n + i)]G of setup(tau, world*n)
+        params = kzg_amd.KZGParams(kzg_amd.setup_shard(engine, TAU, rank * n, n))
+        srs = params.gs
+        scal = engine.alloc_scalars(n).fill_random(1 + rank, u64_valued=args.u64)
+    c, W = srs.window_info()
+    out = ctypes.create_string_buffer(96 * max(args.batch, 1))
+
+    if world == 1:
+        def step():
+            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, srs.handle, 0, scal.ptr, n, args.batch, scal.sfmt,
+                                             L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            if rc:
+                raise RuntimeError(engine.last_error())
+        units_per_step = args.batch
+    else:
+        from kzg_amd.distributed import ShardedCommitter
+        committer = ShardedCommitter.for_engine(engine, srs, dist, rank, world)
+
+        def step():
+            committer.commit(scal)
+        units_per_step = world            # world * n terms = `world` degree-2^20 equivalents
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- roofline of the dominant kernel: HIP events on the engine's stream, single-stream runs ----
+    roofline = None
+    latency_ms = None
+    if rank == 0:
+        engine.prof_enable(True)
+        engine.prof_reset()
+        one = ctypes.create_string_buffer(96)
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            rc = engine.lib.kzg_msm_g1(engine.ctx, srs.handle, 0, scal.ptr, n, scal.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
+            if rc:
+                raise RuntimeError(engine.last_error())
+        latency_ms = (time.perf_counter() - t1) / reps * 1e3
+        prof = engine.prof_all()
+        engine.prof_enable(False)
+        launches, total_ms = prof.get("k_accum_affine", (0, 0.0))
+        if launches:
+            avg_s = total_ms / launches / 1e3
+            achieved = BYTES_PER_TERM * n / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get("k_accum_affine_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            roofline = {"bound": "hbm", "kernel": "k_accum_affine", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "avg_kernel_ms": round(avg_s * 1e3, 4),
+                        "kernel_ms_per_msm": {k: round(v[1] / reps, 4) for k, v in sorted(prof.items())}}
+
+    if rank == 0:
+        value = units_per_step * args.steps / dt
+        res = {
+            "metric": "commitments/sec + MSM G1-adds/sec at degree 2^20, 1/2/4/8 MI355X",
+            "value": round(value, 3),
+            "unit": "commitments/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (Fq 381-bit / Fr 255-bit Montgomery integer arithmetic)",
+            "data": "synthetic",
+            "config": {
+                "workload": ("degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step"
+                             % (args.log_n, args.batch)) if world == 1 else
+                            ("degree-%d*2^%d coeff_form commit, SRS sharded 2^%d terms per rank over %d GPUs, "
+                             "RCCL all_gather of 96-B partials + local sum" % (world, args.log_n, args.log_n, world)),
+                "scalars": "u64-valued Fr" if args.u64 else "uniform full-width Fr (SplitMix64 counter stream, seed 1)",
+                "terms_per_rank": n, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",
+                "inputs_resident_in_hbm": True,
+            },
+            "g1_adds_per_sec": round(value * g1_adds_per_msm(n, c, W), 1),
+            "msm_terms_per_sec": round(value * n, 1),
+            "single_commit_latency_ms": None if latency_ms is None else round(latency_ms, 4),
+        }
+        if world > 1:
+            res["unit_note"] = "N>1: value = (terms processed by all ranks / 2^20) per second (degree-2^20 equivalents)"
+        if roofline:
+            res["roofline"] = roofline
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                res["cpu_baseline"] = cpu_baseline(engine, params)
+            except Exception as e:  # the baseline must never take the bench line down
+                res["cpu_baseline"] = {"value": None, "unit": "commitments/s", "cores": 1, "kind": "port",
+                                       "sample": f"failed: {e}"}
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    engine.close()
+
+
+if __name__ == "__main__":
+    main()

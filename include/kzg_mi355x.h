@@ -76,6 +76,8 @@ int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value);
 int kzg_srs_upload_g1(kzg_ctx *ctx, const void *pts, size_t n, int pfmt, kzg_srs **out);
 /* setup(s, n), G1 half (src/lib.rs:38-47): gs[i] = [s^i]G, generated on the GPU. */
 int kzg_srs_setup_g1(kzg_ctx *ctx, const void *s, int sfmt, size_t n, kzg_srs **out);
+/* One contiguous shard of the same SRS: gs[first .. first+n) = [s^(first+i)]G (multi-GPU sharding). */
+int kzg_srs_setup_g1_shard(kzg_ctx *ctx, const void *s, int sfmt, size_t first, size_t n, kzg_srs **out);
 /* Lagrange-basis SRS for a known secret: L_i(s) G, i < d, d a power of two.  Same group elements
  * as compute_lagrange_basis(&setup(s, d)).0 (src/eval_form.rs:254-280), in O(d) not O(d^3). */
 int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *s, int sfmt, size_t d, kzg_srs **out);

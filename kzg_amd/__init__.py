@@ -9,4 +9,4 @@ from ._lib import (FR_CANONICAL, FR_MONT, G1_AFFINE_MONT, G1_JACOBIAN_MONT, G1_Z
 from .api import (DeviceBuffer, Engine, EngineError, EvaluationDomain, KZGBatchWitness, KZGError, KZGParams,
                   KZGProver, KZGProverEvalForm, KZGVerifier, KZGVerifierEvalForm, PointNotOnPolynomial, Polynomial,
                   PolynomialDegreeTooLarge, ReferencePanic, Srs, compute_lagrange_basis, compute_omega, pack_scalars,
-                  setup, setup_lagrange, splitmix_scalar, unpack_scalars)
+                  setup, setup_lagrange, setup_shard, splitmix_scalar, unpack_scalars)

@@ -51,6 +51,7 @@ def load():
         "kzg_ctx_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
         "kzg_srs_upload_g1": (i32, [vp, vp, sz, i32, c_void_pp]),
         "kzg_srs_setup_g1": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_setup_g1_shard": (i32, [vp, vp, i32, sz, sz, c_void_pp]),
         "kzg_srs_setup_lagrange_g1": (i32, [vp, vp, i32, sz, c_void_pp]),
         "kzg_srs_lagrange_from_monomial_g1": (i32, [vp, vp, c_void_pp]),
         "kzg_srs_download_g1": (i32, [vp, vp, sz, sz, vp, i32]),

@@ -331,6 +331,16 @@ def setup(engine, s, num_coeffs):
     return KZGParams(Srs(engine, h))
 
 
+def setup_shard(engine, s, first, n):
+    """gs[first .. first+n) of setup(s, first+n): the contiguous SRS shard one rank holds."""
+    h = ctypes.c_void_p()
+    rc = engine.lib.kzg_srs_setup_g1_shard(engine.ctx, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, first, n,
+                                           ctypes.byref(h))
+    if rc:
+        _raise(engine, rc)
+    return Srs(engine, h)
+
+
 def setup_lagrange(engine, s, d):
     """lagrange_basis_g for a known secret: same elements as compute_lagrange_basis(&setup(s, d)).0."""
     h = ctypes.c_void_p()

@@ -267,10 +267,10 @@ int fixed_base_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_scalars_mont, s
 }
 
 // scalars for setup(): s^i ; for the Lagrange basis: (s^d - 1) w^i / (d (s - w^i))
-__global__ __launch_bounds__(256) void k_powers(Fr base, size_t n, Fr *out) {
+__global__ __launch_bounds__(256) void k_powers(Fr base, size_t first, size_t n, Fr *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    out[i] = pow_u64(base, (uint64_t)i);
+    out[i] = pow_u64(base, (uint64_t)(first + i));
 }
 
 __global__ __launch_bounds__(256) void k_lagrange_den(Fr s, Fr omega, Fr d_mont, size_t d, Fr *den) {
@@ -368,6 +368,10 @@ static int srs_from_scalars(kzg_ctx *ctx, kzg_srs *s, Fr *d_scalars) {
 }
 
 extern "C" int kzg_srs_setup_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t n, kzg_srs **out) {
+    return kzg_srs_setup_g1_shard(ctx, sec, sfmt, 0, n, out);
+}
+
+extern "C" int kzg_srs_setup_g1_shard(kzg_ctx *ctx, const void *sec, int sfmt, size_t first, size_t n, kzg_srs **out) {
     if (!ctx || !out || !sec) return KZG_ERR_SHAPE;
     std::lock_guard<std::mutex> g(ctx->mu);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
@@ -381,7 +385,7 @@ extern "C" int kzg_srs_setup_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t 
         Fr *sc = nullptr;
         if (hipMalloc((void **)&sc, n * sizeof(Fr)) != hipSuccess) rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(setup scalars)");
         if (rc == KZG_OK) {
-            KZG_LAUNCH(ctx, st, "k_powers", k_powers, (unsigned)((n + 255) / 256), 256, 0, tau, n, sc);
+            KZG_LAUNCH(ctx, st, "k_powers", k_powers, (unsigned)((n + 255) / 256), 256, 0, tau, first, n, sc);
             rc = srs_from_scalars(ctx, s, sc);
         }
         if (sc) hipFree(sc);

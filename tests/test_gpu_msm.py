@@ -187,3 +187,24 @@ def test_msm_batch_and_sum(engine, srs_small):
     assert total == acc
     assert engine.g1_sum([]) == bytes(96)
     assert engine.g1_sum([want[0], C.point_to_blob(M.g1_neg(C.blob_to_point(want[0])))]) == bytes(96)
+
+
+def test_sharded_srs_partials_sum_to_full_commit(engine):
+    """Multi-GPU data path on one GPU: 4 contiguous SRS shards (kzg_srs_setup_g1_shard), one partial MSM
+    each, kzg_g1_sum of the partials == commit against the full SRS == [p(tau)]G."""
+    from kzg_amd.distributed import shard_range
+    rng = random.Random(77)
+    n, world = 1 << 12, 4
+    coeffs = rand_scalars(rng, n)
+    full = kzg_amd.setup(engine, TAU, n)
+    want = kzg_amd.KZGProver(full).commit(kzg_amd.Polynomial(coeffs))
+    assert want == C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU))
+    parts = []
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        shard = kzg_amd.setup_shard(engine, TAU, lo, hi - lo)
+        assert shard.download() == full.gs.download(lo, hi - lo)
+        parts.append(engine.msm(shard, coeffs[lo:hi]))
+        shard.free()
+    assert engine.g1_sum(parts) == want
+    full.gs.free()

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_fmul(F *out, const F *in, int iters) {
 
 __global__ __launch_bounds__(256) void k_madd(G1Xyzz *out, const G1Affine *pts, int iters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    G1Xyzz acc = G1Xyzz::from_affine(pts[i]);
+    G1Xyzz acc = G1Xyzz::from_affine(pts[i & 4095]);
     for (int k = 0; k < iters; k++) acc = g1_madd(acc, pts[(i + k + 1) & 4095]);
     out[i] = acc;
 }
