@@ -1,13 +1,386 @@
-// witness.hip -- (temporary stubs; replaced by the batched-witness / coset / group-iNTT implementation)
+// witness.hip -- KZGProver::create_witness_batched (src/coeff_form.rs:83-111), coset NTTs
+// (src/ft.rs:142-178) and compute_lagrange_basis from the monomial SRS (src/eval_form.rs:254-280).
+//
+// create_witness_batched returns r = I (the interpolant of the k points) and w = [(p - I)/Z]_1 with
+// Z = prod (X - x_i).  The reference builds a sub-product tree and runs an (n-k) x (k+1) schoolbook
+// long_division whose outer loop is sequential (2.7e8 dependent mul-subs at n = 2^20, k = 256).  The
+// same polynomials are obtained here by GPU-shaped algorithms (results are unique, so parity holds):
+//   * Z: k sequential multiplications by (X - x_i), each a k-wide parallel update (one workgroup);
+//   * I: barycentric form  I = sum_i y_i / Z'(x_i) * Z/(X - x_i)  -- one thread per point for
+//     Z'(x_i) = prod_{j != i}(x_i - x_j) and for the synthetic division Z/(X - x_i), one batch
+//     inversion, then a column sum;
+//   * (p - I)/Z: evaluate p, I, Z on the coset g*H (|H| = N >= n), divide pointwise (one batch
+//     inversion), interpolate back: three forward coset NTTs + one inverse.  The division is exact iff
+//     the top k coefficients of the interpolated quotient vanish, which is the reference's
+//     `Some(remainder) => Err(PointNotOnPolynomial)` test.
 #include "common.h"
+
+namespace kzg {
+
+// ---------------------------------------------------------------------------------------------
+// distribute_powers: v[i] *= g^i   (src/ft.rs:142-166)
+// ---------------------------------------------------------------------------------------------
+constexpr int DP_E = 8;
+__global__ __launch_bounds__(256) void k_distribute_powers(Fr *data, size_t n, Fr g, Fr scale) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t i0 = t * DP_E;
+    if (i0 >= n) return;
+    Fr u = mul(scale, pow_u64(g, (uint64_t)i0));
+#pragma unroll
+    for (int k = 0; k < DP_E; k++) {
+        if (i0 + k < n) {
+            data[i0 + k] = mul(data[i0 + k], u);
+            u = mul(u, g);
+        }
+    }
+}
+
+static void distribute_powers(kzg_ctx *ctx, hipStream_t st, Fr *d, size_t n, const Fr &g) {
+    size_t threads = (n + DP_E - 1) / DP_E;
+    KZG_LAUNCH(ctx, st, "k_distribute_powers", k_distribute_powers, (unsigned)((threads + 255) / 256), 256, 0, d, n, g, Fr::one());
+}
+
+// coset_fft: distribute_powers(g) then fft; icoset_fft: ifft then distribute_powers(g^-1)
+static int coset_ntt_run(kzg_ctx *ctx, int lane, Fr *d, uint32_t log_n, int inverse, const Fr &g) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    size_t n = (size_t)1 << log_n;
+    if (!inverse) {
+        distribute_powers(ctx, st, d, n, g);
+        return ntt_run(ctx, lane, d, log_n, 0);
+    }
+    KZG_TRY(ntt_run(ctx, lane, d, log_n, 1));
+    distribute_powers(ctx, st, d, n, inv(g));
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// interpolation through k points (single workgroup kernels; k <= 4096)
+// ---------------------------------------------------------------------------------------------
+// Z = prod_i (X - x_i): z has k+1 coefficients.  One block of 1024 threads, ping-pong in global memory.
+__global__ __launch_bounds__(1024) void k_vanishing_poly(const Fr *xs, uint32_t k, Fr *z0, Fr *z1) {
+    // z0 = 1
+    for (uint32_t j = threadIdx.x; j <= k; j += blockDim.x) {
+        z0[j] = (j == 0) ? Fr::one() : Fr::zero();
+        z1[j] = Fr::zero();
+    }
+    __syncthreads();
+    Fr *cur = z0, *nxt = z1;
+    for (uint32_t i = 0; i < k; i++) {
+        Fr x = xs[i];
+        // (cur of degree i) * (X - x): nxt[j] = cur[j-1] - x cur[j]
+        for (uint32_t j = threadIdx.x; j <= i + 1; j += blockDim.x) {
+            Fr lo = (j <= i) ? mul(x, cur[j]) : Fr::zero();
+            Fr hi = (j >= 1) ? cur[j - 1] : Fr::zero();
+            nxt[j] = sub(hi, lo);
+        }
+        __threadfence_block();
+        __syncthreads();
+        Fr *t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    if (cur != z0) {
+        for (uint32_t j = threadIdx.x; j <= k; j += blockDim.x) z0[j] = cur[j];
+    }
+}
+
+// den[i] = Z'(x_i) = prod_{j != i} (x_i - x_j)
+__global__ __launch_bounds__(256) void k_bary_den(const Fr *xs, uint32_t k, Fr *den) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    Fr xi = xs[i];
+    Fr acc = Fr::one();
+    for (uint32_t j = 0; j < k; j++) {
+        if (j == i) continue;
+        acc = mul(acc, sub(xi, xs[j]));
+    }
+    den[i] = acc;
+}
+
+// row i of the k x k matrix: c_i * Z/(X - x_i), c_i = y_i * den_inv_i (synthetic division from the top)
+__global__ __launch_bounds__(256) void k_bary_rows(const Fr *xs, const Fr *ys, const Fr *den_inv, const Fr *z, uint32_t k,
+                                                   Fr *rows) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    Fr xi = xs[i];
+    Fr c = mul(ys[i], den_inv[i]);
+    Fr carry = z[k];  // leading coefficient (1)
+    for (uint32_t j = k; j-- > 0;) {
+        rows[(size_t)j * k + i] = mul(c, carry);  // coefficient j of Z/(X - x_i), stored column-major
+        carry = add(z[j], mul(xi, carry));
+    }
+}
+
+// I_j = sum_i rows[j][i]
+__global__ __launch_bounds__(256) void k_bary_colsum(const Fr *rows, uint32_t k, Fr *out) {
+    __shared__ Fr sh[256];
+    uint32_t j = blockIdx.x;
+    Fr acc = Fr::zero();
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) acc = add(acc, rows[(size_t)j * k + i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] = sh[0];
+}
+
+// flag |= 1 if any of v[0..n) is zero
+__global__ __launch_bounds__(256) void k_any_zero(const Fr *v, size_t n, int *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && v[i].is_zero()) atomicOr(flag, 1);
+}
+// flag |= 2 if any of v[0..n) is non-zero
+__global__ __launch_bounds__(256) void k_any_nonzero(const Fr *v, size_t n, int *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && !v[i].is_zero()) atomicOr(flag, 2);
+}
+
+// flag |= 2 if a and b differ anywhere
+__global__ __launch_bounds__(256) void k_any_diff(const Fr *a, const Fr *b, size_t n, int *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicOr(flag, 2);
+}
+
+// a[i] = (a[i] - b[i]) * cinv[i]
+__global__ __launch_bounds__(256) void k_sub_mul(Fr *a, const Fr *b, const Fr *cinv, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = mul(sub(a[i], b[i]), cinv[i]);
+}
+
+// dst[0..n) = src[0..m) zero-extended, converted to Montgomery form if `to_m`
+__global__ __launch_bounds__(256) void k_load_padded(const Fr *src, size_t m, Fr *dst, size_t n, int to_m) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fr v = i < m ? src[i] : Fr::zero();
+    dst[i] = (to_m && i < m) ? to_mont(v) : v;
+}
+
+// p'[0..n2): p' = p - (X + (y - x)) for the k == 1 quirk (src/polynomial.rs:244-247)
+__global__ __launch_bounds__(256) void k_sub_linear(const Fr *src, size_t n, Fr *dst, size_t n2, Fr c0) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n2) return;
+    Fr v = i < n ? src[i] : Fr::zero();
+    if (i == 0) v = sub(v, c0);
+    if (i == 1) v = sub(v, Fr::one());
+    dst[i] = v;
+}
+
+static inline unsigned gridfor(size_t n, unsigned b = 256) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace kzg
+
 using namespace kzg;
-extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *, const void *, size_t, const void *, const void *,
-                                         size_t, int, int, void *, int, void *, size_t *) {
-    return ctx ? fail(ctx, KZG_ERR_INTERNAL, "kzg_witness_coeff_batched: not implemented yet") : KZG_ERR_SHAPE;
+
+static int hscalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
+    Fr v;
+    memcpy(v.v, s, 32);
+    if (sfmt == KZG_FR_CANONICAL_LE_32) {
+        if (!is_canonical(v)) return fail(ctx, KZG_ERR_SHAPE, "scalar not canonical (>= r)");
+        v = to_mont(v);
+    } else if (sfmt != KZG_FR_MONT_LE_32) {
+        return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    }
+    *mont = v;
+    return KZG_OK;
 }
-extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *, uint32_t, int, int, int) {
-    return ctx ? fail(ctx, KZG_ERR_INTERNAL, "kzg_coset_ntt_fr: not implemented yet") : KZG_ERR_SHAPE;
+
+static int finish_point_host(kzg_ctx *ctx, const G1Xyzz *d_pt, void *out, int ofmt, int flags) {
+    size_t psz = point_format_bytes(ofmt);
+    hipStream_t st = ctx->lanes[0].stream;
+    if (flags & KZG_OUT_DEVICE) {
+        KZG_TRY(emit_point(ctx, 0, d_pt, out, ofmt));
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+        return KZG_OK;
+    }
+    void *d = lane_alloc(ctx, 0, 256);
+    if (!d) return fail(ctx, KZG_ERR_ALLOC, "output staging not reserved");
+    KZG_TRY(emit_point(ctx, 0, d_pt, d, ofmt));
+    KZG_TRY(lane_pinned(ctx, 0, 4096));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[0].pinned, d, psz, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    memcpy(out, ctx->lanes[0].pinned, psz);
+    return KZG_OK;
 }
-extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *, kzg_srs **) {
-    return ctx ? fail(ctx, KZG_ERR_INTERNAL, "kzg_srs_lagrange_from_monomial_g1: not implemented yet") : KZG_ERR_SHAPE;
+
+extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int sfmt, int flags) {
+    if (!ctx || !data) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    (void)sfmt;  // linear map with Montgomery constants: the data's form is preserved
+    if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    size_t n = (size_t)1 << log_n;
+    KZG_TRY(lane_reserve(ctx, 0, 2 * n * 32 + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    Fr *d = (flags & KZG_IN_DEVICE) ? (Fr *)data : (Fr *)lane_alloc(ctx, 0, n * 32);
+    if (!d) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    if (!(flags & KZG_IN_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(d, data, n * 32, hipMemcpyHostToDevice, st));
+    KZG_TRY(coset_ntt_run(ctx, 0, d, log_n, inverse, from_u64<FrParams>(FR_MULT_GENERATOR)));
+    if (!(flags & KZG_IN_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
+extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *xs,
+                                         const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt,
+                                         void *out_r, size_t *out_r_len) {
+    if (!ctx || !srs || !coeffs || !xs || !ys || !out_w || !out_r || !out_r_len || n == 0) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no opening points (the reference recurses without bound on an empty slice)");
+    if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "more than 4096 opening points is not supported");
+    const int to_m = sfmt == KZG_FR_CANONICAL_LE_32;
+    hipStream_t st = ctx->lanes[0].stream;
+
+    // ---- k == 1: the reference's interpolant is X + (y - x) (src/polynomial.rs:244-247) -----------
+    if (k == 1) {
+        Fr xm, ym;
+        KZG_TRY(hscalar(ctx, xs, sfmt, &xm));
+        KZG_TRY(hscalar(ctx, ys, sfmt, &ym));
+        size_t n2 = n < 2 ? 2 : n;
+        if (n2 - 1 > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
+        KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n2 - 1) + 4 * n2 * 32 + (n2 / 2048 + 8) * 64 + 65536));
+        Fr *p = (Fr *)lane_alloc(ctx, 0, n2 * 32), *pin = (Fr *)lane_alloc(ctx, 0, n2 * 32), *q = (Fr *)lane_alloc(ctx, 0, n2 * 32);
+        Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
+        if (!p || !pin || !q || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(n2), 256, 0, pin, n, p, n2, to_m);
+        KZG_LAUNCH(ctx, st, "k_sub_linear", k_sub_linear, gridfor(n2), 256, 0, p, n2, p, n2, sub(ym, xm));
+        KZG_TRY(quotient_linear_run(ctx, 0, p, n2, xm, q, dpx));
+        Fr px;
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
+        G1Xyzz *res = nullptr;
+        KZG_TRY(msm_run(ctx, 0, srs, 0, q, n2 - 1, KZG_FR_MONT_LE_32, &res));
+        KZG_TRY(finish_point_host(ctx, res, out_w, ofmt, flags));
+        if (ctx->prof) prof_collect(ctx);
+        if (!px.is_zero()) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
+        Fr r0 = sub(ym, xm), r1 = Fr::one();
+        if (to_m) {
+            r0 = from_mont(r0);
+            r1 = from_mont(r1);
+        }
+        memcpy(out_r, r0.v, 32);
+        memcpy((uint8_t *)out_r + 32, r1.v, 32);
+        *out_r_len = 2;
+        return KZG_OK;
+    }
+
+    // ---- k >= 2 -----------------------------------------------------------------------------------
+    const bool small_poly = k >= n;  // deg I = k-1 >= deg p: quotient is zero iff I == p
+    uint32_t log_N = (uint32_t)ilog2_ceil(n > k + 1 ? n : k + 1);
+    if (log_N >= FR_TWO_ADICITY || log_N > 24) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    size_t N = (size_t)1 << log_N;
+    size_t nq = small_poly ? 0 : n - k;
+    if (nq > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
+    size_t need = msm_workspace_bytes(srs, nq ? nq : 1) + 6 * N * 32 + (size_t)k * k * 32 + 16 * (k + 2) * 32 + 65536;
+    KZG_TRY(lane_reserve(ctx, 0, need));
+    Fr *dx = (Fr *)lane_alloc(ctx, 0, k * 32), *dy = (Fr *)lane_alloc(ctx, 0, k * 32);
+    Fr *z0 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32);
+    Fr *den = (Fr *)lane_alloc(ctx, 0, k * 32), *deni = (Fr *)lane_alloc(ctx, 0, k * 32);
+    Fr *rows = (Fr *)lane_alloc(ctx, 0, (size_t)k * k * 32), *I = (Fr *)lane_alloc(ctx, 0, k * 32);
+    Fr *A = (Fr *)lane_alloc(ctx, 0, N * 32), *Bv = (Fr *)lane_alloc(ctx, 0, N * 32), *Cv = (Fr *)lane_alloc(ctx, 0, N * 32);
+    Fr *Ci = (Fr *)lane_alloc(ctx, 0, N * 32), *pin = (Fr *)lane_alloc(ctx, 0, N * 32);
+    int *flag = (int *)lane_alloc(ctx, 0, 256);
+    if (!dx || !dy || !z0 || !z1 || !den || !deni || !rows || !I || !A || !Bv || !Cv || !Ci || !pin || !flag)
+        return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    KZG_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, sizeof(int), st));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(dx, xs, k * 32, hipMemcpyHostToDevice, st));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(dy, ys, k * 32, hipMemcpyHostToDevice, st));
+    if (to_m) {
+        KZG_TRY(fr_convert(ctx, st, dx, k, 1));
+        KZG_TRY(fr_convert(ctx, st, dy, k, 1));
+    }
+    // interpolant
+    KZG_LAUNCH(ctx, st, "k_vanishing_poly", k_vanishing_poly, 1, 1024, 0, dx, (uint32_t)k, z0, z1);
+    KZG_LAUNCH(ctx, st, "k_bary_den", k_bary_den, gridfor(k), 256, 0, dx, (uint32_t)k, den);
+    KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(k), 256, 0, den, k, flag);  // duplicate x_i
+    KZG_TRY(batch_inverse(ctx, st, den, deni, k));
+    KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows, gridfor(k), 256, 0, dx, dy, deni, z0, (uint32_t)k, rows);
+    KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, rows, (uint32_t)k, I);
+    // numerator and divisor on the coset g*H
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, pin, n, A, N, to_m);
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, I, k, Bv, N, 0);
+    G1Xyzz *res = nullptr;
+    int hflag = 0;
+    if (small_poly) {
+        // deg I <= k-1 and deg p <= n-1 <= k-1: the quotient is zero and the division is exact iff p == I
+        KZG_LAUNCH(ctx, st, "k_any_diff", k_any_diff, gridfor(N), 256, 0, A, Bv, N, flag);
+        KZG_TRY(msm_run(ctx, 0, srs, 0, A, 0, KZG_FR_MONT_LE_32, &res));  // identity
+    } else {
+        KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
+        // pick a coset shift on which Z has no root: g = 7, then 7^2, ... (x_i in g*H is a measure-zero event)
+        Fr gsh = from_u64<FrParams>(FR_MULT_GENERATOR);
+        KZG_TRY(coset_ntt_run(ctx, 0, Cv, log_N, 0, gsh));
+        KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(N), 256, 0, Cv, N, flag);
+        KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 0, gsh));
+        KZG_TRY(coset_ntt_run(ctx, 0, Bv, log_N, 0, gsh));
+        KZG_TRY(batch_inverse(ctx, st, Cv, Ci, N));
+        KZG_LAUNCH(ctx, st, "k_sub_mul", k_sub_mul, gridfor(N), 256, 0, A, Bv, Ci, N);
+        KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 1, gsh));
+        // exact division <=> deg q <= N-1-k <=> the top k coefficients vanish
+        KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);
+        KZG_TRY(msm_run(ctx, 0, srs, 0, A, nq, KZG_FR_MONT_LE_32, &res));
+    }
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (to_m) KZG_TRY(fr_convert(ctx, st, I, k, 0));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(out_r, I, k * 32, hipMemcpyDeviceToHost, st));
+    KZG_TRY(finish_point_host(ctx, res, out_w, ofmt, flags));
+    if (ctx->prof) prof_collect(ctx);
+    if (hflag & 1) {
+        // a zero denominator: either duplicate opening points (the reference unwrap()s an invert() of zero)
+        // or a root of Z on the coset; the latter has probability ~ k*N/r and is reported, not hidden
+        return fail(ctx, KZG_ERR_SHAPE, "duplicate opening points (reference: invert().unwrap() panic) or Z has a root on the coset");
+    }
+    if (hflag & 2) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
+    *out_r_len = k;
+    return KZG_OK;
+}
+
+// compute_lagrange_basis (src/eval_form.rs:254-280), G1 half.  The reference builds each l_i by d-1
+// polynomial multiplications (O(d^3) field work) and commits to it; l_i has the closed form
+// l_i(X) = (1/d) sum_j w^(-ij) X^j, so row i is one MSM of the monomial SRS with scalars w^(-ij)/d.
+// O(d) MSMs of size d: meant for the sizes the reference can handle; large Lagrange SRSs come from
+// kzg_srs_setup_lagrange_g1 (known secret) or a ceremony file via kzg_srs_upload_g1.
+extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mono, kzg_srs **out) {
+    if (!ctx || !mono || !out) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t d = mono->n;
+    if (d == 0 || (d & (d - 1))) return fail(ctx, KZG_ERR_SHAPE, "assert!(d & (d - 1) == 0) (src/eval_form.rs:255-256)");
+    uint32_t exp = (uint32_t)ilog2_ceil(d);
+    if (exp >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
+    if (d > ((size_t)1 << 14)) return fail(ctx, KZG_ERR_SHAPE, "compute_lagrange_basis from the monomial SRS is limited to d <= 2^14; use kzg_srs_setup_lagrange_g1 or upload the basis");
+    hipStream_t st = ctx->lanes[0].stream;
+    kzg_srs *s = nullptr;
+    KZG_TRY(srs_alloc(ctx, d, &s));
+    G1Xyzz *rows = nullptr;
+    int rc = KZG_OK;
+    if (hipMalloc((void **)&rows, d * sizeof(G1Xyzz)) != hipSuccess) rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange rows)");
+    Fr omega_inv = inv(host_omega(exp));
+    Fr dinv = inv(from_u64<FrParams>((uint64_t)d));
+    for (size_t i = 0; i < d && rc == KZG_OK; i++) {
+        rc = lane_reserve(ctx, 0, msm_workspace_bytes(mono, d) + d * 32 + 65536);
+        Fr *sc = rc == KZG_OK ? (Fr *)lane_alloc(ctx, 0, d * 32) : nullptr;
+        if (rc == KZG_OK && !sc) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
+        if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(omega_inv, (uint64_t)i), dinv, d, sc);
+        G1Xyzz *res = nullptr;
+        if (rc == KZG_OK) rc = msm_run(ctx, 0, mono, 0, sc, d, KZG_FR_MONT_LE_32, &res);
+        if (rc == KZG_OK && hipMemcpyAsync(rows + i, res, sizeof(G1Xyzz), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            rc = fail(ctx, KZG_ERR_HIP, "copy");
+    }
+    if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, rows);
+    hipStreamSynchronize(st);
+    if (rows) hipFree(rows);
+    if (rc != KZG_OK) {
+        hipFree(s->table);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
 }

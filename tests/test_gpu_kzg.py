@@ -124,3 +124,107 @@ def test_eval_form(engine, d):
         prover.commit(short)  # assert!(self.d == evals.d)
     assert prover.create_witness_all() == bytes(96)
     params.gs.free(); lag.free()
+
+
+def _batched_oracle(coeffs, xs, ys, tau):
+    """Reference semantics via the python model (sub-product tree + long_division) and known tau."""
+    p = M.Polynomial(coeffs)
+    tree = M.SubProductTree.new_from_points(xs)
+    I = M.Polynomial.lagrange_interpolation_with_tree(xs, ys, tree)
+    Z = 1
+    for v in xs:
+        Z = Z * (tau - v) % M.R
+    w = C.g1_mul(G(), (p.eval(tau) - I.eval(tau)) * M.fr_inv(Z) % M.R)
+    return I, w
+
+
+@pytest.mark.parametrize("n,k", [(15, 8), (64, 2), (300, 7), (1024, 256), (5000, 33)])
+def test_create_witness_batched(engine, n, k):
+    """test_eval_batched (src/coeff_form.rs:344-375): r == interpolant, w == [(p - I)/Z]_1; other points fail."""
+    rng = random.Random(600 + n + k)
+    tau = rng.getrandbits(64)
+    params = kzg_amd.setup(engine, tau, n)
+    prover = kzg_amd.KZGProver(params)
+    coeffs = [rng.getrandbits(64) for _ in range(n)] if n < 100 else rand_scalars(rng, n)
+    p = kzg_amd.Polynomial(coeffs)
+    xs = rand_scalars(rng, k)
+    ys = [C.poly_eval(coeffs, x) for x in xs]
+    wit = prover.create_witness_batched(p, xs, ys)
+    I, w = _batched_oracle(coeffs, xs, ys, tau)
+    assert wit.polynomial().coeffs == I.coeffs[:k] and wit.polynomial().degree == k - 1
+    assert wit.elem() == w
+    if n <= 300:  # the reference's own path end to end: long_division by the tree product + MSM
+        num = M.Polynomial(coeffs).sub_ref(I)
+        psi, rem = num.long_division(M.SubProductTree.new_from_points(xs).product)
+        assert rem is None
+        assert wit.elem() == C.msm_g1(params.gs.download(0, psi.num_coeffs()), psi.slice_coeffs())
+    bad = list(ys)
+    bad[k // 2] = (bad[k // 2] + 1) % M.R
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        prover.create_witness_batched(p, xs, bad)
+    params.gs.free()
+
+
+def test_create_witness_batched_edge_cases(engine):
+    rng = random.Random(77)
+    tau = rng.getrandbits(64)
+    n = 14
+    params = kzg_amd.setup(engine, tau, 15)
+    prover = kzg_amd.KZGProver(params)
+    coeffs = [rng.getrandbits(64) for _ in range(n)]
+    p = kzg_amd.Polynomial(coeffs)
+    # test_eval_batched_all_points (src/coeff_form.rs:377-397): k == num_coeffs -> zero quotient -> identity
+    xs = [rng.getrandbits(64) for _ in range(n)]
+    ys = [C.poly_eval(coeffs, x) for x in xs]
+    wit = prover.create_witness_batched(p, xs, ys)
+    assert wit.elem() == bytes(96)
+    assert wit.polynomial().coeffs == coeffs           # the interpolant is p itself
+    ys2 = list(ys); ys2[3] = (ys2[3] + 5) % M.R
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        prover.create_witness_batched(p, xs, ys2)
+    # k == 1 quirk (src/polynomial.rs:244-247): r = X + (y - x), w = [(p - r)/(X - x)]
+    x = rng.getrandbits(64)
+    y = C.poly_eval(coeffs, x)
+    wit = prover.create_witness_batched(p, [x], [y])
+    assert wit.polynomial().coeffs == [(y - x) % M.R, 1] and wit.polynomial().degree == 1
+    Ir, w = _batched_oracle(coeffs, [x], [y], tau)
+    assert Ir.coeffs == [(y - x) % M.R, 1] and wit.elem() == w
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        prover.create_witness_batched(p, [x], [(y + 1) % M.R])
+    # duplicate opening points: the reference panics (invert of zero)
+    with pytest.raises(kzg_amd.ReferencePanic):
+        prover.create_witness_batched(p, [5, 5, 6], [C.poly_eval(coeffs, 5)] * 2 + [C.poly_eval(coeffs, 6)])
+    params.gs.free()
+
+
+@pytest.mark.parametrize("log_n", [0, 3, 9, 13])
+def test_coset_fft_roundtrip_and_values(engine, log_n):
+    """coset_fft / icoset_fft (src/ft.rs:168-178) vs the python model; fft_composition round trips."""
+    rng = random.Random(700 + log_n)
+    xs = rand_scalars(rng, 1 << log_n)
+    got = engine.coset_ntt(xs, log_n)
+    if log_n <= 9:
+        e = M.EvaluationDomain.from_coeffs(xs)
+        e.coset_fft()
+        assert got == e.coeffs
+        e.icoset_fft()
+        assert e.coeffs == xs
+    assert engine.coset_ntt(got, log_n, inverse=True) == xs
+    assert engine.coset_ntt(engine.coset_ntt(xs, log_n, inverse=True), log_n) == xs
+
+
+@pytest.mark.parametrize("d", [1, 2, 8, 64])
+def test_compute_lagrange_basis_from_monomial(engine, d):
+    """compute_lagrange_basis (src/eval_form.rs:254-280) from the monomial SRS alone."""
+    tau = 0xABCDEF0123
+    params = kzg_amd.setup(engine, tau, d)
+    lag = kzg_amd.compute_lagrange_basis(params)
+    want = kzg_amd.setup_lagrange(engine, tau, d)
+    assert lag.download() == want.download()
+    if d <= 8:
+        mp = M.KZGParams(M.setup_g1(tau, d))
+        assert lag.download() == b"".join(M.g1_to_affine_mont(P) for P in M.compute_lagrange_basis_g1(mp))
+    odd = kzg_amd.setup(engine, tau, 6)
+    with pytest.raises(kzg_amd.ReferencePanic):
+        kzg_amd.compute_lagrange_basis(odd)
+    params.gs.free(); lag.free(); want.free(); odd.gs.free()
