@@ -276,7 +276,7 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     size_t N = (size_t)1 << log_N;
     size_t nq = small_poly ? 0 : n - k;
     if (nq > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
-    size_t need = msm_workspace_bytes(srs, nq ? nq : 1) + 6 * N * 32 + (size_t)k * k * 32 + 16 * (k + 2) * 32 + 65536;
+    size_t need = msm_workspace_bytes(srs, nq ? nq : 1) + 12 * N * 32 + (size_t)k * k * 32 + 16 * (k + 2) * 32 + (1 << 20);
     KZG_TRY(lane_reserve(ctx, 0, need));
     Fr *dx = (Fr *)lane_alloc(ctx, 0, k * 32), *dy = (Fr *)lane_alloc(ctx, 0, k * 32);
     Fr *z0 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32);
