@@ -1,0 +1,66 @@
+"""The HIP path against the committed golden fixtures (tests/golden/*.json), through the C ABI, using the
+canonical wire formats (32-byte LE scalars, zcash-compressed G1) on both input and output."""
+import pytest
+
+import kzg_amd
+from kzg_amd import _lib as L
+from tests import golden_util as GU
+from tests.gpu_common import engine  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", GU.load("msm.json")["cases"], ids=lambda c: c["name"])
+def test_golden_msm(engine, case):
+    raw = b"".join(bytes.fromhex(h) for h in case["points"])
+    n = len(case["points"])
+    srs = kzg_amd.Srs.upload(engine, raw, n, L.G1_ZCASH_COMPRESSED)
+    scal = b"".join(bytes.fromhex(h) for h in case["scalars"])
+    assert engine.msm(srs, scal, ofmt=L.G1_ZCASH_COMPRESSED).hex() == case["result"]
+    srs.free()
+
+
+@pytest.mark.parametrize("case", GU.load("ntt.json")["cases"], ids=lambda c: f"log{c['log_n']}")
+def test_golden_ntt(engine, case):
+    xs = [GU.sc(h) for h in case["input"]]
+    want = [GU.sc(h) for h in case["fft"]]
+    assert engine.ntt(xs, case["log_n"]) == want
+    assert engine.ntt(want, case["log_n"], inverse=True) == xs
+    assert kzg_amd.compute_omega(len(xs))[2] == GU.sc(case["omega"])
+
+
+def test_golden_kzg(engine):
+    g = GU.load("kzg.json")
+    tau = GU.sc(g["tau"])
+    params = kzg_amd.setup(engine, tau, 16)
+    up = kzg_amd.Srs.upload(engine, b"".join(bytes.fromhex(h) for h in g["srs_compressed"]), 16, L.G1_ZCASH_COMPRESSED)
+    assert params.gs.download() == up.download()
+    prover = kzg_amd.KZGProver(params)
+    c = g["coeff"]
+    p = kzg_amd.Polynomial([GU.sc(h) for h in c["coeffs"]])
+    assert prover.commit(p, ofmt=L.G1_ZCASH_COMPRESSED).hex() == c["commit"]
+    assert prover.create_witness(p, (GU.sc(c["x"]), GU.sc(c["y"])), ofmt=L.G1_ZCASH_COMPRESSED).hex() == c["witness"]
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        prover.create_witness(p, (GU.sc(c["x"]), GU.sc(c["wrong_y"])))
+    d1 = g["degree1"]
+    p1 = kzg_amd.Polynomial([GU.sc(h) for h in d1["coeffs"]] + [0] * 11)
+    assert prover.create_witness(p1, (GU.sc(d1["x"]), GU.sc(d1["y"])), ofmt=L.G1_ZCASH_COMPRESSED).hex() == d1["witness"]
+    b = g["batched"]
+    wit = prover.create_witness_batched(p, [GU.sc(h) for h in b["xs"]], [GU.sc(h) for h in b["ys"]],
+                                        ofmt=L.G1_ZCASH_COMPRESSED)
+    assert wit.elem().hex() == b["w"]
+    assert wit.polynomial().coeffs == [GU.sc(h) for h in b["r"]]
+    e = g["eval"]
+    pe = kzg_amd.setup(engine, tau, e["d"])
+    lag = kzg_amd.compute_lagrange_basis(pe)
+    lag_up = kzg_amd.Srs.upload(engine, b"".join(bytes.fromhex(h) for h in e["lagrange_compressed"]), e["d"],
+                                L.G1_ZCASH_COMPRESSED)
+    assert lag.download() == lag_up.download()
+    evp = kzg_amd.KZGProverEvalForm(pe, lag)
+    ev = kzg_amd.EvaluationDomain.from_coeffs([GU.sc(h) for h in e["coeffs"]])
+    ev.fft(engine)
+    assert ev.coeffs == [GU.sc(h) for h in e["evals"]]
+    assert evp.commit(ev, ofmt=L.G1_ZCASH_COMPRESSED).hex() == e["commit"]
+    assert evp.create_witness(ev, e["index"], ofmt=L.G1_ZCASH_COMPRESSED).hex() == e["witness"]
+    for s in (params.gs, up, pe.gs, lag, lag_up):
+        s.free()
