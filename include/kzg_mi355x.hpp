@@ -1,0 +1,216 @@
+// kzg_mi355x.hpp -- header-only C++ host mirror of the reference's prover surface over the C ABI
+// (include/kzg_mi355x.h).  Same names, argument meaning and error behaviour as proxima-one/kzg:
+//   setup / KZGParams            src/lib.rs:14-55           Polynomial          src/polynomial.rs:24-165
+//   EvaluationDomain             src/ft.rs:17-140           KZGProver           src/coeff_form.rs:37-112
+//   KZGProverEvalForm            src/eval_form.rs:39-147
+// Result<_, KZGError> becomes a thrown kzg::KZGError; a reference panic becomes kzg::ReferencePanic.
+// Scalars are 32-byte canonical little-endian (kzg::Scalar), points 96-byte affine Montgomery (kzg::G1Affine).
+#pragma once
+#include <array>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kzg_mi355x.h"
+
+namespace kzg {
+
+struct Scalar {
+    std::array<uint8_t, 32> le{};  // canonical, < r
+    static Scalar from_u64(uint64_t v) {
+        Scalar s;
+        for (int i = 0; i < 8; i++) s.le[i] = (uint8_t)(v >> (8 * i));
+        return s;
+    }
+    bool operator==(const Scalar &o) const { return le == o.le; }
+    bool is_zero() const {
+        for (auto b : le) if (b) return false;
+        return true;
+    }
+};
+struct G1Affine {
+    std::array<uint8_t, 96> bytes{};  // blst_p1_affine; identity = all zero
+    bool operator==(const G1Affine &o) const { return bytes == o.bytes; }
+};
+using KZGCommitment = G1Affine;  // src/lib.rs:22
+using KZGWitness = G1Affine;     // src/lib.rs:24
+
+struct KZGError : std::runtime_error {  // src/lib.rs:26-36
+    enum Kind { PointNotOnPolynomial = 1, PolynomialDegreeTooLarge = 2 } kind;
+    KZGError(Kind k, const std::string &m) : std::runtime_error(m), kind(k) {}
+};
+struct ReferencePanic : std::runtime_error { using std::runtime_error::runtime_error; };
+struct EngineError : std::runtime_error { using std::runtime_error::runtime_error; };
+
+class Engine {
+  public:
+    explicit Engine(int device = 0) {
+        if (int rc = kzg_ctx_create(device, &ctx_)) throw EngineError("kzg_ctx_create failed (no CPU fallback): " + std::to_string(rc));
+    }
+    ~Engine() { kzg_ctx_destroy(ctx_); }
+    Engine(const Engine &) = delete;
+    Engine &operator=(const Engine &) = delete;
+    kzg_ctx *ctx() const { return ctx_; }
+    void check(int rc) const {
+        if (rc == KZG_OK) return;
+        std::string msg = kzg_last_error(ctx_);
+        if (rc == KZG_ERR_POINT_NOT_ON_POLY) throw KZGError(KZGError::PointNotOnPolynomial, "point not on polynomial!");
+        if (rc == KZG_ERR_DEGREE_TOO_LARGE) throw KZGError(KZGError::PolynomialDegreeTooLarge, "polynomial degree too large");
+        if (rc == KZG_ERR_SHAPE) throw ReferencePanic(msg);
+        throw EngineError("kzg_mi355x error " + std::to_string(rc) + ": " + msg);
+    }
+
+  private:
+    kzg_ctx *ctx_ = nullptr;
+};
+
+// KZGParams (G1 half): `gs` lives on the GPU.
+struct KZGParams {
+    const Engine *engine = nullptr;
+    kzg_srs *gs = nullptr;
+    size_t len() const { return kzg_srs_len(gs); }
+    KZGParams() = default;
+    KZGParams(const KZGParams &) = delete;
+    KZGParams &operator=(const KZGParams &) = delete;
+    KZGParams(KZGParams &&o) noexcept : engine(o.engine), gs(o.gs) { o.gs = nullptr; }
+    ~KZGParams() { if (gs) kzg_srs_free(engine->ctx(), gs); }
+};
+
+inline KZGParams setup(const Engine &e, const Scalar &s, size_t num_coeffs) {  // src/lib.rs:38-55
+    KZGParams p;
+    p.engine = &e;
+    e.check(kzg_srs_setup_g1(e.ctx(), s.le.data(), KZG_FR_CANONICAL_LE_32, num_coeffs, &p.gs));
+    return p;
+}
+
+struct Polynomial {  // src/polynomial.rs:24-27
+    size_t degree = 0;
+    std::vector<Scalar> coeffs;
+    static size_t compute_degree(const std::vector<Scalar> &c, size_t upper) {  // :94-105
+        size_t i = upper;
+        while (i > 0 && c[i].is_zero()) i--;
+        return i;
+    }
+    static Polynomial make(std::vector<Scalar> c) {  // Polynomial::new, :83-87
+        Polynomial p;
+        p.degree = compute_degree(c, c.size() - 1);
+        p.coeffs = std::move(c);
+        return p;
+    }
+    static Polynomial new_from_coeffs(std::vector<Scalar> c, size_t degree) {  // :89-92
+        Polynomial p;
+        p.degree = degree;
+        p.coeffs = std::move(c);
+        return p;
+    }
+    size_t num_coeffs() const { return degree + 1; }  // :135-137
+    Scalar eval(const Engine &e, const Scalar &x) const {  // :156-165
+        Scalar y;
+        e.check(kzg_poly_eval(e.ctx(), coeffs.data(), num_coeffs(), x.le.data(), KZG_FR_CANONICAL_LE_32, 0, y.le.data()));
+        return y;
+    }
+};
+
+struct EvaluationDomain {  // src/ft.rs:17-25
+    std::vector<Scalar> coeffs;
+    size_t d = 0;
+    uint32_t exp = 0;
+    Scalar omega;
+    static EvaluationDomain from_coeffs(std::vector<Scalar> c) {  // :94-109
+        EvaluationDomain e;
+        int rc = kzg_compute_omega(c.size(), &e.d, &e.exp, e.omega.le.data(), KZG_FR_CANONICAL_LE_32);
+        if (rc == KZG_ERR_DEGREE_TOO_LARGE) throw KZGError(KZGError::PolynomialDegreeTooLarge, "polynomial degree too large");
+        c.resize(e.d);
+        e.coeffs = std::move(c);
+        return e;
+    }
+    size_t len() const { return coeffs.size(); }
+    void fft(const Engine &e) { e.check(kzg_ntt_fr(e.ctx(), coeffs.data(), exp, 0, 0)); }   // :111-113
+    void ifft(const Engine &e) { e.check(kzg_ntt_fr(e.ctx(), coeffs.data(), exp, 1, 0)); }  // :115-140
+    void coset_fft(const Engine &e) { e.check(kzg_coset_ntt_fr(e.ctx(), coeffs.data(), exp, 0, KZG_FR_CANONICAL_LE_32, 0)); }
+    void icoset_fft(const Engine &e) { e.check(kzg_coset_ntt_fr(e.ctx(), coeffs.data(), exp, 1, KZG_FR_CANONICAL_LE_32, 0)); }
+};
+
+struct KZGBatchWitness {  // src/coeff_form.rs:12-35
+    Polynomial r;
+    G1Affine w;
+    const G1Affine &elem() const { return w; }
+    const Polynomial &polynomial() const { return r; }
+};
+
+class KZGProver {  // src/coeff_form.rs:37-112
+  public:
+    explicit KZGProver(const KZGParams &params) : params_(params), e_(*params.engine) {}
+    const KZGParams &parameters() const { return params_; }
+    KZGCommitment commit(const Polynomial &p) const {  // :59-64
+        G1Affine out;
+        e_.check(kzg_commit_coeff(e_.ctx(), params_.gs, p.coeffs.data(), p.num_coeffs(), KZG_FR_CANONICAL_LE_32, 0,
+                                  out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+    KZGWitness create_witness(const Polynomial &p, const Scalar &x, const Scalar &y) const {  // :66-81
+        G1Affine out;
+        e_.check(kzg_witness_coeff(e_.ctx(), params_.gs, p.coeffs.data(), p.num_coeffs(), x.le.data(), y.le.data(),
+                                   KZG_FR_CANONICAL_LE_32, 0, out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+    KZGBatchWitness create_witness_batched(const Polynomial &p, const std::vector<Scalar> &xs,
+                                           const std::vector<Scalar> &ys) const {  // :83-111
+        if (xs.size() != ys.size()) throw ReferencePanic("assert_eq!(xs.len(), ys.len())");
+        KZGBatchWitness wit;
+        std::vector<Scalar> r(xs.size() < 2 ? 2 : xs.size());
+        size_t rlen = 0;
+        e_.check(kzg_witness_coeff_batched(e_.ctx(), params_.gs, p.coeffs.data(), p.num_coeffs(), xs.data(), ys.data(),
+                                           xs.size(), KZG_FR_CANONICAL_LE_32, 0, wit.w.bytes.data(), KZG_G1_AFFINE_MONT_96,
+                                           r.data(), &rlen));
+        r.resize(rlen);
+        wit.r = Polynomial::new_from_coeffs(std::move(r), rlen - 1);
+        return wit;
+    }
+    bool verify_poly(const KZGCommitment &c, const Polynomial &p) const {  // KZGVerifier::verify_poly, :119-124
+        int ok = 0;
+        e_.check(kzg_verify_poly_coeff(e_.ctx(), params_.gs, c.bytes.data(), KZG_G1_AFFINE_MONT_96, p.coeffs.data(),
+                                       p.num_coeffs(), KZG_FR_CANONICAL_LE_32, 0, &ok));
+        return ok != 0;
+    }
+
+  private:
+    const KZGParams &params_;
+    const Engine &e_;
+};
+
+class KZGProverEvalForm {  // src/eval_form.rs:39-147
+  public:
+    KZGProverEvalForm(const KZGParams &params, const kzg_srs *lagrange_basis_g)  // :88-100
+        : params_(params), lag_(lagrange_basis_g), e_(*params.engine) {
+        int rc = kzg_compute_omega(params.len(), &d_, &exp_, omega_.le.data(), KZG_FR_CANONICAL_LE_32);
+        if (rc) throw ReferencePanic("compute_omega(...).unwrap()");
+    }
+    size_t degree() const { return d_; }
+    Scalar omega() const { return omega_; }
+    KZGCommitment commit(const EvaluationDomain &ev) const {  // :114-122
+        if (d_ != ev.d) throw ReferencePanic("assert!(self.d == evals.d)");
+        G1Affine out;
+        e_.check(kzg_commit_eval(e_.ctx(), lag_, ev.coeffs.data(), ev.len(), KZG_FR_CANONICAL_LE_32, 0, out.bytes.data(),
+                                 KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+    KZGWitness create_witness(const EvaluationDomain &ev, size_t i) const {  // :124-140
+        G1Affine out;
+        e_.check(kzg_witness_eval(e_.ctx(), lag_, ev.coeffs.data(), ev.len(), i, KZG_FR_CANONICAL_LE_32, 0,
+                                  out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+    KZGWitness create_witness_all() const { return G1Affine{}; }  // :142-146: the identity
+
+  private:
+    const KZGParams &params_;
+    const kzg_srs *lag_;
+    const Engine &e_;
+    size_t d_ = 0;
+    uint32_t exp_ = 0;
+    Scalar omega_;
+};
+
+}  // namespace kzg

@@ -1,0 +1,36 @@
+// Exercises include/kzg_mi355x.hpp (the C++ host mirror) on the GPU: the reference's test_eval_basic
+// degree-1 edge case (src/coeff_form.rs:332-341) and commit/verify_poly (test_basic, :271-285).
+#include <cstdio>
+#include "../include/kzg_mi355x.hpp"
+using namespace kzg;
+int main() {
+    Engine e(0);
+    KZGParams params = setup(e, Scalar::from_u64(0x1234567), 13);
+    KZGProver prover(params);
+    std::vector<Scalar> c(13);
+    c[0] = Scalar::from_u64(3);
+    c[1] = Scalar::from_u64(1);
+    Polynomial p = Polynomial::make(c);
+    if (p.num_coeffs() != 2) return 1;
+    if (!(p.eval(e, Scalar::from_u64(1)) == Scalar::from_u64(4))) return 2;
+    KZGCommitment cm = prover.commit(p);
+    if (!prover.verify_poly(cm, p)) return 3;
+    KZGWitness w = prover.create_witness(p, Scalar::from_u64(1), Scalar::from_u64(4));  // quotient = 1 -> gs[0]
+    uint8_t g[96];
+    if (kzg_srs_download_g1(e.ctx(), params.gs, 0, 1, g, KZG_G1_AFFINE_MONT_96)) return 4;
+    if (std::memcmp(w.bytes.data(), g, 96) != 0) return 5;
+    try {
+        prover.create_witness(p, Scalar::from_u64(1), Scalar::from_u64(5));
+        return 6;
+    } catch (const KZGError &err) {
+        if (err.kind != KZGError::PointNotOnPolynomial) return 7;
+    }
+    EvaluationDomain ev = EvaluationDomain::from_coeffs({Scalar::from_u64(1), Scalar::from_u64(2), Scalar::from_u64(3)});
+    if (ev.d != 4 || ev.exp != 2) return 8;
+    std::vector<Scalar> orig = ev.coeffs;
+    ev.fft(e);
+    ev.ifft(e);
+    if (!(ev.coeffs == orig)) return 9;
+    std::printf("cpp mirror ok\n");
+    return 0;
+}
