@@ -10,9 +10,10 @@
 //     buckets: there is no per-window bucket reduction and no window-combine doubling chain.
 //   * Digits -> buckets by a one-pass counting sort whose 2^(c-1)-entry histogram / cursor array
 //     lives in LDS (128 KiB of the CU's 160 KiB at c = 16): k_hist, k_scan_*, k_scatter.
-//   * Bucket accumulation is cut into tasks of at most L1 = 64 sorted entries (k_accum_affine,
-//     XYZZ mixed adds, points gathered from the resident table), then partial sums are folded by
-//     key in rounds of fan-in LK (k_accum_xyzz) until every bucket holds one point.  No atomics, no
+//   * Bucket accumulation (k_accum_affine) is an equal split of the sorted entry list over exactly
+//     the resident thread slots (XYZZ mixed adds, points gathered from the resident table, one partial
+//     per bucket a thread touches), then partial sums are folded by key in rounds of fan-in LK
+//     (k_accum_xyzz) until every bucket holds one point.  No atomics, no
 //     unbounded per-thread chain, so adversarial inputs (all-equal scalars) stay bounded.
 //   * sum_b (b+1) * B_b by chunked running sums + small scalar-muls (k_bucket_reduce), a plain
 //     tree sum (k_sum_level), and one Fq inversion for the affine result (k_emit_point).
@@ -22,7 +23,7 @@
 
 namespace kzg {
 
-constexpr int L1 = 64;  // sorted entries per round-1 task
+constexpr uint32_t ACC_SLOTS = 256 * 8 * 64;  // resident threads of k_accum_affine: 256 CUs x 2 waves/SIMD x 4 SIMDs x 64
 constexpr int LK = 4;   // fan-in of the later fold rounds
 constexpr int SUM_L = 4;  // fan-in of the plain tree sum
 constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
@@ -35,7 +36,8 @@ struct MsmState {
     uint32_t final_level;  // index of the start[] array describing the final partial list
     uint32_t final_buf;    // which ping-pong buffer holds it
     uint32_t max_cnt;
-    uint32_t pad[2];
+    uint32_t E;            // sorted entries per round-1 thread (equal split)
+    uint32_t pad[1];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -141,15 +143,24 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *o
     return total;
 }
 
-// bucket_start[] from total[]; task_start[] for round 1 (ceil(cnt / L1) tasks per bucket)
+// bucket_start[] from total[]; then the round-1 layout.  Round 1 is an EQUAL SPLIT: thread s folds
+// the sorted entries [s*E, (s+1)*E), E = ceil(M / slots), and emits one partial per (thread, bucket) run.
+// Run starts are the multiples of E and the non-empty bucket starts, so the partial list is ordered by
+// bucket and bucket b's partials are [S1[b], S1[b+1]) with
+//     S1[b] = ceil(start[b] / E) + #{non-empty b' < b : start[b'] mod E != 0}.
 __global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t *total, int B, uint32_t *bucket_start,
-                                                       uint32_t *task_start, MsmState *st) {
+                                                       uint32_t *s1, MsmState *st, uint32_t slots) {
     __shared__ uint32_t lds[1024];
     uint32_t M = block_exclusive_scan(B, [&](int b) { return total[b]; }, bucket_start, lds);
-    uint32_t T = block_exclusive_scan(B, [&](int b) { return (total[b] + L1 - 1) / L1; }, task_start, lds);
+    uint32_t E = (M + slots - 1) / slots;
+    if (E < 8) E = 8;
+    block_exclusive_scan(
+        B, [&](int b) { return (total[b] != 0 && (bucket_start[b] % E) != 0) ? 1u : 0u; }, s1, lds);
+    for (int b = threadIdx.x; b <= B; b += blockDim.x) s1[b] += (bucket_start[b] + E - 1) / E;
     if (threadIdx.x == 0) {
         st->M = M;
-        st->ntasks = T;
+        st->E = E;
+        st->ntasks = (M + E - 1) / E;
         st->done = 0;
         st->final_level = 0;
         st->final_buf = 0;
@@ -195,28 +206,49 @@ __device__ __forceinline__ G1Affine load_entry_point(const G1Affine *table, uint
     return p;
 }
 
-// round 1: each task folds <= L1 table points (gathered by sorted entry) into one XYZZ partial
+// round 1 (dominant kernel): thread s folds its E consecutive sorted entries with XYZZ mixed adds,
+// gathering each precomputed affine point from the resident table (next point prefetched under the
+// add), and writes one partial per bucket it touches.  Every thread has the same amount of work, so
+// the kernel ends without a straggler round.
 __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
-                                                      const uint32_t *task_start, int B, const G1Affine *table,
+                                                      const uint32_t *s1, int B, const G1Affine *table,
                                                       G1Xyzz *out, const MsmState *st) {
-    const uint32_t T = st->ntasks;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        uint32_t b, j;
-        find_task(task_start, B, t, b, j);
-        uint32_t s = bucket_start[b] + j * L1;
-        uint32_t e = bucket_start[b + 1];
-        e = s + L1 < e ? s + L1 : e;
-        G1Affine cur = load_entry_point(table, entries[s]);
-        G1Xyzz acc = G1Xyzz::from_affine(cur);
-        if (s + 1 < e) cur = load_entry_point(table, entries[s + 1]);
-        for (uint32_t k = s + 1; k < e; k++) {
-            G1Affine nxt = cur;
-            if (k + 1 < e) nxt = load_entry_point(table, entries[k + 1]);  // prefetch under the add
-            acc = g1_madd(acc, cur);
-            cur = nxt;
-        }
-        out[t] = acc;
+    const uint32_t E = st->E, M = st->M;
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t lo64 = (uint64_t)s * E;
+    if (lo64 >= M) return;
+    const uint32_t lo = (uint32_t)lo64;
+    const uint32_t hi = (M - lo < E) ? M : lo + E;
+    // bucket containing entry lo: start[b] <= lo < start[b+1]
+    uint32_t bl = 0, bh = (uint32_t)B;  // start[bl] <= lo < start[bh]
+    while (bh - bl > 1) {
+        uint32_t mid = (bl + bh) >> 1;
+        if (bucket_start[mid] <= lo) bl = mid; else bh = mid;
     }
+    uint32_t b = bl;
+    uint32_t bend = bucket_start[b + 1];
+    // first output slot: run starts before lo = s multiples of E + non-aligned non-empty bucket starts < lo
+    uint32_t f_next = s1[b + 1] - (bucket_start[b + 1] + E - 1) / E;  // F[b+1]
+    uint32_t pos = s + f_next;
+    G1Affine cur = load_entry_point(table, entries[lo]);
+    G1Xyzz acc = G1Xyzz::from_affine(cur);
+    if (lo + 1 < hi) cur = load_entry_point(table, entries[lo + 1]);
+    for (uint32_t k = lo + 1; k < hi; k++) {
+        G1Affine nxt = cur;
+        if (k + 1 < hi) nxt = load_entry_point(table, entries[k + 1]);  // prefetch under the add
+        if (k == bend) {  // bucket boundary: flush and restart
+            out[pos++] = acc;
+            do {
+                b++;
+                bend = bucket_start[b + 1];
+            } while (bend <= k);
+            acc = G1Xyzz::from_affine(cur);
+        } else {
+            acc = g1_madd(acc, cur);
+        }
+        cur = nxt;
+    }
+    out[pos] = acc;
 }
 
 // per-level task layout: ntask[b] = ceil(cnt[b] / L); also detects "every bucket <= 1 partial"
@@ -392,7 +424,8 @@ static int sort_blocks(size_t n) {
 }
 
 static int worst_case_levels(size_t M) {  // fold rounds after round 1 until one partial per bucket
-    size_t c = (M + L1 - 1) / L1;
+    size_t c = M / 8 + 1;  // round 1 leaves at most ceil(M / E) partials in one bucket, E >= 8
+    if (c > ACC_SLOTS) c = ACC_SLOTS;
     int lv = 0;
     while (c > 1) {
         c = (c + LK - 1) / LK;
@@ -415,7 +448,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.B = 1 << (srs->c - 1);
     L.G = sort_blocks(n);
     L.M_max = n * (size_t)srs->W;
-    L.T1_max = L.M_max / L1 + L.B + 1;
+    L.T1_max = (size_t)ACC_SLOTS + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
     L.levels = worst_case_levels(L.M_max);
     if (L.levels > MAX_LEVELS) L.levels = MAX_LEVELS;
     size_t o = 0;
@@ -499,10 +532,12 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
     // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
-    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state);
+    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, ACC_SLOTS);
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
-    unsigned grid1 = (unsigned)((L.T1_max + 255) / 256);
+    // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
+    size_t thr1 = L.M_max / 8 + 1 < (size_t)ACC_SLOTS ? L.M_max / 8 + 1 : (size_t)ACC_SLOTS;
+    unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
                srs->table, bufs[0], state);
     // fold rounds: level k input list lives in bufs[(k-1)&1] with per-bucket starts start_arr(k-1)
