@@ -29,3 +29,7 @@ void hm_g1_jac_roundtrip(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1
     G1Xyzz p = g1_scalar_mul(x, k); G1Jacobian j = g1_to_jacobian(p); G1Affine r = g1_to_affine(g1_from_jacobian(j)); memcpy(o, &r, 96); }
 int hm_g1_on_curve(const uint32_t *a) { G1Affine x; memcpy(&x, a, 96); return g1_on_curve(x); }
 }
+extern "C" {
+void hm_fq_inv_fermat(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv_fermat(x); memcpy(o, z.v, 48); }
+void hm_fr_inv_fermat(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv_fermat(x); memcpy(o, z.v, 32); }
+}
