@@ -68,6 +68,9 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="use the N>1 code path (process group, sharded SRS, RCCL all_gather) even at world size 1")
+    ap.add_argument("--check", action="store_true", help="verify the timed result against [p(tau)]G (known-tau identity)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,10 +83,15 @@ def main():
     from kzg_amd import _lib as L
 
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.sharded
+    if sharded:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     engine = kzg_amd.Engine(local_rank)
 
     def barrier():
@@ -92,7 +100,7 @@ def main():
         torch.cuda.synchronize()
 
     # ---- inputs, resident in HBM before the timed region -----------------------------------------
-    if world == 1:
+    if not sharded:
         params = kzg_amd.setup(engine, TAU, n)                       # gs[i] = [tau^i]G
         srs = params.gs
         scal = engine.alloc_scalars(n * args.batch).fill_random(1, u64_valued=args.u64)
@@ -100,11 +108,12 @@ def main():
         # rank r holds the contiguous shard gs[r*n .. (r+1)*n) = [tau^(r*n + i)]G of setup(tau, world*n)
         params = kzg_amd.KZGParams(kzg_amd.setup_shard(engine, TAU, rank * n, n))
         srs = params.gs
-        scal = engine.alloc_scalars(n).fill_random(1 + rank, u64_valued=args.u64)
+        scal = engine.alloc_scalars(n * args.batch).fill_random(1 + 1000 * rank, u64_valued=args.u64)
     c, W = srs.window_info()
     out = ctypes.create_string_buffer(96 * max(args.batch, 1))
 
-    if world == 1:
+    last = {}
+    if not sharded:
         def step():
             rc = engine.lib.kzg_msm_g1_batch(engine.ctx, srs.handle, 0, scal.ptr, n, args.batch, scal.sfmt,
                                              L.IN_DEVICE, out, L.G1_AFFINE_MONT)
@@ -113,11 +122,11 @@ def main():
         units_per_step = args.batch
     else:
         from kzg_amd.distributed import ShardedCommitter
-        committer = ShardedCommitter.for_engine(engine, srs, dist, rank, world)
+        committer = ShardedCommitter.for_engine(engine, srs, dist, rank, world, max_batch=args.batch, always_gather=True)
 
         def step():
-            committer.commit(scal)
-        units_per_step = world            # world * n terms = `world` degree-2^20 equivalents
+            last["commitments"] = committer.commit_batch(scal, args.batch)
+        units_per_step = world * args.batch   # world * n terms per polynomial = `world` degree-2^20 equivalents each
 
     for _ in range(args.warmup):
         step()
@@ -131,6 +140,25 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    check = None
+    if args.check:
+        # known-tau identity: commitment == [p(tau)]G.  p(tau) = sum_r tau^(r*n) * p_r(tau) from per-rank GPU Horner
+        # evaluations; the single scalar multiplication of G is done by the oracle (checker only, outside the timing).
+        from oracle import c_oracle as C
+        R = kzg_amd.api.R_MODULUS
+        mine = pow(TAU, rank * n, R) * engine.poly_eval(scal, TAU, n=n) % R if sharded else None  # polynomial 0 of the batch
+        if sharded:
+            vals = [None] * world
+            if world > 1:
+                dist.all_gather_object(vals, mine)
+            else:
+                vals = [mine]
+            want = C.g1_mul(C.g1_generator(), sum(vals) % R)
+            check = bool(last.get("commitments", [None])[0] == want)
+        else:
+            want = C.g1_mul(C.g1_generator(), engine.poly_eval(scal, TAU, n=n))
+            check = bool(out.raw[:96] == want)
 
     # ---- roofline of the dominant kernel: HIP events on the engine's stream, single-stream runs ----
     roofline = None
@@ -181,9 +209,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": ("degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step"
-                             % (args.log_n, args.batch)) if world == 1 else
-                            ("degree-%d*2^%d coeff_form commit, SRS sharded 2^%d terms per rank over %d GPUs, "
-                             "RCCL all_gather of 96-B partials + local sum" % (world, args.log_n, args.log_n, world)),
+                             % (args.log_n, args.batch)) if not sharded else
+                            ("degree-%d*2^%d coeff_form commit, SRS sharded 2^%d terms per rank over %d GPUs, batch of %d "
+                             "per step, one RCCL all_gather of the 96-B partials + local sums"
+                             % (world, args.log_n, args.log_n, world, args.batch)),
                 "scalars": "u64-valued Fr" if args.u64 else "uniform full-width Fr (SplitMix64 counter stream, seed 1)",
                 "terms_per_rank": n, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",
                 "inputs_resident_in_hbm": True,
@@ -192,11 +221,13 @@ def main():
             "msm_terms_per_sec": round(value * n, 1),
             "single_commit_latency_ms": None if latency_ms is None else round(latency_ms, 4),
         }
+        if check is not None:
+            res["result_matches_known_tau"] = check
         if world > 1:
             res["unit_note"] = "N>1: value = (terms processed by all ranks / 2^20) per second (degree-2^20 equivalents)"
         if roofline:
             res["roofline"] = roofline
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not sharded and not args.no_cpu_baseline:
             try:
                 res["cpu_baseline"] = cpu_baseline(engine, params)
             except Exception as e:  # the baseline must never take the bench line down

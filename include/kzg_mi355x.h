@@ -98,6 +98,9 @@ int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void
                      size_t batch, int sfmt, int flags, void *out, int ofmt);
 /* sum of `count` G1 points (multi-GPU combine of per-rank partial MSMs). points in pfmt. */
 int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pfmt, int flags, void *out, int ofmt);
+/* `groups` independent sums: out[g] = sum_i points[g*count + i] (batched multi-GPU combine). */
+int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t groups, int pfmt, int flags, void *out,
+                     int ofmt);
 
 /* ---- NTT: EvaluationDomain::fft / ifft (src/ft.rs:111-140; best_fft :274-288) --------------- */
 /* EvaluationDomain::compute_omega (src/ft.rs:55-76): m = next pow2 >= d, exp = log2 m, omega.

@@ -61,6 +61,7 @@ def load():
         "kzg_msm_g1": (i32, [vp, vp, sz, vp, sz, i32, i32, vp, i32]),
         "kzg_msm_g1_batch": (i32, [vp, vp, sz, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_g1_sum": (i32, [vp, vp, sz, i32, i32, vp, i32]),
+        "kzg_g1_sum_batch": (i32, [vp, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_compute_omega": (i32, [sz, ctypes.POINTER(sz), ctypes.POINTER(u32), vp, i32]),
         "kzg_ntt_fr": (i32, [vp, vp, u32, i32, i32]),
         "kzg_coset_ntt_fr": (i32, [vp, vp, u32, i32, i32, i32]),

@@ -200,6 +200,16 @@ class Engine:
             _raise(self, rc)
         return out.raw
 
+    def g1_sum_batch(self, blobs, count, groups, pfmt=L.G1_AFFINE_MONT, ofmt=L.G1_AFFINE_MONT):
+        """out[g] = sum_i blobs[g*count + i]."""
+        raw = b"".join(blobs)
+        psz = L.POINT_BYTES[ofmt]
+        out = ctypes.create_string_buffer(psz * groups)
+        rc = self.lib.kzg_g1_sum_batch(self.ctx, raw, count, groups, pfmt, 0, out, ofmt)
+        if rc:
+            _raise(self, rc)
+        return [out.raw[i * psz:(i + 1) * psz] for i in range(groups)]
+
     def ntt(self, data, log_n, inverse=False):
         """data: DeviceBuffer (in place) or ints/blob (returns list of ints)."""
         if isinstance(data, DeviceBuffer):

@@ -444,6 +444,35 @@ extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pf
     return KZG_OK;
 }
 
+extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t groups, int pfmt, int flags,
+                                void *out, int ofmt) {
+    if (!ctx || !out || !points || count == 0 || groups == 0) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t psz = point_format_bytes(pfmt), osz = point_format_bytes(ofmt);
+    if (!psz || !osz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
+    size_t total = count * groups;
+    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(total * psz, flags) + (total + groups + 4) * sizeof(G1Xyzz) + groups * 144 + 65536));
+    hipStream_t st = ctx->lanes[0].stream;
+    G1Xyzz *pts = (G1Xyzz *)lane_alloc(ctx, 0, total * sizeof(G1Xyzz));
+    G1Xyzz *tmp = (G1Xyzz *)lane_alloc(ctx, 0, groups * sizeof(G1Xyzz));
+    int *bad = (int *)lane_alloc(ctx, 0, 256);
+    void *d_out = (flags & KZG_OUT_DEVICE) ? out : lane_alloc(ctx, 0, groups * osz);
+    if (!pts || !tmp || !bad || !d_out) return fail(ctx, KZG_ERR_ALLOC, "sum workspace not reserved");
+    KZG_HIP_CHECK(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
+    const void *d_raw = nullptr;
+    KZG_TRY(stage_in(ctx, 0, points, total * psz, flags, &d_raw));
+    KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, pts, bad));
+    KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, tmp, d_out, ofmt));
+    int hbad = 0;
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
+    if (!(flags & KZG_OUT_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, groups * osz, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    if (hbad) return fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode or is not on the curve");
+    return KZG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // NTT
 // ---------------------------------------------------------------------------------------------

@@ -133,6 +133,8 @@ size_t sum_points_scratch_count(size_t count);
 // writes one point in `ofmt` (from XYZZ) to d_out (device); single thread incl. the Fq inversion
 int emit_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_point, void *d_out, int ofmt);
 size_t point_format_bytes(int fmt);
+int sum_groups_emit(kzg_ctx *ctx, int lane, const G1Xyzz *d_pts, size_t count, size_t groups, G1Xyzz *d_tmp, void *d_out,
+                    int ofmt);
 
 // srs.hip
 int srs_choose_window(kzg_ctx *ctx, size_t n);

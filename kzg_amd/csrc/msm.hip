@@ -395,6 +395,25 @@ __global__ __launch_bounds__(64) void k_emit_points(const G1Xyzz *pts, size_t co
     }
 }
 
+// out[g] = sum_{i < count} pts[g * count + i]   (count is small: one partial per GPU)
+__global__ __launch_bounds__(64) void k_sum_groups(const G1Xyzz *pts, uint32_t count, uint32_t groups, G1Xyzz *out) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= groups) return;
+    G1Xyzz acc = G1Xyzz::inf();
+    for (uint32_t i = 0; i < count; i++) acc = g1_add(acc, pts[(size_t)g * count + i]);
+    out[g] = acc;
+}
+
+int sum_groups_emit(kzg_ctx *ctx, int lane, const G1Xyzz *d_pts, size_t count, size_t groups, G1Xyzz *d_tmp, void *d_out,
+                    int ofmt) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    KZG_LAUNCH(ctx, st, "k_sum_groups", k_sum_groups, (unsigned)((groups + 63) / 64), 64, 0, d_pts, (uint32_t)count,
+               (uint32_t)groups, d_tmp);
+    KZG_LAUNCH(ctx, st, "k_emit_points", k_emit_points, (unsigned)((groups + 63) / 64), 64, 0, d_tmp, groups, (size_t)1,
+               (uint8_t *)d_out, ofmt);
+    return KZG_OK;
+}
+
 size_t point_format_bytes(int fmt) {
     switch (fmt) {
         case KZG_G1_AFFINE_MONT_96: return 96;

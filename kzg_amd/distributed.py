@@ -1,10 +1,11 @@
 """Multi-GPU MSM: the SRS is sharded contiguously, one process per GPU (torch.distributed; backend
-"nccl" is RCCL on ROCm), each rank reduces its shard to ONE partial commitment on its own GPU and the
-96-byte partials are exchanged with a single all_gather over xGMI; every rank then adds the N partial
-points locally (EC addition is not an RCCL reduction op, so "all-reduce" = all-gather + local sum).
+"nccl" is RCCL on ROCm).  Each rank reduces its shard to ONE partial commitment per polynomial on its
+own GPU; the 96-byte partials of a batch of B polynomials are exchanged with a single all_gather over
+xGMI (world x B x 96 bytes); every rank then adds, per polynomial, the `world` partial points locally
+(EC addition is not an RCCL reduction op, so "all-reduce" = all-gather + local sum).
 
-The collective moves N x 96 bytes -- latency-bound, independent of the polynomial size -- which is why
-buckets are reduced locally first (exchanging raw buckets would move tens of MiB per commitment).
+The collective is latency-bound and independent of the polynomial size -- which is why buckets are
+reduced locally first (exchanging raw buckets would move ~6 MiB per rank per commitment).
 
 `ShardedCommitter` takes the two local operations as callables so the sharding / collective logic can
 be exercised on CPU with the gloo backend (tests/test_distributed_gloo.py injects the oracle there);
@@ -23,42 +24,51 @@ def shard_range(n, rank, world):
 
 
 class ShardedCommitter:
-    def __init__(self, dist, rank, world, local_msm, local_sum, device="cpu"):
-        """local_msm(scalar_shard) -> torch.uint8[96] partial point (affine Montgomery) on `device`;
-        local_sum(torch.uint8[world*96]) -> 96-byte result."""
+    def __init__(self, dist, rank, world, local_msm, local_sum, device="cpu", always_gather=False):
+        """local_msm(scalar_shards, batch) -> torch.uint8[batch*96]: this rank's partial points (affine
+        Montgomery) on `device`;  local_sum(torch.uint8[batch*world*96] laid out [batch][world][96],
+        batch) -> list of `batch` 96-byte results."""
         self.dist, self.rank, self.world = dist, rank, world
         self.local_msm, self.local_sum, self.device = local_msm, local_sum, device
+        self.always_gather = always_gather  # run the collective even at world size 1 (testing the RCCL path)
+
+    def commit_batch(self, scalar_shards, batch):
+        import torch
+        mine = self.local_msm(scalar_shards, batch)                      # [batch][96]
+        if self.world == 1 and not self.always_gather:
+            return self.local_sum(mine, batch)
+        gathered = torch.empty(self.world * batch * 96, dtype=torch.uint8, device=self.device)
+        self.dist.all_gather_into_tensor(gathered, mine)                 # [world][batch][96]
+        grouped = gathered.view(self.world, batch, 96).transpose(0, 1).contiguous().view(-1)  # [batch][world][96]
+        return self.local_sum(grouped, batch)
 
     def commit(self, scalar_shard):
-        import torch
-        mine = self.local_msm(scalar_shard)
-        if self.world == 1:
-            return self.local_sum(mine)
-        gathered = torch.empty(self.world * 96, dtype=torch.uint8, device=self.device)
-        self.dist.all_gather_into_tensor(gathered, mine)
-        return self.local_sum(gathered)
+        return self.commit_batch(scalar_shard, 1)[0]
 
     @staticmethod
-    def for_engine(engine, srs_shard, dist, rank, world):
-        """Product wiring: partial MSM and final sum both run in libkzg_mi355x.so on this rank's GPU."""
+    def for_engine(engine, srs_shard, dist, rank, world, max_batch=16, always_gather=False):
+        """Product wiring: partial MSMs and final sums both run in libkzg_mi355x.so on this rank's GPU.
+        Shards are kzg_amd.DeviceBuffer objects holding batch * n_shard scalars resident on this GPU."""
         import torch
         dev = torch.device("cuda", engine.device)
-        part = torch.empty(96, dtype=torch.uint8, device=dev)
-        out = ctypes.create_string_buffer(96)
+        part = torch.empty(max_batch * 96, dtype=torch.uint8, device=dev)
+        out = ctypes.create_string_buffer(96 * max_batch)
 
-        def local_msm(shard):  # shard: kzg_amd.DeviceBuffer resident on this GPU
-            rc = engine.lib.kzg_msm_g1(engine.ctx, srs_shard.handle, 0, shard.ptr, shard.n, shard.sfmt,
-                                       L.IN_DEVICE | L.OUT_DEVICE, ctypes.c_void_p(part.data_ptr()), L.G1_AFFINE_MONT)
+        def local_msm(shard, batch):
+            n = shard.n // batch
+            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, srs_shard.handle, 0, shard.ptr, n, batch, shard.sfmt,
+                                             L.IN_DEVICE | L.OUT_DEVICE, ctypes.c_void_p(part.data_ptr()), L.G1_AFFINE_MONT)
             if rc:
                 raise RuntimeError(engine.last_error())
-            return part
+            return part[: batch * 96]
 
-        def local_sum(gathered):
+        def local_sum(grouped, batch):
             torch.cuda.current_stream(dev).synchronize()
-            rc = engine.lib.kzg_g1_sum(engine.ctx, ctypes.c_void_p(gathered.data_ptr()), gathered.numel() // 96,
-                                       L.G1_AFFINE_MONT, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            count = grouped.numel() // (96 * batch)
+            rc = engine.lib.kzg_g1_sum_batch(engine.ctx, ctypes.c_void_p(grouped.data_ptr()), count, batch,
+                                             L.G1_AFFINE_MONT, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
             if rc:
                 raise RuntimeError(engine.last_error())
-            return out.raw
+            return [out.raw[96 * b: 96 * (b + 1)] for b in range(batch)]
 
-        return ShardedCommitter(dist, rank, world, local_msm, local_sum, device=dev)
+        return ShardedCommitter(dist, rank, world, local_msm, local_sum, device=dev, always_gather=always_gather)

@@ -32,18 +32,23 @@ def _worker(rank, world, port, n, tau, seed, q):
     full = C.setup_g1(tau, n)
     shard = full[96 * lo: 96 * hi]
 
-    def local_msm(sc):
-        return torch.frombuffer(bytearray(C.msm_g1(shard, sc)), dtype=torch.uint8)
+    def local_msm(polys, batch):
+        return torch.frombuffer(bytearray(b"".join(C.msm_g1(shard, sc) for sc in polys)), dtype=torch.uint8)
 
-    def local_sum(gathered):
-        acc = bytes(96)
-        raw = bytes(gathered.numpy().tobytes())
-        for i in range(0, len(raw), 96):
-            acc = C.g1_add(acc, raw[i:i + 96])
-        return acc
+    def local_sum(grouped, batch):
+        raw = bytes(grouped.numpy().tobytes())
+        per = len(raw) // batch
+        res = []
+        for b in range(batch):
+            acc = bytes(96)
+            for i in range(0, per, 96):
+                acc = C.g1_add(acc, raw[b * per + i: b * per + i + 96])
+            res.append(acc)
+        return res
 
     committer = ShardedCommitter(dist, rank, world, local_msm, local_sum)
-    got = committer.commit(coeffs[lo:hi])
+    # a batch of two polynomials: p and 3*p (tests the [world][batch] -> [batch][world] regrouping)
+    got = committer.commit_batch([coeffs[lo:hi], [3 * c % M.R for c in coeffs[lo:hi]]], 2)
     q.put((rank, got))
     dist.barrier()
     dist.destroy_process_group()
@@ -72,5 +77,6 @@ def test_sharded_commit_world2_gloo():
         assert p.exitcode == 0
     rng = random.Random(seed)
     coeffs = [rng.randrange(M.R) for _ in range(n)]
-    want = C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, tau))   # [p(tau)]G
+    ptau = C.poly_eval(coeffs, tau)
+    want = [C.g1_mul(C.g1_generator(), ptau), C.g1_mul(C.g1_generator(), 3 * ptau % M.R)]   # [p(tau)]G, [3p(tau)]G
     assert results[0] == results[1] == want

@@ -208,3 +208,14 @@ def test_sharded_srs_partials_sum_to_full_commit(engine):
         shard.free()
     assert engine.g1_sum(parts) == want
     full.gs.free()
+
+
+def test_g1_sum_batch(engine, srs_small):
+    srs, blob = srs_small
+    pts = [blob[96 * i: 96 * (i + 1)] for i in range(12)]
+    got = engine.g1_sum_batch(pts, 3, 4)
+    for g in range(4):
+        acc = bytes(96)
+        for i in range(3):
+            acc = C.g1_add(acc, pts[3 * g + i])
+        assert got[g] == acc
