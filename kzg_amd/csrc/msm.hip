@@ -200,8 +200,13 @@ __device__ __forceinline__ void find_task(const uint32_t *task_start, int B, uin
     j = t - task_start[lo];
 }
 
-__device__ __forceinline__ G1Affine load_entry_point(const G1Affine *table, uint32_t ent) {
-    G1Affine p = table[ent & 0x7fffffffu];
+template <int STRIDE16>
+__device__ __forceinline__ G1Affine load_entry_point(const uint4 *table, uint32_t ent) {
+    const uint4 *src = table + (size_t)(ent & 0x7fffffffu) * STRIDE16;
+    G1Affine p;
+    uint4 *dst = reinterpret_cast<uint4 *>(&p);
+#pragma unroll
+    for (int k = 0; k < 6; k++) dst[k] = src[k];
     if (ent >> 31) p.y = neg(p.y);
     return p;
 }
@@ -210,9 +215,10 @@ __device__ __forceinline__ G1Affine load_entry_point(const G1Affine *table, uint
 // gathering each precomputed affine point from the resident table (next point prefetched under the
 // add), and writes one partial per bucket it touches.  Every thread has the same amount of work, so
 // the kernel ends without a straggler round.
-__global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
-                                                      const uint32_t *s1, int B, const G1Affine *table,
-                                                      G1Xyzz *out, const MsmState *st) {
+template <int STRIDE16, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
+                                                           const uint32_t *s1, int B, const uint4 *table,
+                                                           G1Xyzz *out, const MsmState *st) {
     const uint32_t E = st->E, M = st->M;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t lo64 = (uint64_t)s * E;
@@ -230,12 +236,12 @@ __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, c
     // first output slot: run starts before lo = s multiples of E + non-aligned non-empty bucket starts < lo
     uint32_t f_next = s1[b + 1] - (bucket_start[b + 1] + E - 1) / E;  // F[b+1]
     uint32_t pos = s + f_next;
-    G1Affine cur = load_entry_point(table, entries[lo]);
+    G1Affine cur = load_entry_point<STRIDE16>(table, entries[lo]);
     G1Xyzz acc = G1Xyzz::from_affine(cur);
-    if (lo + 1 < hi) cur = load_entry_point(table, entries[lo + 1]);
+    if (lo + 1 < hi) cur = load_entry_point<STRIDE16>(table, entries[lo + 1]);
     for (uint32_t k = lo + 1; k < hi; k++) {
         G1Affine nxt = cur;
-        if (k + 1 < hi) nxt = load_entry_point(table, entries[k + 1]);  // prefetch under the add
+        if (k + 1 < hi) nxt = load_entry_point<STRIDE16>(table, entries[k + 1]);  // prefetch under the add
         if (k == bend) {  // bucket boundary: flush and restart
             out[pos++] = acc;
             do {
@@ -444,7 +450,7 @@ static int sort_blocks(size_t n) {
 
 static int worst_case_levels(size_t M) {  // fold rounds after round 1 until one partial per bucket
     size_t c = M / 8 + 1;  // round 1 leaves at most ceil(M / E) partials in one bucket, E >= 8
-    if (c > ACC_SLOTS) c = ACC_SLOTS;
+    if (c > ACC_SLOTS / 2 * 3) c = ACC_SLOTS / 2 * 3;
     int lv = 0;
     while (c > 1) {
         c = (c + LK - 1) / LK;
@@ -467,7 +473,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.B = 1 << (srs->c - 1);
     L.G = sort_blocks(n);
     L.M_max = n * (size_t)srs->W;
-    L.T1_max = (size_t)ACC_SLOTS + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
+    L.T1_max = (size_t)ACC_SLOTS / 2 * 3 + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
     L.levels = worst_case_levels(L.M_max);
     if (L.levels > MAX_LEVELS) L.levels = MAX_LEVELS;
     size_t o = 0;
@@ -551,14 +557,25 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
     // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
-    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, ACC_SLOTS);
+    const uint32_t slots = ctx->opt_accum_occ == 3 ? ACC_SLOTS / 2 * 3 : ACC_SLOTS;
+    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, slots);
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
     // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
-    size_t thr1 = L.M_max / 8 + 1 < (size_t)ACC_SLOTS ? L.M_max / 8 + 1 : (size_t)ACC_SLOTS;
+    size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
-               srs->table, bufs[0], state);
+    {
+        const bool pad = srs->table128 != nullptr && ctx->opt_pad_rows;
+        const uint4 *tab = pad ? (const uint4 *)srs->table128 : (const uint4 *)srs->table;
+        if (pad && ctx->opt_accum_occ == 3)
+            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<8, 3>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
+        else if (pad)
+            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<8, 2>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
+        else if (ctx->opt_accum_occ == 3)
+            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<6, 3>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
+        else
+            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<6, 2>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
+    }
     // fold rounds: level k input list lives in bufs[(k-1)&1] with per-bucket starts start_arr(k-1)
     size_t tmax = L.T1_max;
     for (int lv = 1; lv <= L.levels + 1; lv++) {

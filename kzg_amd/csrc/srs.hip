@@ -82,6 +82,24 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     return KZG_OK;
 }
 
+__global__ __launch_bounds__(256) void k_pad_rows(const uint4 *src, uint4 *dst, size_t npoints) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-B piece per thread
+    if (i >= npoints * 8) return;
+    size_t pt = i >> 3, k = i & 7;
+    dst[i] = k < 6 ? src[pt * 6 + k] : make_uint4(0, 0, 0, 0);
+}
+
+static int srs_make_padded(kzg_ctx *ctx, kzg_srs *srs) {
+    if (!ctx->opt_pad_rows || srs->n == 0) return KZG_OK;
+    size_t npts = (size_t)srs->W * srs->npad;
+    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table128, npts * 128));
+    hipStream_t st = ctx->lanes[0].stream;
+    KZG_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows, (unsigned)((npts * 8 + 255) / 256), 256, 0, (const uint4 *)srs->table,
+               (uint4 *)srs->table128, npts);
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    return KZG_OK;
+}
+
 int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     if (srs->n == 0) return KZG_OK;
     hipStream_t st = ctx->lanes[0].stream;
@@ -100,7 +118,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     }
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     KZG_HIP_CHECK(ctx, hipFree(tmp));
-    return KZG_OK;
+    return srs_make_padded(ctx, srs);
 }
 
 int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz) {
@@ -471,5 +489,6 @@ extern "C" void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs) {
         for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
     }
     if (srs->table) hipFree(srs->table);
+    if (srs->table128) hipFree(srs->table128);
     delete srs;
 }
