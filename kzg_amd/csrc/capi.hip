@@ -260,11 +260,6 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "streams") {
         if (value < 1 || value > 16) return fail(ctx, KZG_ERR_SHAPE, "streams must be 1..16");
         ctx->opt_streams = (int)value;
-    } else if (k == "pad_rows") {
-        ctx->opt_pad_rows = value != 0;
-    } else if (k == "accum_occupancy") {
-        if (value != 2 && value != 3) return fail(ctx, KZG_ERR_SHAPE, "accum_occupancy must be 2 or 3");
-        ctx->opt_accum_occ = (int)value;
     } else {
         return fail(ctx, KZG_ERR_SHAPE, "unknown option " + k);
     }

@@ -49,8 +49,6 @@ struct kzg_ctx {
     std::vector<kzg::Lane> lanes;
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 4;
-    int opt_pad_rows = 0;     // gather from the 128-B-aligned copy of the SRS table
-    int opt_accum_occ = 2;    // waves/SIMD k_accum_affine is compiled for (2 or 3)
     int num_cus = 256;
     // profiling
     bool prof = false;
@@ -69,7 +67,7 @@ struct kzg_srs {
     int c = 0;           // window bits (signed digits, 2^(c-1) buckets)
     int W = 0;           // windows = ceil(256 / c); table row w holds 2^(c*w) * P_i
     kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
-    void *table128 = nullptr;        // optional copy with every point padded to 128 B (one cache line per gather)
+    void *table29 = nullptr;         // [W][npad] G1Affine29 (2 x 14 x 29-bit limbs, 112 B): what k_accum_affine gathers
     int device = 0;
 };
 

@@ -5,7 +5,9 @@
 // is free, so the structure below is chosen for the MI355X, not for the CPU the reference runs on:
 //
 //   * The SRS is resident in HBM as W = ceil(256/c) rows, row w holding the affine points
-//     2^(c*w) * P_i (built once at upload; 1.5 GiB for 2^20 points at c = 16 -- cheap in 288 GB).
+//     2^(c*w) * P_i (built once at upload; 1.5 GiB for 2^20 points at c = 16 -- cheap in 288 GB), plus
+//     a copy of the same table in the unsaturated 29-bit representation the inner loop computes in
+//     (112 B per point, 1.75 GiB at 2^20).
 //     Every signed c-bit digit of every scalar therefore lands in ONE shared set of 2^(c-1)
 //     buckets: there is no per-window bucket reduction and no window-combine doubling chain.
 //   * Digits -> buckets by a one-pass counting sort whose 2^(c-1)-entry histogram / cursor array
@@ -20,6 +22,7 @@
 //
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
 #include "common.h"
+#include "curve29.h"
 
 namespace kzg {
 
@@ -200,25 +203,24 @@ __device__ __forceinline__ void find_task(const uint32_t *task_start, int B, uin
     j = t - task_start[lo];
 }
 
-template <int STRIDE16>
-__device__ __forceinline__ G1Affine load_entry_point(const uint4 *table, uint32_t ent) {
-    const uint4 *src = table + (size_t)(ent & 0x7fffffffu) * STRIDE16;
-    G1Affine p;
+// table29 entry: G1Affine29 = 2 x 14 limbs = 112 B = 7 x 16 B
+__device__ __forceinline__ G1Affine29 load_entry_point29(const uint4 *table29, uint32_t ent) {
+    const uint4 *src = table29 + (size_t)(ent & 0x7fffffffu) * 7;
+    G1Affine29 p;
     uint4 *dst = reinterpret_cast<uint4 *>(&p);
 #pragma unroll
-    for (int k = 0; k < 6; k++) dst[k] = src[k];
-    if (ent >> 31) p.y = neg(p.y);
+    for (int k = 0; k < 7; k++) dst[k] = src[k];
     return p;
 }
 
-// round 1 (dominant kernel): thread s folds its E consecutive sorted entries with XYZZ mixed adds,
-// gathering each precomputed affine point from the resident table (next point prefetched under the
-// add), and writes one partial per bucket it touches.  Every thread has the same amount of work, so
-// the kernel ends without a straggler round.
-template <int STRIDE16, int OCC>
-__global__ __launch_bounds__(256, OCC) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
-                                                           const uint32_t *s1, int B, const uint4 *table,
-                                                           G1Xyzz *out, const MsmState *st) {
+// round 1 (dominant kernel): thread s folds its E consecutive sorted entries with XYZZ mixed adds in the
+// unsaturated 29-bit field representation (curve29.h), gathering each precomputed point from the
+// resident 29-bit table (next point prefetched under the add), and writes one partial -- converted back
+// to the canonical saturated form -- per bucket it touches.  Every thread has the same amount of work,
+// so the kernel ends without a straggler round.
+__global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
+                                                      const uint32_t *s1, int B, const uint4 *table29,
+                                                      G1Xyzz *out, const MsmState *st) {
     const uint32_t E = st->E, M = st->M;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t lo64 = (uint64_t)s * E;
@@ -236,25 +238,42 @@ __global__ __launch_bounds__(256, OCC) void k_accum_affine(const uint32_t *entri
     // first output slot: run starts before lo = s multiples of E + non-aligned non-empty bucket starts < lo
     uint32_t f_next = s1[b + 1] - (bucket_start[b + 1] + E - 1) / E;  // F[b+1]
     uint32_t pos = s + f_next;
-    G1Affine cur = load_entry_point<STRIDE16>(table, entries[lo]);
-    G1Xyzz acc = G1Xyzz::from_affine(cur);
-    if (lo + 1 < hi) cur = load_entry_point<STRIDE16>(table, entries[lo + 1]);
+    uint32_t ent = entries[lo];
+    G1Affine29 cur = load_entry_point29(table29, ent);
+    G1Xyzz29 acc = g1_from_affine29(cur, ent >> 31);
+    if (lo + 1 < hi) {
+        ent = entries[lo + 1];
+        cur = load_entry_point29(table29, ent);
+    }
     for (uint32_t k = lo + 1; k < hi; k++) {
-        G1Affine nxt = cur;
-        if (k + 1 < hi) nxt = load_entry_point<STRIDE16>(table, entries[k + 1]);  // prefetch under the add
+        // `cur` / `ent` hold entry k.  mode 0: mixed add; 1: restart the accumulator from cur; 2: skip (identity point)
+        const bool neg_k = (ent >> 31) != 0;
+        const uint32_t ent_k = ent;
+        int mode = 0;
+        Madd29Mid mid;
         if (k == bend) {  // bucket boundary: flush and restart
-            out[pos++] = acc;
+            out[pos++] = g1_xyzz_from29(acc);
             do {
                 b++;
                 bend = bucket_start[b + 1];
             } while (bend <= k);
-            acc = G1Xyzz::from_affine(cur);
-        } else {
-            acc = g1_madd(acc, cur);
+            mode = 1;
+        } else if (cur.is_inf()) {
+            mode = 2;
+        } else if (acc.inf) {
+            mode = 1;
         }
-        cur = nxt;
+        if (mode == 0) mid = g1_madd29_phase1(acc, cur, neg_k);
+        if (mode == 1) acc = g1_from_affine29(cur, neg_k);
+        // entry k's point is dead now: start the gather of entry k+1 into the same registers; its latency
+        // hides under the eight remaining multiplies of this addition
+        if (k + 1 < hi) {
+            ent = entries[k + 1];
+            cur = load_entry_point29(table29, ent);
+        }
+        if (mode == 0) acc = g1_madd29_phase2(acc, mid, neg_k, [&]() { return load_entry_point29(table29, ent_k); });
     }
-    out[pos] = acc;
+    out[pos] = g1_xyzz_from29(acc);
 }
 
 // per-level task layout: ntask[b] = ceil(cnt[b] / L); also detects "every bucket <= 1 partial"
@@ -450,7 +469,7 @@ static int sort_blocks(size_t n) {
 
 static int worst_case_levels(size_t M) {  // fold rounds after round 1 until one partial per bucket
     size_t c = M / 8 + 1;  // round 1 leaves at most ceil(M / E) partials in one bucket, E >= 8
-    if (c > ACC_SLOTS / 2 * 3) c = ACC_SLOTS / 2 * 3;
+    if (c > ACC_SLOTS) c = ACC_SLOTS;
     int lv = 0;
     while (c > 1) {
         c = (c + LK - 1) / LK;
@@ -473,7 +492,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.B = 1 << (srs->c - 1);
     L.G = sort_blocks(n);
     L.M_max = n * (size_t)srs->W;
-    L.T1_max = (size_t)ACC_SLOTS / 2 * 3 + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
+    L.T1_max = (size_t)ACC_SLOTS + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
     L.levels = worst_case_levels(L.M_max);
     if (L.levels > MAX_LEVELS) L.levels = MAX_LEVELS;
     size_t o = 0;
@@ -557,25 +576,15 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
     // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
-    const uint32_t slots = ctx->opt_accum_occ == 3 ? ACC_SLOTS / 2 * 3 : ACC_SLOTS;
+    const uint32_t slots = ACC_SLOTS;
     KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, slots);
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
     // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    {
-        const bool pad = srs->table128 != nullptr && ctx->opt_pad_rows;
-        const uint4 *tab = pad ? (const uint4 *)srs->table128 : (const uint4 *)srs->table;
-        if (pad && ctx->opt_accum_occ == 3)
-            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<8, 3>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
-        else if (pad)
-            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<8, 2>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
-        else if (ctx->opt_accum_occ == 3)
-            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<6, 3>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
-        else
-            KZG_LAUNCH(ctx, st, "k_accum_affine", (k_accum_affine<6, 2>), grid1, 256, 0, entries, bucket_start, start_arr(0), B, tab, bufs[0], state);
-    }
+    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
+               (const uint4 *)srs->table29, bufs[0], state);
     // fold rounds: level k input list lives in bufs[(k-1)&1] with per-bucket starts start_arr(k-1)
     size_t tmax = L.T1_max;
     for (int lv = 1; lv <= L.levels + 1; lv++) {

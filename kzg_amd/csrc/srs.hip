@@ -3,6 +3,7 @@
 // points, row w = 2^(c*w) * P_i (see msm.hip for why).  Also the GPU versions of the untimed input
 // generators: setup() (src/lib.rs:38-47, G1 half) and the Lagrange basis for a known secret.
 #include "common.h"
+#include "curve29.h"
 
 namespace kzg {
 
@@ -82,20 +83,20 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     return KZG_OK;
 }
 
-__global__ __launch_bounds__(256) void k_pad_rows(const uint4 *src, uint4 *dst, size_t npoints) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // one 16-B piece per thread
-    if (i >= npoints * 8) return;
-    size_t pt = i >> 3, k = i & 7;
-    dst[i] = k < 6 ? src[pt * 6 + k] : make_uint4(0, 0, 0, 0);
+// the 29-bit copy of the table that k_accum_affine gathers from (one thread per point, 2 multiplies)
+__global__ __launch_bounds__(256) void k_table_to29(const G1Affine *src, G1Affine29 *dst, size_t npoints) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npoints) return;
+    dst[i] = g1_affine_to29(src[i]);
 }
 
-static int srs_make_padded(kzg_ctx *ctx, kzg_srs *srs) {
-    if (!ctx->opt_pad_rows || srs->n == 0) return KZG_OK;
+static int srs_make_table29(kzg_ctx *ctx, kzg_srs *srs) {
+    if (srs->n == 0) return KZG_OK;
     size_t npts = (size_t)srs->W * srs->npad;
-    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table128, npts * 128));
+    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table29, npts * sizeof(G1Affine29)));
     hipStream_t st = ctx->lanes[0].stream;
-    KZG_LAUNCH(ctx, st, "k_pad_rows", k_pad_rows, (unsigned)((npts * 8 + 255) / 256), 256, 0, (const uint4 *)srs->table,
-               (uint4 *)srs->table128, npts);
+    KZG_LAUNCH(ctx, st, "k_table_to29", k_table_to29, (unsigned)((npts + 255) / 256), 256, 0, srs->table,
+               (G1Affine29 *)srs->table29, npts);
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     return KZG_OK;
 }
@@ -118,7 +119,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     }
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     KZG_HIP_CHECK(ctx, hipFree(tmp));
-    return srs_make_padded(ctx, srs);
+    return srs_make_table29(ctx, srs);
 }
 
 int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz) {
@@ -489,6 +490,6 @@ extern "C" void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs) {
         for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
     }
     if (srs->table) hipFree(srs->table);
-    if (srs->table128) hipFree(srs->table128);
+    if (srs->table29) hipFree(srs->table29);
     delete srs;
 }

@@ -33,3 +33,17 @@ extern "C" {
 void hm_fq_inv_fermat(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv_fermat(x); memcpy(o, z.v, 48); }
 void hm_fr_inv_fermat(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv_fermat(x); memcpy(o, z.v, 32); }
 }
+#include "../kzg_amd/csrc/curve29.h"
+extern "C" {
+// Fq29: x*R384 (48 B) -> to29 -> mul29 -> from29 -> 48 B, must equal the saturated Montgomery product
+void hm_mul29(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48);
+    Fq z = from29(mul29(to29(x), to29(y))); memcpy(o, z.v, 48); }
+void hm_roundtrip29(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = from29(to29(x)); memcpy(o, z.v, 48); }
+void hm_packunpack29(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = pack29(unpack29(x)); memcpy(o, z.v, 48); }
+// chain of n mixed additions in the 29-bit representation: acc = first; acc += pts[i] (sign bit i of `signs`)
+void hm_madd29_chain(const uint32_t *pts, int n, uint64_t signs, uint32_t *o) {
+    const G1Affine *p = (const G1Affine *)pts;
+    G1Xyzz29 acc = g1_from_affine29(g1_affine_to29(p[0]), signs & 1);
+    for (int i = 1; i < n; i++) acc = g1_madd29(acc, g1_affine_to29(p[i]), (signs >> i) & 1);
+    G1Affine r = g1_to_affine(g1_xyzz_from29(acc)); memcpy(o, &r, 96); }
+}

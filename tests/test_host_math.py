@@ -82,3 +82,42 @@ def test_g1_ops(L):
         assert pt(L.hm_g1_jac_roundtrip, P, b(k, 32)) == C.g1_mul(P, k)
     assert L.hm_g1_on_curve(P) == 1 and L.hm_g1_on_curve(INF) == 1
     assert L.hm_g1_on_curve(P[:95] + bytes([P[95] ^ 1])) == 0
+
+
+def test_fq29_unsaturated_layer(L):
+    """field29.h / curve29.h (the 14 x 29-bit representation used by k_accum_affine) vs the oracle."""
+    rng = random.Random(29)
+    Rq = M.FQ_MONT_R
+    ri = pow(Rq, -1, M.Q)
+    vals = [0, 1, M.Q - 1, M.Q - 2, (1 << 380) % M.Q] + [rng.randrange(M.Q) for _ in range(200)]
+    for a in vals:
+        assert call(L.hm_packunpack29, b(a, 48)) == a
+        assert call(L.hm_roundtrip29, b(a, 48)) == a
+    for i in range(200):
+        a, c = vals[i % len(vals)], vals[(7 * i + 3) % len(vals)]
+        assert call(L.hm_mul29, b(a, 48), b(c, 48)) == a * c * ri % M.Q
+    G, INF = C.g1_generator(), bytes(96)
+
+    def chain(ps, signs):
+        o = ctypes.create_string_buffer(96)
+        L.hm_madd29_chain(b"".join(ps), len(ps), ctypes.c_uint64(signs), o)
+        return o.raw
+
+    def ref(ps, signs):
+        acc = INF
+        for i, p in enumerate(ps):
+            q = C.point_to_blob(M.g1_neg(C.blob_to_point(p))) if (signs >> i) & 1 else p
+            acc = C.g1_add(acc, q)
+        return acc
+
+    pts = [C.g1_mul(G, rng.randrange(1, M.R)) for _ in range(8)]
+    P = pts[0]
+    cases = [([P, P], 0), ([P, P], 2), ([P, P, P], 0), ([P, P, P, P], 0b0110), ([P, INF, P], 0), ([INF, P], 0),
+             ([INF, INF, P, P], 0b1000), ([P, P, P], 0b010), ([P] + [pts[1]] * 5, 0), ([P, P, pts[2], P, P], 0b11000)]
+    for ps, s in cases:            # doubling, inverse, identity points, infinity mid-chain
+        assert chain(ps, s) == ref(ps, s), (len(ps), s)
+    for trial in range(6):         # random chains (the lazy-reduction bounds are exercised repeatedly)
+        k = rng.randrange(2, 40)
+        ps = [rng.choice(pts) if rng.random() < 0.3 else C.g1_mul(G, rng.randrange(1, M.R)) for _ in range(k)]
+        s = rng.getrandbits(k)
+        assert chain(ps, s) == ref(ps, s)
