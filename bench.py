@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="commitments per step (N = 1)")
+    ap.add_argument("--streams", type=int, default=0, help="HIP streams the engine pipelines a batch over (0 = engine default)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -93,6 +94,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     engine = kzg_amd.Engine(local_rank)
+    if args.streams:
+        engine.set_option("streams", args.streams)
 
     def barrier():
         if dist is not None:
