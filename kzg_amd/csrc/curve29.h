@@ -95,12 +95,12 @@ template <class Reload>
 KZG_HD G1Xyzz29 g1_madd29_phase2(const G1Xyzz29 &p, const Madd29Mid &m, bool negate, Reload reload) {
     Fq29 Pp = sub29<32>(m.U2, p.x);
     Fq29 R = sub29<16>(m.S2, p.y);
-    Fq29 PP = mul29(Pp, Pp);
-    if (is_zero_mod_q_lt4q(PP)) {
+    Fq29 PP = sqr29(Pp);
+    if (is_zero_mod_q_product(PP)) {
         // same x: either the same point (double it) or its inverse (infinity).  Rare: done in the
         // saturated representation.
-        Fq29 RR = mul29(R, R);
-        if (!is_zero_mod_q_lt4q(RR)) {
+        Fq29 RR = sqr29(R);
+        if (!is_zero_mod_q_product(RR)) {
             G1Xyzz29 r = p;
             r.inf = true;
             return r;
@@ -119,7 +119,7 @@ KZG_HD G1Xyzz29 g1_madd29_phase2(const G1Xyzz29 &p, const Madd29Mid &m, bool neg
     r.zzz = mul29(p.zzz, PPP);
     Fq29 Bm = mul29(p.y, PPP);
     Fq29 t = add2x29(PPP, Q);
-    r.x = sub29<16>(mul29(R, R), t);
+    r.x = sub29<16>(sqr29(R), t);
     r.y = sub29<8>(mul29(R, sub29<32>(Q, r.x)), Bm);
     return r;
 }

@@ -72,8 +72,9 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     s->c = srs_choose_window(ctx, n);
     s->W = (256 + s->c - 1) / s->c;
     s->device = ctx->device;
-    size_t bytes = (size_t)s->W * s->npad * sizeof(G1Affine);
-    hipError_t e = hipMalloc((void **)&s->table, bytes);
+    // `table` keeps row 0 only (the points themselves, canonical saturated form: download, re-upload);
+    // the W window rows live in the 29-bit table built by srs_precompute.
+    hipError_t e = hipMalloc((void **)&s->table, s->npad * sizeof(G1Affine));
     if (e != hipSuccess) {
         delete s;
         ctx->err = std::string("hipMalloc(SRS table): ") + hipGetErrorString(e);
@@ -83,43 +84,47 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     return KZG_OK;
 }
 
-// the 29-bit copy of the table that k_accum_affine gathers from (one thread per point, 2 multiplies)
+// the 29-bit rows that k_accum_affine gathers from (one thread per point, 2 multiplies)
 __global__ __launch_bounds__(256) void k_table_to29(const G1Affine *src, G1Affine29 *dst, size_t npoints) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npoints) return;
     dst[i] = g1_affine_to29(src[i]);
 }
 
-static int srs_make_table29(kzg_ctx *ctx, kzg_srs *srs) {
-    if (srs->n == 0) return KZG_OK;
-    size_t npts = (size_t)srs->W * srs->npad;
-    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table29, npts * sizeof(G1Affine29)));
-    hipStream_t st = ctx->lanes[0].stream;
-    KZG_LAUNCH(ctx, st, "k_table_to29", k_table_to29, (unsigned)((npts + 255) / 256), 256, 0, srs->table,
-               (G1Affine29 *)srs->table29, npts);
-    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    return KZG_OK;
-}
-
+// rows w = 1..W-1: row w = 2^c * row (w-1), computed in the saturated representation through two ping-pong
+// row buffers and converted row by row into the resident 29-bit table.
 int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     if (srs->n == 0) return KZG_OK;
     hipStream_t st = ctx->lanes[0].stream;
+    const size_t n = srs->n;
+    size_t npts = (size_t)srs->W * srs->npad;
+    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table29, npts * sizeof(G1Affine29)));
+    G1Affine29 *t29 = (G1Affine29 *)srs->table29;
     const size_t CHUNK = (size_t)1 << 20;
-    size_t chunk = srs->n < CHUNK ? srs->n : CHUNK;
+    size_t chunk = n < CHUNK ? n : CHUNK;
     G1Xyzz *tmp = nullptr;
+    G1Affine *rows[2] = {nullptr, nullptr};
     KZG_HIP_CHECK(ctx, hipMalloc((void **)&tmp, chunk * sizeof(G1Xyzz)));
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&rows[0], n * sizeof(G1Affine)));
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&rows[1], n * sizeof(G1Affine)));
+    unsigned gn = (unsigned)((n + 255) / 256);
+    KZG_LAUNCH(ctx, st, "k_table_to29", k_table_to29, gn, 256, 0, srs->table, t29, n);
+    const G1Affine *prev = srs->table;
     for (int w = 1; w < srs->W; w++) {
-        for (size_t o = 0; o < srs->n; o += chunk) {
-            size_t m = srs->n - o < chunk ? srs->n - o : chunk;
-            const G1Affine *src = srs->table + (size_t)(w - 1) * srs->npad + o;
-            G1Affine *dst = srs->table + (size_t)w * srs->npad + o;
-            KZG_LAUNCH(ctx, st, "k_dbl_c", k_dbl_c, (unsigned)((m + 255) / 256), 256, 0, src, tmp, m, srs->c);
-            KZG_TRY(batch_to_affine(ctx, st, tmp, dst, m));
+        G1Affine *cur = rows[w & 1];
+        for (size_t o = 0; o < n; o += chunk) {
+            size_t m = n - o < chunk ? n - o : chunk;
+            KZG_LAUNCH(ctx, st, "k_dbl_c", k_dbl_c, (unsigned)((m + 255) / 256), 256, 0, prev + o, tmp, m, srs->c);
+            KZG_TRY(batch_to_affine(ctx, st, tmp, cur + o, m));
         }
+        KZG_LAUNCH(ctx, st, "k_table_to29", k_table_to29, gn, 256, 0, cur, t29 + (size_t)w * srs->npad, n);
+        prev = cur;
     }
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     KZG_HIP_CHECK(ctx, hipFree(tmp));
-    return srs_make_table29(ctx, srs);
+    KZG_HIP_CHECK(ctx, hipFree(rows[0]));
+    KZG_HIP_CHECK(ctx, hipFree(rows[1]));
+    return KZG_OK;
 }
 
 int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz) {
