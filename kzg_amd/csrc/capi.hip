@@ -129,7 +129,7 @@ static int stage_in(kzg_ctx *ctx, int lane, const void *src, size_t bytes, int f
 static size_t stage_bytes(size_t bytes, int flags) { return (flags & KZG_IN_DEVICE) ? 0 : align_up(bytes + 256, 256); }
 
 // result point: XYZZ on device -> ofmt at `out` (host or device)
-static int finish_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_pt, void *out, int ofmt, int flags) {
+static int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
     size_t psz = point_format_bytes(ofmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     hipStream_t st = ctx->lanes[lane].stream;
@@ -347,7 +347,7 @@ static int msm_locked(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const voi
     KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
     const void *d_sc = nullptr;
     KZG_TRY(stage_in(ctx, 0, scalars, n * 32, flags, &d_sc));
-    G1Xyzz *res = nullptr;
+    MsmPoint *res = nullptr;
     KZG_TRY(msm_run(ctx, 0, srs, offset, d_sc, n, sfmt, &res));
     return finish_point(ctx, 0, res, out, ofmt, flags);
 }
@@ -399,7 +399,7 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
         ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
         const void *d_sc = nullptr;
         rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
-        G1Xyzz *res = nullptr;
+        MsmPoint *res = nullptr;
         if (rc == KZG_OK) rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res);
         if (rc == KZG_OK) rc = emit_point(ctx, l, res, d_out + b * psz, ofmt);
     }
@@ -420,21 +420,23 @@ extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pf
     size_t psz = point_format_bytes(pfmt);
     if (!psz || !point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
     size_t cnt = count ? count : 1;
-    size_t need = stage_bytes(cnt * psz, flags) + (cnt + 2 * sum_points_scratch_count(cnt) + 4) * sizeof(G1Xyzz) + 8192;
+    size_t need = stage_bytes(cnt * psz, flags) + cnt * sizeof(G1Xyzz) + (cnt + 2 * sum_points_scratch_count(cnt) + 4) * sizeof(MsmPoint) + 8192;
     KZG_TRY(lane_reserve(ctx, 0, need));
     hipStream_t st = ctx->lanes[0].stream;
-    G1Xyzz *pts = (G1Xyzz *)lane_alloc(ctx, 0, cnt * sizeof(G1Xyzz));
-    G1Xyzz *scratch = (G1Xyzz *)lane_alloc(ctx, 0, 2 * sum_points_scratch_count(cnt) * sizeof(G1Xyzz));
+    G1Xyzz *dec = (G1Xyzz *)lane_alloc(ctx, 0, cnt * sizeof(G1Xyzz));
+    MsmPoint *pts = (MsmPoint *)lane_alloc(ctx, 0, cnt * sizeof(MsmPoint));
+    MsmPoint *scratch = (MsmPoint *)lane_alloc(ctx, 0, 2 * sum_points_scratch_count(cnt) * sizeof(MsmPoint));
     int *bad = (int *)lane_alloc(ctx, 0, 256);
-    if (!pts || !scratch || !bad) return fail(ctx, KZG_ERR_ALLOC, "sum workspace not reserved");
+    if (!dec || !pts || !scratch || !bad) return fail(ctx, KZG_ERR_ALLOC, "sum workspace not reserved");
     KZG_HIP_CHECK(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
-    G1Xyzz *res = pts;
+    MsmPoint *res = pts;
     if (count == 0) {
-        KZG_HIP_CHECK(ctx, hipMemsetAsync(pts, 0, sizeof(G1Xyzz), st));
+        KZG_TRY(point_set_infinity(ctx, st, pts));
     } else {
         const void *d_raw = nullptr;
         KZG_TRY(stage_in(ctx, 0, points, count * psz, flags, &d_raw));
-        KZG_TRY(decode_points(ctx, st, d_raw, count, pfmt, pts, bad));
+        KZG_TRY(decode_points(ctx, st, d_raw, count, pfmt, dec, bad));
+        KZG_TRY(points_to29(ctx, st, dec, pts, count));
         KZG_TRY(sum_points_run(ctx, 0, pts, count, scratch, &res));
     }
     int hbad = 0;
@@ -452,17 +454,19 @@ extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, 
     size_t psz = point_format_bytes(pfmt), osz = point_format_bytes(ofmt);
     if (!psz || !osz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
     size_t total = count * groups;
-    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(total * psz, flags) + (total + groups + 4) * sizeof(G1Xyzz) + groups * 144 + 65536));
+    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(total * psz, flags) + total * sizeof(G1Xyzz) + (total + groups + 4) * sizeof(MsmPoint) + groups * 144 + 65536));
     hipStream_t st = ctx->lanes[0].stream;
-    G1Xyzz *pts = (G1Xyzz *)lane_alloc(ctx, 0, total * sizeof(G1Xyzz));
-    G1Xyzz *tmp = (G1Xyzz *)lane_alloc(ctx, 0, groups * sizeof(G1Xyzz));
+    G1Xyzz *dec = (G1Xyzz *)lane_alloc(ctx, 0, total * sizeof(G1Xyzz));
+    MsmPoint *pts = (MsmPoint *)lane_alloc(ctx, 0, total * sizeof(MsmPoint));
+    MsmPoint *tmp = (MsmPoint *)lane_alloc(ctx, 0, groups * sizeof(MsmPoint));
     int *bad = (int *)lane_alloc(ctx, 0, 256);
     void *d_out = (flags & KZG_OUT_DEVICE) ? out : lane_alloc(ctx, 0, groups * osz);
-    if (!pts || !tmp || !bad || !d_out) return fail(ctx, KZG_ERR_ALLOC, "sum workspace not reserved");
+    if (!dec || !pts || !tmp || !bad || !d_out) return fail(ctx, KZG_ERR_ALLOC, "sum workspace not reserved");
     KZG_HIP_CHECK(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
     const void *d_raw = nullptr;
     KZG_TRY(stage_in(ctx, 0, points, total * psz, flags, &d_raw));
-    KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, pts, bad));
+    KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, dec, bad));
+    KZG_TRY(points_to29(ctx, st, dec, pts, total));
     KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, tmp, d_out, ofmt));
     int hbad = 0;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -604,7 +608,7 @@ extern "C" int kzg_witness_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *c
     KZG_TRY(quotient_linear_run(ctx, 0, (const Fr *)d, n, xm, dq, dpx));
     Fr px;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
-    G1Xyzz *res = nullptr;
+    MsmPoint *res = nullptr;
     KZG_TRY(msm_run(ctx, 0, srs, 0, dq, n - 1, sfmt, &res));
     KZG_TRY(finish_point(ctx, 0, res, out, ofmt, flags));  // synchronises the stream
     // remainder of (p - y)/(X - x) is p(x) - y: Some(_) => Err(PointNotOnPolynomial)
@@ -631,12 +635,12 @@ extern "C" int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const voi
     Fr *dq = (Fr *)lane_alloc(ctx, 0, d * 32);
     if (!dq) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_TRY(quotient_eval_run(ctx, 0, (const Fr *)de, log_d, i, sfmt, dq));
-    G1Xyzz *res = nullptr;
+    MsmPoint *res = nullptr;
     KZG_TRY(msm_run(ctx, 0, lagrange, 0, dq, d, sfmt, &res));
     return finish_point(ctx, 0, res, out, ofmt, flags);
 }
 
-static int verify_against(kzg_ctx *ctx, const G1Xyzz *res, const void *commitment, int pfmt, int *ok) {
+static int verify_against(kzg_ctx *ctx, const MsmPoint *res, const void *commitment, int pfmt, int *ok) {
     size_t psz = point_format_bytes(pfmt);
     if (!psz || pfmt == KZG_G1_JACOBIAN_MONT_144)
         return fail(ctx, KZG_ERR_SHAPE, "verify_poly takes the commitment in an affine format (KZGCommitment = G1Affine)");
@@ -657,7 +661,7 @@ extern "C" int kzg_verify_poly_coeff(kzg_ctx *ctx, const kzg_srs *srs, const voi
     KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
     const void *d = nullptr;
     KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
-    G1Xyzz *res = nullptr;
+    MsmPoint *res = nullptr;
     KZG_TRY(msm_run(ctx, 0, srs, 0, d, n, sfmt, &res));
     return verify_against(ctx, res, commitment, pfmt, ok);
 }
@@ -679,7 +683,7 @@ extern "C" int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const
     if (!work) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(work, evals, d * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     KZG_TRY(ntt_run(ctx, 0, work, log_d, 1));
-    G1Xyzz *res = nullptr;
+    MsmPoint *res = nullptr;
     KZG_TRY(msm_run(ctx, 0, monomial, 0, work, d, sfmt, &res));
     return verify_against(ctx, res, commitment, pfmt, ok);
 }

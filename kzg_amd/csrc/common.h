@@ -12,6 +12,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "curve.h"
+#include "curve29.h"
 
 namespace kzg {
 
@@ -122,19 +123,27 @@ inline int ilog2_ceil(size_t x) {
     return l;
 }
 
+// The point type the MSM pipeline computes in and hands between its kernels: extended Jacobian coordinates in
+// the unsaturated 29-bit field representation (curve29.h).  Canonical encodings are produced by emit_point.
+typedef G1Xyzz29 MsmPoint;
+
 // ---- cross-TU entry points -------------------------------------------------------------------
 // msm.hip
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n);
-// d_scalars: device pointer to n scalars (sfmt); result: device XYZZ point (192 B) in the lane arena
+// d_scalars: device pointer to n scalars (sfmt); result: one device MsmPoint in the lane arena
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-            G1Xyzz **d_result);
-// d_points: count XYZZ points -> one XYZZ point (plain sum)
-int sum_points_run(kzg_ctx *ctx, int lane, G1Xyzz *d_points, size_t count, G1Xyzz *d_scratch, G1Xyzz **d_result);
+            MsmPoint **d_result);
+// d_points: count points -> one point (plain sum)
+int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result);
+// conversions between the canonical saturated XYZZ form and MsmPoint (device arrays)
+int points_to29(kzg_ctx *ctx, hipStream_t st, const G1Xyzz *d_in, MsmPoint *d_out, size_t n);
+int points_from29(kzg_ctx *ctx, hipStream_t st, const MsmPoint *d_in, G1Xyzz *d_out, size_t n);
+int point_set_infinity(kzg_ctx *ctx, hipStream_t st, MsmPoint *d_pt);
 size_t sum_points_scratch_count(size_t count);
 // writes one point in `ofmt` (from XYZZ) to d_out (device); single thread incl. the Fq inversion
-int emit_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_point, void *d_out, int ofmt);
+int emit_point(kzg_ctx *ctx, int lane, const MsmPoint *d_point, void *d_out, int ofmt);
 size_t point_format_bytes(int fmt);
-int sum_groups_emit(kzg_ctx *ctx, int lane, const G1Xyzz *d_pts, size_t count, size_t groups, G1Xyzz *d_tmp, void *d_out,
+int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count, size_t groups, MsmPoint *d_tmp, void *d_out,
                     int ofmt);
 
 // srs.hip

@@ -22,7 +22,6 @@
 //
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
 #include "common.h"
-#include "curve29.h"
 
 namespace kzg {
 
@@ -215,12 +214,12 @@ __device__ __forceinline__ G1Affine29 load_entry_point29(const uint4 *table29, u
 
 // round 1 (dominant kernel): thread s folds its E consecutive sorted entries with XYZZ mixed adds in the
 // unsaturated 29-bit field representation (curve29.h), gathering each precomputed point from the
-// resident 29-bit table (next point prefetched under the add), and writes one partial -- converted back
-// to the canonical saturated form -- per bucket it touches.  Every thread has the same amount of work,
+// resident 29-bit table (next point prefetched under the add), and writes one partial per bucket it
+// touches.  Every thread has the same amount of work,
 // so the kernel ends without a straggler round.
 __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
                                                       const uint32_t *s1, int B, const uint4 *table29,
-                                                      G1Xyzz *out, const MsmState *st) {
+                                                      MsmPoint *out, const MsmState *st) {
     const uint32_t E = st->E, M = st->M;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t lo64 = (uint64_t)s * E;
@@ -252,7 +251,7 @@ __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, c
         int mode = 0;
         Madd29Mid mid;
         if (k == bend) {  // bucket boundary: flush and restart
-            out[pos++] = g1_xyzz_from29(acc);
+            out[pos++] = acc;
             do {
                 b++;
                 bend = bucket_start[b + 1];
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, c
         }
         if (mode == 0) acc = g1_madd29_phase2(acc, mid, neg_k, [&]() { return load_entry_point29(table29, ent_k); });
     }
-    out[pos] = g1_xyzz_from29(acc);
+    out[pos] = acc;
 }
 
 // per-level task layout: ntask[b] = ceil(cnt[b] / L); also detects "every bucket <= 1 partial"
@@ -308,8 +307,8 @@ __global__ __launch_bounds__(1024) void k_level_scan(const uint32_t *in_start, u
     }
 }
 
-__global__ __launch_bounds__(256) void k_accum_xyzz(const G1Xyzz *in, const uint32_t *in_start,
-                                                    const uint32_t *task_start, int B, int L, G1Xyzz *out,
+__global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const uint32_t *in_start,
+                                                    const uint32_t *task_start, int B, int L, MsmPoint *out,
                                                     const MsmState *st) {
     if (st->done) return;
     const uint32_t T = st->ntasks;
@@ -319,8 +318,8 @@ __global__ __launch_bounds__(256) void k_accum_xyzz(const G1Xyzz *in, const uint
         uint32_t s = in_start[b] + j * L;
         uint32_t e = in_start[b + 1];
         e = s + L < e ? s + L : e;
-        G1Xyzz acc = in[s];
-        for (uint32_t k = s + 1; k < e; k++) acc = g1_add(acc, in[k]);
+        MsmPoint acc = in[s];
+        for (uint32_t k = s + 1; k < e; k++) acc = g1_add29(acc, in[k]);
         out[t] = acc;
     }
 }
@@ -328,40 +327,40 @@ __global__ __launch_bounds__(256) void k_accum_xyzz(const G1Xyzz *in, const uint
 // ---------------------------------------------------------------------------------------------
 // sum_b (b + 1) * bucket[b]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_bucket_reduce(const G1Xyzz *buf0, const G1Xyzz *buf1,
-                                                      const uint32_t *starts, int B, int CH, G1Xyzz *out,
+__global__ __launch_bounds__(64) void k_bucket_reduce(const MsmPoint *buf0, const MsmPoint *buf1,
+                                                      const uint32_t *starts, int B, int CH, MsmPoint *out,
                                                       const MsmState *st) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int nchunks = B / CH;
     if (t >= nchunks) return;
     const uint32_t *start = starts + (size_t)st->final_level * (B + 1);
-    const G1Xyzz *buf = st->final_buf ? buf1 : buf0;
+    const MsmPoint *buf = st->final_buf ? buf1 : buf0;
     int lo = t * CH;
-    G1Xyzz run = G1Xyzz::inf(), acc = G1Xyzz::inf();
+    MsmPoint run = MsmPoint::infinity(), acc = MsmPoint::infinity();
     for (int b = lo + CH - 1; b >= lo; b--) {
         uint32_t s = start[b];
-        if (start[b + 1] > s) run = g1_add(run, buf[s]);
-        acc = g1_add(acc, run);
+        if (start[b + 1] > s) run = g1_add29(run, buf[s]);
+        acc = g1_add29(acc, run);
     }
     // acc = sum (b - lo + 1) B_b ; add lo * run
-    if (lo != 0 && !run.is_inf()) {
-        G1Xyzz m = G1Xyzz::inf();
+    if (lo != 0 && !run.inf) {
+        MsmPoint m = MsmPoint::infinity();
         for (int bit = 30; bit >= 0; bit--) {
-            m = g1_dbl(m);
-            if ((lo >> bit) & 1) m = g1_add(m, run);
+            m = g1_dbl29(m);
+            if ((lo >> bit) & 1) m = g1_add29(m, run);
         }
-        acc = g1_add(acc, m);
+        acc = g1_add29(acc, m);
     }
     out[t] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_sum_level(const G1Xyzz *in, uint32_t count, int L, G1Xyzz *out) {
+__global__ __launch_bounds__(64) void k_sum_level(const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nout = (count + L - 1) / L;
     if (t >= nout) return;
     uint32_t s = t * L, e = s + L < count ? s + L : count;
-    G1Xyzz acc = in[s];
-    for (uint32_t k = s + 1; k < e; k++) acc = g1_add(acc, in[k]);
+    MsmPoint acc = in[s];
+    for (uint32_t k = s + 1; k < e; k++) acc = g1_add29(acc, in[k]);
     out[t] = acc;
 }
 
@@ -383,10 +382,10 @@ __device__ bool fq_lexicographically_largest(const Fq &canon) {  // y > (q-1)/2
     return false;
 }
 
-__global__ __launch_bounds__(64) void k_emit_points(const G1Xyzz *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
+__global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const G1Xyzz p = pts[i * stride_pts];
+    const G1Xyzz p = g1_xyzz_from29(pts[i * stride_pts]);
     if (fmt == KZG_G1_JACOBIAN_MONT_144) {
         G1Jacobian j = g1_to_jacobian(p);
         *reinterpret_cast<G1Jacobian *>(out + i * 144) = j;
@@ -421,21 +420,44 @@ __global__ __launch_bounds__(64) void k_emit_points(const G1Xyzz *pts, size_t co
 }
 
 // out[g] = sum_{i < count} pts[g * count + i]   (count is small: one partial per GPU)
-__global__ __launch_bounds__(64) void k_sum_groups(const G1Xyzz *pts, uint32_t count, uint32_t groups, G1Xyzz *out) {
+__global__ __launch_bounds__(64) void k_sum_groups(const MsmPoint *pts, uint32_t count, uint32_t groups, MsmPoint *out) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
-    G1Xyzz acc = G1Xyzz::inf();
-    for (uint32_t i = 0; i < count; i++) acc = g1_add(acc, pts[(size_t)g * count + i]);
+    MsmPoint acc = MsmPoint::infinity();
+    for (uint32_t i = 0; i < count; i++) acc = g1_add29(acc, pts[(size_t)g * count + i]);
     out[g] = acc;
 }
 
-int sum_groups_emit(kzg_ctx *ctx, int lane, const G1Xyzz *d_pts, size_t count, size_t groups, G1Xyzz *d_tmp, void *d_out,
+int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count, size_t groups, MsmPoint *d_tmp, void *d_out,
                     int ofmt) {
     hipStream_t st = ctx->lanes[lane].stream;
     KZG_LAUNCH(ctx, st, "k_sum_groups", k_sum_groups, (unsigned)((groups + 63) / 64), 64, 0, d_pts, (uint32_t)count,
                (uint32_t)groups, d_tmp);
     KZG_LAUNCH(ctx, st, "k_emit_points", k_emit_points, (unsigned)((groups + 63) / 64), 64, 0, d_tmp, groups, (size_t)1,
                (uint8_t *)d_out, ofmt);
+    return KZG_OK;
+}
+
+__global__ __launch_bounds__(256) void k_points_to29(const G1Xyzz *in, MsmPoint *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = g1_xyzz_to29(in[i]);
+}
+__global__ __launch_bounds__(256) void k_points_from29(const MsmPoint *in, G1Xyzz *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = g1_xyzz_from29(in[i]);
+}
+__global__ void k_point_set_infinity(MsmPoint *p) { *p = MsmPoint::infinity(); }
+
+int points_to29(kzg_ctx *ctx, hipStream_t st, const G1Xyzz *d_in, MsmPoint *d_out, size_t n) {
+    if (n) KZG_LAUNCH(ctx, st, "k_points_to29", k_points_to29, (unsigned)((n + 255) / 256), 256, 0, d_in, d_out, n);
+    return KZG_OK;
+}
+int points_from29(kzg_ctx *ctx, hipStream_t st, const MsmPoint *d_in, G1Xyzz *d_out, size_t n) {
+    if (n) KZG_LAUNCH(ctx, st, "k_points_from29", k_points_from29, (unsigned)((n + 255) / 256), 256, 0, d_in, d_out, n);
+    return KZG_OK;
+}
+int point_set_infinity(kzg_ctx *ctx, hipStream_t st, MsmPoint *d_pt) {
+    KZG_LAUNCH(ctx, st, "k_point_set_infinity", k_point_set_infinity, 1, 1, 0, d_pt);
     return KZG_OK;
 }
 
@@ -449,7 +471,7 @@ size_t point_format_bytes(int fmt) {
     }
 }
 
-int emit_point(kzg_ctx *ctx, int lane, const G1Xyzz *d_point, void *d_out, int ofmt) {
+int emit_point(kzg_ctx *ctx, int lane, const MsmPoint *d_point, void *d_out, int ofmt) {
     if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     hipStream_t st = ctx->lanes[lane].stream;
     KZG_LAUNCH(ctx, st, "k_emit_points", k_emit_points, 1, 64, 0, d_point, (size_t)1, (size_t)1, (uint8_t *)d_out,
@@ -507,23 +529,23 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.off_starts = take((size_t)(L.levels + 2) * (L.B + 1) * 4);
     L.off_state = take(sizeof(MsmState));
     L.off_entries = take(L.M_max * 4 + 16);
-    L.off_bufA = take(L.T1_max * sizeof(G1Xyzz));
+    L.off_bufA = take(L.T1_max * sizeof(MsmPoint));
     size_t t2 = L.T1_max / LK + L.B + 1;
-    L.off_bufB = take(t2 * sizeof(G1Xyzz));
+    L.off_bufB = take(t2 * sizeof(MsmPoint));
     int nchunks = L.B / (L.B < REDUCE_CH ? L.B : REDUCE_CH);
-    L.off_chunks = take((size_t)nchunks * sizeof(G1Xyzz));
-    L.off_sum = take(sum_points_scratch_count(nchunks) * 2 * sizeof(G1Xyzz));
-    L.off_result = take(sizeof(G1Xyzz));
+    L.off_chunks = take((size_t)nchunks * sizeof(MsmPoint));
+    L.off_sum = take(sum_points_scratch_count(nchunks) * 2 * sizeof(MsmPoint));
+    L.off_result = take(sizeof(MsmPoint));
     L.bytes = o;
     return L;
 }
 
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) { return msm_layout(srs, n ? n : 1).bytes; }
 
-int sum_points_run(kzg_ctx *ctx, int lane, G1Xyzz *d_points, size_t count, G1Xyzz *d_scratch, G1Xyzz **d_result) {
+int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result) {
     hipStream_t st = ctx->lanes[lane].stream;
-    G1Xyzz *in = d_points;
-    G1Xyzz *bufs[2] = {d_scratch, d_scratch + sum_points_scratch_count(count)};
+    MsmPoint *in = d_points;
+    MsmPoint *bufs[2] = {d_scratch, d_scratch + sum_points_scratch_count(count)};
     int which = 0;
     while (count > 1) {
         size_t nout = (count + SUM_L - 1) / SUM_L;
@@ -540,18 +562,17 @@ int sum_points_run(kzg_ctx *ctx, int lane, G1Xyzz *d_points, size_t count, G1Xyz
 static bool g_attr_set = false;
 
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-            G1Xyzz **d_result) {
+            MsmPoint **d_result) {
     if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
     hipStream_t st = ctx->lanes[lane].stream;
     MsmLayout L = msm_layout(srs, n ? n : 1);
     char *base = (char *)lane_alloc(ctx, lane, L.bytes);
     if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
-    G1Xyzz *result = (G1Xyzz *)(base + L.off_result);
+    MsmPoint *result = (MsmPoint *)(base + L.off_result);
     *d_result = result;
     if (n == 0) {
-        KZG_HIP_CHECK(ctx, hipMemsetAsync(result, 0, sizeof(G1Xyzz), st));
-        return KZG_OK;
+        return point_set_infinity(ctx, st, result);
     }
     if (!g_attr_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
@@ -565,9 +586,9 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     uint32_t *starts = (uint32_t *)(base + L.off_starts);
     MsmState *state = (MsmState *)(base + L.off_state);
     uint32_t *entries = (uint32_t *)(base + L.off_entries);
-    G1Xyzz *bufs[2] = {(G1Xyzz *)(base + L.off_bufA), (G1Xyzz *)(base + L.off_bufB)};
-    G1Xyzz *chunks = (G1Xyzz *)(base + L.off_chunks);
-    G1Xyzz *sum_scratch = (G1Xyzz *)(base + L.off_sum);
+    MsmPoint *bufs[2] = {(MsmPoint *)(base + L.off_bufA), (MsmPoint *)(base + L.off_bufB)};
+    MsmPoint *chunks = (MsmPoint *)(base + L.off_chunks);
+    MsmPoint *sum_scratch = (MsmPoint *)(base + L.off_sum);
     const Fr *sc = (const Fr *)d_scalars;
     size_t per_block = (n + G - 1) / G;
     size_t lds_bytes = (size_t)B * 4;
@@ -601,9 +622,9 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     int nchunks = B / CH;
     KZG_LAUNCH(ctx, st, "k_bucket_reduce", k_bucket_reduce, (nchunks + 63) / 64, 64, 0, bufs[0], bufs[1], starts, B,
                CH, chunks, state);
-    G1Xyzz *sum = nullptr;
+    MsmPoint *sum = nullptr;
     KZG_TRY(sum_points_run(ctx, lane, chunks, nchunks, sum_scratch, &sum));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(result, sum, sizeof(G1Xyzz), hipMemcpyDeviceToDevice, st));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(result, sum, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
     return KZG_OK;
 }
 

@@ -186,7 +186,7 @@ static int hscalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
     return KZG_OK;
 }
 
-static int finish_point_host(kzg_ctx *ctx, const G1Xyzz *d_pt, void *out, int ofmt, int flags) {
+static int finish_point_host(kzg_ctx *ctx, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
     size_t psz = point_format_bytes(ofmt);
     hipStream_t st = ctx->lanes[0].stream;
     if (flags & KZG_OUT_DEVICE) {
@@ -253,7 +253,7 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(quotient_linear_run(ctx, 0, p, n2, xm, q, dpx));
         Fr px;
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
-        G1Xyzz *res = nullptr;
+        MsmPoint *res = nullptr;
         KZG_TRY(msm_run(ctx, 0, srs, 0, q, n2 - 1, KZG_FR_MONT_LE_32, &res));
         KZG_TRY(finish_point_host(ctx, res, out_w, ofmt, flags));
         if (ctx->prof) prof_collect(ctx);
@@ -305,7 +305,7 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, pin, n, A, N, to_m);
     KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, I, k, Bv, N, 0);
-    G1Xyzz *res = nullptr;
+    MsmPoint *res = nullptr;
     int hflag = 0;
     if (small_poly) {
         // deg I <= k-1 and deg p <= n-1 <= k-1: the quotient is zero and the division is exact iff p == I
@@ -359,8 +359,10 @@ extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mo
     kzg_srs *s = nullptr;
     KZG_TRY(srs_alloc(ctx, d, &s));
     G1Xyzz *rows = nullptr;
+    MsmPoint *rows29 = nullptr;
     int rc = KZG_OK;
-    if (hipMalloc((void **)&rows, d * sizeof(G1Xyzz)) != hipSuccess) rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange rows)");
+    if (hipMalloc((void **)&rows, d * sizeof(G1Xyzz)) != hipSuccess || hipMalloc((void **)&rows29, d * sizeof(MsmPoint)) != hipSuccess)
+        rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange rows)");
     Fr omega_inv = inv(host_omega(exp));
     Fr dinv = inv(from_u64<FrParams>((uint64_t)d));
     for (size_t i = 0; i < d && rc == KZG_OK; i++) {
@@ -368,14 +370,16 @@ extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mo
         Fr *sc = rc == KZG_OK ? (Fr *)lane_alloc(ctx, 0, d * 32) : nullptr;
         if (rc == KZG_OK && !sc) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
         if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(omega_inv, (uint64_t)i), dinv, d, sc);
-        G1Xyzz *res = nullptr;
+        MsmPoint *res = nullptr;
         if (rc == KZG_OK) rc = msm_run(ctx, 0, mono, 0, sc, d, KZG_FR_MONT_LE_32, &res);
-        if (rc == KZG_OK && hipMemcpyAsync(rows + i, res, sizeof(G1Xyzz), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        if (rc == KZG_OK && hipMemcpyAsync(rows29 + i, res, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st) != hipSuccess)
             rc = fail(ctx, KZG_ERR_HIP, "copy");
     }
+    if (rc == KZG_OK) rc = points_from29(ctx, st, rows29, rows, d);
     if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, rows);
     hipStreamSynchronize(st);
     if (rows) hipFree(rows);
+    if (rows29) hipFree(rows29);
     if (rc != KZG_OK) {
         hipFree(s->table);
         delete s;

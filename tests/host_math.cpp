@@ -47,3 +47,17 @@ void hm_madd29_chain(const uint32_t *pts, int n, uint64_t signs, uint32_t *o) {
     for (int i = 1; i < n; i++) acc = g1_madd29(acc, g1_affine_to29(p[i]), (signs >> i) & 1);
     G1Affine r = g1_to_affine(g1_xyzz_from29(acc)); memcpy(o, &r, 96); }
 }
+extern "C" {
+// general 29-bit addition / doubling on de-normalised operands built from madd29 / dbl29 chains
+void hm_add29(const uint32_t *a, const uint32_t *b, uint32_t *o) { G1Affine x, y; memcpy(&x, a, 96); memcpy(&y, b, 96);
+    G1Affine29 x29 = g1_affine_to29(x), y29 = g1_affine_to29(y);
+    // p = 2x - x (via dbl29 + madd29 of -x), q = (y + y) - y: non-trivial ZZ/ZZZ and lazy coordinates
+    G1Xyzz29 p = g1_madd29(g1_dbl29(g1_from_affine29(x29, false)), x29, true);
+    G1Xyzz29 q = g1_madd29(g1_madd29(g1_from_affine29(y29, false), y29, false), y29, true);
+    G1Affine r = g1_to_affine(g1_xyzz_from29(g1_add29(p, q))); memcpy(o, &r, 96); }
+// [k]P by double-and-add with dbl29 / add29 only (k: 8 x u32)
+void hm_mul29_scalar(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1Affine x; memcpy(&x, a, 96);
+    G1Xyzz29 base = g1_from_affine29(g1_affine_to29(x), false), acc = G1Xyzz29::infinity();
+    for (int i = 255; i >= 0; i--) { acc = g1_dbl29(acc); if ((k[i >> 5] >> (i & 31)) & 1) acc = g1_add29(acc, base); }
+    G1Affine r = g1_to_affine(g1_xyzz_from29(acc)); memcpy(o, &r, 96); }
+}

@@ -121,3 +121,16 @@ def test_fq29_unsaturated_layer(L):
         ps = [rng.choice(pts) if rng.random() < 0.3 else C.g1_mul(G, rng.randrange(1, M.R)) for _ in range(k)]
         s = rng.getrandbits(k)
         assert chain(ps, s) == ref(ps, s)
+
+
+def test_fq29_general_add_and_double(L):
+    """g1_add29 / g1_dbl29 (tail kernels of the MSM) on de-normalised, lazily-reduced operands."""
+    rng = random.Random(31)
+    G, INF = C.g1_generator(), bytes(96)
+    P = C.g1_mul(G, rng.randrange(1, M.R))
+    Q = C.g1_mul(G, rng.randrange(1, M.R))
+    nP = C.point_to_blob(M.g1_neg(C.blob_to_point(P)))
+    for a, c in [(P, Q), (P, P), (P, nP), (INF, P), (P, INF), (INF, INF), (Q, P)]:
+        assert pt(L.hm_add29, a, c) == C.g1_add(a, c)
+    for k in (0, 1, 2, 3, M.R - 1, rng.randrange(M.R)):
+        assert pt(L.hm_mul29_scalar, P, b(k, 32)) == C.g1_mul(P, k)
