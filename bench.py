@@ -64,7 +64,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4, help="commitments per step (N = 1)")
+    ap.add_argument("--batch", type=int, default=8, help="commitments per step (pipelined on the engine's HIP streams)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams the engine pipelines a batch over (0 = engine default)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
@@ -220,7 +220,7 @@ def main():
                 "workload": ("degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step"
                              % (args.log_n, args.batch)) if not sharded else
                             ("degree-%d*2^%d coeff_form commit, SRS sharded 2^%d terms per rank over %d GPUs, batch of %d "
-                             "per step, one RCCL all_gather of the 96-B partials + local sums"
+                             "per step, one RCCL all_gather of the 144-B Jacobian partials + local sums"
                              % (world, args.log_n, args.log_n, world, args.batch)),
                 "scalars": "u64-valued Fr" if args.u64 else "uniform full-width Fr (SplitMix64 counter stream, seed 1)",
                 "terms_per_rank": n, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",

@@ -219,3 +219,42 @@ def test_g1_sum_batch(engine, srs_small):
         for i in range(3):
             acc = C.g1_add(acc, pts[3 * g + i])
         assert got[g] == acc
+
+
+def test_concurrent_callers(engine, srs_small):
+    """The C ABI is thread-safe: many host threads on one kzg_ctx (serialised on its mutex) and on separate
+    contexts (truly concurrent on the GPU) all get the right answers."""
+    import threading
+    srs, blob = srs_small
+    rng = random.Random(55)
+    jobs = [rand_scalars(rng, 64 + 8 * i) for i in range(8)]
+    want = [C.msm_g1(blob[: 96 * len(j)], j) for j in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(i, eng, s):
+        try:
+            for _ in range(3):
+                got[i] = eng.msm(s, jobs[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i, engine, srs)) for i in range(len(jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs and got == want
+    # separate contexts on the same GPU
+    engines = [kzg_amd.Engine(0) for _ in range(3)]
+    srss = [kzg_amd.Srs.upload(e, blob, 300) for e in engines]
+    got = [None] * len(jobs)
+    ths = [threading.Thread(target=work, args=(i, engines[i % 3], srss[i % 3])) for i in range(len(jobs))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs and got == want
+    for e, s in zip(engines, srss):
+        s.free()
+        e.close()
