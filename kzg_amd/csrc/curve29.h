@@ -7,7 +7,7 @@
 //   table point x2, y2 < 2q;  -y2 = 4q - y2 < 4q
 //   acc.zz, acc.zzz : M            acc.x < 19q            acc.y < 11q
 //   P  = U2 - X1 + 32q < 35q       R  = S2 - Y1 + 16q < 19q
-//   X3 = R^2 - (PPP + 2Q) + 16q < 19q      Q - X3 + 32q < 35q      Y3 = R(Q - X3) - Y1*PPP + 8q < 11q
+//   X3 = R^2 - (PPP + 2Q) + 16q < 19q      Q - X3 + 32q < 35q      Y3 = (R(Q - X3) + (16q - Y1)*PPP)/R29 < 1.0001q
 // General addition / doubling (g1_add29, g1_dbl29) accept any X < 20q, Y < 12q (ZZ, ZZZ are always
 // products) and return X, Y < 5.0001q, so every mix of the three operations stays inside the classes.
 // All far below the 2^12 q limit of mul29.
@@ -182,10 +182,10 @@ KZG_HD G1Xyzz29 g1_madd29_phase2(const G1Xyzz29 &p, const Madd29Mid &m, bool neg
     r.pad[0] = r.pad[1] = r.pad[2] = 0;
     r.zz = mul29(p.zz, PP);
     r.zzz = mul29(p.zzz, PPP);
-    Fq29 Bm = mul29(p.y, PPP);
     Fq29 t = add2x29(PPP, Q);
     r.x = sub29<16>(sqr29(R), t);
-    r.y = sub29<8>(mul29(R, sub29<32>(Q, r.x)), Bm);
+    // Y3 = R (Q - X3) + (16q - Y1) PPP: one double-width accumulation, one reduction (< 1.0001 q)
+    r.y = muladd29_inline(R, sub29<32>(Q, r.x), sub29<16>(zero29(), p.y), PPP);
     return r;
 }
 

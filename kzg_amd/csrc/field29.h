@@ -71,6 +71,41 @@ KZG_HD Fq29 mul29_inline(const Fq29 &a, const Fq29 &b) {
     return r;
 }
 
+// (a*b + c*d)/R29 with ONE reduction: both double-width products accumulate in the same columns
+// (<= 14 + 14 + 14 products below 2^58 per column < 2^64).  All four operands limb-normalised (< 2^29).
+// Result < q (1 + (a*b + c*d)/(q R29)): lazy, limbs normalised.  Inlined at its (single) call site.
+KZG_HD Fq29 muladd29_inline(const Fq29 &a, const Fq29 &b, const Fq29 &c, const Fq29 &d) {
+    uint32_t m[F29_N];
+    Fq29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < F29_N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)a.v[i] * b.v[k - i];
+            acc += (uint64_t)c.v[i] * d.v[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fq29Consts::mod(k - i);
+        m[k] = ((uint32_t)acc * Fq29Consts::INV) & F29_MASK;
+        acc += (uint64_t)m[k] * Fq29Consts::mod(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = F29_N; k < 2 * F29_N - 1; k++) {
+#pragma unroll
+        for (int i = k - F29_N + 1; i < F29_N; i++) {
+            acc += (uint64_t)a.v[i] * b.v[k - i];
+            acc += (uint64_t)c.v[i] * d.v[k - i];
+            acc += (uint64_t)m[i] * Fq29Consts::mod(k - i);
+        }
+        r.v[k - F29_N] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    r.v[F29_N - 1] = (uint32_t)acc;
+    return r;
+}
+
 // Montgomery square: the 91 cross products are formed once against a pre-doubled copy of a (limbs < 2^30),
 // 105 + 196 mads instead of 392.
 KZG_HD Fq29 sqr29_inline(const Fq29 &a) {

@@ -119,23 +119,36 @@ __global__ void k_scan_blocks(uint32_t *blk_hist, int G, int B, uint32_t *total)
 }
 
 // Single-block exclusive scan helper over `B` per-bucket values produced by f(b); writes out[0..B].
+// Each thread sums a contiguous run serially, one wave-level shuffle scan (64 lanes), one 16-entry
+// cross-wave pass through LDS: two barriers in total instead of two per Hillis-Steele step.
 template <class F>
 __device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *out, uint32_t *lds) {
     const int T = blockDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = T >> 6;
     int per = (B + T - 1) / T;
     int b0 = threadIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
     uint32_t local = 0;
     for (int b = b0; b < b1; b++) local += f(b);
-    lds[threadIdx.x] = local;
-    __syncthreads();
-    for (int off = 1; off < T; off <<= 1) {  // Hillis-Steele inclusive scan
-        uint32_t v = threadIdx.x >= off ? lds[threadIdx.x - off] : 0;
-        __syncthreads();
-        lds[threadIdx.x] += v;
-        __syncthreads();
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t v = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += v;
     }
-    uint32_t run = lds[threadIdx.x] - local;
-    uint32_t total = lds[T - 1];
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < nwaves; w++) {
+            uint32_t t = lds[w];
+            lds[w] = run;
+            run += t;
+        }
+        lds[nwaves] = run;
+    }
+    __syncthreads();
+    uint32_t run = lds[wave] + incl - local;
+    uint32_t total = lds[nwaves];
     for (int b = b0; b < b1; b++) {
         out[b] = run;
         run += f(b);
