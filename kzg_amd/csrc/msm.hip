@@ -118,24 +118,37 @@ __global__ void k_scan_blocks(uint32_t *blk_hist, int G, int B, uint32_t *total)
     total[b] = run;
 }
 
-// Single-block exclusive scan helper over `B` per-bucket values produced by f(b); writes out[0..B].
-// Each thread sums a contiguous run serially, one wave-level shuffle scan (64 lanes), one 16-entry
-// cross-wave pass through LDS: two barriers in total instead of two per Hillis-Steele step.
+// Single-block exclusive scan over `B` per-bucket values produced by f(b); writes out[0..B] and returns the
+// total.  Each wave owns a contiguous segment and walks it in rounds of 64 consecutive buckets, so every
+// global access is a coalesced 256-B row; all rounds are loaded into registers first (their latencies
+// overlap), then scanned with wave shuffles and a running carry; one LDS pass combines the <= 16 waves.
+constexpr int SCAN_MAX_ROUNDS = 32;  // 1024 threads x 32 rounds = 2^15 buckets (c <= 16)
 template <class F>
 __device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *out, uint32_t *lds) {
-    const int T = blockDim.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = T >> 6;
-    int per = (B + T - 1) / T;
-    int b0 = threadIdx.x * per, b1 = b0 + per < B ? b0 + per : B;
-    uint32_t local = 0;
-    for (int b = b0; b < b1; b++) local += f(b);
-    uint32_t incl = local;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int seg = (B + nwaves - 1) / nwaves;          // buckets per wave
+    const int rounds = (seg + 63) >> 6;                  // <= SCAN_MAX_ROUNDS
+    const int base = wave * seg;
+    const int end = base + seg < B ? base + seg : B;
+    uint32_t v[SCAN_MAX_ROUNDS];
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t v = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += v;
+    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
+        int b = base + r * 64 + lane;
+        v[r] = (r < rounds && b < end) ? f(b) : 0u;
     }
-    if (lane == 63) lds[wave] = incl;
+    uint32_t carry = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
+        uint32_t x = v[r], incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        v[r] = incl - x + carry;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) lds[wave] = carry;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t run = 0;
@@ -147,11 +160,11 @@ __device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *o
         lds[nwaves] = run;
     }
     __syncthreads();
-    uint32_t run = lds[wave] + incl - local;
-    uint32_t total = lds[nwaves];
-    for (int b = b0; b < b1; b++) {
-        out[b] = run;
-        run += f(b);
+    const uint32_t woff = lds[wave], total = lds[nwaves];
+#pragma unroll
+    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
+        int b = base + r * 64 + lane;
+        if (r < rounds && b < end) out[b] = v[r] + woff;
     }
     if (threadIdx.x == 0) out[B] = total;
     __syncthreads();
