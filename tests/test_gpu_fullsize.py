@@ -1,0 +1,161 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (known-tau identities, eval-form ==
+coeff-form, linearity, round trips), plus adversarial scalar distributions that force the deep paths of the MSM
+(multi-level bucket folding, single-bucket inputs, every window size).  The oracle only supplies one scalar
+multiplication per check."""
+import ctypes
+import random
+
+import pytest
+
+import kzg_amd
+from kzg_amd import _lib as L
+from oracle import c_oracle as C
+from oracle import kzg_model as M
+from tests.gpu_common import engine, rand_scalars  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+R = M.R
+TAU = 0x5EED5EED5EED5EED
+
+
+@pytest.fixture(scope="module")
+def big(engine):
+    n = 1 << 20
+    params = kzg_amd.setup(engine, TAU, n)
+    lag = kzg_amd.setup_lagrange(engine, TAU, n)
+    yield n, params, lag
+    params.gs.free()
+    lag.free()
+
+
+def _msm_dev(engine, srs, buf, n, offset=0):
+    out = ctypes.create_string_buffer(96)
+    rc = engine.lib.kzg_msm_g1(engine.ctx, srs.handle, offset, buf.ptr, n, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0, engine.last_error()
+    return out.raw
+
+
+def test_config2_commit_2_20(engine, big):
+    """configs[1]: degree-2^20 coeff-form commit == [p(tau)]G, full-width and u64-valued coefficients."""
+    n, params, _ = big
+    for seed, u64 in ((11, False), (12, True)):
+        buf = engine.alloc_scalars(n).fill_random(seed, u64_valued=u64)
+        got = _msm_dev(engine, params.gs, buf, n)
+        assert got == C.g1_mul(C.g1_generator(), engine.poly_eval(buf, TAU))
+        buf.free()
+
+
+def test_config3_eval_form_equals_coeff_form_2_20(engine, big):
+    """configs[2]: NTT then Lagrange-SRS MSM gives the same commitment as the monomial MSM; iNTT round trip."""
+    n, params, lag = big
+    buf = engine.alloc_scalars(n).fill_random(13)
+    orig = buf.download()
+    c1 = _msm_dev(engine, params.gs, buf, n)
+    engine.ntt(buf, 20)
+    c2 = _msm_dev(engine, lag, buf, n)
+    assert c1 == c2
+    ok = ctypes.c_int()
+    rc = engine.lib.kzg_verify_poly_eval(engine.ctx, params.gs.handle, c1, L.G1_AFFINE_MONT, buf.ptr, n, buf.sfmt, L.IN_DEVICE, ctypes.byref(ok))
+    assert rc == 0 and ok.value == 1
+    engine.ntt(buf, 20, inverse=True)
+    assert buf.download() == orig
+    buf.free()
+
+
+def test_config4_witnesses_2_20(engine, big):
+    """configs[3]: create_witness (single opening) and create_witness_batched (k = 256) at degree 2^20."""
+    n, params, lag = big
+    buf = engine.alloc_scalars(n).fill_random(14)
+    ptau = engine.poly_eval(buf, TAU)
+    x = kzg_amd.splitmix_scalar(99, 0)
+    y = engine.poly_eval(buf, x)
+    out = ctypes.create_string_buffer(96)
+    b32 = lambda v: (v % R).to_bytes(32, "little")  # noqa: E731
+    rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(x), b32(y), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and out.raw == C.g1_mul(C.g1_generator(), (ptau - y) * pow(TAU - x, -1, R) % R)
+    rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(x), b32(y + 1), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == L.KZG_ERR_POINT_NOT_ON_POLY
+    k = 256
+    xs = [kzg_amd.splitmix_scalar(7, i) for i in range(k)]
+    ys = [engine.poly_eval(buf, v) for v in xs]
+    rbuf, rlen = ctypes.create_string_buffer(32 * k), ctypes.c_size_t()
+    rc = engine.lib.kzg_witness_coeff_batched(engine.ctx, params.gs.handle, buf.ptr, n, kzg_amd.pack_scalars(xs), kzg_amd.pack_scalars(ys),
+                                              k, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
+    assert rc == 0 and rlen.value == k
+    I = kzg_amd.unpack_scalars(rbuf.raw)
+    assert all(engine.poly_eval(I, xs[i]) == ys[i] for i in (0, 17, 255))
+    Z = 1
+    for v in xs:
+        Z = Z * (TAU - v) % R
+    assert out.raw == C.g1_mul(C.g1_generator(), (ptau - engine.poly_eval(I, TAU)) * pow(Z, -1, R) % R)
+    # eval-form witness at index m == coeff-form witness at w^m
+    m = 54321
+    xm = pow(kzg_amd.compute_omega(n)[2], m, R)
+    ym = engine.poly_eval(buf, xm)
+    rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(xm), b32(ym), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    w_coeff = out.raw
+    engine.ntt(buf, 20)
+    rc2 = engine.lib.kzg_witness_eval(engine.ctx, lag.handle, buf.ptr, n, m, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and rc2 == 0 and out.raw == w_coeff
+    buf.free()
+
+
+def test_msm_linearity_and_offsets_2_20(engine, big):
+    """MSM(a) + MSM(b) == MSM(a + b); MSM over [0, n) == MSM[0, h) + MSM[h, n)."""
+    n, params, _ = big
+    a = engine.alloc_scalars(n).fill_random(21)
+    b = engine.alloc_scalars(n).fill_random(22)
+    ca, cb = _msm_dev(engine, params.gs, a, n), _msm_dev(engine, params.gs, b, n)
+    # a + b evaluated through the known-tau identity: p_a(tau) + p_b(tau)
+    s = (engine.poly_eval(a, TAU) + engine.poly_eval(b, TAU)) % R
+    assert engine.g1_sum([ca, cb]) == C.g1_mul(C.g1_generator(), s)
+    h = 333_333
+    lo = _msm_dev(engine, params.gs, a, h)
+    hi_buf = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    hi_buf.engine, hi_buf.n, hi_buf.sfmt, hi_buf.ptr = engine, n - h, a.sfmt, ctypes.c_void_p(a.ptr.value + 32 * h)
+    hi = _msm_dev(engine, params.gs, hi_buf, n - h, offset=h)
+    assert engine.g1_sum([lo, hi]) == ca
+    a.free(); b.free()
+
+
+@pytest.mark.parametrize("case", ["all_equal", "two_values", "zeros_and_ones", "single_window", "max_digits"])
+def test_adversarial_scalars_2_16(engine, case):
+    """Distributions that put everything into a handful of buckets: exercises several fold rounds."""
+    n = 1 << 16
+    rng = random.Random(hash(case) & 0xFFFF)
+    params = kzg_amd.setup(engine, TAU, n)
+    if case == "all_equal":
+        sc = [rng.randrange(R)] * n
+    elif case == "two_values":
+        v = [rng.randrange(R), R - 1]
+        sc = [v[i & 1] for i in range(n)]
+    elif case == "zeros_and_ones":
+        sc = [i % 3 % 2 for i in range(n)]
+    elif case == "single_window":
+        sc = [0x1234 << 48] * n
+    else:  # every signed digit at its extreme
+        sc = [int("8000" * 15, 16) % R] * n
+    got = engine.msm(params.gs, sc)
+    ptau = 0
+    # sum_i sc_i tau^i with few distinct values: group by value
+    pw = 1
+    acc = {}
+    for i in range(n):
+        acc[sc[i]] = (acc.get(sc[i], 0) + pw) % R
+        pw = pw * TAU % R
+    ptau = sum(v * s for v, s in acc.items()) % R
+    assert got == C.g1_mul(C.g1_generator(), ptau)
+    params.gs.free()
+
+
+@pytest.mark.parametrize("n", [5, 17, 33, 100, 700, 3000, 9000, 40000])
+def test_every_window_size(engine, n):
+    """SRS sizes that select every window width c = 4 .. 14 (c = 16 is covered by the 2^20 tests)."""
+    rng = random.Random(n)
+    params = kzg_amd.setup(engine, TAU, n)
+    c, W = params.gs.window_info()
+    assert W == -(-256 // c)
+    sc = rand_scalars(rng, n)
+    got = engine.msm(params.gs, sc)
+    assert got == C.g1_mul(C.g1_generator(), C.poly_eval(sc, TAU))
+    params.gs.free()
