@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=16, help="commitments per step (pipelined on the engine's HIP streams)")
     ap.add_argument("--streams", type=int, default=0, help="HIP streams the engine pipelines a batch over (0 = engine default)")
+    ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks (0 = default)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -96,6 +97,8 @@ def main():
     engine = kzg_amd.Engine(local_rank)
     if args.streams:
         engine.set_option("streams", args.streams)
+    if args.accum_blocks:
+        engine.set_option("accum_blocks", args.accum_blocks)
 
     def barrier():
         if dist is not None:

@@ -260,6 +260,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "streams") {
         if (value < 1 || value > 16) return fail(ctx, KZG_ERR_SHAPE, "streams must be 1..16");
         ctx->opt_streams = (int)value;
+    } else if (k == "accum_blocks") {
+        if (value < 64 || value > 512) return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 64..512");
+        ctx->opt_accum_blocks = (int)value;
     } else {
         return fail(ctx, KZG_ERR_SHAPE, "unknown option " + k);
     }

@@ -50,6 +50,7 @@ struct kzg_ctx {
     std::vector<kzg::Lane> lanes;
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 4;
+    int opt_accum_blocks = 512;  // 256-thread blocks of k_accum_affine (512 = every SIMD holds its 2 waves)
     int num_cus = 256;
     // profiling
     bool prof = false;
