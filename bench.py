@@ -98,7 +98,7 @@ def main():
     if args.streams:
         engine.set_option("streams", args.streams)
     if args.accum_blocks:
-        engine.set_option("accum_blocks", args.accum_blocks)
+        engine.set_option("accum_blocks_batch", args.accum_blocks)
 
     def barrier():
         if dist is not None:

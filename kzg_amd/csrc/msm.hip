@@ -623,7 +623,7 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
     // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
-    const uint32_t slots = (uint32_t)ctx->opt_accum_blocks * 256u;  // resident threads k_accum_affine is split over
+    const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
     KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, slots);
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
