@@ -154,6 +154,11 @@ int kzg_quotient_linear(kzg_ctx *ctx, const void *coeffs, size_t n, const void *
 /* div_by_omega_i (src/eval_form.rs:58-84) applied to (evals - evals[i]). */
 int kzg_quotient_eval(kzg_ctx *ctx, const void *evals, size_t d, size_t i, int sfmt, int flags, void *q_out);
 
+/* Polynomial::fft_mul / best_mul (src/polynomial.rs:167-191): out = a * b, na + nb - 1 coefficients, by three
+ * NTTs of size next_pow2(na + nb) and a pointwise product (EvaluationDomain::mul_assign, src/ft.rs:220-244).
+ * The product is unique, so it equals the reference's naive Mul (:473-487) as well.  Host or device buffers. */
+int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, int sfmt, int flags, void *out);
+
 /* ---- device memory + measurement ------------------------------------------------------------- */
 int kzg_dev_alloc(kzg_ctx *ctx, size_t bytes, void **out);
 int kzg_dev_free(kzg_ctx *ctx, void *p);

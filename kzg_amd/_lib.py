@@ -75,6 +75,7 @@ def load():
         "kzg_poly_eval": (i32, [vp, vp, sz, vp, i32, i32, vp]),
         "kzg_quotient_linear": (i32, [vp, vp, sz, vp, vp, i32, i32, vp]),
         "kzg_quotient_eval": (i32, [vp, vp, sz, sz, i32, i32, vp]),
+        "kzg_poly_mul": (i32, [vp, vp, sz, vp, sz, i32, i32, vp]),
         "kzg_dev_alloc": (i32, [vp, sz, c_void_pp]),
         "kzg_dev_free": (i32, [vp, vp]),
         "kzg_dev_upload": (i32, [vp, vp, vp, sz]),

@@ -253,6 +253,16 @@ class Engine:
             _raise(self, rc)
         return unpack_scalars(out.raw[: (n - 1) * 32])
 
+    def poly_mul(self, a, b):
+        """Polynomial::fft_mul / best_mul: coefficient list of a * b."""
+        ab, bb = pack_scalars(a), pack_scalars(b)
+        na, nb = len(ab) // 32, len(bb) // 32
+        out = ctypes.create_string_buffer(32 * (na + nb - 1))
+        rc = self.lib.kzg_poly_mul(self.ctx, ab, na, bb, nb, L.FR_CANONICAL, 0, out)
+        if rc:
+            _raise(self, rc)
+        return unpack_scalars(out.raw)
+
     def quotient_eval(self, evals, i):
         blob = pack_scalars(evals)
         d = len(blob) // 32
@@ -394,6 +404,12 @@ class Polynomial:
 
     def eval(self, engine, x):  # :156-165
         return engine.poly_eval(self.slice_coeffs(), x)
+
+    def fft_mul(self, engine, other):  # :167-183 (and best_mul :185-191: the product is the same polynomial)
+        coeffs = engine.poly_mul(self.slice_coeffs(), other.slice_coeffs())
+        return Polynomial(coeffs)  # From<EvaluationDomain> = Polynomial::new (src/ft.rs:27-31)
+
+    best_mul = fft_mul
 
     def __eq__(self, other):  # :29-40
         return self.degree == other.degree and all(a == b for a, b in zip(self.coeffs, other.coeffs))

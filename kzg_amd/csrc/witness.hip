@@ -204,6 +204,42 @@ static int finish_point_host(kzg_ctx *ctx, const MsmPoint *d_pt, void *out, int 
     return KZG_OK;
 }
 
+// a[i] *= b[i]  (Montgomery product; with b in Montgomery form the result keeps a's form)
+__global__ __launch_bounds__(256) void k_mul_assign(Fr *a, const Fr *b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = mul(a[i], b[i]);
+}
+
+extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, int sfmt, int flags, void *out) {
+    // Polynomial::fft_mul (src/polynomial.rs:167-183)
+    if (!ctx || !a || !b || !out || na == 0 || nb == 0) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    uint32_t log_n = (uint32_t)ilog2_ceil(na + nb);   // from_coeffs(resize(n + k)) rounds up to 2^exp
+    if (log_n >= FR_TWO_ADICITY || log_n > 24) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    size_t N = (size_t)1 << log_n, nout = na + nb - 1;
+    KZG_TRY(lane_reserve(ctx, 0, 8 * N * 32 + (1 << 20)));
+    hipStream_t st = ctx->lanes[0].stream;
+    Fr *A = (Fr *)lane_alloc(ctx, 0, N * 32), *Bv = (Fr *)lane_alloc(ctx, 0, N * 32), *ia = (Fr *)lane_alloc(ctx, 0, N * 32),
+       *ib = (Fr *)lane_alloc(ctx, 0, N * 32);
+    if (!A || !Bv || !ia || !ib) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    hipMemcpyKind kind = (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(ia, a, na * 32, kind, st));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(ib, b, nb * 32, kind, st));
+    // a keeps its form; b goes to Montgomery form so that the pointwise Montgomery product preserves a's form
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, ia, na, A, N, 0);
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, ib, nb, Bv, N, sfmt == KZG_FR_CANONICAL_LE_32);
+    KZG_TRY(ntt_run(ctx, 0, A, log_n, 0));
+    KZG_TRY(ntt_run(ctx, 0, Bv, log_n, 0));
+    KZG_LAUNCH(ctx, st, "k_mul_assign", k_mul_assign, gridfor(N), 256, 0, A, Bv, N);
+    KZG_TRY(ntt_run(ctx, 0, A, log_n, 1));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, A, nout * 32, (flags & KZG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
 extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int sfmt, int flags) {
     if (!ctx || !data) return KZG_ERR_SHAPE;
     std::lock_guard<std::mutex> g(ctx->mu);

@@ -129,3 +129,23 @@ def test_fill_random_definition(engine):
     got = kzg_amd.unpack_scalars(buf.download())
     assert got == [kzg_amd.splitmix_scalar(7, i, True) for i in range(1000)] and max(got) < 1 << 64
     buf.free()
+
+
+def test_fft_mul_polynomial_arith(engine):
+    """polynomial_arith (src/ft.rs:411-434): fft_mul == naive Mul for sizes {1,5,10,50}^2, plus a 2^12 x 2^12 case
+    and the sub-product-tree root of 256 opening points (two degree-128 factors -> best_mul takes the NTT path)."""
+    rng = random.Random(42)
+    for ca in (1, 5, 10, 50):
+        for cb in (1, 5, 10, 50):
+            a, b = rand_scalars(rng, ca), rand_scalars(rng, cb)
+            want = M.Polynomial(a, ca - 1).mul_naive(M.Polynomial(b, cb - 1))
+            assert engine.poly_mul(a, b) == want.coeffs
+    a, b = rand_scalars(rng, 4096), rand_scalars(rng, 3000)
+    got = engine.poly_mul(a, b)
+    x = rng.randrange(M.R)
+    assert C.poly_eval(got, x) == C.poly_eval(a, x) * C.poly_eval(b, x) % M.R and len(got) == 7095
+    xs = rand_scalars(rng, 256)
+    left = M.SubProductTree.new_from_points(xs[:128]).product
+    right = M.SubProductTree.new_from_points(xs[128:]).product
+    pa, pb = kzg_amd.Polynomial(left.coeffs), kzg_amd.Polynomial(right.coeffs)
+    assert pa.best_mul(engine, pb).coeffs == left.fft_mul(right).coeffs
