@@ -61,3 +61,7 @@ void hm_mul29_scalar(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1Affi
     for (int i = 255; i >= 0; i--) { acc = g1_dbl29(acc); if ((k[i >> 5] >> (i & 31)) & 1) acc = g1_add29(acc, base); }
     G1Affine r = g1_to_affine(g1_xyzz_from29(acc)); memcpy(o, &r, 96); }
 }
+extern "C" {
+void hm_fq_inv_bgcd(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv_bgcd(x); memcpy(o, z.v, 48); }
+void hm_fr_inv_bgcd(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv_bgcd(x); memcpy(o, z.v, 32); }
+}

@@ -52,15 +52,25 @@ def test_field_ops(L):
         assert call(L.hm_fr_sub, b(a, 32), b(c, 32), n=32) == (a - c) % M.R
         assert call(L.hm_fr_to_mont, b(a, 32), n=32) == a * Rr % M.R
         assert call(L.hm_fr_from_mont, b(a, 32), n=32) == a * pow(Rr, -1, M.R) % M.R
-    # inv() = binary extended GCD, inv_fermat() = a^(p-2): both against python, incl. edge values
-    for a in [1, 2, 3, M.Q - 1, M.Q - 2, (M.Q + 1) // 2, 1 << 380] + [rng.randrange(1, M.Q) for _ in range(40)]:
+    # inv() = safegcd (Bernstein-Yang divsteps), inv_bgcd() = binary extended GCD, inv_fermat() = a^(p-2):
+    # all three against python, incl. edge values and values around the 30-bit limb boundaries
+    for a in [1, 2, 3, M.Q - 1, M.Q - 2, (M.Q + 1) // 2, 1 << 380, 2 ** 30, 2 ** 30 - 1, 2 ** 60 + 1] + \
+            [rng.randrange(1, M.Q) for _ in range(400)]:
         want = pow(a, -1, M.Q) * Rq % M.Q
         assert call(L.hm_fq_inv, b(a * Rq % M.Q, 48)) == want
-        assert call(L.hm_fq_inv_fermat, b(a * Rq % M.Q, 48)) == want
-    for a in [1, 2, 3, M.R - 1, M.R - 2, (M.R + 1) // 2, 1 << 254] + [rng.randrange(1, M.R) for _ in range(40)]:
+        if a % 10 < 2:
+            assert call(L.hm_fq_inv_bgcd, b(a * Rq % M.Q, 48)) == want
+            assert call(L.hm_fq_inv_fermat, b(a * Rq % M.Q, 48)) == want
+    for a in [1, 2, 3, M.R - 1, M.R - 2, (M.R + 1) // 2, 1 << 254, 2 ** 30, 2 ** 30 - 1] + \
+            [rng.randrange(1, M.R) for _ in range(400)]:
         want = pow(a, -1, M.R) * Rr % M.R
         assert call(L.hm_fr_inv, b(a * Rr % M.R, 32), n=32) == want
-        assert call(L.hm_fr_inv_fermat, b(a * Rr % M.R, 32), n=32) == want
+        if a % 10 < 2:
+            assert call(L.hm_fr_inv_bgcd, b(a * Rr % M.R, 32), n=32) == want
+            assert call(L.hm_fr_inv_fermat, b(a * Rr % M.R, 32), n=32) == want
+    for am in list(range(1, 100)) + [M.Q - k for k in range(1, 30)]:   # small raw Montgomery residues
+        a = am * pow(Rq, -1, M.Q) % M.Q
+        assert call(L.hm_fq_inv, b(am, 48)) == pow(a, -1, M.Q) * Rq % M.Q
     assert call(L.hm_fq_inv, b(0, 48)) == 0 and call(L.hm_fr_inv, b(0, 32), n=32) == 0
     assert call(L.hm_fr_root_of_unity, n=32) == M.FR_ROOT_OF_UNITY
 
