@@ -148,4 +148,6 @@ def test_fft_mul_polynomial_arith(engine):
     left = M.SubProductTree.new_from_points(xs[:128]).product
     right = M.SubProductTree.new_from_points(xs[128:]).product
     pa, pb = kzg_amd.Polynomial(left.coeffs), kzg_amd.Polynomial(right.coeffs)
-    assert pa.best_mul(engine, pb).coeffs == left.fft_mul(right).coeffs
+    got, want = pa.best_mul(engine, pb), left.fft_mul(right)   # the reference keeps the zero-padded 2^k vector;
+    assert got.degree == want.degree == 256                     # PartialEq = degree + zipped prefix (:29-40)
+    assert got.slice_coeffs() == want.slice_coeffs()
