@@ -1,0 +1,157 @@
+// fr29.h -- Fr in the UNSATURATED 9 x 29-bit representation (Montgomery radix 2^261) used inside the NTT
+// kernels.  Same idea as field29.h: a product-scanning multiply whose columns (<= 18 products < 2^58) sum
+// in one 64-bit accumulator, so every partial product is a bare v_mad_u64_u32 (162 per multiply instead of
+// 128 mads + 128 carry folds), and lazily reduced butterflies: u + t and u - t + 2r are limb-wise adds.
+//
+// The NTT is linear, so data needs NO conversion multiply: the 256-bit integer found in memory (canonical or
+// blst_fr Montgomery form, either way some residue) is just unpacked into 29-bit limbs; the twiddles are
+// stored as w * 2^261 mod r, and mul29r(x, w*2^261) = x*w keeps whatever form x was in.
+// Bounds: a twiddle product is < 1.4 r for any x below 26 r (2^261 = 70 r), values grow by at most 2 r per
+// butterfly stage, 12 stages at most -> everything stays below 26 r < 2^261.  The last multiplication of a pass
+// (inter-pass twiddle, d^-1 scale, or one) brings the value below 1.4 r and one conditional subtraction
+// makes it canonical before it is packed back into 8 x 32-bit words.
+#pragma once
+#include "field29.h"
+
+namespace kzg {
+
+constexpr int R29_N = 9;
+
+struct Fr29 {
+    uint32_t v[R29_N];
+};
+
+KZG_HD Fr29 fr29_normalize(Fr29 a) {
+#pragma unroll
+    for (int i = 0; i < R29_N - 1; i++) {
+        a.v[i + 1] += a.v[i] >> 29;
+        a.v[i] &= F29_MASK;
+    }
+    return a;
+}
+
+// a*b/2^261 mod r (lazy).  Limbs of b < 2^29 (twiddle), limbs of a < 2^30.
+KZG_HD Fr29 mul29r_inline(const Fr29 &a, const Fr29 &b) {
+    uint32_t m[R29_N];
+    Fr29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < R29_N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * Fr29Consts::mod(k - i);
+        m[k] = ((uint32_t)acc * Fr29Consts::INV) & F29_MASK;
+        acc += (uint64_t)m[k] * Fr29Consts::mod(0);
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = R29_N; k < 2 * R29_N - 1; k++) {
+#pragma unroll
+        for (int i = k - R29_N + 1; i < R29_N; i++) {
+            acc += (uint64_t)a.v[i] * b.v[k - i];
+            acc += (uint64_t)m[i] * Fr29Consts::mod(k - i);
+        }
+        r.v[k - R29_N] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    r.v[R29_N - 1] = (uint32_t)acc;
+    return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef uint32_t u32x9 __attribute__((ext_vector_type(9)));
+__device__ __noinline__ u32x9 mul29r_ool(u32x9 a, u32x9 b) {
+    Fr29 x, y;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        x.v[i] = a[i];
+        y.v[i] = b[i];
+    }
+    Fr29 z = mul29r_inline(x, y);
+    u32x9 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) r[i] = z.v[i];
+    return r;
+}
+KZG_HD Fr29 mul29r(const Fr29 &a, const Fr29 &b) {
+    u32x9 x, y;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        x[i] = a.v[i];
+        y[i] = b.v[i];
+    }
+    u32x9 z = mul29r_ool(x, y);
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) r.v[i] = z[i];
+    return r;
+}
+#else
+KZG_HD Fr29 mul29r(const Fr29 &a, const Fr29 &b) { return mul29r_inline(a, b); }
+#endif
+
+// butterfly: (u, t) -> (u + t, u - t + 2r), t a twiddle product (normalised, < 1.4 r); outputs normalised
+KZG_HD void fr29_butterfly(Fr29 &u, Fr29 &v_out, const Fr29 &t) {
+    Fr29 s, d;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        s.v[i] = u.v[i] + t.v[i];
+        d.v[i] = u.v[i] + Fr29Consts::sub2(i) - t.v[i];
+    }
+    u = fr29_normalize(s);
+    v_out = fr29_normalize(d);
+}
+
+// 8 x 32-bit words (any 256-bit integer) <-> 9 x 29-bit limbs
+KZG_HD Fr29 fr29_unpack(const Fr &a) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        uint32_t lo = a.v[w] >> sh;
+        uint32_t hi = (sh > 3 && w + 1 < 8) ? (a.v[w + 1] << (32 - sh)) : 0u;
+        r.v[i] = (lo | hi) & F29_MASK;
+    }
+    return r;
+}
+
+// x < 2r, normalised  ->  canonical residue packed into 8 x 32-bit words
+KZG_HD Fr fr29_pack_canonical(const Fr29 &x) {
+    Fr r = Fr::zero();
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        if (w < 8) r.v[w] |= x.v[i] << sh;
+        if (sh > 3 && w + 1 < 8) r.v[w + 1] |= x.v[i] >> (32 - sh);
+    }
+    // the value is < 2r < 2^256, so it fits; one conditional subtraction of r
+    Fr t = r;
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t dd = (uint64_t)t.v[i] - FrParams::mod(i) - borrow;
+        t.v[i] = (uint32_t)dd;
+        borrow = (uint32_t)(dd >> 63);
+    }
+    return borrow ? r : t;
+}
+
+KZG_HD Fr29 fr29_one() {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) r.v[i] = Fr29Consts::one(i);
+    return r;
+}
+
+// twiddle conversion: w * 2^256 (saturated Montgomery form, canonical) -> w * 2^261 in 29-bit limbs (< 1.1 r; then
+// reduced below r so that it can serve as the small operand everywhere)
+KZG_HD Fr29 fr29_twiddle_from_mont(const Fr &w_mont) {
+    Fr29 k;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) k.v[i] = Fr29Consts::k_to29(i);
+    Fr29 t = mul29r(fr29_unpack(w_mont), k);
+    return fr29_unpack(fr29_pack_canonical(t));
+}
+
+}  // namespace kzg

@@ -14,18 +14,19 @@
 // Data may be canonical or Montgomery: the butterflies are linear and the twiddles are Montgomery
 // constants, so mont_mul(a, w) preserves whichever form a is in.
 #include "common.h"
+#include "fr29.h"
 
 namespace kzg {
 
 struct NttPlan {
     uint32_t log_n = 0, k1 = 0, k2 = 0;
     int inverse = 0;
-    Fr *tw1 = nullptr;   // w_{n1}^i, i < n1/2 (or w_n^i for the single-tile case)
-    Fr *tw2 = nullptr;   // w_{n2}^i, i < n2/2
-    Fr *tw_lo = nullptr; // w_n^i, i < 2^lo_bits
-    Fr *tw_hi = nullptr; // w_n^(i << lo_bits)
+    Fr29 *tw1 = nullptr;   // w_{n1}^i, i < n1/2 (or w_n^i for the single-tile case), as w * 2^261 in 29-bit limbs
+    Fr29 *tw2 = nullptr;   // w_{n2}^i, i < n2/2
+    Fr29 *tw_lo = nullptr; // w_n^i, i < 2^lo_bits
+    Fr29 *tw_hi = nullptr; // w_n^(i << lo_bits)
     uint32_t lo_bits = 0;
-    Fr scale;            // d^-1 for the inverse, one otherwise (Montgomery)
+    Fr29 scale;            // d^-1 for the inverse, one otherwise (twiddle form)
 };
 
 Fr host_omega(uint32_t exp) {
@@ -46,87 +47,133 @@ int pow_table(kzg_ctx *ctx, hipStream_t stream, const Fr &base_mont, const Fr &s
     return KZG_OK;
 }
 
-extern __shared__ __attribute__((aligned(16))) Fr lds_fr[];
+// twiddle tables for the kernels: base^i as w * 2^261 in 29-bit limbs
+__global__ __launch_bounds__(256) void k_pow_table29(Fr base, size_t count, Fr29 *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    out[i] = fr29_twiddle_from_mont(pow_u64(base, (uint64_t)i));
+}
+
+extern __shared__ __attribute__((aligned(16))) Fr29 lds_fr29[];
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// radix-2 DIT stages over `vec` independent 2^t-point vectors held in LDS as lds[v << t | pos],
-// input already in bit-reversed position order.
-__device__ __forceinline__ void lds_ntt_stages(Fr *lds, uint32_t t, uint32_t vec, const Fr *tw) {
-    const uint32_t half = 1u << (t - 1);
-    const uint32_t total = vec << (t - 1);
-    for (uint32_t s = 0; s < t; s++) {
-        const uint32_t m = 1u << s;
+// DIT stages over `vec` independent 2^t-point vectors held in LDS as lds[v << t | pos] (36-byte elements: odd
+// dword stride, no power-of-two bank aliasing), input already in bit-reversed position order.  Stage pairs
+// (s, s+1) are fused: a thread takes the 4 elements {p, p+m, p+2m, p+3m}, m = 2^s, through both stages in
+// registers (radix-4), halving the LDS round trips and barriers; an odd t starts with one radix-2 stage.
+// Butterflies are lazy (fr29.h): values grow by < 2r per stage and are reduced by the next twiddle product.
+__device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t vec, const Fr29 *tw) {
+    uint32_t s = 0;
+    if (t & 1) {  // radix-2, twiddle 1
+        const uint32_t total = vec << (t - 1);
         for (uint32_t b = threadIdx.x; b < total; b += blockDim.x) {
-            uint32_t v = b >> (t - 1);
-            uint32_t i = b & (half - 1);
+            uint32_t p0 = b << 1;
+            Fr29 u = lds[p0], w = lds[p0 + 1], d;
+            fr29_butterfly(u, d, w);
+            lds[p0] = u;
+            lds[p0 + 1] = d;
+        }
+        __syncthreads();
+        s = 1;
+    }
+    const uint32_t quarter = 1u << (t - 2);
+    for (; s + 1 < t; s += 2) {
+        const uint32_t m = 1u << s;
+        const uint32_t total = vec << (t - 2);
+        for (uint32_t b = threadIdx.x; b < total; b += blockDim.x) {
+            uint32_t v = b >> (t - 2);
+            uint32_t i = b & (quarter - 1);
             uint32_t j = i & (m - 1);
-            uint32_t p0 = (v << t) | (((i >> s) << (s + 1)) | j);
-            uint32_t p1 = p0 + m;
-            Fr u = lds[p0];
-            Fr w = lds[p1];
-            if (s != 0) w = mul(w, tw[j << (t - 1 - s)]);  // stage 0 twiddle is 1
-            lds[p0] = add(u, w);
-            lds[p1] = sub(u, w);
+            uint32_t p0 = (v << t) | (((i >> s) << (s + 2)) | j);
+            Fr29 x0 = lds[p0], x1 = lds[p0 + m], x2 = lds[p0 + 2 * m], x3 = lds[p0 + 3 * m];
+            if (s != 0) {  // stage s: twiddle w_{2m}^j on the odd halves (1 when s == 0)
+                Fr29 a = tw[j << (t - 1 - s)];
+                x1 = mul29r(x1, a);
+                x3 = mul29r(x3, a);
+            }
+            Fr29 y1, y3;
+            fr29_butterfly(x0, y1, x1);
+            fr29_butterfly(x2, y3, x3);
+            // stage s+1: twiddles w_{4m}^j and w_{4m}^(j+m)
+            if (s != 0) x2 = mul29r(x2, tw[j << (t - 2 - s)]);
+            y3 = mul29r(y3, tw[(j + m) << (t - 2 - s)]);
+            Fr29 z2, z3;
+            fr29_butterfly(x0, z2, x2);
+            fr29_butterfly(y1, z3, y3);
+            lds[p0] = x0;
+            lds[p0 + m] = y1;
+            lds[p0 + 2 * m] = z2;
+            lds[p0 + 3 * m] = z3;
         }
         __syncthreads();
     }
 }
 
 // Whole transform in one tile (log_n <= 12).
-__global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const Fr *tw, Fr scale, int do_scale) {
+__global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const Fr29 *tw, Fr29 scale) {
     const uint32_t n = 1u << t;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_fr[bitrev(i, t)] = data[i];
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_fr29[bitrev(i, t)] = fr29_unpack(data[i]);
     __syncthreads();
-    if (t) lds_ntt_stages(lds_fr, t, 1, tw);
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-        Fr v = lds_fr[i];
-        if (do_scale) v = mul(v, scale);
-        data[i] = v;
+    if (t == 1) {
+        if (threadIdx.x == 0) {
+            Fr29 u = lds_fr29[0], d;
+            fr29_butterfly(u, d, lds_fr29[1]);
+            lds_fr29[0] = u;
+            lds_fr29[1] = d;
+        }
+        __syncthreads();
+    } else if (t >= 2) {
+        lds_ntt_stages29(lds_fr29, t, 1, tw);
     }
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) data[i] = fr29_pack_canonical(mul29r(lds_fr29[i], scale));
 }
 
 // pass 1: columns j2 = blockIdx.x*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
 __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr *tw1, const Fr *tw_lo, const Fr *tw_hi, uint32_t lo_bits) {
+                                                    const Fr29 *tw1, const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits) {
     const uint32_t n1 = 1u << k1, vec = 1u << vec_log;
     const uint32_t j2_0 = blockIdx.x << vec_log;
     const uint32_t total = n1 << vec_log;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), j1 = e >> vec_log;  // consecutive threads -> consecutive columns
-        lds_fr[(v << k1) | bitrev(j1, k1)] = in[((size_t)j1 << k2) + j2_0 + v];
+        lds_fr29[(v << k1) | bitrev(j1, k1)] = fr29_unpack(in[((size_t)j1 << k2) + j2_0 + v]);
     }
     __syncthreads();
-    lds_ntt_stages(lds_fr, k1, vec, tw1);
+    lds_ntt_stages29(lds_fr29, k1, vec, tw1);
     const uint32_t lo_mask = (1u << lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk1 = e >> vec_log;
         uint32_t j2 = j2_0 + v;
         uint64_t ex = (uint64_t)j2 * kk1;  // < n
-        Fr val = lds_fr[(v << k1) | kk1];
-        Fr w = mul(tw_hi[ex >> lo_bits], tw_lo[ex & lo_mask]);
-        out[((size_t)kk1 << k2) + j2] = mul(val, w);
+        Fr29 w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & lo_mask]);
+        out[((size_t)kk1 << k2) + j2] = fr29_pack_canonical(mul29r(lds_fr29[(v << k1) | kk1], w));
     }
 }
 
 // pass 2: rows k1 = blockIdx.x*vec .. +vec-1; row k1 contiguous at in[k1*n2 ..]; out[k1 + n1*k2]
 __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr *tw2, Fr scale, int do_scale) {
+                                                    const Fr29 *tw2, Fr29 scale) {
     const uint32_t n2 = 1u << k2, vec = 1u << vec_log;
     const uint32_t r0 = blockIdx.x << vec_log;
     const uint32_t total = n2 << vec_log;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t j2 = e & (n2 - 1), v = e >> k2;  // consecutive threads -> consecutive row elements
-        lds_fr[(v << k2) | bitrev(j2, k2)] = in[((size_t)(r0 + v) << k2) + j2];
+        lds_fr29[(v << k2) | bitrev(j2, k2)] = fr29_unpack(in[((size_t)(r0 + v) << k2) + j2]);
     }
     __syncthreads();
-    lds_ntt_stages(lds_fr, k2, vec, tw2);
+    lds_ntt_stages29(lds_fr29, k2, vec, tw2);
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk2 = e >> vec_log;  // consecutive threads -> consecutive k1
-        Fr val = lds_fr[(v << k2) | kk2];
-        if (do_scale) val = mul(val, scale);
-        out[((size_t)kk2 << k1) + r0 + v] = val;
+        out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(mul29r(lds_fr29[(v << k2) | kk2], scale));
     }
+}
+
+static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t count, Fr29 **out) {
+    if (!count) count = 1;
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)out, count * sizeof(Fr29)));
+    KZG_LAUNCH(ctx, st, "k_pow_table29", k_pow_table29, (unsigned)((count + 255) / 256), 256, 0, base, count, *out);
+    return KZG_OK;
 }
 
 static bool g_ntt_attr = false;
@@ -150,29 +197,22 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
     Fr w = host_omega(log_n);
     if (inverse) w = inv(w);
     size_t n = (size_t)1 << log_n;
-    p->scale = inverse ? inv(from_u64<FrParams>((uint64_t)n)) : Fr::one();
+    Fr scale = inverse ? inv(from_u64<FrParams>((uint64_t)n)) : Fr::one();
+    p->scale = fr29_twiddle_from_mont(scale);
     if (log_n <= 12) {
         p->k1 = log_n;
         p->k2 = 0;
-        size_t cnt = log_n ? (n >> 1) : 1;
-        KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw1, cnt * sizeof(Fr)));
-        KZG_TRY(pow_table(ctx, st, w, Fr::one(), cnt, p->tw1));
+        KZG_TRY(pow_table29(ctx, st, w, log_n ? (n >> 1) : 1, &p->tw1));
     } else {
         p->k1 = (log_n + 1) / 2;
         p->k2 = log_n - p->k1;
         size_t n1 = (size_t)1 << p->k1, n2 = (size_t)1 << p->k2;
-        Fr w1 = pow_u64(w, (uint64_t)n2);  // w_{n1}
-        Fr w2 = pow_u64(w, (uint64_t)n1);  // w_{n2}
         p->lo_bits = p->k1;
         size_t nlo = (size_t)1 << p->lo_bits, nhi = (size_t)1 << (log_n - p->lo_bits);
-        KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw1, (n1 >> 1) * sizeof(Fr)));
-        KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw2, (n2 >> 1) * sizeof(Fr)));
-        KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw_lo, nlo * sizeof(Fr)));
-        KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw_hi, nhi * sizeof(Fr)));
-        KZG_TRY(pow_table(ctx, st, w1, Fr::one(), n1 >> 1, p->tw1));
-        KZG_TRY(pow_table(ctx, st, w2, Fr::one(), n2 >> 1, p->tw2));
-        KZG_TRY(pow_table(ctx, st, w, Fr::one(), nlo, p->tw_lo));
-        KZG_TRY(pow_table(ctx, st, pow_u64(w, (uint64_t)nlo), Fr::one(), nhi, p->tw_hi));
+        KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n2), n1 >> 1, &p->tw1));  // w_{n1}
+        KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n1), n2 >> 1, &p->tw2));  // w_{n2}
+        KZG_TRY(pow_table29(ctx, st, w, nlo, &p->tw_lo));
+        KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)nlo), nhi, &p->tw_hi));
     }
     ctx->ntt_plans[key] = p;
     *out = p;
@@ -187,23 +227,21 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     KZG_TRY(ntt_plan(ctx, st, log_n, inverse, &p));
     if (log_n <= 12) {
         size_t n = (size_t)1 << log_n;
-        unsigned threads = n >= 2048 ? 1024 : (n >= 128 ? (unsigned)(n / 2) : 64);
-        KZG_LAUNCH(ctx, st, "k_ntt_single", k_ntt_single, 1, threads, n * sizeof(Fr), d_data, log_n, p->tw1, p->scale,
-                   inverse);
+        unsigned threads = n >= 4096 ? 1024 : (n >= 256 ? (unsigned)(n / 4) : 64);
+        KZG_LAUNCH(ctx, st, "k_ntt_single", k_ntt_single, 1, threads, n * sizeof(Fr29), d_data, log_n, p->tw1, p->scale);
         return KZG_OK;
     }
     size_t n = (size_t)1 << log_n;
     Fr *scratch = (Fr *)lane_alloc(ctx, lane, n * sizeof(Fr));
     if (!scratch) return fail(ctx, KZG_ERR_ALLOC, "NTT workspace not reserved");
-    // vec adjacent columns/rows per block: as many as fit 128 KiB of LDS, at most 4 (128-B segments)
+    // vec adjacent columns/rows per block: as many as fit the LDS (4096 elements x 36 B = 144 KiB), at most 4
     uint32_t vec1 = 12 - p->k1 < 2 ? 12 - p->k1 : 2;
     uint32_t vec2 = 12 - p->k2 < 2 ? 12 - p->k2 : 2;
-    size_t lds1 = ((size_t)1 << (p->k1 + vec1)) * sizeof(Fr), lds2 = ((size_t)1 << (p->k2 + vec2)) * sizeof(Fr);
+    size_t lds1 = ((size_t)1 << (p->k1 + vec1)) * sizeof(Fr29), lds2 = ((size_t)1 << (p->k2 + vec2)) * sizeof(Fr29);
     unsigned g1 = 1u << (p->k2 - vec1), g2 = 1u << (p->k1 - vec2);
     KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, 1024, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
                p->tw_hi, p->lo_bits);
-    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, 1024, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
-               inverse);
+    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, 1024, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale);
     return KZG_OK;
 }
 

@@ -65,3 +65,16 @@ extern "C" {
 void hm_fq_inv_bgcd(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv_bgcd(x); memcpy(o, z.v, 48); }
 void hm_fr_inv_bgcd(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv_bgcd(x); memcpy(o, z.v, 32); }
 }
+#include "../kzg_amd/csrc/fr29.h"
+extern "C" {
+// x (any 256-bit integer < 2^256), w_mont = w*2^256 mod r  ->  canonical (x * w) mod r via the 29-bit path
+void hm_fr29_mul(const uint32_t *x, const uint32_t *w_mont, uint32_t *o) { Fr a, w; memcpy(a.v, x, 32); memcpy(w.v, w_mont, 32);
+    Fr z = fr29_pack_canonical(mul29r(fr29_unpack(a), fr29_twiddle_from_mont(w))); memcpy(o, z.v, 32); }
+// `stages` lazy butterflies in a row on (u, v) with twiddle w, then a final multiplication by one: returns both canonical
+void hm_fr29_butterflies(const uint32_t *u, const uint32_t *v, const uint32_t *w_mont, int stages, uint32_t *ou, uint32_t *ov) {
+    Fr a, b, w; memcpy(a.v, u, 32); memcpy(b.v, v, 32); memcpy(w.v, w_mont, 32);
+    Fr29 U = fr29_unpack(a), V = fr29_unpack(b), W = fr29_twiddle_from_mont(w);
+    for (int s = 0; s < stages; s++) { Fr29 t = mul29r(V, W); fr29_butterfly(U, V, t); }
+    Fr zu = fr29_pack_canonical(mul29r(U, fr29_one())), zv = fr29_pack_canonical(mul29r(V, fr29_one()));
+    memcpy(ou, zu.v, 32); memcpy(ov, zv.v, 32); }
+}

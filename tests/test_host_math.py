@@ -144,3 +144,28 @@ def test_fq29_general_add_and_double(L):
         assert pt(L.hm_add29, a, c) == C.g1_add(a, c)
     for k in (0, 1, 2, 3, M.R - 1, rng.randrange(M.R)):
         assert pt(L.hm_mul29_scalar, P, b(k, 32)) == C.g1_mul(P, k)
+
+
+def test_fr29_ntt_arithmetic(L):
+    """fr29.h: the unsaturated 9 x 29-bit Fr of the NTT kernels -- multiply against any 256-bit input, and up to
+    12 consecutive lazy butterflies (the worst-case growth inside one LDS tile) followed by the closing multiply."""
+    rng = random.Random(5)
+    R, R256 = M.R, 1 << 256
+    for it in range(300):
+        x = rng.randrange(R256) if it % 3 else rng.randrange(R)
+        w = rng.randrange(R)
+        if it < 4:
+            x, w = [0, R256 - 1, R - 1, 1][it], [5, R - 1, R - 1, 0][it]
+        o = ctypes.create_string_buffer(32)
+        L.hm_fr29_mul(b(x, 32), b(w * R256 % R, 32), o)
+        assert int.from_bytes(o.raw, "little") == x * w % R
+    for stages in (1, 2, 5, 10, 12):
+        for _ in range(20):
+            u, v, w = rng.randrange(R), rng.randrange(R), rng.randrange(R)
+            ou, ov = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32)
+            L.hm_fr29_butterflies(b(u, 32), b(v, 32), b(w * R256 % R, 32), stages, ou, ov)
+            U, V = u, v
+            for _s in range(stages):
+                t = V * w % R
+                U, V = (U + t) % R, (U - t) % R
+            assert int.from_bytes(ou.raw, "little") == U and int.from_bytes(ov.raw, "little") == V
