@@ -263,6 +263,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_blocks" || k == "accum_blocks_batch") {
         if (value < 64 || value > 512) return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 64..512");
         (k == "accum_blocks" ? ctx->opt_accum_blocks : ctx->opt_accum_blocks_batch) = (int)value;
+    } else if (k == "ntt_vec_log") {
+        if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_vec_log must be 0..2");
+        ctx->opt_ntt_vec_log = (int)value;
     } else {
         return fail(ctx, KZG_ERR_SHAPE, "unknown option " + k);
     }

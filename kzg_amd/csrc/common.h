@@ -51,6 +51,7 @@ struct kzg_ctx {
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 8;
     int opt_accum_blocks = 512;        // k_accum_affine grid for a single MSM: every SIMD holds its 2 waves
+    int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
     int opt_accum_blocks_batch = 480;  // batched MSMs: leave 1/16 of the wave slots to the latency-bound tail and sort
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)
     int cur_accum_blocks = 512;        // value msm_run uses (set by the entry point)

@@ -15,6 +15,7 @@
 // constants, so mont_mul(a, w) preserves whichever form a is in.
 #include "common.h"
 #include "fr29.h"
+#include <algorithm>
 
 namespace kzg {
 
@@ -58,21 +59,54 @@ extern __shared__ __attribute__((aligned(16))) Fr29 lds_fr29[];
 
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
 
-// DIT stages over `vec` independent 2^t-point vectors held in LDS as lds[v << t | pos] (36-byte elements: odd
-// dword stride, no power-of-two bank aliasing), input already in bit-reversed position order.  Stage pairs
+// LDS bank swizzle.  Every access set of these kernels is "idx = const ^ (lane bit i -> idx bit B[i])": radix-4
+// stages leave two index bits fixed and spread the lanes over bits up to 6, the tile loads place consecutive
+// sources at bit-reversed positions (lane bits -> top index bits), the stores interleave the vectors.  With plain
+// lds[idx] those sets alias on 4..32 lanes per bank (rocprofv3: 80 % of LDS cycles were conflict replays).
+// Elements are 9 dwords (odd), so 32 lanes are conflict-free iff their indices differ mod 32; the linear map
+// phys = idx ^ XOR_{b>=5, idx bit b set} MASK[b] with the per-shape masks below (tools/find_lds_swizzle.py
+// checks every pattern's GF(2) rank) makes that hold for every phase.  Index [t][vec_log], 5 bits per mask.
+static const uint64_t LDS_SWIZZLE[13][3] = {
+    {0x0ull, 0x0ull, 0x0ull},  // t = 0
+    {0x0ull, 0x0ull, 0x0ull},  // t = 1
+    {0x0ull, 0x0ull, 0x0ull},  // t = 2
+    {0x0ull, 0x0ull, 0x0ull},  // t = 3
+    {0x0ull, 0x0ull, 0x0ull},  // t = 4
+    {0x0ull, 0x1full, 0x36dull},  // t = 5
+    {0x7ull, 0x33full, 0x3355ull},  // t = 6
+    {0x36dull, 0x4acbull, 0xfb36dull},  // t = 7
+    {0xb3full, 0xf0b3full, 0x1c7076dull},  // t = 8
+    {0x94d9bull, 0x1c7076dull, 0x2d9f8dbbull},  // t = 9
+    {0x1c7076dull, 0x306fb36dull, 0x6997f0f6dull},  // t = 10
+    {0x306fb36dull, 0x4966d065dull, 0x0ull},  // t = 11
+    {0x6997f0f6dull, 0x0ull, 0x0ull},  // t = 12
+};
+
+__device__ __forceinline__ uint32_t swz(uint32_t idx, uint64_t masks) {
+    uint32_t x = idx;
+#pragma unroll
+    for (int b = 0; b < 9; ++b) {
+        uint32_t bit = (uint32_t)((int32_t)(idx << (26 - b)) >> 31);  // all-ones iff idx bit 5+b is set
+        x ^= bit & ((uint32_t)(masks >> (5 * b)) & 31u);
+    }
+    return x;
+}
+
+// DIT stages over `vec` independent 2^t-point vectors held in LDS at lds[swz(v << t | pos)] (36-byte elements),
+// input already in bit-reversed position order.  Stage pairs
 // (s, s+1) are fused: a thread takes the 4 elements {p, p+m, p+2m, p+3m}, m = 2^s, through both stages in
 // registers (radix-4), halving the LDS round trips and barriers; an odd t starts with one radix-2 stage.
 // Butterflies are lazy (fr29.h): values grow by < 2r per stage and are reduced by the next twiddle product.
-__device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t vec, const Fr29 *tw) {
+__device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t vec, const Fr29 *tw, uint64_t sw) {
     uint32_t s = 0;
     if (t & 1) {  // radix-2, twiddle 1
         const uint32_t total = vec << (t - 1);
         for (uint32_t b = threadIdx.x; b < total; b += blockDim.x) {
-            uint32_t p0 = b << 1;
-            Fr29 u = lds[p0], w = lds[p0 + 1], d;
+            uint32_t p0 = swz(b << 1, sw), p1 = p0 ^ 1;
+            Fr29 u = lds[p0], w = lds[p1], d;
             fr29_butterfly(u, d, w);
             lds[p0] = u;
-            lds[p0 + 1] = d;
+            lds[p1] = d;
         }
         __syncthreads();
         s = 1;
@@ -81,12 +115,14 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
     for (; s + 1 < t; s += 2) {
         const uint32_t m = 1u << s;
         const uint32_t total = vec << (t - 2);
+        const uint32_t d1 = swz(m, sw), d2 = swz(2 * m, sw);  // the swizzle is linear: swz(p ^ m) = swz(p) ^ swz(m)
         for (uint32_t b = threadIdx.x; b < total; b += blockDim.x) {
             uint32_t v = b >> (t - 2);
             uint32_t i = b & (quarter - 1);
             uint32_t j = i & (m - 1);
-            uint32_t p0 = (v << t) | (((i >> s) << (s + 2)) | j);
-            Fr29 x0 = lds[p0], x1 = lds[p0 + m], x2 = lds[p0 + 2 * m], x3 = lds[p0 + 3 * m];
+            const uint32_t p0 = swz((v << t) | (((i >> s) << (s + 2)) | j), sw);
+            const uint32_t p1 = p0 ^ d1, p2 = p0 ^ d2, p3 = p1 ^ d2;
+            Fr29 x0 = lds[p0], x1 = lds[p1], x2 = lds[p2], x3 = lds[p3];
             if (s != 0) {  // stage s: twiddle w_{2m}^j on the odd halves (1 when s == 0)
                 Fr29 a = tw[j << (t - 1 - s)];
                 x1 = mul29r(x1, a);
@@ -102,18 +138,18 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
             fr29_butterfly(x0, z2, x2);
             fr29_butterfly(y1, z3, y3);
             lds[p0] = x0;
-            lds[p0 + m] = y1;
-            lds[p0 + 2 * m] = z2;
-            lds[p0 + 3 * m] = z3;
+            lds[p1] = y1;
+            lds[p2] = z2;
+            lds[p3] = z3;
         }
         __syncthreads();
     }
 }
 
 // Whole transform in one tile (log_n <= 12).
-__global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const Fr29 *tw, Fr29 scale) {
+__global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const Fr29 *tw, Fr29 scale, uint64_t sw) {
     const uint32_t n = 1u << t;
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_fr29[bitrev(i, t)] = fr29_unpack(data[i]);
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_fr29[swz(bitrev(i, t), sw)] = fr29_unpack(data[i]);
     __syncthreads();
     if (t == 1) {
         if (threadIdx.x == 0) {
@@ -124,48 +160,49 @@ __global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const
         }
         __syncthreads();
     } else if (t >= 2) {
-        lds_ntt_stages29(lds_fr29, t, 1, tw);
+        lds_ntt_stages29(lds_fr29, t, 1, tw, sw);
     }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) data[i] = fr29_pack_canonical(mul29r(lds_fr29[i], scale));
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) data[i] = fr29_pack_canonical(mul29r(lds_fr29[swz(i, sw)], scale));
 }
 
 // pass 1: columns j2 = blockIdx.x*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
 __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr29 *tw1, const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits) {
+                                                    const Fr29 *tw1, const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits,
+                                                    uint64_t sw) {
     const uint32_t n1 = 1u << k1, vec = 1u << vec_log;
     const uint32_t j2_0 = blockIdx.x << vec_log;
     const uint32_t total = n1 << vec_log;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), j1 = e >> vec_log;  // consecutive threads -> consecutive columns
-        lds_fr29[(v << k1) | bitrev(j1, k1)] = fr29_unpack(in[((size_t)j1 << k2) + j2_0 + v]);
+        lds_fr29[swz((v << k1) | bitrev(j1, k1), sw)] = fr29_unpack(in[((size_t)j1 << k2) + j2_0 + v]);
     }
     __syncthreads();
-    lds_ntt_stages29(lds_fr29, k1, vec, tw1);
+    lds_ntt_stages29(lds_fr29, k1, vec, tw1, sw);
     const uint32_t lo_mask = (1u << lo_bits) - 1;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk1 = e >> vec_log;
         uint32_t j2 = j2_0 + v;
         uint64_t ex = (uint64_t)j2 * kk1;  // < n
         Fr29 w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & lo_mask]);
-        out[((size_t)kk1 << k2) + j2] = fr29_pack_canonical(mul29r(lds_fr29[(v << k1) | kk1], w));
+        out[((size_t)kk1 << k2) + j2] = fr29_pack_canonical(mul29r(lds_fr29[swz((v << k1) | kk1, sw)], w));
     }
 }
 
 // pass 2: rows k1 = blockIdx.x*vec .. +vec-1; row k1 contiguous at in[k1*n2 ..]; out[k1 + n1*k2]
 __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr29 *tw2, Fr29 scale) {
+                                                    const Fr29 *tw2, Fr29 scale, uint64_t sw) {
     const uint32_t n2 = 1u << k2, vec = 1u << vec_log;
     const uint32_t r0 = blockIdx.x << vec_log;
     const uint32_t total = n2 << vec_log;
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t j2 = e & (n2 - 1), v = e >> k2;  // consecutive threads -> consecutive row elements
-        lds_fr29[(v << k2) | bitrev(j2, k2)] = fr29_unpack(in[((size_t)(r0 + v) << k2) + j2]);
+        lds_fr29[swz((v << k2) | bitrev(j2, k2), sw)] = fr29_unpack(in[((size_t)(r0 + v) << k2) + j2]);
     }
     __syncthreads();
-    lds_ntt_stages29(lds_fr29, k2, vec, tw2);
+    lds_ntt_stages29(lds_fr29, k2, vec, tw2, sw);
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk2 = e >> vec_log;  // consecutive threads -> consecutive k1
-        out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(mul29r(lds_fr29[(v << k2) | kk2], scale));
+        out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(mul29r(lds_fr29[swz((v << k2) | kk2, sw)], scale));
     }
 }
 
@@ -228,20 +265,25 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     if (log_n <= 12) {
         size_t n = (size_t)1 << log_n;
         unsigned threads = n >= 4096 ? 1024 : (n >= 256 ? (unsigned)(n / 4) : 64);
-        KZG_LAUNCH(ctx, st, "k_ntt_single", k_ntt_single, 1, threads, n * sizeof(Fr29), d_data, log_n, p->tw1, p->scale);
+        KZG_LAUNCH(ctx, st, "k_ntt_single", k_ntt_single, 1, threads, n * sizeof(Fr29), d_data, log_n, p->tw1, p->scale,
+                   LDS_SWIZZLE[log_n][0]);
         return KZG_OK;
     }
     size_t n = (size_t)1 << log_n;
     Fr *scratch = (Fr *)lane_alloc(ctx, lane, n * sizeof(Fr));
     if (!scratch) return fail(ctx, KZG_ERR_ALLOC, "NTT workspace not reserved");
     // vec adjacent columns/rows per block: as many as fit the LDS (4096 elements x 36 B = 144 KiB), at most 4
-    uint32_t vec1 = 12 - p->k1 < 2 ? 12 - p->k1 : 2;
-    uint32_t vec2 = 12 - p->k2 < 2 ? 12 - p->k2 : 2;
+    const uint32_t vmax = (uint32_t)ctx->opt_ntt_vec_log;
+    uint32_t vec1 = 12 - p->k1 < vmax ? 12 - p->k1 : vmax;
+    uint32_t vec2 = 12 - p->k2 < vmax ? 12 - p->k2 : vmax;
     size_t lds1 = ((size_t)1 << (p->k1 + vec1)) * sizeof(Fr29), lds2 = ((size_t)1 << (p->k2 + vec2)) * sizeof(Fr29);
     unsigned g1 = 1u << (p->k2 - vec1), g2 = 1u << (p->k1 - vec2);
-    KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, 1024, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
-               p->tw_hi, p->lo_bits);
-    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, 1024, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale);
+    // one radix-4 butterfly per thread and stage; smaller tiles leave room for a second block per CU
+    unsigned th1 = std::min(1024u, 1u << (p->k1 + vec1 - 2)), th2 = std::min(1024u, 1u << (p->k2 + vec2 - 2));
+    KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, th1, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
+               p->tw_hi, p->lo_bits, LDS_SWIZZLE[p->k1][vec1]);
+    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
+               LDS_SWIZZLE[p->k2][vec2]);
     return KZG_OK;
 }
 

@@ -7,6 +7,8 @@ import kzg_amd
 log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 e = kzg_amd.Engine(0)
+if len(sys.argv) > 3:
+    e.set_option('ntt_vec_log', int(sys.argv[3]))
 buf = e.alloc_scalars(1 << log_n).fill_random(5)
 orig = buf.download()
 e.ntt(buf, log_n); e.ntt(buf, log_n, inverse=True)
