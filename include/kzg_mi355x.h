@@ -24,6 +24,10 @@
  *   KZG_G1_ZCASH_UNCOMPRESSED_96 / KZG_G1_ZCASH_COMPRESSED_48   big-endian canonical with flag bits
  *                            (bit7 compressed, bit6 infinity, bit5 y-sign) = G1Affine::to_uncompressed
  *                            / to_compressed
+ *   KZG_G2_AFFINE_MONT_192   x.c0,x.c1,y.c0,y.c1 Montgomery limbs; identity all zero (= blst_p2_affine)
+ *   KZG_G2_JACOBIAN_MONT_288 X,Y,Z in Fq2; identity has Z = 0 (= blst_p2 = G2Projective)
+ *   KZG_G2_ZCASH_UNCOMPRESSED_192 / KZG_G2_ZCASH_COMPRESSED_96  x.c1 || x.c0 [|| y.c1 || y.c0] big-endian
+ *                            with the same flag bits (= G2Affine::to_uncompressed / to_compressed)
  */
 #ifndef KZG_MI355X_H
 #define KZG_MI355X_H
@@ -37,6 +41,7 @@ extern "C" {
 
 typedef struct kzg_ctx kzg_ctx;
 typedef struct kzg_srs kzg_srs;
+typedef struct kzg_srs_g2 kzg_srs_g2; /* the G2 half of KZGParams (hs) or a G2 Lagrange basis */
 
 typedef enum {
     KZG_OK = 0,
@@ -57,6 +62,12 @@ enum {
     KZG_G1_JACOBIAN_MONT_144 = 1,
     KZG_G1_ZCASH_UNCOMPRESSED_96 = 2,
     KZG_G1_ZCASH_COMPRESSED_48 = 3
+};
+enum {
+    KZG_G2_AFFINE_MONT_192 = 0,
+    KZG_G2_JACOBIAN_MONT_288 = 1,
+    KZG_G2_ZCASH_UNCOMPRESSED_192 = 2,
+    KZG_G2_ZCASH_COMPRESSED_96 = 3
 };
 enum { KZG_IN_DEVICE = 1, KZG_OUT_DEVICE = 2 };
 
@@ -143,6 +154,43 @@ int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, s
 /* KZGVerifierEvalForm::verify_poly (:162-171): ifft then monomial MSM, compare. */
 int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const void *commitment, int pfmt,
                          const void *evals, size_t d, int sfmt, int flags, int *ok);
+
+/* ---- verifier: G2 parameters and pairing checks (src/coeff_form.rs:126-182, src/eval_form.rs:173-217) ----
+ * The reference runs these on the CPU through blstrs' pairing(); here one GPU thread evaluates one check
+ * (shared Miller loop over both pairs + one final exponentiation), so `count` openings verify in one launch.
+ * Host-resident inputs only; commitments / witnesses in an affine G1 format (KZGCommitment = G1Affine). */
+/* setup(), G2 half (src/lib.rs:48-52): hs[i] = [s^i] H for i < n. */
+int kzg_srs_setup_g2(kzg_ctx *ctx, const void *s, int sfmt, size_t n, kzg_srs_g2 **out);
+/* [L_i(s)] H over the size-d domain (lagrange_basis_h of KZGVerifierEvalForm::new, src/eval_form.rs:150). */
+int kzg_srs_setup_lagrange_g2(kzg_ctx *ctx, const void *s, int sfmt, size_t d, kzg_srs_g2 **out);
+/* KZGParams.hs supplied by the caller (Vec<G2Projective> = KZG_G2_JACOBIAN_MONT_288, or any G2 format);
+ * KZG_ERR_BAD_POINT if a point does not decode / is not on the twist. */
+int kzg_srs_upload_g2(kzg_ctx *ctx, const void *pts, size_t n, int pfmt, kzg_srs_g2 **out);
+int kzg_srs_download_g2(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t offset, size_t n, void *out, int pfmt);
+size_t kzg_srs_g2_len(const kzg_srs_g2 *srs);
+void kzg_srs_g2_free(kzg_ctx *ctx, kzg_srs_g2 *srs);
+/* G2Projective::multi_exp (call site src/coeff_form.rs:156): sum scalars[i] * srs[offset+i]; meant for the
+ * verifier's small n (one thread per term). */
+int kzg_msm_g2(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t offset, const void *scalars, size_t n, int sfmt, void *out,
+               int ofmt);
+/* ok[c] = (prod_{i < pairs_per_check} e(g1[c*ppc + i], g2[c*ppc + i]) == 1), 1 <= pairs_per_check <= 4. */
+int kzg_pairing_check(kzg_ctx *ctx, const void *g1_points, int pfmt1, const void *g2_points, int pfmt2,
+                      size_t pairs_per_check, size_t checks, uint8_t *ok);
+/* KZGVerifier::verify_eval (src/coeff_form.rs:126-142) for `count` independent (x, y, commitment, witness)
+ * tuples: ok[c] = e(w_c, hs[1] - [x_c]hs[0]) == e(C_c - [y_c]gs[0], hs[0]).  KZGVerifierEvalForm::verify_eval
+ * (src/eval_form.rs:173-190) is the same check at x = omega^i.  KZG_ERR_SHAPE if hs has fewer than 2 points. */
+int kzg_verify_eval(kzg_ctx *ctx, const kzg_srs *gs, const kzg_srs_g2 *hs, const void *xs, const void *ys, int sfmt,
+                    const void *commitments, const void *witnesses, int pfmt, size_t count, uint8_t *ok);
+/* KZGVerifier::verify_eval_batched (src/coeff_form.rs:144-182): z = prod (X - xs[i]), hz = MSM(hs, z),
+ * gr = MSM(gs, r) with r = witness.r (r_len = num_coeffs), *ok = e(w, hz) == e(C - gr, hs[0]).
+ * KZG_ERR_SHAPE if k + 1 > len(hs) or r_len > len(gs) (slice index panics), k = 0, or k > 4096. */
+int kzg_verify_eval_batched(kzg_ctx *ctx, const kzg_srs *gs, const kzg_srs_g2 *hs, const void *xs, size_t k,
+                            const void *r_coeffs, size_t r_len, int sfmt, const void *commitment, const void *witness,
+                            int pfmt, int *ok);
+/* KZGVerifierEvalForm::verify_eval_all (src/eval_form.rs:192-217) exactly as written there. */
+int kzg_verify_eval_all(kzg_ctx *ctx, const kzg_srs *lagrange_g, const kzg_srs_g2 *lagrange_h, const kzg_srs_g2 *hs,
+                        const void *ys, size_t ys_len, int sfmt, const void *commitment, const void *witness, int pfmt,
+                        int *ok);
 
 /* ---- Fr polynomial helpers on the path (device) ---------------------------------------------- */
 /* Polynomial::eval (src/polynomial.rs:156-165) at one point. */

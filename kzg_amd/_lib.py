@@ -23,6 +23,8 @@ G1_JACOBIAN_MONT = 1
 G1_ZCASH_UNCOMPRESSED = 2
 G1_ZCASH_COMPRESSED = 3
 POINT_BYTES = {0: 96, 1: 144, 2: 96, 3: 48}
+G2_AFFINE_MONT, G2_JACOBIAN_MONT, G2_UNCOMPRESSED, G2_COMPRESSED = 0, 1, 2, 3
+G2_POINT_BYTES = {0: 192, 1: 288, 2: 192, 3: 96}
 IN_DEVICE = 1
 OUT_DEVICE = 2
 
@@ -72,6 +74,17 @@ def load():
         "kzg_commit_eval": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
         "kzg_witness_eval": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_verify_poly_eval": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
+        "kzg_srs_setup_g2": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_setup_lagrange_g2": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_upload_g2": (i32, [vp, vp, sz, i32, c_void_pp]),
+        "kzg_srs_download_g2": (i32, [vp, vp, sz, sz, vp, i32]),
+        "kzg_srs_g2_len": (sz, [vp]),
+        "kzg_srs_g2_free": (None, [vp, vp]),
+        "kzg_msm_g2": (i32, [vp, vp, sz, vp, sz, i32, vp, i32]),
+        "kzg_pairing_check": (i32, [vp, vp, i32, vp, i32, sz, sz, vp]),
+        "kzg_verify_eval": (i32, [vp, vp, vp, vp, vp, i32, vp, vp, i32, sz, vp]),
+        "kzg_verify_eval_batched": (i32, [vp, vp, vp, vp, sz, vp, sz, i32, vp, vp, i32, ctypes.POINTER(i32)]),
+        "kzg_verify_eval_all": (i32, [vp, vp, vp, vp, vp, sz, i32, vp, vp, i32, ctypes.POINTER(i32)]),
         "kzg_poly_eval": (i32, [vp, vp, sz, vp, i32, i32, vp]),
         "kzg_quotient_linear": (i32, [vp, vp, sz, vp, vp, i32, i32, vp]),
         "kzg_quotient_eval": (i32, [vp, vp, sz, sz, i32, i32, vp]),

@@ -334,21 +334,87 @@ class Srs:
         return Srs(engine, h)
 
 
+class SrsG2:
+    """Resident G2 points (kzg_srs_g2): the `hs` half of KZGParams or a G2 Lagrange basis."""
+
+    def __init__(self, engine, handle):
+        self.engine, self.handle = engine, handle
+
+    def __len__(self):
+        return self.engine.lib.kzg_srs_g2_len(self.handle)
+
+    def download(self, offset=0, n=None, pfmt=L.G2_AFFINE_MONT):
+        n = len(self) - offset if n is None else n
+        sz = L.G2_POINT_BYTES[pfmt]
+        out = ctypes.create_string_buffer(sz * max(n, 1))
+        rc = self.engine.lib.kzg_srs_download_g2(self.engine.ctx, self.handle, offset, n, out, pfmt)
+        if rc:
+            _raise(self.engine, rc)
+        return out.raw[: sz * n]
+
+    def msm(self, scalars, offset=0, ofmt=L.G2_AFFINE_MONT):
+        """G2Projective::multi_exp(&hs[offset..offset+len], scalars) (call site src/coeff_form.rs:156)"""
+        blob = pack_scalars(scalars)
+        out = ctypes.create_string_buffer(L.G2_POINT_BYTES[ofmt])
+        rc = self.engine.lib.kzg_msm_g2(self.engine.ctx, self.handle, offset, blob, len(blob) // 32, L.FR_CANONICAL, out, ofmt)
+        if rc:
+            _raise(self.engine, rc)
+        return out.raw
+
+    def free(self):
+        if self.handle:
+            self.engine.lib.kzg_srs_g2_free(self.engine.ctx, self.handle)
+            self.handle = None
+
+    @staticmethod
+    def upload(engine, blob, n, pfmt=L.G2_AFFINE_MONT):
+        h = ctypes.c_void_p()
+        assert len(blob) == n * L.G2_POINT_BYTES[pfmt]
+        rc = engine.lib.kzg_srs_upload_g2(engine.ctx, blob, n, pfmt, ctypes.byref(h))
+        if rc:
+            _raise(engine, rc)
+        return SrsG2(engine, h)
+
+
 class KZGParams:
-    """src/lib.rs:14-19 (G1 half; `hs` and pairings stay on the CPU side of the reference)."""
+    """src/lib.rs:14-19: gs = [s^i]G (resident G1 SRS), hs = [s^i]H (resident G2 points; None if not generated)."""
 
-    def __init__(self, gs):
-        self.gs = gs
+    def __init__(self, gs, hs=None):
+        self.gs, self.hs = gs, hs
 
 
-def setup(engine, s, num_coeffs):
-    """setup(s, num_coeffs) (src/lib.rs:38-55): gs[i] = [s^i]G, generated on the GPU."""
+def setup_g2(engine, s, n):
+    """the hs half of setup() (src/lib.rs:48-52): hs[i] = [s^i]H for i < n."""
+    h = ctypes.c_void_p()
+    rc = engine.lib.kzg_srs_setup_g2(engine.ctx, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, n, ctypes.byref(h))
+    if rc:
+        _raise(engine, rc)
+    return SrsG2(engine, h)
+
+
+def setup_lagrange_g2(engine, s, d):
+    """lagrange_basis_h for a known secret: same elements as compute_lagrange_basis(&setup(s, d)).1."""
+    h = ctypes.c_void_p()
+    rc = engine.lib.kzg_srs_setup_lagrange_g2(engine.ctx, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, d,
+                                              ctypes.byref(h))
+    if rc:
+        _raise(engine, rc)
+    return SrsG2(engine, h)
+
+
+def setup(engine, s, num_coeffs, g2_len=None):
+    """setup(s, num_coeffs) (src/lib.rs:38-55): gs[i] = [s^i]G and hs[i] = [s^i]H, generated on the GPU.
+    The reference always builds num_coeffs G2 powers; only the verifier reads them (hs[0], hs[1], and hs[..k+1] for a
+    k-point batched opening), so `g2_len` caps that half (default min(num_coeffs, 257): enough for 256-point batches;
+    pass g2_len=num_coeffs for the reference's full vector, 0 to skip it)."""
     h = ctypes.c_void_p()
     rc = engine.lib.kzg_srs_setup_g1(engine.ctx, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, num_coeffs,
                                      ctypes.byref(h))
     if rc:
         _raise(engine, rc)
-    return KZGParams(Srs(engine, h))
+    if g2_len is None:
+        g2_len = min(num_coeffs, 257)
+    return KZGParams(Srs(engine, h), setup_g2(engine, s, g2_len) if g2_len else None)
 
 
 def setup_shard(engine, s, first, n):
@@ -503,11 +569,43 @@ class KZGProver:
 
 
 class KZGVerifier:
-    """src/coeff_form.rs:114-124 (verify_poly only; the pairing checks are outside the hot path)."""
+    """src/coeff_form.rs:114-183; the pairing checks run on the GPU, one thread per opening."""
 
     def __init__(self, parameters):
         self.parameters = parameters
         self.engine = parameters.gs.engine
+
+    def _hs(self):
+        if self.parameters.hs is None:
+            raise ReferencePanic("KZGParams.hs is empty (index out of bounds)")
+        return self.parameters.hs
+
+    def verify_eval(self, point, commitment, witness, pfmt=L.G1_AFFINE_MONT):  # :126-142
+        return self.verify_eval_many([point], [commitment], [witness], pfmt)[0]
+
+    def verify_eval_many(self, points, commitments, witnesses, pfmt=L.G1_AFFINE_MONT):
+        """verify_eval for many independent openings in one launch -> list of bool"""
+        e = self.engine
+        n = len(points)
+        assert len(commitments) == n and len(witnesses) == n
+        ok = ctypes.create_string_buffer(max(n, 1))
+        rc = e.lib.kzg_verify_eval(e.ctx, self.parameters.gs.handle, self._hs().handle,
+                                   pack_scalars([p[0] for p in points]), pack_scalars([p[1] for p in points]),
+                                   L.FR_CANONICAL, b"".join(commitments), b"".join(witnesses), pfmt, n, ok)
+        if rc:
+            _raise(e, rc)
+        return [bool(b) for b in ok.raw[:n]]
+
+    def verify_eval_batched(self, xs, commitment, witness, pfmt=L.G1_AFFINE_MONT):  # :144-182
+        e = self.engine
+        r = witness.r
+        ok = ctypes.c_int()
+        rc = e.lib.kzg_verify_eval_batched(e.ctx, self.parameters.gs.handle, self._hs().handle, pack_scalars(xs), len(xs),
+                                           pack_scalars(r.slice_coeffs()), r.num_coeffs(), L.FR_CANONICAL, commitment,
+                                           witness.w, pfmt, ctypes.byref(ok))
+        if rc:
+            _raise(e, rc)
+        return bool(ok.value)
 
     def verify_poly(self, commitment, polynomial, pfmt=L.G1_AFFINE_MONT):
         e = self.engine
@@ -560,12 +658,30 @@ class KZGProverEvalForm:
 
 
 class KZGVerifierEvalForm:
-    """src/eval_form.rs:149-171 (verify_poly only)."""
+    """src/eval_form.rs:149-218"""
 
-    def __init__(self, parameters, lagrange_basis_g):
+    def __init__(self, parameters, lagrange_basis_g, lagrange_basis_h=None):
         self.parameters = parameters
         self.lagrange_basis_g = lagrange_basis_g
+        self.lagrange_basis_h = lagrange_basis_h
         self.engine = parameters.gs.engine
+        self.d, self.exp, self.omega = compute_omega(len(parameters.gs))
+
+    def verify_eval(self, point, commitment, witness, pfmt=L.G1_AFFINE_MONT):  # :173-190
+        i, y = point
+        return KZGVerifier(self.parameters).verify_eval((pow(self.omega, i, R_MODULUS), y), commitment, witness, pfmt)
+
+    def verify_eval_all(self, ys, commitment, witness, pfmt=L.G1_AFFINE_MONT):  # :192-217
+        e = self.engine
+        if self.lagrange_basis_h is None or self.parameters.hs is None:
+            raise ReferencePanic("lagrange_basis_h / hs missing (index out of bounds)")
+        ok = ctypes.c_int()
+        rc = e.lib.kzg_verify_eval_all(e.ctx, self.lagrange_basis_g.handle, self.lagrange_basis_h.handle,
+                                       self.parameters.hs.handle, pack_scalars(ys), len(ys), L.FR_CANONICAL, commitment,
+                                       witness, pfmt, ctypes.byref(ok))
+        if rc:
+            _raise(e, rc)
+        return bool(ok.value)
 
     def verify_poly(self, commitment, evals, pfmt=L.G1_AFFINE_MONT):
         e = self.engine

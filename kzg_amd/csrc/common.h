@@ -159,6 +159,11 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs);                              // 
 int batch_to_affine(kzg_ctx *ctx, hipStream_t stream, const G1Xyzz *d_in, G1Affine *d_out, size_t n);
 int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad);
 int fixed_base_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_scalars_mont, size_t n, G1Xyzz *d_out);
+int powers_run(kzg_ctx *ctx, hipStream_t st, const Fr &base_mont, size_t first, size_t n, Fr *d_out);  // base^(first+i)
+int lagrange_scalars_run(kzg_ctx *ctx, hipStream_t st, const Fr &tau_mont, size_t d, Fr *d_out);      // L_i(tau)
+
+// witness.hip
+int vanishing_poly_run(kzg_ctx *ctx, hipStream_t st, const Fr *d_xs_mont, size_t k, Fr *d_z, Fr *d_tmp);  // k+1 coeffs each
 
 // ntt.hip
 int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse);

@@ -391,6 +391,36 @@ static int srs_from_scalars(kzg_ctx *ctx, kzg_srs *s, Fr *d_scalars) {
     return rc;
 }
 
+// scalar generators shared with the G2 SRS construction (pairing.hip): Montgomery-form outputs on the device
+namespace kzg {
+int powers_run(kzg_ctx *ctx, hipStream_t st, const Fr &base_mont, size_t first, size_t n, Fr *d_out) {
+    if (n) KZG_LAUNCH(ctx, st, "k_powers", k_powers, (unsigned)((n + 255) / 256), 256, 0, base_mont, first, n, d_out);
+    return KZG_OK;
+}
+
+// L_i(tau) = (tau^d - 1) w^i / (d (tau - w^i)); a tau on the domain gives the indicator vector
+int lagrange_scalars_run(kzg_ctx *ctx, hipStream_t st, const Fr &tau, size_t d, Fr *d_out) {
+    uint32_t exp = (uint32_t)ilog2_ceil(d);
+    Fr omega = host_omega(exp);
+    Fr zt = sub(pow_u64(tau, (uint64_t)d), Fr::one());
+    Fr dm = from_u64<FrParams>((uint64_t)d);
+    Fr *den = nullptr, *deni = nullptr;
+    int rc = KZG_OK;
+    if (hipMalloc((void **)&den, d * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&deni, d * sizeof(Fr)) != hipSuccess)
+        rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange scalars)");
+    if (rc == KZG_OK) {
+        unsigned grid = (unsigned)((d + 255) / 256);
+        KZG_LAUNCH(ctx, st, "k_lagrange_den", k_lagrange_den, grid, 256, 0, tau, omega, dm, d, den);
+        rc = batch_inverse(ctx, st, den, deni, d);
+        if (rc == KZG_OK) KZG_LAUNCH(ctx, st, "k_lagrange_scalars", k_lagrange_scalars, grid, 256, 0, zt, omega, d, den, deni, d_out);
+    }
+    hipStreamSynchronize(st);
+    if (den) hipFree(den);
+    if (deni) hipFree(deni);
+    return rc;
+}
+}  // namespace kzg
+
 extern "C" int kzg_srs_setup_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t n, kzg_srs **out) {
     return kzg_srs_setup_g1_shard(ctx, sec, sfmt, 0, n, out);
 }
@@ -432,26 +462,14 @@ extern "C" int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *sec, int sfmt
     if (exp >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
     Fr tau;
     KZG_TRY(load_host_scalar(ctx, sec, sfmt, &tau));
-    Fr omega = host_omega(exp);
-    Fr zt = sub(pow_u64(tau, (uint64_t)d), Fr::one());
-    Fr dm = from_u64<FrParams>((uint64_t)d);
     kzg_srs *s = nullptr;
     KZG_TRY(srs_alloc(ctx, d, &s));
     hipStream_t st = ctx->lanes[0].stream;
     Fr *den = nullptr, *deni = nullptr, *sc = nullptr;
     int rc = KZG_OK;
-    if (hipMalloc((void **)&den, d * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&deni, d * sizeof(Fr)) != hipSuccess ||
-        hipMalloc((void **)&sc, d * sizeof(Fr)) != hipSuccess)
-        rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange scalars)");
-    if (rc == KZG_OK) {
-        unsigned grid = (unsigned)((d + 255) / 256);
-        KZG_LAUNCH(ctx, st, "k_lagrange_den", k_lagrange_den, grid, 256, 0, tau, omega, dm, d, den);
-        rc = batch_inverse(ctx, st, den, deni, d);
-        if (rc == KZG_OK) {
-            KZG_LAUNCH(ctx, st, "k_lagrange_scalars", k_lagrange_scalars, grid, 256, 0, zt, omega, d, den, deni, sc);
-            rc = srs_from_scalars(ctx, s, sc);
-        }
-    }
+    if (hipMalloc((void **)&sc, d * sizeof(Fr)) != hipSuccess) rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange scalars)");
+    if (rc == KZG_OK) rc = lagrange_scalars_run(ctx, st, tau, d, sc);
+    if (rc == KZG_OK) rc = srs_from_scalars(ctx, s, sc);
     hipStreamSynchronize(st);
     if (den) hipFree(den);
     if (deni) hipFree(deni);

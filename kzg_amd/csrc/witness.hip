@@ -84,6 +84,11 @@ __global__ __launch_bounds__(1024) void k_vanishing_poly(const Fr *xs, uint32_t 
     }
 }
 
+int vanishing_poly_run(kzg_ctx *ctx, hipStream_t st, const Fr *d_xs_mont, size_t k, Fr *d_z, Fr *d_tmp) {
+    KZG_LAUNCH(ctx, st, "k_vanishing_poly", k_vanishing_poly, 1, 1024, 0, d_xs_mont, (uint32_t)k, d_z, d_tmp);
+    return KZG_OK;
+}
+
 // den[i] = Z'(x_i) = prod_{j != i} (x_i - x_j)
 __global__ __launch_bounds__(256) void k_bary_den(const Fr *xs, uint32_t k, Fr *den) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
