@@ -2,7 +2,7 @@
 // (include/kzg_mi355x.h).  Same names, argument meaning and error behaviour as proxima-one/kzg:
 //   setup / KZGParams            src/lib.rs:14-55           Polynomial          src/polynomial.rs:24-165
 //   EvaluationDomain             src/ft.rs:17-140           KZGProver           src/coeff_form.rs:37-112
-//   KZGProverEvalForm            src/eval_form.rs:39-147
+//   KZGProverEvalForm            src/eval_form.rs:39-147    KZGVerifier         src/coeff_form.rs:114-183
 // Result<_, KZGError> becomes a thrown kzg::KZGError; a reference panic becomes kzg::ReferencePanic.
 // Scalars are 32-byte canonical little-endian (kzg::Scalar), points 96-byte affine Montgomery (kzg::G1Affine).
 #pragma once
@@ -65,22 +65,30 @@ class Engine {
     kzg_ctx *ctx_ = nullptr;
 };
 
-// KZGParams (G1 half): `gs` lives on the GPU.
+// KZGParams: `gs` (G1 powers) and `hs` (G2 powers, read by the verifier only) live on the GPU.
 struct KZGParams {
     const Engine *engine = nullptr;
     kzg_srs *gs = nullptr;
+    kzg_srs_g2 *hs = nullptr;
     size_t len() const { return kzg_srs_len(gs); }
     KZGParams() = default;
     KZGParams(const KZGParams &) = delete;
     KZGParams &operator=(const KZGParams &) = delete;
-    KZGParams(KZGParams &&o) noexcept : engine(o.engine), gs(o.gs) { o.gs = nullptr; }
-    ~KZGParams() { if (gs) kzg_srs_free(engine->ctx(), gs); }
+    KZGParams(KZGParams &&o) noexcept : engine(o.engine), gs(o.gs), hs(o.hs) { o.gs = nullptr; o.hs = nullptr; }
+    ~KZGParams() {
+        if (gs) kzg_srs_free(engine->ctx(), gs);
+        if (hs) kzg_srs_g2_free(engine->ctx(), hs);
+    }
 };
 
-inline KZGParams setup(const Engine &e, const Scalar &s, size_t num_coeffs) {  // src/lib.rs:38-55
+// src/lib.rs:38-55.  The reference builds num_coeffs G2 powers too; only the verifier reads them (hs[0], hs[1] and
+// hs[..k+1] for a k-point batched opening), so `g2_len` caps that half (SIZE_MAX = min(num_coeffs, 257)).
+inline KZGParams setup(const Engine &e, const Scalar &s, size_t num_coeffs, size_t g2_len = (size_t)-1) {
     KZGParams p;
     p.engine = &e;
     e.check(kzg_srs_setup_g1(e.ctx(), s.le.data(), KZG_FR_CANONICAL_LE_32, num_coeffs, &p.gs));
+    if (g2_len == (size_t)-1) g2_len = num_coeffs < 257 ? num_coeffs : 257;
+    if (g2_len) e.check(kzg_srs_setup_g2(e.ctx(), s.le.data(), KZG_FR_CANONICAL_LE_32, g2_len, &p.hs));
     return p;
 }
 
@@ -172,6 +180,36 @@ class KZGProver {  // src/coeff_form.rs:37-112
         int ok = 0;
         e_.check(kzg_verify_poly_coeff(e_.ctx(), params_.gs, c.bytes.data(), KZG_G1_AFFINE_MONT_96, p.coeffs.data(),
                                        p.num_coeffs(), KZG_FR_CANONICAL_LE_32, 0, &ok));
+        return ok != 0;
+    }
+
+  private:
+    const KZGParams &params_;
+    const Engine &e_;
+};
+
+class KZGVerifier {  // src/coeff_form.rs:114-183; the pairing checks run on the GPU
+  public:
+    explicit KZGVerifier(const KZGParams &params) : params_(params), e_(*params.engine) {}
+    bool verify_poly(const KZGCommitment &c, const Polynomial &p) const {  // :119-124
+        int ok = 0;
+        e_.check(kzg_verify_poly_coeff(e_.ctx(), params_.gs, c.bytes.data(), KZG_G1_AFFINE_MONT_96, p.coeffs.data(),
+                                       p.num_coeffs(), KZG_FR_CANONICAL_LE_32, 0, &ok));
+        return ok != 0;
+    }
+    bool verify_eval(const Scalar &x, const Scalar &y, const KZGCommitment &c, const KZGWitness &w) const {  // :126-142
+        if (!params_.hs) throw ReferencePanic("KZGParams.hs is empty (index out of bounds)");
+        uint8_t ok = 0;
+        e_.check(kzg_verify_eval(e_.ctx(), params_.gs, params_.hs, x.le.data(), y.le.data(), KZG_FR_CANONICAL_LE_32,
+                                 c.bytes.data(), w.bytes.data(), KZG_G1_AFFINE_MONT_96, 1, &ok));
+        return ok != 0;
+    }
+    bool verify_eval_batched(const std::vector<Scalar> &xs, const KZGCommitment &c, const KZGBatchWitness &w) const {  // :144-182
+        if (!params_.hs) throw ReferencePanic("KZGParams.hs is empty (index out of bounds)");
+        int ok = 0;
+        e_.check(kzg_verify_eval_batched(e_.ctx(), params_.gs, params_.hs, xs.data(), xs.size(), w.r.coeffs.data(),
+                                         w.r.num_coeffs(), KZG_FR_CANONICAL_LE_32, c.bytes.data(), w.w.bytes.data(),
+                                         KZG_G1_AFFINE_MONT_96, &ok));
         return ok != 0;
     }
 

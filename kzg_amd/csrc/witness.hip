@@ -84,6 +84,15 @@ __global__ __launch_bounds__(1024) void k_vanishing_poly(const Fr *xs, uint32_t 
     }
 }
 
+// flag |= 1 if some x_i lies on the coset g*H_N, i.e. (x_i / g)^N == 1
+__global__ __launch_bounds__(256) void k_any_on_coset(const Fr *xs, size_t k, Fr ginv, uint32_t log_N, int *flag) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= k) return;
+    Fr t = mul(xs[i], ginv);
+    for (uint32_t s = 0; s < log_N; s++) t = sqr(t);
+    if (t == Fr::one()) atomicOr(flag, 1);
+}
+
 int vanishing_poly_run(kzg_ctx *ctx, hipStream_t st, const Fr *d_xs_mont, size_t k, Fr *d_z, Fr *d_tmp) {
     KZG_LAUNCH(ctx, st, "k_vanishing_poly", k_vanishing_poly, 1, 1024, 0, d_xs_mont, (uint32_t)k, d_z, d_tmp);
     return KZG_OK;
@@ -354,8 +363,21 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(msm_run(ctx, 0, srs, 0, A, 0, KZG_FR_MONT_LE_32, &res));  // identity
     } else {
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
-        // pick a coset shift on which Z has no root: g = 7, then 7^2, ... (x_i in g*H is a measure-zero event)
-        Fr gsh = from_u64<FrParams>(FR_MULT_GENERATOR);
+        // pick a coset shift on which Z has no root: g = 7, then 7^2, ...  An opening point inside g*H (x = 7 is
+        // one) would make Z vanish there; the cosets 7^j*H are pairwise distinct, so at most k candidates fail.
+        Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = g1;
+        int *cflag = (int *)lane_alloc(ctx, 0, 256);
+        if (!cflag) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+        for (size_t attempt = 0;; attempt++) {
+            int on = 0;
+            KZG_HIP_CHECK(ctx, hipMemsetAsync(cflag, 0, sizeof(int), st));
+            KZG_LAUNCH(ctx, st, "k_any_on_coset", k_any_on_coset, gridfor(k), 256, 0, dx, k, inv(gsh), log_N, cflag);
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(&on, cflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            if (!on) break;
+            if (attempt > k) return fail(ctx, KZG_ERR_INTERNAL, "no usable coset shift");
+            gsh = mul(gsh, g1);
+        }
         KZG_TRY(coset_ntt_run(ctx, 0, Cv, log_N, 0, gsh));
         KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(N), 256, 0, Cv, N, flag);
         KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 0, gsh));
@@ -373,9 +395,8 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     KZG_TRY(finish_point_host(ctx, res, out_w, ofmt, flags));
     if (ctx->prof) prof_collect(ctx);
     if (hflag & 1) {
-        // a zero denominator: either duplicate opening points (the reference unwrap()s an invert() of zero)
-        // or a root of Z on the coset; the latter has probability ~ k*N/r and is reported, not hidden
-        return fail(ctx, KZG_ERR_SHAPE, "duplicate opening points (reference: invert().unwrap() panic) or Z has a root on the coset");
+        // a zero denominator: duplicate opening points (the reference unwrap()s an invert() of zero)
+        return fail(ctx, KZG_ERR_SHAPE, "duplicate opening points (reference: invert().unwrap() panic)");
     }
     if (hflag & 2) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
     *out_r_len = k;

@@ -1,5 +1,6 @@
 // Exercises include/kzg_mi355x.hpp (the C++ host mirror) on the GPU: the reference's test_eval_basic
-// degree-1 edge case (src/coeff_form.rs:332-341) and commit/verify_poly (test_basic, :271-285).
+// degree-1 edge case (src/coeff_form.rs:332-341) incl. verify_eval, commit/verify_poly (test_basic, :271-285) and
+// a 3-point batched opening with verify_eval_batched (test_eval_batched, :344-376).
 #include <cstdio>
 #include "../include/kzg_mi355x.hpp"
 using namespace kzg;
@@ -31,6 +32,19 @@ int main() {
     ev.fft(e);
     ev.ifft(e);
     if (!(ev.coeffs == orig)) return 9;
+    KZGVerifier verifier(params);
+    if (!verifier.verify_eval(Scalar::from_u64(1), Scalar::from_u64(4), cm, w)) return 10;
+    if (verifier.verify_eval(Scalar::from_u64(1), Scalar::from_u64(5), cm, w)) return 11;
+    std::vector<Scalar> c2(13);
+    for (int i = 0; i < 7; i++) c2[i] = Scalar::from_u64(1000 + 17 * i);
+    Polynomial p2 = Polynomial::make(c2);
+    KZGCommitment cm2 = prover.commit(p2);
+    std::vector<Scalar> xs = {Scalar::from_u64(5), Scalar::from_u64(6), Scalar::from_u64(7)}, ys;
+    for (auto &x : xs) ys.push_back(p2.eval(e, x));
+    KZGBatchWitness bw = prover.create_witness_batched(p2, xs, ys);
+    if (!verifier.verify_eval_batched(xs, cm2, bw)) return 12;
+    xs[1] = Scalar::from_u64(9);
+    if (verifier.verify_eval_batched(xs, cm2, bw)) return 13;
     std::printf("cpp mirror ok\n");
     return 0;
 }

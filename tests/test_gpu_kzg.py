@@ -194,6 +194,14 @@ def test_create_witness_batched_edge_cases(engine):
     # duplicate opening points: the reference panics (invert of zero)
     with pytest.raises(kzg_amd.ReferencePanic):
         prover.create_witness_batched(p, [5, 5, 6], [C.poly_eval(coeffs, 5)] * 2 + [C.poly_eval(coeffs, 6)])
+    # opening points ON the cosets 7*H, 7^2*H the (p - I)/Z division would evaluate on (7 = the coset shift itself):
+    # the engine must move to a coset without roots of Z; results equal the oracle's schoolbook division
+    w16 = pow(M.FR_ROOT_OF_UNITY, 1 << (M.FR_S - 4), M.R)
+    for xs in ([5, 6, 7], [7, 49, 7 * w16 % M.R], [49 * w16 % M.R, 343, 11]):
+        ys = [C.poly_eval(coeffs, x) for x in xs]
+        wit = prover.create_witness_batched(p, xs, ys)
+        Ir, w = _batched_oracle(coeffs, xs, ys, tau)
+        assert wit.elem() == w and wit.polynomial().coeffs == Ir.coeffs, xs
     params.gs.free()
 
 
