@@ -107,7 +107,7 @@ def main():
 
     # ---- inputs, resident in HBM before the timed region -----------------------------------------
     if not sharded:
-        params = kzg_amd.setup(engine, TAU, n)                       # gs[i] = [tau^i]G
+        params = kzg_amd.setup(engine, TAU, n, g2_len=0)                       # gs[i] = [tau^i]G
         srs = params.gs
         scal = engine.alloc_scalars(n * args.batch).fill_random(1, u64_valued=args.u64)
     else:

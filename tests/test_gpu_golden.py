@@ -64,3 +64,41 @@ def test_golden_kzg(engine):
     assert evp.create_witness(ev, e["index"], ofmt=L.G1_ZCASH_COMPRESSED).hex() == e["witness"]
     for s in (params.gs, up, pe.gs, lag, lag_up):
         s.free()
+
+
+def test_golden_verify(engine):
+    """Verifier half against tests/golden/verify.json (G2 parameters, G2 MSM, pairing products, verifier verdicts)."""
+    import ctypes
+    g = GU.load("verify.json")
+    tau, n = GU.sc(g["tau"]), g["n"]
+    params = kzg_amd.setup(engine, tau, n, g2_len=n)
+    assert params.hs.download(0, 6, pfmt=L.G2_COMPRESSED).hex() == "".join(g["hs_compressed"])
+    assert params.hs.download(1, 1, pfmt=L.G2_UNCOMPRESSED).hex() == g["hs1_uncompressed"]
+    up = kzg_amd.SrsG2.upload(engine, bytes.fromhex("".join(g["hs_compressed"])), 6, L.G2_COMPRESSED)
+    assert up.download() == params.hs.download(0, 6)
+    assert up.msm([GU.sc(h) for h in g["msm_g2"]["scalars"]], ofmt=L.G2_COMPRESSED).hex() == g["msm_g2"]["result"]
+    lag_h = kzg_amd.setup_lagrange_g2(engine, tau, 4)
+    assert lag_h.download(pfmt=L.G2_COMPRESSED).hex() == "".join(g["lagrange_h_d4"])
+    checks = g["pairing_checks"]
+    ok = ctypes.create_string_buffer(len(checks))
+    rc = engine.lib.kzg_pairing_check(engine.ctx, bytes.fromhex("".join(h for c in checks for h in c["g1"])),
+                                      L.G1_ZCASH_COMPRESSED, bytes.fromhex("".join(h for c in checks for h in c["g2"])),
+                                      L.G2_COMPRESSED, 2, len(checks), ok)
+    assert rc == 0, engine.last_error()
+    assert [bool(b) for b in ok.raw] == [c["is_one"] for c in checks]
+    verifier = kzg_amd.KZGVerifier(params)
+    v = g["verify_eval"]
+    c, w = bytes.fromhex(v["commitment"]), bytes.fromhex(v["witness"])
+    pts = [(GU.sc(a), GU.sc(b)) for a, b in v["points"]]
+    assert verifier.verify_eval_many(pts, [c] * len(pts), [w] * len(pts), pfmt=L.G1_ZCASH_COMPRESSED) == v["ok"]
+    prover = kzg_amd.KZGProver(params)
+    poly = kzg_amd.Polynomial([GU.sc(h) for h in v["coeffs"]])
+    assert prover.commit(poly, ofmt=L.G1_ZCASH_COMPRESSED) == c
+    assert prover.create_witness(poly, pts[0], ofmt=L.G1_ZCASH_COMPRESSED) == w
+    b = g["verify_eval_batched"]
+    r = [GU.sc(h) for h in b["r"]]
+    wit = kzg_amd.KZGBatchWitness(kzg_amd.Polynomial.new_from_coeffs(r, len(r) - 1), bytes.fromhex(b["w"]))
+    assert verifier.verify_eval_batched([GU.sc(h) for h in b["xs"]], c, wit, pfmt=L.G1_ZCASH_COMPRESSED) == b["ok"]
+    assert verifier.verify_eval_batched([GU.sc(h) for h in b["xs_bad"]], c, wit, pfmt=L.G1_ZCASH_COMPRESSED) == b["ok_bad"]
+    for h in (params.gs, params.hs, up, lag_h):
+        h.free()

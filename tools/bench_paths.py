@@ -30,7 +30,7 @@ def main():
     n = 1 << log_n
     e = kzg_amd.Engine(0)
     lib, ctx = e.lib, e.ctx
-    t0 = time.perf_counter(); params = kzg_amd.setup(e, TAU, n); t_setup = time.perf_counter() - t0
+    t0 = time.perf_counter(); params = kzg_amd.setup(e, TAU, n, g2_len=0); t_setup = time.perf_counter() - t0
     t0 = time.perf_counter(); lag = kzg_amd.setup_lagrange(e, TAU, n); t_lag = time.perf_counter() - t0
     srs = params.gs
     res = {"log_n": log_n, "setup_s": round(t_setup, 3), "setup_lagrange_s": round(t_lag, 3), "window": srs.window_info()}
