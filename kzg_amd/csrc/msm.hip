@@ -585,8 +585,6 @@ int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, Msm
     return KZG_OK;
 }
 
-static bool g_attr_set = false;
-
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result) {
     if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
@@ -600,10 +598,10 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     if (n == 0) {
         return point_set_infinity(ctx, st, result);
     }
-    if (!g_attr_set) {
+    if (!ctx->attr_msm_set) {  // per context (= per device): the LDS opt-in is a per-device function attribute
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        g_attr_set = true;
+        ctx->attr_msm_set = true;
     }
     const int B = L.B, G = L.G, c = srs->c, W = srs->W;
     uint32_t *blk_hist = (uint32_t *)(base + L.off_blk_hist);

@@ -213,8 +213,6 @@ static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t coun
     return KZG_OK;
 }
 
-static bool g_ntt_attr = false;
-
 static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, NttPlan **out) {
     uint32_t key = log_n * 2 + (inverse ? 1 : 0);
     auto it = ctx->ntt_plans.find(key);
@@ -222,11 +220,11 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
         *out = it->second;
         return KZG_OK;
     }
-    if (!g_ntt_attr) {
+    if (!ctx->attr_ntt_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_single, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        g_ntt_attr = true;
+        ctx->attr_ntt_set = true;
     }
     NttPlan *p = new NttPlan();
     p->log_n = log_n;

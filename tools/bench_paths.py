@@ -49,6 +49,12 @@ def main():
     if check:
         from oracle import c_oracle as C
         assert commitment == C.g1_mul(C.g1_generator(), ptau), "commit != [p(tau)]G"
+    # the same commit with HOST-resident coefficients: one 32*n-byte PCIe copy per call (never bench.py's `value`)
+    host_coeffs = coeffs.download()
+    def commit_host():
+        assert lib.kzg_commit_coeff(ctx, srs.handle, host_coeffs, n, coeffs.sfmt, 0, out, L.G1_AFFINE_MONT) == 0, e.last_error()
+    res["commit_coeff_host_resident_ms"] = round(timeit(commit_host), 3)
+    assert out.raw == commitment
     # witness (coeff form)
     x = kzg_amd.splitmix_scalar(99, 0)
     y = e.poly_eval(coeffs, x)
