@@ -236,7 +236,9 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
         if (l.stream) hipStreamDestroy(l.stream);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
-    // cached tables (NTT plans, eval-domain tables, fixed-base table) are released with the process
+    ntt_plans_free(ctx);
+    eval_tabs_free(ctx);
+    fixed_base_free(ctx);
     delete ctx;
 }
 

@@ -166,6 +166,11 @@ int lagrange_scalars_run(kzg_ctx *ctx, hipStream_t st, const Fr &tau_mont, size_
 // witness.hip
 int vanishing_poly_run(kzg_ctx *ctx, hipStream_t st, const Fr *d_xs_mont, size_t k, Fr *d_z, Fr *d_tmp);  // k+1 coeffs each
 
+// cached per-context tables, released by kzg_ctx_destroy
+void ntt_plans_free(kzg_ctx *ctx);   // ntt.hip
+void eval_tabs_free(kzg_ctx *ctx);   // poly.hip
+void fixed_base_free(kzg_ctx *ctx);  // srs.hip
+
 // ntt.hip
 int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse);
 int pow_table(kzg_ctx *ctx, hipStream_t stream, const Fr &base_mont, const Fr &scale_mont, size_t count, Fr *d_out);

@@ -137,6 +137,28 @@ KZG_HD Fr fr29_pack_canonical(const Fr29 &x) {
     return borrow ? r : t;
 }
 
+// x < 26 r, normalised (limbs below 2^29, the excess in the top limb)  ->  the same residue below 2r.
+// q = floor(top / (r_top + 1)) with top = x >> 232 never exceeds floor(x / r) and falls short of it by at most 1
+// ((top + r_top + 1) / (r_top (r_top + 1)) < 4e-6), so x - q r lies in [0, 2r): ~50 instructions instead of a
+// Montgomery multiplication by one.
+KZG_HD Fr29 fr29_reduce_below_2r(const Fr29 &x) {
+    constexpr uint32_t R_TOP = 0x73eda7u;  // r >> 232
+    const uint32_t q = x.v[R29_N - 1] / (R_TOP + 1);
+    Fr29 r;
+    int64_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        int64_t t = (int64_t)x.v[i] - (int64_t)((uint64_t)q * Fr29Consts::mod(i)) + carry;
+        if (i < R29_N - 1) {
+            r.v[i] = (uint32_t)t & F29_MASK;
+            carry = t >> 29;
+        } else {
+            r.v[i] = (uint32_t)t;
+        }
+    }
+    return r;
+}
+
 KZG_HD Fr29 fr29_one() {
     Fr29 r;
 #pragma unroll

@@ -27,6 +27,7 @@ struct NttPlan {
     Fr29 *tw_lo = nullptr; // w_n^i, i < 2^lo_bits
     Fr29 *tw_hi = nullptr; // w_n^(i << lo_bits)
     uint32_t lo_bits = 0;
+    Fr29 *tw_full = nullptr;  // log_n <= 21: w_n^(j2*k1) * scale at [k1*n2 + j2] -- ONE inter-pass multiply, scale folded in
     Fr29 scale;            // d^-1 for the inverse, one otherwise (twiddle form)
 };
 
@@ -53,6 +54,18 @@ __global__ __launch_bounds__(256) void k_pow_table29(Fr base, size_t count, Fr29
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     out[i] = fr29_twiddle_from_mont(pow_u64(base, (uint64_t)i));
+}
+
+// full inter-pass twiddle table: out[k1*n2 + j2] = w_n^(j2*k1) * scale (HBM has an order of magnitude of slack in these
+// kernels, the VALU has none: one 36-byte read replaces one of the two inter-pass multiplications)
+__global__ __launch_bounds__(256) void k_twiddle_full(const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits, uint32_t k2,
+                                                      Fr29 scale, size_t n, Fr29 *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t ex = (uint64_t)(i & (((size_t)1 << k2) - 1)) * (uint64_t)(i >> k2);
+    Fr29 w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & ((1u << lo_bits) - 1)]);
+    w = mul29r(w, scale);
+    out[i] = fr29_unpack(fr29_pack_canonical(w));  // canonical limbs: usable as the small operand of mul29r
 }
 
 extern __shared__ __attribute__((aligned(16))) Fr29 lds_fr29[];
@@ -168,7 +181,7 @@ __global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const
 // pass 1: columns j2 = blockIdx.x*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
 __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
                                                     const Fr29 *tw1, const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits,
-                                                    uint64_t sw) {
+                                                    const Fr29 *tw_full, uint64_t sw) {
     const uint32_t n1 = 1u << k1, vec = 1u << vec_log;
     const uint32_t j2_0 = blockIdx.x << vec_log;
     const uint32_t total = n1 << vec_log;
@@ -182,15 +195,20 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk1 = e >> vec_log;
         uint32_t j2 = j2_0 + v;
-        uint64_t ex = (uint64_t)j2 * kk1;  // < n
-        Fr29 w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & lo_mask]);
+        Fr29 w;
+        if (tw_full) {
+            w = tw_full[((size_t)kk1 << k2) + j2];
+        } else {
+            uint64_t ex = (uint64_t)j2 * kk1;  // < n
+            w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & lo_mask]);
+        }
         out[((size_t)kk1 << k2) + j2] = fr29_pack_canonical(mul29r(lds_fr29[swz((v << k1) | kk1, sw)], w));
     }
 }
 
 // pass 2: rows k1 = blockIdx.x*vec .. +vec-1; row k1 contiguous at in[k1*n2 ..]; out[k1 + n1*k2]
 __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr29 *tw2, Fr29 scale, uint64_t sw) {
+                                                    const Fr29 *tw2, Fr29 scale, int scale_folded, uint64_t sw) {
     const uint32_t n2 = 1u << k2, vec = 1u << vec_log;
     const uint32_t r0 = blockIdx.x << vec_log;
     const uint32_t total = n2 << vec_log;
@@ -202,7 +220,10 @@ __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint3
     lds_ntt_stages29(lds_fr29, k2, vec, tw2, sw);
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk2 = e >> vec_log;  // consecutive threads -> consecutive k1
-        out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(mul29r(lds_fr29[swz((v << k2) | kk2, sw)], scale));
+        Fr29 x = lds_fr29[swz((v << k2) | kk2, sw)];
+        // the scale already sits in the inter-pass table: only canonicalise (x < 26 r) -- no multiplication
+        x = scale_folded ? fr29_reduce_below_2r(x) : mul29r(x, scale);
+        out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(x);
     }
 }
 
@@ -248,10 +269,25 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
         KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n1), n2 >> 1, &p->tw2));  // w_{n2}
         KZG_TRY(pow_table29(ctx, st, w, nlo, &p->tw_lo));
         KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)nlo), nhi, &p->tw_hi));
+        if (log_n <= 21) {  // 36 B per element, 38 MB at 2^20 per direction; measured -7.5 % at 2^20, nothing at 2^22
+            KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw_full, n * sizeof(Fr29)));
+            KZG_LAUNCH(ctx, st, "k_twiddle_full", k_twiddle_full, (unsigned)((n + 255) / 256), 256, 0, p->tw_lo, p->tw_hi, p->lo_bits,
+                       p->k2, p->scale, n, p->tw_full);
+        }
     }
     ctx->ntt_plans[key] = p;
     *out = p;
     return KZG_OK;
+}
+
+void ntt_plans_free(kzg_ctx *ctx) {
+    for (auto &kv : ctx->ntt_plans) {
+        NttPlan *p = kv.second;
+        for (Fr29 *t : {p->tw1, p->tw2, p->tw_lo, p->tw_hi, p->tw_full})
+            if (t) hipFree(t);
+        delete p;
+    }
+    ctx->ntt_plans.clear();
 }
 
 int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
@@ -279,9 +315,9 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     // one radix-4 butterfly per thread and stage; smaller tiles leave room for a second block per CU
     unsigned th1 = std::min(1024u, 1u << (p->k1 + vec1 - 2)), th2 = std::min(1024u, 1u << (p->k2 + vec2 - 2));
     KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, th1, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
-               p->tw_hi, p->lo_bits, LDS_SWIZZLE[p->k1][vec1]);
+               p->tw_hi, p->lo_bits, p->tw_full, LDS_SWIZZLE[p->k1][vec1]);
     KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
-               LDS_SWIZZLE[p->k2][vec2]);
+               p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2]);
     return KZG_OK;
 }
 

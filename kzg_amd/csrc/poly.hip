@@ -212,6 +212,15 @@ struct EvalDomainTables {
     Fr *inv1 = nullptr;  // 1/(w^t - 1), inv1[0] = 0
 };
 
+void eval_tabs_free(kzg_ctx *ctx) {
+    for (auto &kv : ctx->eval_tabs) {
+        if (kv.second->pw) hipFree(kv.second->pw);
+        if (kv.second->inv1) hipFree(kv.second->inv1);
+        delete kv.second;
+    }
+    ctx->eval_tabs.clear();
+}
+
 __global__ __launch_bounds__(256) void k_sub_one(const Fr *in, Fr *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;

@@ -249,6 +249,13 @@ __global__ __launch_bounds__(64) void k_fb_build(G1Xyzz *out) {
     }
 }
 
+void fixed_base_free(kzg_ctx *ctx) {
+    if (!ctx->fixed_base) return;
+    if (ctx->fixed_base->table) hipFree(ctx->fixed_base->table);
+    delete ctx->fixed_base;
+    ctx->fixed_base = nullptr;
+}
+
 static int fixed_base_table(kzg_ctx *ctx, hipStream_t st, FixedBaseTable **out) {
     if (!ctx->fixed_base) {
         FixedBaseTable *t = new FixedBaseTable();
