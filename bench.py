@@ -30,6 +30,13 @@ sys.path.insert(0, ROOT)
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_TERM = 128           # 32 B scalar + 96 B affine point per MSM term
+# The resource that actually binds k_accum_affine: v_mad_u64_u32 issue.  One bucket addition executes
+# 8 mul29 (392 mads) + 2 sqr29 (301) + one fused double product (588) = 3934 mads per lane (static count from the ISA);
+# tools/microbench.hip measured the chip's v_mad_u64_u32 rate: 30.9 T lane-op/s at 8 waves/SIMD, 23.2 T at the 2
+# waves/SIMD a 256-VGPR kernel can hold (profiles/r01_microbench.txt).
+MADS_PER_ADD = 8 * 392 + 2 * 301 + 588
+MAD_PEAK_TLANE_S = 30.93
+MAD_PEAK_OCC2_TLANE_S = 23.21
 TAU = 0x5EED5EED5EED5EED       # known secret for the synthetic SRS (setup(s, n), src/lib.rs:38)
 
 
@@ -193,6 +200,15 @@ def main():
                         "note": "binding resource is integer VALU issue (~5e4 32-bit multiply-adds per term), not HBM; "
                                 "see DESIGN.md 3.2",
                         "kernel_ms_per_msm": {k: round(v[1] / per_msm, 4) for k, v in sorted(prof.items())}}
+            # informational: the same kernel against the integer-multiply issue rate, over the whole timed region
+            # (launches overlap on 8 streams, so the aggregate rate is the meaningful one)
+            mads = float(launches) * n * W * MADS_PER_ADD
+            t_mad = mads / dt / 1e12
+            roofline["valu"] = {"resource": "v_mad_u64_u32 issue", "achieved": round(t_mad, 2), "unit": "T lane-mad/s",
+                                "peak": MAD_PEAK_TLANE_S, "frac": round(t_mad / MAD_PEAK_TLANE_S, 4),
+                                "peak_at_2_waves_per_simd": MAD_PEAK_OCC2_TLANE_S,
+                                "frac_of_occupancy_2_peak": round(t_mad / MAD_PEAK_OCC2_TLANE_S, 4),
+                                "mads_per_bucket_add": MADS_PER_ADD}
         # single-commit latency (one MSM alone on the GPU), outside the timed region
         one = ctypes.create_string_buffer(96)
         reps = 2
