@@ -163,6 +163,8 @@ int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const void *comm
 int kzg_srs_setup_g2(kzg_ctx *ctx, const void *s, int sfmt, size_t n, kzg_srs_g2 **out);
 /* [L_i(s)] H over the size-d domain (lagrange_basis_h of KZGVerifierEvalForm::new, src/eval_form.rs:150). */
 int kzg_srs_setup_lagrange_g2(kzg_ctx *ctx, const void *s, int sfmt, size_t d, kzg_srs_g2 **out);
+/* compute_lagrange_basis, G2 half, from hs alone (src/eval_form.rs:254-280); d = len(hs) a power of two <= 1024. */
+int kzg_srs_lagrange_from_monomial_g2(kzg_ctx *ctx, const kzg_srs_g2 *hs, kzg_srs_g2 **out);
 /* KZGParams.hs supplied by the caller (Vec<G2Projective> = KZG_G2_JACOBIAN_MONT_288, or any G2 format);
  * KZG_ERR_BAD_POINT if a point does not decode / is not on the twist. */
 int kzg_srs_upload_g2(kzg_ctx *ctx, const void *pts, size_t n, int pfmt, kzg_srs_g2 **out);

@@ -9,6 +9,6 @@ from ._lib import (FR_CANONICAL, FR_MONT, G1_AFFINE_MONT, G1_JACOBIAN_MONT, G1_Z
                    OUT_DEVICE, SO_PATH, load)
 from .api import (DeviceBuffer, Engine, EngineError, EvaluationDomain, KZGBatchWitness, KZGError, KZGParams,
                   KZGProver, KZGProverEvalForm, KZGVerifier, KZGVerifierEvalForm, PointNotOnPolynomial, Polynomial,
-                  PolynomialDegreeTooLarge, ReferencePanic, Srs, SrsG2, compute_lagrange_basis, compute_omega,
+                  PolynomialDegreeTooLarge, ReferencePanic, Srs, SrsG2, compute_lagrange_basis, compute_lagrange_basis_g2, compute_omega,
                   pack_scalars, setup, setup_g2, setup_lagrange, setup_lagrange_g2, setup_shard, splitmix_scalar,
                   unpack_scalars)

@@ -76,6 +76,7 @@ def load():
         "kzg_verify_poly_eval": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
         "kzg_srs_setup_g2": (i32, [vp, vp, i32, sz, c_void_pp]),
         "kzg_srs_setup_lagrange_g2": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_lagrange_from_monomial_g2": (i32, [vp, vp, c_void_pp]),
         "kzg_srs_upload_g2": (i32, [vp, vp, sz, i32, c_void_pp]),
         "kzg_srs_download_g2": (i32, [vp, vp, sz, sz, vp, i32]),
         "kzg_srs_g2_len": (sz, [vp]),

@@ -447,6 +447,18 @@ def compute_lagrange_basis(params):
     return Srs(e, h)
 
 
+def compute_lagrange_basis_g2(params):
+    """compute_lagrange_basis (src/eval_form.rs:254-280), G2 half, from hs alone (hs must hold all d powers)."""
+    e = params.gs.engine
+    if params.hs is None:
+        raise ReferencePanic("KZGParams.hs is empty")
+    h = ctypes.c_void_p()
+    rc = e.lib.kzg_srs_lagrange_from_monomial_g2(e.ctx, params.hs.handle, ctypes.byref(h))
+    if rc:
+        _raise(e, rc)
+    return SrsG2(e, h)
+
+
 class Polynomial:
     """src/polynomial.rs:24-27: dense coefficients + explicit degree."""
 

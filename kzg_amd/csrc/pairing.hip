@@ -482,6 +482,45 @@ static int g2_msm_device(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t offset, con
     return KZG_OK;
 }
 
+// compute_lagrange_basis (src/eval_form.rs:254-280), G2 half: row i = MSM(hs[..d], w^(-ij)/d), as for G1
+// (kzg_srs_lagrange_from_monomial_g1).  d*d scalar multiplications: meant for the sizes the reference's O(d^3)
+// construction can handle; larger bases come from kzg_srs_setup_lagrange_g2 or an upload.
+extern "C" int kzg_srs_lagrange_from_monomial_g2(kzg_ctx *ctx, const kzg_srs_g2 *hs, kzg_srs_g2 **out) {
+    if (!ctx || !hs || !out) return KZG_ERR_SHAPE;
+    Lock g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    size_t d = hs->n;
+    if (d == 0 || (d & (d - 1))) return fail(ctx, KZG_ERR_SHAPE, "assert!(d & (d - 1) == 0) (src/eval_form.rs:255-256)");
+    if (d > 1024) return fail(ctx, KZG_ERR_SHAPE, "compute_lagrange_basis (G2) from hs is limited to d <= 1024; use kzg_srs_setup_lagrange_g2 or upload the basis");
+    uint32_t exp = (uint32_t)ilog2_ceil(d);
+    hipStream_t st = ctx->lanes[0].stream;
+    kzg_srs_g2 *s = new kzg_srs_g2();
+    s->n = d;
+    s->device = ctx->device;
+    if (hipMalloc((void **)&s->pts, d * sizeof(G2Affine)) != hipSuccess) {
+        delete s;
+        return fail(ctx, KZG_ERR_ALLOC, "hipMalloc(G2 basis)");
+    }
+    Fr omega_inv = inv(host_omega(exp));
+    Fr dinv = inv(from_u64<FrParams>((uint64_t)d));
+    int rc = KZG_OK;
+    for (size_t i = 0; i < d && rc == KZG_OK; i++) {
+        rc = lane_reserve(ctx, 0, d * 32 + (d + 64) * sizeof(G2Jacobian) + 65536);
+        Fr *sc = rc == KZG_OK ? (Fr *)lane_alloc(ctx, 0, d * 32) : nullptr;
+        if (rc == KZG_OK && !sc) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
+        if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(omega_inv, (uint64_t)i), dinv, d, sc);
+        if (rc == KZG_OK) rc = g2_msm_device(ctx, hs, 0, sc, d, 1, s->pts + i);
+    }
+    if (hipStreamSynchronize(st) != hipSuccess && rc == KZG_OK) rc = fail(ctx, KZG_ERR_HIP, "G2 basis kernels failed");
+    if (rc != KZG_OK) {
+        hipFree(s->pts);
+        delete s;
+        return rc;
+    }
+    *out = s;
+    return KZG_OK;
+}
+
 extern "C" int kzg_msm_g2(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t offset, const void *scalars, size_t n, int sfmt, void *out,
                           int ofmt) {
     // G2Projective::multi_exp (src/coeff_form.rs:156): small-n G2 multi-exponentiation, host-resident scalars

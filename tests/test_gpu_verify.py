@@ -191,6 +191,12 @@ def test_eval_form_verifier(engine):  # src/eval_form.rs:173-217
     lag_h = kzg_amd.setup_lagrange_g2(engine, tau, d)
     want_h = P.lagrange_basis_g2_known_tau(tau, d)
     assert lag_h.download(pfmt=L.G2_UNCOMPRESSED) == b"".join(P.g2_to_uncompressed(p) for p in want_h)
+    # compute_lagrange_basis from hs alone (src/eval_form.rs:254-280) yields the same elements
+    full = kzg_amd.setup(engine, tau, d, g2_len=d)
+    from_hs = kzg_amd.compute_lagrange_basis_g2(full)
+    assert from_hs.download() == lag_h.download()
+    for h in (full.gs, full.hs, from_hs):
+        h.free()
     prover = kzg_amd.KZGProverEvalForm(params, lag_g)
     verifier = kzg_amd.KZGVerifierEvalForm(params, lag_g, lag_h)
     coeffs = [rng.getrandbits(64) for _ in range(d)]
