@@ -12,6 +12,8 @@
 struct kzg_srs_g2 {
     size_t n = 0;
     kzg::G2Affine *pts = nullptr;  // affine Montgomery (= blst_p2_affine), identity all-zero
+    kzg::Fq2 *lines = nullptr;     // Miller-loop lines of pts[0] and pts[1] (2 x 2*MILLER_LINES Fq2): the verifier's
+                                   // second pairing argument is always one of these two, so a check does no G2 arithmetic
     int device = 0;
 };
 
@@ -238,6 +240,13 @@ __global__ void k_g2_sub(const G2Affine *a, const G2Affine *b, G2Affine *out) {
     *out = r;
 }
 
+// lines[j] = stored Miller lines of pts[j], j < count <= 2
+__global__ void k_g2_lines(const G2Affine *pts, int count, Fq2 *lines) {
+    int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    g2_precompute_lines(pts[j], lines + (size_t)j * 2 * MILLER_LINES);
+}
+
 // ------------------------------------------------------------------------------------------------
 // pairing checks
 // ------------------------------------------------------------------------------------------------
@@ -256,44 +265,46 @@ __global__ __launch_bounds__(64) void k_pairing_check(const G1Xyzz *Ps, const G2
     ok[c] = pairing_product_is_one(P, Q, T, np) ? 1 : 0;
 }
 
-// verify_eval (src/coeff_form.rs:126-142):  e(w, h1 - [x]h0) == e(C - [y]g0, h0)
+// verify_eval (src/coeff_form.rs:126-142):  e(w, h1 - [x]h0) == e(C - [y]g0, h0).  By bilinearity the product
+// e(w, h1 - [x]h0) e(-(C - [y]g0), h0) equals  e(w, h1) e(-([x]w + C - [y]g0), h0): both G2 arguments are SRS points
+// whose lines are stored, so the per-opening work is two G1 scalar multiplications, the shared Miller loop and the
+// final exponentiation -- no G2 arithmetic.
 __global__ __launch_bounds__(64) void k_verify_eval(const Fr *xs, const Fr *ys, int is_mont, const G1Xyzz *Cs, const G1Xyzz *Ws,
-                                                    const G1Affine *g0, const G2Affine *hs, size_t count, uint8_t *ok) {
+                                                    const G1Affine *g0, const G2Affine *hs, const Fq2 *lines, size_t count,
+                                                    uint8_t *ok) {
     size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= count) return;
     uint32_t k[8];
     G1Affine P[2];
     G2Affine Q[2], T[2];
-    // A = C - [y] g0 ;  P1 = -A
+    const Fq2 *tabs[2] = {lines + 2 * MILLER_LINES, lines};  // pair 0 against hs[1], pair 1 against hs[0]
+    G1Affine w = g1_to_affine(Ws[c]);
+    // B = [x]w + C - [y]g0 ;  P1 = -B
     scalar_bits(k, ys[c], is_mont);
     G1Xyzz yg = g1_scalar_mul(*g0, k);
     if (!yg.y.is_zero()) yg.y = neg(yg.y);
-    G1Affine a = g1_to_affine(g1_add(Cs[c], yg));
-    P[0] = g1_to_affine(Ws[c]);
-    P[1] = g1_neg(a);
-    // Q0 = h1 - [x] h0
     scalar_bits(k, xs[c], is_mont);
-    G2Jacobian xh, h1;
-    g2_scalar_mul(xh, hs[0], k);
-    f2_neg(xh.y, xh.y);
-    g2_from_affine(h1, hs[1]);
-    g2_add(xh, xh, h1);
-    g2_to_affine(Q[0], xh);
+    G1Xyzz acc = g1_add(g1_add(g1_scalar_mul(w, k), Cs[c]), yg);
+    P[0] = w;
+    P[1] = g1_neg(g1_to_affine(acc));
+    Q[0] = hs[1];
     Q[1] = hs[0];
-    ok[c] = pairing_product_is_one(P, Q, T, 2) ? 1 : 0;
+    ok[c] = pairing_product_is_one(P, Q, T, 2, tabs) ? 1 : 0;
 }
 
-// e(w, hz) == e(C - gr, h0)   (verify_eval_batched src/coeff_form.rs:144-182, verify_eval_all src/eval_form.rs:192-217)
+// e(w, hz) == e(C - gr, h0)   (verify_eval_batched src/coeff_form.rs:144-182, verify_eval_all src/eval_form.rs:192-217);
+// hz varies per call (lines on the fly), h0 uses its stored lines
 __global__ void k_verify_finish(const G1Xyzz *C, const G1Affine *gr, const G1Xyzz *w, const G2Affine *hz, const G2Affine *h0,
-                                uint8_t *ok) {
+                                const Fq2 *lines_h0, uint8_t *ok) {
     G1Affine P[2];
     G2Affine Q[2], T[2];
+    const Fq2 *tabs[2] = {nullptr, lines_h0};
     G1Xyzz ngr = G1Xyzz::from_affine(g1_neg(*gr));
     P[0] = g1_to_affine(*w);
     P[1] = g1_neg(g1_to_affine(g1_add(*C, ngr)));
     Q[0] = *hz;
     Q[1] = *h0;
-    ok[0] = pairing_product_is_one(P, Q, T, 2) ? 1 : 0;
+    ok[0] = pairing_product_is_one(P, Q, T, 2, tabs) ? 1 : 0;
 }
 
 }  // namespace kzg
@@ -319,6 +330,15 @@ int load_scalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
     return KZG_OK;
 }
 
+// stored Miller lines of the first two points (called once the points are on the device)
+int g2_make_lines(kzg_ctx *ctx, hipStream_t st, kzg_srs_g2 *s) {
+    int cnt = s->n < 2 ? (int)s->n : 2;
+    if (hipMalloc((void **)&s->lines, 2 * 2 * MILLER_LINES * sizeof(Fq2)) != hipSuccess) return fail(ctx, KZG_ERR_ALLOC, "hipMalloc(G2 lines)");
+    if (hipMemsetAsync(s->lines, 0, 2 * 2 * MILLER_LINES * sizeof(Fq2), st) != hipSuccess) return fail(ctx, KZG_ERR_HIP, "memset");
+    if (cnt) KZG_LAUNCH(ctx, st, "k_g2_lines", k_g2_lines, 1, 64, 0, s->pts, cnt, s->lines);
+    return KZG_OK;
+}
+
 int g2_from_scalars(kzg_ctx *ctx, hipStream_t st, const Fr *d_scalars_mont, size_t n, kzg_srs_g2 **out) {
     kzg_srs_g2 *s = new kzg_srs_g2();
     s->n = n;
@@ -328,10 +348,12 @@ int g2_from_scalars(kzg_ctx *ctx, hipStream_t st, const Fr *d_scalars_mont, size
         return fail(ctx, KZG_ERR_ALLOC, "hipMalloc(G2 SRS)");
     }
     if (n) KZG_LAUNCH(ctx, st, "k_g2_gen_mul", k_g2_gen_mul, (unsigned)((n + 63) / 64), 64, 0, d_scalars_mont, n, s->pts);
-    if (hipStreamSynchronize(st) != hipSuccess) {
+    int lrc = g2_make_lines(ctx, st, s);
+    if (hipStreamSynchronize(st) != hipSuccess || lrc != KZG_OK) {
         hipFree(s->pts);
+        if (s->lines) hipFree(s->lines);
         delete s;
-        return fail(ctx, KZG_ERR_HIP, "G2 SRS kernel failed");
+        return lrc != KZG_OK ? lrc : fail(ctx, KZG_ERR_HIP, "G2 SRS kernel failed");
     }
     *out = s;
     return KZG_OK;
@@ -426,10 +448,15 @@ extern "C" int kzg_srs_upload_g2(kzg_ctx *ctx, const void *pts, size_t n, int pf
         if (hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "G2 decode failed");
         if (rc == KZG_OK && hbad) rc = fail(ctx, KZG_ERR_BAD_POINT, "a G2 point failed to decode / is not on the curve");
     }
+    if (rc == KZG_OK) {
+        rc = g2_make_lines(ctx, st, s);
+        if (rc == KZG_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "G2 lines failed");
+    }
     if (raw) hipFree(raw);
     if (bad) hipFree(bad);
     if (rc != KZG_OK) {
         if (s->pts) hipFree(s->pts);
+        if (s->lines) hipFree(s->lines);
         delete s;
         return rc;
     }
@@ -464,10 +491,9 @@ extern "C" void kzg_srs_g2_free(kzg_ctx *ctx, kzg_srs_g2 *srs) {
         Lock g(ctx);
         hipSetDevice(ctx->device);
         hipStreamSynchronize(ctx->lanes[0].stream);
-        hipFree(srs->pts);
-    } else {
-        hipFree(srs->pts);
     }
+    hipFree(srs->pts);
+    if (srs->lines) hipFree(srs->lines);
     delete srs;
 }
 
@@ -511,9 +537,11 @@ extern "C" int kzg_srs_lagrange_from_monomial_g2(kzg_ctx *ctx, const kzg_srs_g2 
         if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(omega_inv, (uint64_t)i), dinv, d, sc);
         if (rc == KZG_OK) rc = g2_msm_device(ctx, hs, 0, sc, d, 1, s->pts + i);
     }
+    if (rc == KZG_OK) rc = g2_make_lines(ctx, st, s);
     if (hipStreamSynchronize(st) != hipSuccess && rc == KZG_OK) rc = fail(ctx, KZG_ERR_HIP, "G2 basis kernels failed");
     if (rc != KZG_OK) {
         hipFree(s->pts);
+        if (s->lines) hipFree(s->lines);
         delete s;
         return rc;
     }
@@ -601,13 +629,13 @@ extern "C" int kzg_verify_eval(kzg_ctx *ctx, const kzg_srs *gs, const kzg_srs_g2
     KZG_TRY(g1_inputs(ctx, commitments, count, pfmt, &C, bad));
     KZG_TRY(g1_inputs(ctx, witnesses, count, pfmt, &W, bad));
     KZG_LAUNCH(ctx, st, "k_verify_eval", k_verify_eval, (unsigned)((count + 63) / 64), 64, 0, dx, dy, sfmt == KZG_FR_MONT_LE_32 ? 1 : 0, C, W,
-               gs->table, hs->pts, count, d_ok);
+               gs->table, hs->pts, hs->lines, count, d_ok);
     return fetch_ok(ctx, d_ok, bad, count, ok);
 }
 
 // shared tail of verify_eval_batched / verify_eval_all: gr = MSM(g1 basis, r), then the pairing check against d_hz
 static int verify_with_hz(kzg_ctx *ctx, const kzg_srs *basis_g, const void *r, size_t r_len, int sfmt, const G2Affine *d_hz,
-                          const G2Affine *d_h0, const void *commitment, const void *witness, int pfmt, int *ok) {
+                          const G2Affine *d_h0, const Fq2 *d_lines_h0, const void *commitment, const void *witness, int pfmt, int *ok) {
     hipStream_t st = ctx->lanes[0].stream;
     int *bad = (int *)lane_alloc(ctx, 0, 256);
     uint8_t *d_ok = (uint8_t *)lane_alloc(ctx, 0, 256);
@@ -622,7 +650,7 @@ static int verify_with_hz(kzg_ctx *ctx, const kzg_srs *basis_g, const void *r, s
     MsmPoint *res = nullptr;
     KZG_TRY(msm_run(ctx, 0, basis_g, 0, dr, r_len, sfmt, &res));
     KZG_TRY(emit_point(ctx, 0, res, gr, KZG_G1_AFFINE_MONT_96));
-    KZG_LAUNCH(ctx, st, "k_verify_finish", k_verify_finish, 1, 1, 0, C, gr, W, d_hz, d_h0, d_ok);
+    KZG_LAUNCH(ctx, st, "k_verify_finish", k_verify_finish, 1, 1, 0, C, gr, W, d_hz, d_h0, d_lines_h0, d_ok);
     uint8_t r8 = 0;
     KZG_TRY(fetch_ok(ctx, d_ok, bad, 1, &r8));
     *ok = r8;
@@ -654,7 +682,7 @@ extern "C" int kzg_verify_eval_batched(kzg_ctx *ctx, const kzg_srs *gs, const kz
     if (sfmt == KZG_FR_CANONICAL_LE_32) KZG_TRY(fr_convert(ctx, st, dx, k, 1));
     KZG_TRY(vanishing_poly_run(ctx, st, dx, k, z0, z1));  // Montgomery coefficients
     KZG_TRY(g2_msm_device(ctx, hs, 0, z0, k + 1, 1, hz));
-    return verify_with_hz(ctx, gs, r_coeffs, r_len, sfmt, hz, hs->pts, commitment, witness, pfmt, ok);
+    return verify_with_hz(ctx, gs, r_coeffs, r_len, sfmt, hz, hs->pts, hs->lines, commitment, witness, pfmt, ok);
 }
 
 extern "C" int kzg_verify_eval_all(kzg_ctx *ctx, const kzg_srs *lagrange_g, const kzg_srs_g2 *lagrange_h, const kzg_srs_g2 *hs,
@@ -680,5 +708,5 @@ extern "C" int kzg_verify_eval_all(kzg_ctx *ctx, const kzg_srs *lagrange_g, cons
     } else {
         KZG_LAUNCH(ctx, st, "k_g2_sub", k_g2_sub, 1, 1, 0, lagrange_h->pts + (d - 1), lagrange_h->pts, hz);
     }
-    return verify_with_hz(ctx, lagrange_g, ys, ys_len, sfmt, hz, hs->pts, commitment, witness, pfmt, ok);
+    return verify_with_hz(ctx, lagrange_g, ys, ys_len, sfmt, hz, hs->pts, hs->lines, commitment, witness, pfmt, ok);
 }

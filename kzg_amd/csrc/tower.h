@@ -393,13 +393,40 @@ KZG_NI void g2_scalar_mul(G2Jacobian &r, const G2Affine &p, const uint32_t k[8])
 // ------------------------------------------------------------------------------------------------ pairing
 constexpr uint64_t BLS_Z_ABS = 0xd201000000010000ull;  // the curve parameter is -BLS_Z_ABS
 
-// f *= line of slope lam (on the twist) through T evaluated at P, scaled by w^3 (killed by the final
-// exponentiation):  yP w^3 - lam xP w^2 + (lam xT - yT)   ->  c0 = (lam xT - yT, -lam xP, 0), c1 = (0, yP, 0)
-KZG_NI void f12_mul_line(Fq12 &f, const Fq2 &lam, const G2Affine &T, const G1Affine &P) {
+constexpr int MILLER_LINES = 68;  // 63 doublings + 5 additions (hamming weight of |z| minus one)
+
+// One Miller-loop step for T (doubling when S == nullptr, else the chord through T and *S): the line's slope and
+// constant term  (lam, lam xT - yT)  and the update of T.
+KZG_NI void miller_step(G2Affine &T, const G2Affine *S, Fq2 &lam, Fq2 &cst) {
+    Fq2 t, x3;
+    if (!S) {
+        f2_sqr(lam, T.x);
+        f2_dbl(t, lam);
+        f2_add(lam, lam, t);
+        f2_dbl(t, T.y);
+    } else {
+        f2_sub(lam, S->y, T.y);
+        f2_sub(t, S->x, T.x);
+    }
+    f2_inv(t, t);
+    f2_mul(lam, lam, t);
+    f2_mul(cst, lam, T.x);
+    f2_sub(cst, cst, T.y);
+    f2_sqr(x3, lam);
+    f2_sub(x3, x3, T.x);
+    f2_sub(x3, x3, S ? S->x : T.x);
+    f2_sub(t, T.x, x3);
+    f2_mul(t, lam, t);
+    f2_sub(T.y, t, T.y);
+    T.x = x3;
+}
+
+// f *= the line (lam, cst) evaluated at P, scaled by w^3 (killed by the final exponentiation):
+//   yP w^3 - lam xP w^2 + cst   ->  c0 = (cst, -lam xP, 0), c1 = (0, yP, 0)
+KZG_NI void f12_mul_line(Fq12 &f, const Fq2 &lam, const Fq2 &cst, const G1Affine &P) {
     Fq12 l;
     Fq2 z = Fq2::zero(), t;
-    f2_mul(t, lam, T.x);
-    f2_sub(l.c0.c0, t, T.y);
+    l.c0.c0 = cst;
     f2_mul_fq(t, lam, P.x);
     f2_neg(l.c0.c1, t);
     l.c0.c2 = z;
@@ -410,47 +437,53 @@ KZG_NI void f12_mul_line(Fq12 &f, const Fq2 &lam, const G2Affine &T, const G1Aff
     f12_mul(f, f, l);
 }
 
-// prod_i f_{z,Q_i}(P_i); T_i is kept affine (one Fq inversion per step: cheap next to the Fq12 work and free of
-// projective line formulas).  Pairs with an identity member contribute 1.
-KZG_NI void miller_loop(Fq12 &f, const G1Affine *Ps, const G2Affine *Qs, G2Affine *Ts, int np) {
+// The MILLER_LINES (lam, cst) pairs of a FIXED Q, in loop order: tab[2k], tab[2k+1].  The verifier's second argument
+// is almost always one of two SRS points (hs[0], hs[1]); with their lines stored once a check needs no G2 arithmetic.
+KZG_NI void g2_precompute_lines(const G2Affine &Q, Fq2 *tab) {
+    G2Affine T = Q;
+    int k = 0;
+    for (int b = 62; b >= 0; b--) {
+        if (Q.is_inf()) break;
+        miller_step(T, nullptr, tab[2 * k], tab[2 * k + 1]);
+        k++;
+        if ((BLS_Z_ABS >> b) & 1) {
+            miller_step(T, &Q, tab[2 * k], tab[2 * k + 1]);
+            k++;
+        }
+    }
+    for (; k < MILLER_LINES; k++) {
+        tab[2 * k] = Fq2::zero();
+        tab[2 * k + 1] = Fq2::zero();
+    }
+}
+
+// prod_i f_{z,Q_i}(P_i).  Pair i uses the stored lines tabs[i] when that pointer is non-null, otherwise T_i is kept
+// affine and updated on the fly (one Fq inversion per step: cheap next to the Fq12 work and free of projective line
+// formulas).  Pairs with an identity member contribute 1.
+KZG_NI void miller_loop(Fq12 &f, const G1Affine *Ps, const G2Affine *Qs, G2Affine *Ts, int np, const Fq2 *const *tabs = nullptr) {
     f12_one(f);
     for (int i = 0; i < np; i++) Ts[i] = Qs[i];
+    int k = 0;
     for (int b = 62; b >= 0; b--) {
+        const bool add = ((BLS_Z_ABS >> b) & 1) != 0;
         f12_sqr(f, f);
         for (int i = 0; i < np; i++) {
             if (Ps[i].is_inf() || Qs[i].is_inf()) continue;
-            G2Affine &T = Ts[i];
-            Fq2 lam, t, x3;
-            f2_sqr(lam, T.x);
-            f2_dbl(t, lam);
-            f2_add(lam, lam, t);
-            f2_dbl(t, T.y);
-            f2_inv(t, t);
-            f2_mul(lam, lam, t);
-            f12_mul_line(f, lam, T, Ps[i]);
-            f2_sqr(x3, lam);
-            f2_sub(x3, x3, T.x);
-            f2_sub(x3, x3, T.x);
-            f2_sub(t, T.x, x3);
-            f2_mul(t, lam, t);
-            f2_sub(T.y, t, T.y);
-            T.x = x3;
-            if ((BLS_Z_ABS >> b) & 1) {
-                const G2Affine &S = Qs[i];
-                f2_sub(t, S.x, T.x);
-                f2_inv(t, t);
-                f2_sub(lam, S.y, T.y);
-                f2_mul(lam, lam, t);
-                f12_mul_line(f, lam, T, Ps[i]);
-                f2_sqr(x3, lam);
-                f2_sub(x3, x3, T.x);
-                f2_sub(x3, x3, S.x);
-                f2_sub(t, T.x, x3);
-                f2_mul(t, lam, t);
-                f2_sub(T.y, t, T.y);
-                T.x = x3;
+            const Fq2 *tab = tabs ? tabs[i] : nullptr;
+            Fq2 lam, cst;
+            if (tab) {
+                f12_mul_line(f, tab[2 * k], tab[2 * k + 1], Ps[i]);
+                if (add) f12_mul_line(f, tab[2 * k + 2], tab[2 * k + 3], Ps[i]);
+            } else {
+                miller_step(Ts[i], nullptr, lam, cst);
+                f12_mul_line(f, lam, cst, Ps[i]);
+                if (add) {
+                    miller_step(Ts[i], &Qs[i], lam, cst);
+                    f12_mul_line(f, lam, cst, Ps[i]);
+                }
             }
         }
+        k += add ? 2 : 1;
     }
     f12_conj(f, f);  // z < 0
 }
@@ -494,9 +527,10 @@ KZG_NI void final_exponentiation(Fq12 &r, const Fq12 &f) {
 }
 
 // prod_i e(P_i, Q_i) == 1
-KZG_NI bool pairing_product_is_one(const G1Affine *Ps, const G2Affine *Qs, G2Affine *Ts, int np) {
+KZG_NI bool pairing_product_is_one(const G1Affine *Ps, const G2Affine *Qs, G2Affine *Ts, int np,
+                                   const Fq2 *const *tabs = nullptr) {
     Fq12 f, g;
-    miller_loop(f, Ps, Qs, Ts, np);
+    miller_loop(f, Ps, Qs, Ts, np, tabs);
     final_exponentiation(g, f);
     return f12_is_one(g);
 }

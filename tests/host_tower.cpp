@@ -104,6 +104,22 @@ void ht_miller_loop(const uint8_t *ps, const uint8_t *qs, int np, uint8_t *o) {
     miller_loop(f, P, Q, T, np);
     store_f12(o, f);
 }
+// same product with the lines of every Q precomputed (the verifier's fixed-argument path)
+void ht_miller_loop_fixed(const uint8_t *ps, const uint8_t *qs, int np, uint8_t *o) {
+    G1Affine P[4];
+    G2Affine Q[4], T[4];
+    static Fq2 tabs[4][2 * MILLER_LINES];
+    const Fq2 *tp[4];
+    for (int i = 0; i < np; i++) {
+        P[i] = load_g1(ps + 96 * i);
+        Q[i] = load_g2(qs + 192 * i);
+        g2_precompute_lines(Q[i], tabs[i]);
+        tp[i] = (i & 1) ? nullptr : tabs[i];  // mix stored and on-the-fly pairs
+    }
+    Fq12 f;
+    miller_loop(f, P, Q, T, np, tp);
+    store_f12(o, f);
+}
 void ht_final_exp(const uint8_t *a, uint8_t *o) {
     Fq12 x, y;
     load_f12(x, a);

@@ -218,3 +218,24 @@ def test_eval_form_verifier(engine):  # src/eval_form.rs:173-217
         assert verifier.verify_eval_all(evals.coeffs, c, wit) == ov.verify_eval_all(evals.coeffs, cP, wP)
     for h in (params.gs, params.hs, lag_g, lag_h):
         h.free()
+
+
+def test_verify_eval_degenerate_secret(engine):
+    """tau = 0: hs[1] (and gs[1..]) are the identity -- the stored-lines path must treat the pair as 1, like the oracle."""
+    params = kzg_amd.setup(engine, 0, 6)
+    assert params.hs.download(1, 1) == bytes(192)
+    prover, verifier = kzg_amd.KZGProver(params), kzg_amd.KZGVerifier(params)
+    p = kzg_amd.Polynomial([7, 3, 9, 1, 0, 0])
+    c = prover.commit(p)
+    assert c == g1b(M.g1_mul(M.G1, 7))
+    x, y = 5, p.eval(engine, 5)
+    w = prover.create_witness(p, (x, y))
+    op = P.setup(0, 6, fast=False)
+    ov = P.KZGVerifier(op)
+    cP = M.g1_mul(M.G1, 7)
+    wP = M.KZGProver(op).create_witness(M.Polynomial([7, 3, 9, 1, 0, 0]), (x, y))
+    assert w == g1b(wP)
+    for pt in [(x, y), (x, (y + 1) % M.R), (0, 7), (0, 8)]:
+        assert verifier.verify_eval(pt, c, w) == ov.verify_eval(pt, cP, wP), pt
+    params.gs.free()
+    params.hs.free()

@@ -119,3 +119,9 @@ def test_pairing_matches_oracle_and_is_bilinear(L):
     assert L.ht_pairing_product_is_one(g1b(Pa), g2b(Qc), 1) == 0
     two = f12u(out(L.ht_miller_loop, 576, g1b(Pa) + g1b(neg), g2b(Qc) + g2b(P.G2), 2))
     assert two == P.miller_loop([(Pa, Qc), (neg, P.G2)])
+    # precomputed lines for a fixed Q give the same Miller value (pair 0 stored, pair 1 on the fly; then 3 pairs)
+    assert f12u(out(L.ht_miller_loop_fixed, 576, g1b(Pa) + g1b(neg), g2b(Qc) + g2b(P.G2), 2)) == two
+    three = [(Pa, Qc), (neg, P.G2), (M.g1_mul(M.G1, 5), P.g2_mul(P.G2, 7))]
+    assert f12u(out(L.ht_miller_loop_fixed, 576, b"".join(g1b(p) for p, _ in three), b"".join(g2b(q) for _, q in three), 3)) \
+        == P.miller_loop(three)
+    assert f12u(out(L.ht_miller_loop_fixed, 576, g1b(Pa) + g1b(None), g2b(None) + g2b(Qc), 2)) == P.F12_ONE
