@@ -199,6 +199,47 @@ KZG_NI void f12_sqr(Fq12 &r, const Fq12 &a) {  // complex squaring, 2 Fq6 multip
     f6_sub(r.c0, s, x);
     f6_add(r.c1, t, t);
 }
+// (x + y s)^2 in Fq4 = Fq2[s]/(s^2 - xi): t0 = x^2 + xi y^2, t1 = 2 x y  (2 Fq2 products)
+KZG_NI void f4_sqr(Fq2 &t0, Fq2 &t1, const Fq2 &x, const Fq2 &y) {
+    Fq2 t, u, v;
+    f2_mul(t, x, y);
+    f2_add(u, x, y);
+    f2_mul_xi(v, y);
+    f2_add(v, v, x);
+    f2_mul(u, u, v);
+    f2_sub(u, u, t);
+    f2_mul_xi(v, t);
+    f2_sub(t0, u, v);
+    f2_dbl(t1, t);
+}
+// a^2 for a in the cyclotomic subgroup (Granger-Scott): three Fq4 squarings, 18 Fq multiplies instead of 36
+KZG_NI void f12_cyclotomic_sqr(Fq12 &r, const Fq12 &a) {
+    Fq2 t0, t1, t2, t3, t4, t5, t;
+    f4_sqr(t0, t1, a.c0.c0, a.c1.c1);
+    f4_sqr(t2, t3, a.c1.c0, a.c0.c2);
+    f4_sqr(t4, t5, a.c0.c1, a.c1.c2);
+    Fq12 o;
+    f2_sub(t, t0, a.c0.c0);
+    f2_dbl(t, t);
+    f2_add(o.c0.c0, t, t0);  // 3 t0 - 2 z0
+    f2_add(t, t1, a.c1.c1);
+    f2_dbl(t, t);
+    f2_add(o.c1.c1, t, t1);  // 3 t1 + 2 z1
+    f2_mul_xi(t5, t5);
+    f2_add(t, t5, a.c1.c0);
+    f2_dbl(t, t);
+    f2_add(o.c1.c0, t, t5);  // 3 xi t5 + 2 z2
+    f2_sub(t, t4, a.c0.c2);
+    f2_dbl(t, t);
+    f2_add(o.c0.c2, t, t4);  // 3 t4 - 2 z3
+    f2_sub(t, t2, a.c0.c1);
+    f2_dbl(t, t);
+    f2_add(o.c0.c1, t, t2);  // 3 t2 - 2 z4
+    f2_add(t, t3, a.c1.c2);
+    f2_dbl(t, t);
+    f2_add(o.c1.c2, t, t3);  // 3 t3 + 2 z5
+    r = o;
+}
 KZG_NI void f12_conj(Fq12 &r, const Fq12 &a) {  // a^(q^6)
     r.c0 = a.c0;
     f6_neg(r.c1, a.c1);
@@ -492,7 +533,7 @@ KZG_NI void miller_loop(Fq12 &f, const G1Affine *Ps, const G2Affine *Qs, G2Affin
 KZG_NI void f12_exp_z(Fq12 &r, const Fq12 &a) {
     Fq12 acc = a;
     for (int b = 62; b >= 0; b--) {
-        f12_sqr(acc, acc);
+        f12_cyclotomic_sqr(acc, acc);
         if ((BLS_Z_ABS >> b) & 1) f12_mul(acc, acc, a);
     }
     f12_conj(r, acc);

@@ -336,6 +336,30 @@ _z = -BLS_Z_ABS
 assert (_z - 1) ** 2 * (_z + Q) * (_z * _z + Q * Q - 1) + 3 == HARD_EXP_TIMES_3  # Hayashida-Hayasaka-Teruya
 
 
+def f12_cyclotomic_sqr(a):
+    """a^2 for a in the cyclotomic subgroup (Granger-Scott: three Fq4 squarings, 6 Fq2 products instead of 12)"""
+    nr = lambda x: f2_mul(x, XI)  # noqa: E731
+    dbl = lambda x: f2_add(x, x)  # noqa: E731
+    r0, r4, r3 = a[0], a[2], a[4]  # c0 = (a0, a2, a4), c1 = (a1, a3, a5) in the tower view
+    r2, r1, r5 = a[1], a[3], a[5]
+
+    def fq4_sqr(x, y):
+        t = f2_mul(x, y)
+        return f2_sub(f2_sub(f2_mul(f2_add(x, y), f2_add(nr(y), x)), t), nr(t)), dbl(t)
+
+    t0, t1 = fq4_sqr(r0, r1)
+    t2, t3 = fq4_sqr(r2, r3)
+    t4, t5 = fq4_sqr(r4, r5)
+    z0 = f2_add(dbl(f2_sub(t0, r0)), t0)
+    z1 = f2_add(dbl(f2_add(t1, r1)), t1)
+    t = nr(t5)
+    z2 = f2_add(dbl(f2_add(t, r2)), t)
+    z3 = f2_add(dbl(f2_sub(t4, r3)), t4)
+    z4 = f2_add(dbl(f2_sub(t2, r4)), t2)
+    z5 = f2_add(dbl(f2_add(t3, r5)), t3)
+    return (z0, z2, z4, z1, z3, z5)
+
+
 def _exp_z(a):
     """a^z for a in the cyclotomic subgroup (inverse = conjugate)"""
     return f12_conj(f12_pow(a, BLS_Z_ABS))
@@ -454,4 +478,5 @@ def selfcheck(full=False):
     if full:
         f = miller_loop([(M.G1, G2)])
         assert final_exponentiation(f) == final_exponentiation_naive(f)
+        assert f12_cyclotomic_sqr(e) == f12_sqr(e)
     return True

@@ -55,6 +55,12 @@ void ht_f12_sqr(const uint8_t *a, uint8_t *o) {
     f12_sqr(x, x);
     store_f12(o, x);
 }
+void ht_f12_cyclotomic_sqr(const uint8_t *a, uint8_t *o) {
+    Fq12 x;
+    load_f12(x, a);
+    f12_cyclotomic_sqr(x, x);
+    store_f12(o, x);
+}
 void ht_f12_inv(const uint8_t *a, uint8_t *o) {
     Fq12 x;
     load_f12(x, a);

@@ -109,6 +109,8 @@ def test_pairing_matches_oracle_and_is_bilinear(L):
     f = f12u(out(L.ht_miller_loop, 576, g1b(Pa), g2b(Qc), 1))
     assert f == P.miller_loop([(Pa, Qc)])
     e = f12u(out(L.ht_final_exp, 576, f12b(f)))
+    # cyclotomic squaring (used by the exponentiations by z) == plain squaring on the cyclotomic subgroup
+    assert f12u(out(L.ht_f12_cyclotomic_sqr, 576, f12b(e))) == P.f12_sqr(e) == P.f12_cyclotomic_sqr(e)
     assert e == P.final_exponentiation(f) == P.f12_pow(P.pairing(M.G1, P.G2), a * c % M.R)
     # product checks: e(aG, cH) e(-acG, H) = 1; a wrong exponent is rejected; identity members contribute 1
     neg = M.g1_neg(M.g1_mul(M.G1, a * c % M.R))
