@@ -8,7 +8,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkzg_mi355x.so")
 SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip"]
-HEADERS = ["field.h", "curve.h", "common.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -22,7 +21,9 @@ def _stale(target, deps):
 def build(force=False, verbose=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
-    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.join(HERE, "..", "include", "kzg_mi355x.h")]
+    # every header / generated include: a stale object after a header-only edit would silently ship old kernels
+    hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
+    hdrs.append(os.path.join(HERE, "..", "include", "kzg_mi355x.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

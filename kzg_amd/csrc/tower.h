@@ -32,15 +32,15 @@ struct Fq2 {
     static KZG_HD Fq2 one() { return Fq2{Fq::one(), Fq::zero()}; }
 };
 
-KZG_NI void f2_add(Fq2 &r, const Fq2 &a, const Fq2 &b) {
+KZG_HD void f2_add(Fq2 &r, const Fq2 &a, const Fq2 &b) {
     r.c0 = add(a.c0, b.c0);
     r.c1 = add(a.c1, b.c1);
 }
-KZG_NI void f2_sub(Fq2 &r, const Fq2 &a, const Fq2 &b) {
+KZG_HD void f2_sub(Fq2 &r, const Fq2 &a, const Fq2 &b) {
     r.c0 = sub(a.c0, b.c0);
     r.c1 = sub(a.c1, b.c1);
 }
-KZG_NI void f2_neg(Fq2 &r, const Fq2 &a) {
+KZG_HD void f2_neg(Fq2 &r, const Fq2 &a) {
     r.c0 = a.c0.is_zero() ? a.c0 : neg(a.c0);
     r.c1 = a.c1.is_zero() ? a.c1 : neg(a.c1);
 }
@@ -48,27 +48,27 @@ KZG_HD void f2_conj(Fq2 &r, const Fq2 &a) {
     r.c0 = a.c0;
     r.c1 = a.c1.is_zero() ? a.c1 : neg(a.c1);
 }
-KZG_NI void f2_mul(Fq2 &r, const Fq2 &a, const Fq2 &b) {  // Karatsuba, 3 Fq multiplies
+KZG_HD void f2_mul(Fq2 &r, const Fq2 &a, const Fq2 &b) {  // Karatsuba, 3 Fq multiplies
     Fq t0 = mul(a.c0, b.c0), t1 = mul(a.c1, b.c1);
     Fq s = mul(add(a.c0, a.c1), add(b.c0, b.c1));
     r.c0 = sub(t0, t1);
     r.c1 = sub(sub(s, t0), t1);
 }
-KZG_NI void f2_sqr(Fq2 &r, const Fq2 &a) {  // (a0+a1)(a0-a1), 2 a0 a1
+KZG_HD void f2_sqr(Fq2 &r, const Fq2 &a) {  // (a0+a1)(a0-a1), 2 a0 a1
     Fq t = mul(a.c0, a.c1);
     r.c0 = mul(add(a.c0, a.c1), sub(a.c0, a.c1));
     r.c1 = dbl(t);
 }
-KZG_NI void f2_mul_fq(Fq2 &r, const Fq2 &a, const Fq &k) {
+KZG_HD void f2_mul_fq(Fq2 &r, const Fq2 &a, const Fq &k) {
     r.c0 = mul(a.c0, k);
     r.c1 = mul(a.c1, k);
 }
-KZG_NI void f2_mul_xi(Fq2 &r, const Fq2 &a) {  // (a0 + a1 u)(1 + u)
+KZG_HD void f2_mul_xi(Fq2 &r, const Fq2 &a) {  // (a0 + a1 u)(1 + u)
     Fq t = sub(a.c0, a.c1);
     r.c1 = add(a.c0, a.c1);
     r.c0 = t;
 }
-KZG_NI void f2_inv(Fq2 &r, const Fq2 &a) {
+KZG_HD void f2_inv(Fq2 &r, const Fq2 &a) {
     Fq n = inv(add(sqr(a.c0), sqr(a.c1)));
     Fq m = mul(a.c1, n);
     r.c0 = mul(a.c0, n);
@@ -81,22 +81,22 @@ struct Fq6 {
     Fq2 c0, c1, c2;
 };
 
-KZG_NI void f6_add(Fq6 &r, const Fq6 &a, const Fq6 &b) {
+KZG_HD void f6_add(Fq6 &r, const Fq6 &a, const Fq6 &b) {
     f2_add(r.c0, a.c0, b.c0);
     f2_add(r.c1, a.c1, b.c1);
     f2_add(r.c2, a.c2, b.c2);
 }
-KZG_NI void f6_sub(Fq6 &r, const Fq6 &a, const Fq6 &b) {
+KZG_HD void f6_sub(Fq6 &r, const Fq6 &a, const Fq6 &b) {
     f2_sub(r.c0, a.c0, b.c0);
     f2_sub(r.c1, a.c1, b.c1);
     f2_sub(r.c2, a.c2, b.c2);
 }
-KZG_NI void f6_neg(Fq6 &r, const Fq6 &a) {
+KZG_HD void f6_neg(Fq6 &r, const Fq6 &a) {
     f2_neg(r.c0, a.c0);
     f2_neg(r.c1, a.c1);
     f2_neg(r.c2, a.c2);
 }
-KZG_NI void f6_mul_v(Fq6 &r, const Fq6 &a) {  // (c0, c1, c2) v = (xi c2, c0, c1)
+KZG_HD void f6_mul_v(Fq6 &r, const Fq6 &a) {  // (c0, c1, c2) v = (xi c2, c0, c1)
     Fq2 t;
     f2_mul_xi(t, a.c2);
     r.c2 = a.c1;
@@ -200,7 +200,7 @@ KZG_NI void f12_sqr(Fq12 &r, const Fq12 &a) {  // complex squaring, 2 Fq6 multip
     f6_add(r.c1, t, t);
 }
 // (x + y s)^2 in Fq4 = Fq2[s]/(s^2 - xi): t0 = x^2 + xi y^2, t1 = 2 x y  (2 Fq2 products)
-KZG_NI void f4_sqr(Fq2 &t0, Fq2 &t1, const Fq2 &x, const Fq2 &y) {
+KZG_HD void f4_sqr(Fq2 &t0, Fq2 &t1, const Fq2 &x, const Fq2 &y) {
     Fq2 t, u, v;
     f2_mul(t, x, y);
     f2_add(u, x, y);
