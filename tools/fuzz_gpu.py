@@ -1,0 +1,152 @@
+#!/usr/bin/env python3
+"""Randomised differential run of the HIP engine against the C oracle (checker only): MSM with random sizes, offsets,
+window sizes, scalar shapes and batch counts; NTT round trips and values; single-point witnesses.  Time-boxed:
+    python tools/fuzz_gpu.py [seconds] [seed]
+Prints one line per failure and a summary; exit code 1 if anything differed."""
+import ctypes
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import kzg_amd  # noqa: E402
+from kzg_amd import _lib as L  # noqa: E402
+from oracle import c_oracle as C, kzg_model as M  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = random.Random(seed)
+R = M.R
+e = kzg_amd.Engine(0)
+TAU = rng.getrandbits(64)
+t_end = time.time() + budget
+fails = 0
+cases = {"msm": 0, "msm_batch": 0, "ntt": 0, "witness": 0, "witness_batched": 0, "eval_form": 0}
+
+
+def rand_scalar(kind):
+    if kind == 0:
+        return rng.randrange(R)
+    if kind == 1:
+        return rng.getrandbits(64)
+    if kind == 2:
+        return rng.choice([0, 1, R - 1, R - 2, 1 << 255 if (1 << 255) < R else R - 3, 0x8000, 0x7fff, 0xffff, 0x10000,
+                           int("8000" * 16, 16) % R, int("7fff" * 16, 16) % R, (1 << 128) - 1])
+    return rng.getrandbits(rng.randrange(1, 255))
+
+
+while time.time() < t_end:
+    wb = rng.choice([0, 0, 0, 4, 7, 9, 12, 13, 16])
+    e.set_option("window_bits", wb)
+    nmax = rng.choice([1, 2, 5, 33, 257, 1000, 4097, 20000, 70000])
+    params = kzg_amd.setup(e, TAU, nmax, g2_len=0)
+    srs_blob = params.gs.download()
+    assert srs_blob == C.setup_g1(TAU, nmax), "setup mismatch"
+    for _ in range(4):
+        n = rng.randrange(0, nmax + 1)
+        off = rng.randrange(0, nmax - n + 1)
+        kind = rng.randrange(4)
+        sc = [rand_scalar(kind if rng.random() < 0.8 else rng.randrange(4)) for _ in range(n)]
+        if n and rng.random() < 0.2:
+            sc = [sc[0]] * n  # all equal: one bucket per window
+        want = C.msm_g1(srs_blob[96 * off:96 * (off + n)], sc) if n else bytes(96)
+        got = e.msm(params.gs, sc, offset=off) if n else e.msm(params.gs, [], n=0, offset=off)
+        cases["msm"] += 1
+        if got != want:
+            fails += 1
+            print("MSM MISMATCH", dict(window_bits=wb, nmax=nmax, n=n, off=off, kind=kind, seed=seed), flush=True)
+    if nmax >= 33:
+        n = rng.randrange(1, min(nmax, 3000) + 1)
+        batch = rng.randrange(1, 12)
+        sc = [rand_scalar(rng.randrange(4)) for _ in range(n * batch)]
+        got = e.msm_batch(params.gs, sc, n, batch)
+        cases["msm_batch"] += 1
+        for b in range(batch):
+            if got[b] != C.msm_g1(srs_blob[:96 * n], sc[b * n:(b + 1) * n]):
+                fails += 1
+                print("MSM_BATCH MISMATCH", dict(window_bits=wb, n=n, batch=batch, b=b, seed=seed), flush=True)
+        # single-point witness on a random polynomial (remainder test both ways)
+        n = rng.randrange(2, min(nmax, 5000) + 1)
+        coeffs = [rand_scalar(rng.randrange(2)) for _ in range(n)]
+        if coeffs[-1] == 0:
+            coeffs[-1] = 1
+        poly = kzg_amd.Polynomial(coeffs)
+        x = rand_scalar(rng.randrange(2))
+        y = C.poly_eval(coeffs, x)
+        prover = kzg_amd.KZGProver(params)
+        cases["witness"] += 1
+        if (TAU - x) % R:
+            want = C.g1_mul(C.g1_generator(), (C.poly_eval(coeffs, TAU) - y) * pow(TAU - x, -1, R) % R)
+            if prover.create_witness(poly, (x, y)) != want:
+                fails += 1
+                print("WITNESS MISMATCH", dict(n=n, seed=seed), flush=True)
+        try:
+            prover.create_witness(poly, (x, (y + 1) % R))
+            fails += 1
+            print("WITNESS accepted a wrong y", dict(n=n, seed=seed), flush=True)
+        except kzg_amd.PointNotOnPolynomial:
+            pass
+        # batched witness: r == the interpolant, w == [(p(tau) - I(tau)) / Z(tau)] G  (known-tau identity)
+        n = rng.randrange(2, min(nmax, 2000) + 1)
+        k = rng.randrange(1, min(n + 2, 24))
+        coeffs = [rand_scalar(rng.randrange(2)) for _ in range(n)]
+        coeffs[-1] = coeffs[-1] or 1
+        poly = kzg_amd.Polynomial(coeffs)
+        xs = rng.sample(range(1, 1 << 20), k) if rng.random() < 0.5 else [rng.randrange(R) for _ in range(k)]
+        if rng.random() < 0.3:
+            xs[0] = 7  # on the first division coset
+        if len(set(xs)) == k and all((TAU - x) % R for x in xs):
+            ys = [C.poly_eval(coeffs, x) for x in xs]
+            cases["witness_batched"] += 1
+            wit = prover.create_witness_batched(poly, xs, ys)
+            I = M.Polynomial.lagrange_interpolation(xs, ys)
+            zt = 1
+            for x in xs:
+                zt = zt * (TAU - x) % R
+            want = C.g1_mul(C.g1_generator(), (C.poly_eval(coeffs, TAU) - I.eval(TAU)) * pow(zt, -1, R) % R)
+            if wit.elem() != want or wit.polynomial().coeffs != I.coeffs[:len(wit.polynomial().coeffs)]:
+                fails += 1
+                print("WITNESS_BATCHED MISMATCH", dict(n=n, k=k, seed=seed), flush=True)
+            ys[-1] = (ys[-1] + 1) % R
+            try:
+                prover.create_witness_batched(poly, xs, ys)
+                fails += 1
+                print("WITNESS_BATCHED accepted a wrong y", dict(n=n, k=k, seed=seed), flush=True)
+            except kzg_amd.PointNotOnPolynomial:
+                pass
+    params.gs.free()
+    # eval form: commit(fft(p)) == [p(tau)]G, witness at index m == coeff-form witness at omega^m
+    log_d = rng.randrange(0, 11)
+    d = 1 << log_d
+    pe = kzg_amd.setup(e, TAU, d, g2_len=0)
+    lag = kzg_amd.setup_lagrange(e, TAU, d)
+    coeffs = [rand_scalar(rng.randrange(2)) for _ in range(d)]
+    ev = kzg_amd.EvaluationDomain.from_coeffs(coeffs)
+    ev.fft(e)
+    pf = kzg_amd.KZGProverEvalForm(pe, lag)
+    cases["eval_form"] += 1
+    ptau = C.poly_eval(coeffs, TAU)
+    if pf.commit(ev) != C.g1_mul(C.g1_generator(), ptau):
+        fails += 1
+        print("EVAL COMMIT MISMATCH", dict(d=d, seed=seed), flush=True)
+    m = rng.randrange(d)
+    wm = pow(pf.omega(), m, R)
+    if (TAU - wm) % R:
+        want = C.g1_mul(C.g1_generator(), (ptau - ev.coeffs[m]) * pow(TAU - wm, -1, R) % R)
+        if pf.create_witness(ev, m) != want:
+            fails += 1
+            print("EVAL WITNESS MISMATCH", dict(d=d, m=m, seed=seed), flush=True)
+    pe.gs.free()
+    lag.free()
+    log_n = rng.randrange(0, 15)
+    xs = [rand_scalar(rng.randrange(4)) % R for _ in range(1 << log_n)]
+    got = e.ntt(xs, log_n)
+    cases["ntt"] += 1
+    if got != C.fft(xs) or e.ntt(got, log_n, inverse=True) != xs:
+        fails += 1
+        print("NTT MISMATCH", dict(log_n=log_n, seed=seed), flush=True)
+e.set_option("window_bits", 0)
+print("fuzz done", cases, "failures:", fails, flush=True)
+sys.exit(1 if fails else 0)
