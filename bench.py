@@ -65,6 +65,38 @@ def cpu_baseline(engine, params, scal, log_n):
                       f"{terms_per_s:.0f} terms/s; matches GPU result: {ok}"}
 
 
+def _cpu_chunk(args):
+    pts, sc, n = args
+    from oracle import c_oracle as C
+    return C.msm_g1_raw(pts, sc, n)
+
+
+def cpu_baseline_all_cores(engine, params, scal, log_n):
+    """The same oracle MSM split into one contiguous chunk per host core (processes), partial points added at the end."""
+    import multiprocessing as mp
+    from oracle import c_oracle as C
+    n = 1 << min(log_n, 20)
+    # chunks below ~2^15 terms make the bucket method inefficient (measured: 256 chunks of 4096 take 2.75 s, 5x the
+    # per-term cost), so at most n / 2^15 worker processes are used
+    cores = max(1, min(os.cpu_count() or 1, n >> 15))
+    pts = params.gs.download(0, n)
+    sc = scal.download(n)
+    per = (n + cores - 1) // cores
+    chunks = [(pts[96 * i:96 * min(i + per, n)], sc[32 * i:32 * min(i + per, n)], min(i + per, n) - i) for i in range(0, n, per)]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(_cpu_chunk, chunks[:1])  # warm the workers (library load)
+        t0 = time.perf_counter()
+        parts = pool.map(_cpu_chunk, chunks)
+        acc = parts[0]
+        for p_ in parts[1:]:
+            acc = C.g1_add(acc, p_)
+        dt = time.perf_counter() - t0
+    ok = engine.msm(params.gs, scal, n=n) == acc
+    return {"value": n / dt / (1 << log_n), "unit": "commitments/s", "cores": cores, "kind": "port",
+            "sample": f"one 2^{min(log_n, 20)}-term MSM in {len(chunks)} chunks over {cores} processes, {dt:.2f} s; "
+                      f"matches GPU result: {ok}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +111,11 @@ def main():
     ap.add_argument("--sharded", action="store_true",
                     help="use the N>1 code path (process group, sharded SRS, RCCL all_gather) even at world size 1")
     ap.add_argument("--check", action="store_true", help="verify the timed result against [p(tau)]G (known-tau identity)")
+    ap.add_argument("--replicas", action="store_true",
+                    help="N>1 only: data-parallel replicas (full SRS on every GPU, different polynomials per GPU, no "
+                         "collective in the data path) instead of the sharded-SRS mode (SURVEY 8e, throughput alternative)")
+    ap.add_argument("--cpu-all-cores", action="store_true",
+                    help="also time the oracle MSM split over all host cores (extra field cpu_baseline_all_cores)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,8 +128,8 @@ def main():
     from kzg_amd import _lib as L
 
     dist = None
-    sharded = world > 1 or args.sharded
-    if sharded:
+    sharded = (world > 1 and not args.replicas) or args.sharded
+    if sharded or world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -115,7 +152,7 @@ def main():
     if not sharded:
         params = kzg_amd.setup(engine, TAU, n, g2_len=0)                       # gs[i] = [tau^i]G
         srs = params.gs
-        scal = engine.alloc_scalars(n * args.batch).fill_random(1, u64_valued=args.u64)
+        scal = engine.alloc_scalars(n * args.batch).fill_random(1 + 1000 * rank, u64_valued=args.u64)
     else:
         # rank r holds the contiguous shard gs[r*n .. (r+1)*n) = [tau^(r*n + i)]G of setup(tau, world*n)
         params = kzg_amd.KZGParams(kzg_amd.setup_shard(engine, TAU, rank * n, n))
@@ -131,7 +168,7 @@ def main():
                                              L.IN_DEVICE, out, L.G1_AFFINE_MONT)
             if rc:
                 raise RuntimeError(engine.last_error())
-        units_per_step = args.batch
+        units_per_step = world * args.batch   # replicas: every rank commits its own batch
     else:
         from kzg_amd.distributed import ShardedCommitter
         committer = ShardedCommitter.for_engine(engine, srs, dist, rank, world, max_batch=args.batch, always_gather=True)
@@ -235,8 +272,10 @@ def main():
             "dtype": "u32 limbs (Fq 381-bit / Fr 255-bit Montgomery integer arithmetic)",
             "data": "synthetic",
             "config": {
-                "workload": ("degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step"
-                             % (args.log_n, args.batch)) if not sharded else
+                "workload": (("degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step"
+                              % (args.log_n, args.batch)) if world == 1 else
+                             ("degree-2^%d coeff_form commit, %d data-parallel replicas (full SRS per GPU, batch of %d per "
+                              "rank and step, no data-path collective)" % (args.log_n, world, args.batch))) if not sharded else
                             ("degree-%d*2^%d coeff_form commit, SRS sharded 2^%d terms per rank over %d GPUs, batch of %d "
                              "per step, one RCCL all_gather of the 144-B Jacobian partials + local sums"
                              % (world, args.log_n, args.log_n, world, args.batch)),
@@ -260,6 +299,11 @@ def main():
             except Exception as e:  # the baseline must never take the bench line down
                 res["cpu_baseline"] = {"value": None, "unit": "commitments/s", "cores": 1, "kind": "port",
                                        "sample": f"failed: {e}"}
+            if args.cpu_all_cores:
+                try:
+                    res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(engine, params, scal, args.log_n)
+                except Exception as e:
+                    res["cpu_baseline_all_cores"] = {"value": None, "sample": f"failed: {e}"}
         print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
