@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="HIP streams the engine pipelines a batch over (0 = engine default)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks (0 = default)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--window-bits", type=int, default=0, help="engine option window_bits (0 = engine default)")
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true",
@@ -138,6 +139,8 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
     engine = kzg_amd.Engine(local_rank)
+    if args.window_bits:
+        engine.set_option("window_bits", args.window_bits)
     if args.streams:
         engine.set_option("streams", args.streams)
     if args.accum_blocks:

@@ -257,7 +257,7 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     Guard g(ctx);
     std::string k(key);
     if (k == "window_bits") {
-        if (value != 0 && (value < 4 || value > 16)) return fail(ctx, KZG_ERR_SHAPE, "window_bits must be 0 or 4..16");
+        if (value != 0 && (value < 4 || value > 20)) return fail(ctx, KZG_ERR_SHAPE, "window_bits must be 0 or 4..20");
         ctx->opt_window_bits = (int)value;
     } else if (k == "streams") {
         if (value < 1 || value > 16) return fail(ctx, KZG_ERR_SHAPE, "streams must be 1..16");

@@ -56,7 +56,7 @@ struct kzg_ctx {
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)
     int cur_accum_blocks = 512;        // value msm_run uses (set by the entry point)
     int num_cus = 256;
-    bool attr_msm_set = false, attr_ntt_set = false;  // > 64 KiB dynamic-LDS opt-in done for this device
+    bool attr_msm_set = false, attr_ntt_set = false, attr_wide_set = false;  // > 64 KiB dynamic-LDS opt-in done for this device
     // profiling
     bool prof = false;
     std::map<std::string, kzg::ProfEntry> prof_map;

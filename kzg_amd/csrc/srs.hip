@@ -61,7 +61,10 @@ int srs_choose_window(kzg_ctx *ctx, size_t n) {
         c = l - 4;
     }
     if (c < 4) c = 4;
-    if (c > 16) c = 16;  // 2^(c-1) u32 LDS counters must fit the CU's 160 KiB
+    // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17..20 use the two-pass ("wide") sort of msm.hip and
+    // are only taken when asked for (option window_bits)
+    if (c > 20) c = 20;
+    if (ctx->opt_window_bits == 0 && c > 16) c = 16;
     return c;
 }
 

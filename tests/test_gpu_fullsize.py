@@ -159,3 +159,43 @@ def test_every_window_size(engine, n):
     got = engine.msm(params.gs, sc)
     assert got == C.g1_mul(C.g1_generator(), C.poly_eval(sc, TAU))
     params.gs.free()
+
+
+@pytest.mark.parametrize("wb", [17, 18, 19, 20])
+def test_wide_windows(engine, wb):
+    """Window widths above 16 (option window_bits): two-pass sort, 2^(wb-1) buckets, row/column bucket reduction.  Random,
+    adversarial (one bucket, extreme digits) and u64-valued scalars at 2^16 terms, sub-ranges with an offset, and the
+    batched entry point, each against the known-tau identity."""
+    n = 1 << 16
+    rng = random.Random(wb)
+    engine.set_option("window_bits", wb)
+    try:
+        params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+        c, W = params.gs.window_info()
+        assert c == wb and W == -(-256 // wb)
+        pw = [1]
+        for _ in range(n - 1):
+            pw.append(pw[-1] * TAU % R)
+        G = C.g1_generator()
+
+        def want(sc, off=0):
+            return C.g1_mul(G, sum(s * pw[off + i] for i, s in enumerate(sc)) % R)
+
+        cases = {
+            "random": rand_scalars(rng, n),
+            "u64": rand_scalars(rng, n, "u64"),
+            "all_equal": [rng.randrange(R)] * n,
+            "extreme_digits": [int(("8" + "0" * (wb // 4 - 1)) * (255 // wb), 16) % R] * n,
+            "r_minus_1_and_zero": [(R - 1) * (i & 1) for i in range(n)],
+        }
+        for name, sc in cases.items():
+            assert engine.msm(params.gs, sc) == want(sc), (wb, name)
+        sub = cases["random"][:5000]
+        assert engine.msm(params.gs, sub, offset=12345) == want(sub, 12345)
+        assert engine.msm(params.gs, [], n=0) == bytes(96)
+        batch = [rand_scalars(rng, 3000) for _ in range(5)]
+        got = engine.msm_batch(params.gs, [x for b in batch for x in b], 3000, 5)
+        assert got == [want(b) for b in batch]
+        params.gs.free()
+    finally:
+        engine.set_option("window_bits", 0)
