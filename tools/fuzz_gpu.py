@@ -38,7 +38,7 @@ def rand_scalar(kind):
 
 
 while time.time() < t_end:
-    wb = rng.choice([0, 0, 0, 4, 7, 9, 12, 13, 16])
+    wb = rng.choice([0, 0, 0, 4, 7, 9, 12, 13, 16, 17, 18, 19, 20])
     e.set_option("window_bits", wb)
     nmax = rng.choice([1, 2, 5, 33, 257, 1000, 4097, 20000, 70000])
     params = kzg_amd.setup(e, TAU, nmax, g2_len=0)
