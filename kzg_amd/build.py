@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkzg_mi355x.so")
-SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip"]
+SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip", "msm_wide.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

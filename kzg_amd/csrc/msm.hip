@@ -21,32 +21,9 @@
 //     tree sum (k_sum_level), and one Fq inversion for the affine result (k_emit_point).
 //
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
-#include "common.h"
+#include "msm_internal.h"
 
 namespace kzg {
-
-constexpr uint32_t ACC_SLOTS = 256 * 8 * 64;  // resident threads of k_accum_affine: 256 CUs x 2 waves/SIMD x 4 SIMDs x 64
-constexpr int LK = 4;   // fan-in of the later fold rounds
-constexpr int SUM_L = 4;  // fan-in of the plain tree sum
-constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
-constexpr int MAX_LEVELS = 24;
-// wide windows (16 < c <= 20): bucket id = hi (c - 16 bits) : lo (15 bits).  Pass 1 sorts by lo with the LDS counting sort,
-// pass 2 is a stable partition by hi; between the passes hi travels in bits 27..30 of the entry word, which limits the
-// wide mode to W * npad < 2^27 table rows (n <= 2^22 at W = 13).
-constexpr int WIDE_LO_BITS = 15;
-constexpr int WIDE_HI_SHIFT = 27;
-constexpr uint32_t WIDE_HI_MASK = 0xfu << WIDE_HI_SHIFT;
-
-struct MsmState {
-    uint32_t M;            // sorted entries
-    uint32_t ntasks;       // tasks of the level being run
-    uint32_t done;         // every bucket holds <= 1 partial
-    uint32_t final_level;  // index of the start[] array describing the final partial list
-    uint32_t final_buf;    // which ping-pong buffer holds it
-    uint32_t max_cnt;
-    uint32_t E;            // sorted entries per round-1 thread (equal split)
-    uint32_t pad[1];
-};
 
 // ---------------------------------------------------------------------------------------------
 // scalar -> signed digits
@@ -400,335 +377,6 @@ __global__ __launch_bounds__(64) void k_sum_level(const MsmPoint *in, uint32_t c
 }
 
 // ---------------------------------------------------------------------------------------------
-// wide windows (16 < c <= 20): second sort pass, multi-block scans, row/column bucket reduction
-// ---------------------------------------------------------------------------------------------
-constexpr int HI_BLOCKS = 256;   // blocks of the stable partition
-constexpr int HI_THREADS = 1024;
-
-__device__ __forceinline__ void hi_thread_range(uint32_t M, uint32_t &p0, uint32_t &p1) {
-    const uint32_t chunk = (M + HI_BLOCKS - 1) / HI_BLOCKS;              // items per block
-    const uint32_t run = (chunk + HI_THREADS - 1) / HI_THREADS;          // consecutive items per thread
-    uint64_t b0 = (uint64_t)blockIdx.x * chunk;
-    uint64_t b1 = b0 + chunk < M ? b0 + chunk : M;
-    uint64_t q0 = b0 + (uint64_t)threadIdx.x * run;
-    uint64_t q1 = q0 + run < b1 ? q0 + run : b1;
-    if (q0 > b1) q0 = b1;
-    p0 = (uint32_t)q0;
-    p1 = (uint32_t)(q1 < q0 ? q0 : q1);
-}
-
-// per (block, hi) item counts of the lo-sorted list; blockcnt layout [hi][block]
-__global__ __launch_bounds__(HI_THREADS) void k_hi_count(const uint32_t *entries, const MsmState *st, int nhi, uint32_t *blockcnt) {
-    __shared__ uint32_t cnt[16];
-    if (threadIdx.x < 16) cnt[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t p0, p1;
-    hi_thread_range(st->M, p0, p1);
-    uint32_t mine[16];
-#pragma unroll
-    for (int h = 0; h < 16; h++) mine[h] = 0;
-    for (uint32_t p = p0; p < p1; p++) {
-        uint32_t h = (entries[p] & WIDE_HI_MASK) >> WIDE_HI_SHIFT;
-#pragma unroll
-        for (int k = 0; k < 16; k++) mine[k] += (h == (uint32_t)k) ? 1u : 0u;
-    }
-#pragma unroll
-    for (int h = 0; h < 16; h++)
-        if (mine[h]) atomicAdd(&cnt[h], mine[h]);
-    __syncthreads();
-    if (threadIdx.x < (unsigned)nhi) blockcnt[threadIdx.x * HI_BLOCKS + blockIdx.x] = cnt[threadIdx.x];
-}
-
-// exclusive scan of blockcnt in hi-major order (one block); binbase[hi][block]
-__global__ __launch_bounds__(1024) void k_hi_scan(const uint32_t *blockcnt, int nhi, uint32_t *binbase) {
-    __shared__ uint32_t lds[1024];
-    // nhi * HI_BLOCKS <= 4096 values: 4 per thread
-    const int N = nhi * HI_BLOCKS;
-    uint32_t v[4], sum = 0;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int i = threadIdx.x * 4 + k;
-        v[k] = i < N ? blockcnt[i] : 0u;
-        sum += v[k];
-    }
-    lds[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
-        uint32_t t = threadIdx.x >= (unsigned)off ? lds[threadIdx.x - off] : 0u;
-        __syncthreads();
-        lds[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t run = lds[threadIdx.x] - sum;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        int i = threadIdx.x * 4 + k;
-        if (i < N) binbase[i] = run;
-        run += v[k];
-    }
-}
-
-// Stable partition by hi of the lo-sorted list.  Because the order inside a hi bin stays lo-sorted, the running
-// per-bin offsets at the position where lo bucket b begins ARE the starts of the 2^nhi_bits full buckets (hi, b):
-// the kernel writes the final entry list and bucket_start[] of all nhi * 2^15 buckets without a histogram.
-__global__ __launch_bounds__(HI_THREADS) void k_hi_scatter(const uint32_t *entries, const MsmState *st, int nhi, const uint32_t *binbase,
-                                                           const uint32_t *lo_start, int B_lo, uint32_t *out,
-                                                           uint32_t *bucket_start) {
-    extern __shared__ uint32_t off[];  // [16][HI_THREADS]: per-thread running offsets of every bin
-    const uint32_t M = st->M;
-    uint32_t p0, p1;
-    hi_thread_range(M, p0, p1);
-    {
-        uint32_t mine[16];
-#pragma unroll
-        for (int h = 0; h < 16; h++) mine[h] = 0;
-        for (uint32_t p = p0; p < p1; p++) {
-            uint32_t h = (entries[p] & WIDE_HI_MASK) >> WIDE_HI_SHIFT;
-#pragma unroll
-            for (int k = 0; k < 16; k++) mine[k] += (h == (uint32_t)k) ? 1u : 0u;
-        }
-#pragma unroll
-        for (int h = 0; h < 16; h++) off[h * HI_THREADS + threadIdx.x] = mine[h];
-    }
-    __syncthreads();
-    // wave w scans bin w over the 1024 threads (16 rounds of 64 lanes)
-    {
-        const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        if (w < nhi) {
-            uint32_t carry = binbase[w * HI_BLOCKS + blockIdx.x];
-            for (int r = 0; r < HI_THREADS / 64; r++) {
-                uint32_t x = off[w * HI_THREADS + r * 64 + lane], incl = x;
-#pragma unroll
-                for (int o = 1; o < 64; o <<= 1) {
-                    uint32_t t = __shfl_up(incl, o, 64);
-                    if (lane >= o) incl += t;
-                }
-                off[w * HI_THREADS + r * 64 + lane] = incl - x + carry;
-                carry += __shfl(incl, 63, 64);
-            }
-        }
-    }
-    __syncthreads();
-    // M == 0: bucket_start was zero-filled by the host.  Threads without items have nothing to place; the boundaries
-    // that coincide with the end of the list are emitted by the thread that owns the last item.
-    if (M == 0 || p0 >= p1) return;
-    // first lo bucket whose start is >= p0
-    uint32_t bl = 0, bh = (uint32_t)B_lo;  // invariant: lo_start[bl] < p0 (or bl == 0), lo_start[bh] >= p0
-    if (lo_start[0] >= p0) {
-        bh = 0;
-    } else {
-        while (bh - bl > 1) {
-            uint32_t mid = (bl + bh) >> 1;
-            if (lo_start[mid] < p0) bl = mid; else bh = mid;
-        }
-    }
-    uint32_t b = bh;
-    for (uint32_t p = p0; p < p1; p++) {
-        while (b < (uint32_t)B_lo && lo_start[b] == p) {
-            for (int h = 0; h < nhi; h++) bucket_start[(size_t)h * B_lo + b] = off[h * HI_THREADS + threadIdx.x];
-            b++;
-        }
-        uint32_t e = entries[p];
-        uint32_t h = (e & WIDE_HI_MASK) >> WIDE_HI_SHIFT;
-        uint32_t dst = off[h * HI_THREADS + threadIdx.x]++;
-        out[dst] = e & ~WIDE_HI_MASK;
-    }
-    if (p1 == M) {  // owner of the last item: lo buckets that begin at M are empty in every bin
-        while (b < (uint32_t)B_lo) {
-            if (lo_start[b] == M)
-                for (int h = 0; h < nhi; h++) bucket_start[(size_t)h * B_lo + b] = off[h * HI_THREADS + threadIdx.x];
-            b++;
-        }
-        bucket_start[(size_t)nhi * B_lo] = M;
-    }
-}
-
-// ---- multi-block exclusive scan over B per-bucket values (B a multiple of SEG or smaller than it) ----
-constexpr int SEG = 2048;  // buckets per scan block (256 threads x 8)
-
-struct ScanS1 {  // flags of the equal-split layout: non-empty bucket whose start is not a multiple of E
-    const uint32_t *start;
-    const MsmState *st;
-    __device__ uint32_t operator()(int b) const {
-        uint32_t s0 = start[b], s1 = start[b + 1];
-        return (s1 != s0 && (s0 % st->E) != 0) ? 1u : 0u;
-    }
-    __device__ uint32_t cnt(int) const { return 0; }
-};
-struct ScanLevel {  // tasks of a fold level: ceil(partials / L)
-    const uint32_t *in_start;
-    int L;
-    __device__ uint32_t operator()(int b) const { return (in_start[b + 1] - in_start[b] + L - 1) / L; }
-    __device__ uint32_t cnt(int b) const { return in_start[b + 1] - in_start[b]; }
-};
-
-template <class F>
-__global__ __launch_bounds__(256) void k_seg_sums(F f, int B, const MsmState *st, int check_done, uint32_t *sums, uint32_t *maxs) {
-    if (check_done && st->done) return;
-    __shared__ uint32_t ssum, smax;
-    if (threadIdx.x == 0) {
-        ssum = 0;
-        smax = 0;
-    }
-    __syncthreads();
-    uint32_t a = 0, m = 0;
-    int base = blockIdx.x * SEG;
-    for (int k = 0; k < SEG / 256; k++) {
-        int b = base + k * 256 + threadIdx.x;
-        if (b < B) {
-            a += f(b);
-            uint32_t c = f.cnt(b);
-            m = c > m ? c : m;
-        }
-    }
-    atomicAdd(&ssum, a);
-    atomicMax(&smax, m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        sums[blockIdx.x] = ssum;
-        maxs[blockIdx.x] = smax;
-    }
-}
-
-// one block: exclusive scan of the segment sums; mode 0 = S1 pass (no state change), mode 1 = fold level bookkeeping
-__global__ __launch_bounds__(256) void k_seg_top(uint32_t *sums, const uint32_t *maxs, int nseg, int mode, MsmState *st, uint32_t level,
-                                                 uint32_t in_buf, uint32_t *out_total) {
-    if (mode == 1 && st->done) return;
-    __shared__ uint32_t lds[256];
-    __shared__ uint32_t smax;
-    uint32_t v = threadIdx.x < (unsigned)nseg ? sums[threadIdx.x] : 0u;
-    uint32_t mx = threadIdx.x < (unsigned)nseg ? maxs[threadIdx.x] : 0u;
-    if (threadIdx.x == 0) smax = 0;
-    lds[threadIdx.x] = v;
-    __syncthreads();
-    atomicMax(&smax, mx);
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = threadIdx.x >= (unsigned)off ? lds[threadIdx.x - off] : 0u;
-        __syncthreads();
-        lds[threadIdx.x] += t;
-        __syncthreads();
-    }
-    if (threadIdx.x < (unsigned)nseg) sums[threadIdx.x] = lds[threadIdx.x] - v;
-    if (threadIdx.x == 0) {
-        uint32_t total = lds[255];
-        *out_total = total;
-        if (mode == 1) {
-            if (smax <= 1) {
-                st->done = 1;
-                st->final_level = level;
-                st->final_buf = in_buf;
-                st->max_cnt = smax;
-            } else {
-                st->ntasks = total;
-                st->max_cnt = smax;
-            }
-        }
-    }
-}
-
-// out[b] = exclusive prefix (+ add(b) for the S1 layout), out[B] = total
-template <class F>
-__global__ __launch_bounds__(256) void k_seg_apply(F f, int B, const MsmState *st, int mode, const uint32_t *sums, const uint32_t *total,
-                                                   uint32_t *out) {
-    if (mode == 1 && st->done) return;
-    __shared__ uint32_t lds[256];
-    int base = blockIdx.x * SEG + threadIdx.x * (SEG / 256);
-    uint32_t v[SEG / 256], sum = 0;
-#pragma unroll
-    for (int k = 0; k < SEG / 256; k++) {
-        int b = base + k;
-        v[k] = b < B ? f(b) : 0u;
-        sum += v[k];
-    }
-    lds[threadIdx.x] = sum;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = threadIdx.x >= (unsigned)off ? lds[threadIdx.x - off] : 0u;
-        __syncthreads();
-        lds[threadIdx.x] += t;
-        __syncthreads();
-    }
-    uint32_t run = lds[threadIdx.x] - sum + sums[blockIdx.x];
-#pragma unroll
-    for (int k = 0; k < SEG / 256; k++) {
-        int b = base + k;
-        if (b < B) out[b] = run;
-        run += v[k];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[B] = *total;
-}
-
-// s1[b] += ceil(start[b] / E)   (b <= B), completing the equal-split layout of round 1
-__global__ __launch_bounds__(256) void k_s1_finish(const uint32_t *start, int B, const MsmState *st, uint32_t *s1) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > B) return;
-    const uint32_t E = st->E;
-    s1[b] += (start[b] + E - 1) / E;
-}
-
-// ---- bucket reduction for B = R x C buckets:  sum (b+1) X_b = C * sum_r r Row_r + sum_c (c+1) Col_c ----
-__device__ __forceinline__ MsmPoint final_bucket(const MsmPoint *buf, const uint32_t *start, uint32_t b) {
-    uint32_t s = start[b];
-    return start[b + 1] > s ? buf[s] : MsmPoint::infinity();
-}
-
-// rows: out[r * (C/8) + j] = sum of the 8 consecutive buckets r*C + 8j .. +7
-__global__ __launch_bounds__(64) void k_rows8(const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int Btot, int C,
-                                              const MsmState *st, MsmPoint *out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint32_t)(Btot / 8)) return;
-    const uint32_t *start = starts + (size_t)st->final_level * (Btot + 1);
-    const MsmPoint *buf = st->final_buf ? buf1 : buf0;
-    MsmPoint acc = MsmPoint::infinity();
-    for (int k = 0; k < 8; k++) acc = g1_add29(acc, final_bucket(buf, start, t * 8 + k));
-    out[t] = acc;
-}
-
-// columns: out[c * (R/8) + g] = sum over the 8 rows 8g .. 8g+7 of bucket (row, c)
-__global__ __launch_bounds__(64) void k_cols8(const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int Btot, int C,
-                                              const MsmState *st, MsmPoint *out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int R = Btot / C;
-    if (t >= (uint32_t)(C * (R / 8))) return;
-    const uint32_t *start = starts + (size_t)st->final_level * (Btot + 1);
-    const MsmPoint *buf = st->final_buf ? buf1 : buf0;
-    uint32_t c = t % C, g = t / C;  // consecutive threads -> consecutive columns of the same row group (coalesced starts)
-    MsmPoint acc = MsmPoint::infinity();
-    for (int k = 0; k < 8; k++) acc = g1_add29(acc, final_bucket(buf, start, (g * 8 + k) * C + c));
-    out[(size_t)c * (R / 8) + g] = acc;
-}
-
-// out[t] = sum_{i in chunk t} (i + 1 + first_weight) * pts[i]   (chunks of CH points; N need not be a multiple)
-__global__ __launch_bounds__(64) void k_weighted_chunks(const MsmPoint *pts, int N, int CH, int first_weight, MsmPoint *out) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int nchunks = (N + CH - 1) / CH;
-    if (t >= nchunks) return;
-    int lo = t * CH, hi = lo + CH < N ? lo + CH : N;
-    MsmPoint run = MsmPoint::infinity(), acc = MsmPoint::infinity();
-    for (int i = hi - 1; i >= lo; i--) {
-        run = g1_add29(run, pts[i]);
-        acc = g1_add29(acc, run);
-    }
-    int base = lo + first_weight;  // acc = sum (i - lo + 1) pts[i]; add base * run
-    if (base != 0 && !run.inf) {
-        MsmPoint m = MsmPoint::infinity();
-        for (int bit = 30; bit >= 0; bit--) {
-            m = g1_dbl29(m);
-            if ((base >> bit) & 1) m = g1_add29(m, run);
-        }
-        acc = g1_add29(acc, m);
-    }
-    out[t] = acc;
-}
-
-// result = 2^shift * a + b
-__global__ void k_combine_shifted(const MsmPoint *a, int shift, const MsmPoint *b, MsmPoint *result) {
-    MsmPoint m = *a;
-    for (int k = 0; k < shift; k++) m = g1_dbl29(m);
-    *result = g1_add29(m, *b);
-}
-
-// ---------------------------------------------------------------------------------------------
 // output formatting (Curve::to_affine + serialisation), one thread per point
 // ---------------------------------------------------------------------------------------------
 __device__ void write_be48(uint8_t *dst, const Fq &canon) {
@@ -958,20 +606,6 @@ static WideLayout wide_layout(const kzg_srs *srs, size_t n) {
     return L;
 }
 
-// k_sum_level over groups that must not straddle `per` consecutive inputs; returns the array of count/per ... results
-static MsmPoint *reduce_groups(kzg_ctx *ctx, hipStream_t st, MsmPoint *in, size_t groups, size_t per, MsmPoint *bufs[2]) {
-    int which = 0;
-    while (per > 1) {
-        int Lf = per >= 8 ? 8 : (int)per;
-        size_t count = groups * per, nout = count / Lf;
-        KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + 63) / 64), 64, 0, in, (uint32_t)count, Lf, bufs[which]);
-        in = bufs[which];
-        which ^= 1;
-        per /= Lf;
-    }
-    return in;
-}
-
 static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
                         MsmPoint **d_result) {
     if ((uint64_t)srs->W * srs->npad >= (1ull << WIDE_HI_SHIFT))
@@ -987,10 +621,6 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         ctx->attr_msm_set = true;
-    }
-    if (!ctx->attr_wide_set) {
-        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hi_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 16 * HI_THREADS * 4));
-        ctx->attr_wide_set = true;
     }
     const int B_lo = L.B_lo, Btot = L.Btot, nhi = L.nhi, G = L.G, c = srs->c, W = srs->W;
     uint32_t *blk_hist = (uint32_t *)(base + L.off_blk_hist), *total = (uint32_t *)(base + L.off_total);
@@ -1009,7 +639,6 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     size_t per_block = (n + G - 1) / G;
     size_t lds_bytes = (size_t)B_lo * 4;
     auto start_arr = [&](int level) { return starts + (size_t)level * (Btot + 1); };
-    const int nseg = (Btot + SEG - 1) / SEG;
 
     // pass 1: LDS counting sort by the low 15 bucket bits (hi rides in the entry word)
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist);
@@ -1019,19 +648,9 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
                (uint32_t)srs->npad, (uint32_t)offset, entries1);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
-    KZG_HIP_CHECK(ctx, hipMemsetAsync(bucket_start, 0, (size_t)(Btot + 1) * 4, st));
-    KZG_LAUNCH(ctx, st, "k_hi_count", k_hi_count, HI_BLOCKS, HI_THREADS, 0, entries1, state, nhi, blockcnt);
-    KZG_LAUNCH(ctx, st, "k_hi_scan", k_hi_scan, 1, 1024, 0, blockcnt, nhi, binbase);
-    KZG_LAUNCH(ctx, st, "k_hi_scatter", k_hi_scatter, HI_BLOCKS, HI_THREADS, 16 * HI_THREADS * 4, entries1, state, nhi, binbase,
-               lo_start, B_lo, entries2, bucket_start);
+    KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
     // equal-split layout of round 1 over the full bucket set
-    {
-        ScanS1 f{bucket_start, state};
-        KZG_LAUNCH(ctx, st, "k_seg_sums", k_seg_sums<ScanS1>, nseg, 256, 0, f, Btot, state, 0, segsums, segmaxs);
-        KZG_LAUNCH(ctx, st, "k_seg_top", k_seg_top, 1, 256, 0, segsums, segmaxs, nseg, 0, state, 0u, 0u, segtotal);
-        KZG_LAUNCH(ctx, st, "k_seg_apply", k_seg_apply<ScanS1>, nseg, 256, 0, f, Btot, state, 0, segsums, segtotal, start_arr(0));
-        KZG_LAUNCH(ctx, st, "k_s1_finish", k_s1_finish, (Btot + 1 + 255) / 256, 256, 0, bucket_start, Btot, state, start_arr(0));
-    }
+    KZG_TRY(wide_s1_layout(ctx, st, bucket_start, Btot, state, segsums, segmaxs, segtotal, start_arr(0)));
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, start_arr(0), Btot,
@@ -1039,12 +658,10 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     size_t tmax = L.T1_max;
     for (int lv = 1; lv <= L.levels + 1; lv++) {
         int in_buf = (lv - 1) & 1;
-        ScanLevel f{start_arr(lv - 1), LK};
-        KZG_LAUNCH(ctx, st, "k_seg_sums", k_seg_sums<ScanLevel>, nseg, 256, 0, f, Btot, state, 1, segsums, segmaxs);
-        KZG_LAUNCH(ctx, st, "k_seg_top", k_seg_top, 1, 256, 0, segsums, segmaxs, nseg, 1, state, (uint32_t)(lv - 1), (uint32_t)in_buf,
-                   segtotal);
-        if (lv == L.levels + 1) break;
-        KZG_LAUNCH(ctx, st, "k_seg_apply", k_seg_apply<ScanLevel>, nseg, 256, 0, f, Btot, state, 1, segsums, segtotal, start_arr(lv));
+        const bool last = lv == L.levels + 1;  // the last scan only certifies done
+        KZG_TRY(wide_level_scan(ctx, st, start_arr(lv - 1), last ? nullptr : start_arr(lv), Btot, LK, state, (uint32_t)(lv - 1),
+                                (uint32_t)in_buf, segsums, segmaxs, segtotal, !last));
+        if (last) break;
         tmax = tmax / LK + Btot + 1;
         unsigned grid = (unsigned)((tmax + 255) / 256);
         if (grid > 8192) grid = 8192;  // grid-stride loop inside
@@ -1052,36 +669,19 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
                    bufs[in_buf ^ 1], state);
     }
     // sum (b+1) X_b over Btot = R x C buckets
-    const int C = L.C, R = L.R;
-    KZG_LAUNCH(ctx, st, "k_rows8", k_rows8, (Btot / 8 + 63) / 64, 64, 0, bufs[0], bufs[1], starts, Btot, C, state, rows);
-    KZG_LAUNCH(ctx, st, "k_cols8", k_cols8, (Btot / 8 + 63) / 64, 64, 0, bufs[0], bufs[1], starts, Btot, C, state, cols);
-    MsmPoint *rowsum = reduce_groups(ctx, st, rows, (size_t)R, (size_t)C / 8, red);    // R points
-    // the column reduction must not overwrite the row sums: copy them out first
-    MsmPoint *rowkeep = chunks;  // reuse: R points fit? no -- keep them in `rows` (free now)
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(rows, rowsum, (size_t)R * sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
-    (void)rowkeep;
-    MsmPoint *colsum = reduce_groups(ctx, st, cols, (size_t)C, (size_t)R / 8, red);    // C points
-    int nr = (R - 1 + REDUCE_CH - 1) / REDUCE_CH, nc = (C + REDUCE_CH - 1) / REDUCE_CH;
-    MsmPoint *sumr = nullptr, *sumc = nullptr;
-    MsmPoint *fin = result + 1;  // result[1], result[2]: the two weighted sums
-    if (R > 1) {
-        KZG_LAUNCH(ctx, st, "k_weighted_chunks", k_weighted_chunks, (nr + 63) / 64, 64, 0, rows + 1, R - 1, REDUCE_CH, 0, chunks);
-        KZG_TRY(sum_points_run(ctx, lane, chunks, nr, sum_scratch, &sumr));
-        KZG_HIP_CHECK(ctx, hipMemcpyAsync(fin, sumr, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
-    } else {
-        KZG_TRY(point_set_infinity(ctx, st, fin));
-    }
-    KZG_LAUNCH(ctx, st, "k_weighted_chunks", k_weighted_chunks, (nc + 63) / 64, 64, 0, colsum, C, REDUCE_CH, 0, chunks);
-    KZG_TRY(sum_points_run(ctx, lane, chunks, nc, sum_scratch, &sumc));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(fin + 1, sumc, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
-    int shift = 0;
-    while ((1 << shift) < C) shift++;
-    KZG_LAUNCH(ctx, st, "k_combine_shifted", k_combine_shifted, 1, 1, 0, fin, shift, fin + 1, result);
+    KZG_TRY(wide_bucket_reduce(ctx, lane, bufs[0], bufs[1], starts, Btot, L.C, state, rows, cols, red[0], red[1], chunks, sum_scratch,
+                               result + 1, result));
     return KZG_OK;
 }
 
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) {
     return srs->c > 16 ? wide_layout(srs, n ? n : 1).bytes : msm_layout(srs, n ? n : 1).bytes;
+}
+
+int sum_level_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
+    size_t nout = (count + L - 1) / L;
+    KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + 63) / 64), 64, 0, in, count, L, out);
+    return KZG_OK;
 }
 
 int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result) {

@@ -1,0 +1,53 @@
+// msm_internal.h -- declarations shared by msm.hip (the c <= 16 pipeline and all orchestration) and msm_wide.hip (the
+// kernels only the wide-window path uses; kept in their own translation unit so that they do not perturb the code
+// generation of the hot kernels: a same-box A/B showed k_accum_affine 2.5 % and k_bucket_reduce 13 % slower with
+// everything in one TU).
+#pragma once
+#include "common.h"
+
+namespace kzg {
+
+constexpr uint32_t ACC_SLOTS = 256 * 8 * 64;  // resident threads of k_accum_affine: 256 CUs x 2 waves/SIMD x 4 SIMDs x 64
+constexpr int LK = 4;   // fan-in of the later fold rounds
+constexpr int SUM_L = 4;  // fan-in of the plain tree sum
+constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
+constexpr int MAX_LEVELS = 24;
+// wide windows (16 < c <= 20): bucket id = hi (c - 16 bits) : lo (15 bits).  Pass 1 sorts by lo with the LDS counting sort,
+// pass 2 is a stable partition by hi; between the passes hi travels in bits 27..30 of the entry word, which limits the
+// wide mode to W * npad < 2^27 table rows (n <= 2^22 at W = 13).
+constexpr int WIDE_LO_BITS = 15;
+constexpr int WIDE_HI_SHIFT = 27;
+constexpr uint32_t WIDE_HI_MASK = 0xfu << WIDE_HI_SHIFT;
+
+struct MsmState {
+    uint32_t M;            // sorted entries
+    uint32_t ntasks;       // tasks of the level being run
+    uint32_t done;         // every bucket holds <= 1 partial
+    uint32_t final_level;  // index of the start[] array describing the final partial list
+    uint32_t final_buf;    // which ping-pong buffer holds it
+    uint32_t max_cnt;
+    uint32_t E;            // sorted entries per round-1 thread (equal split)
+    uint32_t pad[1];
+};
+
+
+// msm.hip
+int sum_level_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *in, uint32_t count, int L, MsmPoint *out);
+
+// msm_wide.hip
+constexpr int HI_BLOCKS = 256;   // blocks of the stable partition
+constexpr int HI_THREADS = 1024;
+constexpr int SEG = 2048;        // buckets per scan block (256 threads x 8)
+int wide_sort_pass2(kzg_ctx *ctx, hipStream_t st, const uint32_t *entries1, const MsmState *state, int nhi, uint32_t *blockcnt,
+                    uint32_t *binbase, const uint32_t *lo_start, int B_lo, uint32_t *entries2, uint32_t *bucket_start);
+int wide_s1_layout(kzg_ctx *ctx, hipStream_t st, const uint32_t *bucket_start, int Btot, MsmState *state, uint32_t *segsums,
+                   uint32_t *segmaxs, uint32_t *segtotal, uint32_t *s1_out);
+// one fold level: task counts ceil(partials / L) per bucket, `done` detection; apply = also write out_start
+int wide_level_scan(kzg_ctx *ctx, hipStream_t st, const uint32_t *in_start, uint32_t *out_start, int Btot, int L, MsmState *state,
+                    uint32_t level, uint32_t in_buf, uint32_t *segsums, uint32_t *segmaxs, uint32_t *segtotal, bool apply);
+// sum (b+1) X_b over Btot = R x C buckets -> *result
+int wide_bucket_reduce(kzg_ctx *ctx, int lane, const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int Btot, int C,
+                       const MsmState *state, MsmPoint *rows, MsmPoint *cols, MsmPoint *red0, MsmPoint *red1, MsmPoint *chunks,
+                       MsmPoint *sum_scratch, MsmPoint *scratch3, MsmPoint *result);
+
+}  // namespace kzg
