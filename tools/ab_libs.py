@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
-"""Same-box A/B of two builds of libkzg_mi355x.so (interleaved rounds in one process):
-   python tools/ab_libs.py tools/bin/lib_A.so tools/bin/lib_B.so [log_n]"""
+"""Same-box A/B of several builds of libkzg_mi355x.so (interleaved rounds in one process):
+   python tools/ab_libs.py tools/bin/lib_A.so tools/bin/lib_B.so [...] [log_n]"""
 import ctypes, json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from kzg_amd import _lib as L
 
-paths = sys.argv[1:3]
-log_n = int(sys.argv[3]) if len(sys.argv) > 3 else 20
+paths = [a for a in sys.argv[1:] if not a.isdigit()]
+log_n = int(sys.argv[-1]) if sys.argv[-1].isdigit() else 20
 n = 1 << log_n
 TAU = (0x5EED5EED5EED5EED).to_bytes(32, "little")
 vp, sz, i32, u64 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_uint64
