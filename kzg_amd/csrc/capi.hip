@@ -236,6 +236,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
         if (l.stream) hipStreamDestroy(l.stream);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    if (ctx->batch_out) hipFree(ctx->batch_out);
     ntt_plans_free(ctx);
     eval_tabs_free(ctx);
     fixed_base_free(ctx);
@@ -400,8 +401,19 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
     for (int l = 0; l < nl; l++) KZG_TRY(lane_reserve(ctx, l, per));
     uint8_t *d_out = nullptr;
     bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
-    if (out_dev) d_out = (uint8_t *)out;
-    else KZG_HIP_CHECK(ctx, hipMalloc((void **)&d_out, batch * psz + 256));
+    if (out_dev) {
+        d_out = (uint8_t *)out;
+    } else {
+        // grow-only device staging for the results: a hipMalloc / hipFree pair per call costs a device-wide sync
+        if (ctx->batch_out_bytes < batch * psz + 256) {
+            if (ctx->batch_out) hipFree(ctx->batch_out);
+            ctx->batch_out = nullptr;
+            ctx->batch_out_bytes = 0;
+            KZG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->batch_out, batch * psz + 256));
+            ctx->batch_out_bytes = batch * psz + 256;
+        }
+        d_out = (uint8_t *)ctx->batch_out;
+    }
     int rc = KZG_OK;
     for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
         int l = (int)(b % nl);
@@ -418,7 +430,6 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
         hipError_t e = hipMemcpy(out, d_out, batch * psz, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
     }
-    if (!out_dev) hipFree(d_out);
     if (ctx->prof) prof_collect(ctx);
     return rc;
 }

@@ -66,6 +66,8 @@ struct kzg_ctx {
     std::map<uint32_t, kzg::NttPlan *> ntt_plans;          // key = log_n * 2 + inverse
     std::map<uint32_t, kzg::EvalDomainTables *> eval_tabs;  // key = log_d
     kzg::FixedBaseTable *fixed_base = nullptr;
+    void *batch_out = nullptr;  // device staging of kzg_msm_g1_batch results (grow-only)
+    size_t batch_out_bytes = 0;
 };
 
 struct kzg_srs {
