@@ -27,6 +27,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# One hardware queue per engine stream (the ROCm default multiplexes all streams onto 4 in-order queues, which makes
+# independent MSM lanes wait for each other's tail kernels); must be in the environment before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_TERM = 128           # 32 B scalar + 96 B affine point per MSM term
@@ -103,7 +107,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=32, help="commitments per step (pipelined on the engine's HIP streams)")
-    ap.add_argument("--streams", type=int, default=0, help="HIP streams the engine pipelines a batch over (0 = engine default)")
+    ap.add_argument("--streams", type=int, default=16, help="HIP streams the engine pipelines a batch over (0 = engine default, 8)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks (0 = default)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--window-bits", type=int, default=0, help="engine option window_bits (0 = engine default)")
