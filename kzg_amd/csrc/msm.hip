@@ -102,59 +102,6 @@ __global__ void k_scan_blocks(uint32_t *blk_hist, int G, int B, uint32_t *total)
     total[b] = run;
 }
 
-// Single-block exclusive scan over `B` per-bucket values produced by f(b); writes out[0..B] and returns the
-// total.  Each wave owns a contiguous segment and walks it in rounds of 64 consecutive buckets, so every
-// global access is a coalesced 256-B row; all rounds are loaded into registers first (their latencies
-// overlap), then scanned with wave shuffles and a running carry; one LDS pass combines the <= 16 waves.
-constexpr int SCAN_MAX_ROUNDS = 32;  // 1024 threads x 32 rounds = 2^15 buckets (c <= 16)
-template <class F>
-__device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *out, uint32_t *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int seg = (B + nwaves - 1) / nwaves;          // buckets per wave
-    const int rounds = (seg + 63) >> 6;                  // <= SCAN_MAX_ROUNDS
-    const int base = wave * seg;
-    const int end = base + seg < B ? base + seg : B;
-    uint32_t v[SCAN_MAX_ROUNDS];
-#pragma unroll
-    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
-        int b = base + r * 64 + lane;
-        v[r] = (r < rounds && b < end) ? f(b) : 0u;
-    }
-    uint32_t carry = 0;
-#pragma unroll
-    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
-        uint32_t x = v[r], incl = x;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            uint32_t t = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += t;
-        }
-        v[r] = incl - x + carry;
-        carry += __shfl(incl, 63, 64);
-    }
-    if (lane == 0) lds[wave] = carry;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int w = 0; w < nwaves; w++) {
-            uint32_t t = lds[w];
-            lds[w] = run;
-            run += t;
-        }
-        lds[nwaves] = run;
-    }
-    __syncthreads();
-    const uint32_t woff = lds[wave], total = lds[nwaves];
-#pragma unroll
-    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
-        int b = base + r * 64 + lane;
-        if (r < rounds && b < end) out[b] = v[r] + woff;
-    }
-    if (threadIdx.x == 0) out[B] = total;
-    __syncthreads();
-    return total;
-}
-
 // bucket_start[] from total[]; then the round-1 layout.  Round 1 is an EQUAL SPLIT: thread s folds
 // the sorted entries [s*E, (s+1)*E), E = ceil(M / slots), and emits one partial per (thread, bucket) run.
 // Run starts are the multiples of E and the non-empty bucket starts, so the partial list is ordered by
@@ -204,16 +151,6 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
 // ---------------------------------------------------------------------------------------------
 // accumulation rounds
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void find_task(const uint32_t *task_start, int B, uint32_t t, uint32_t &b, uint32_t &j) {
-    uint32_t lo = 0, hi = (uint32_t)B;  // task_start[lo] <= t < task_start[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (task_start[mid] <= t) lo = mid; else hi = mid;
-    }
-    b = lo;
-    j = t - task_start[lo];
-}
-
 // table29 entry: G1Affine29 = 2 x 14 limbs = 112 B = 7 x 16 B
 __device__ __forceinline__ G1Affine29 load_entry_point29(const uint4 *table29, uint32_t ent) {
     const uint4 *src = table29 + (size_t)(ent & 0x7fffffffu) * 7;
@@ -747,18 +684,20 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
                (const uint4 *)srs->table29, bufs[0], state);
-    // fold rounds: level k input list lives in bufs[(k-1)&1] with per-bucket starts start_arr(k-1)
+    // fold rounds: the list of level k lives in bufs[k & 1] with per-bucket starts start_arr(k).  Two rounds of fan-in
+    // LK settle every input whose buckets were split over <= 16 threads; k_fold_rest finishes the others.
     size_t tmax = L.T1_max;
-    for (int lv = 1; lv <= L.levels + 1; lv++) {
+    const int fast = L.levels < FAST_LEVELS ? L.levels : FAST_LEVELS;
+    for (int lv = 1; lv <= fast; lv++) {
         int in_buf = (lv - 1) & 1;
         KZG_LAUNCH(ctx, st, "k_level_scan", k_level_scan, 1, 1024, 0, start_arr(lv - 1), start_arr(lv), B, LK, state,
                    (uint32_t)(lv - 1), (uint32_t)in_buf);
-        if (lv == L.levels + 1) break;  // the last scan only certifies done
         tmax = tmax / LK + B + 1;
         unsigned grid = (unsigned)((tmax + 255) / 256);
         KZG_LAUNCH(ctx, st, "k_accum_xyzz", k_accum_xyzz, grid, 256, 0, bufs[in_buf], start_arr(lv - 1), start_arr(lv),
                    B, LK, bufs[in_buf ^ 1], state);
     }
+    KZG_TRY(fold_rest_run(ctx, st, bufs[0], bufs[1], starts, B, LK, fast, L.levels, state));
     int CH = B < REDUCE_CH ? B : REDUCE_CH;
     int nchunks = B / CH;
     KZG_LAUNCH(ctx, st, "k_bucket_reduce", k_bucket_reduce, (nchunks + 63) / 64, 64, 0, bufs[0], bufs[1], starts, B,

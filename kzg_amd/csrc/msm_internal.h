@@ -31,6 +31,72 @@ struct MsmState {
 };
 
 
+#if defined(__HIPCC__)
+// Single-block exclusive scan over `B` per-bucket values produced by f(b); writes out[0..B] and returns the
+// total.  Each wave owns a contiguous segment and walks it in rounds of 64 consecutive buckets, so every
+// global access is a coalesced 256-B row; all rounds are loaded into registers first (their latencies
+// overlap), then scanned with wave shuffles and a running carry; one LDS pass combines the <= 16 waves.
+constexpr int SCAN_MAX_ROUNDS = 32;  // 1024 threads x 32 rounds = 2^15 buckets (c <= 16)
+template <class F>
+__device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *out, uint32_t *lds) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int seg = (B + nwaves - 1) / nwaves;          // buckets per wave
+    const int rounds = (seg + 63) >> 6;                  // <= SCAN_MAX_ROUNDS
+    const int base = wave * seg;
+    const int end = base + seg < B ? base + seg : B;
+    uint32_t v[SCAN_MAX_ROUNDS];
+#pragma unroll
+    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
+        int b = base + r * 64 + lane;
+        v[r] = (r < rounds && b < end) ? f(b) : 0u;
+    }
+    uint32_t carry = 0;
+#pragma unroll
+    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
+        uint32_t x = v[r], incl = x;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        v[r] = incl - x + carry;
+        carry += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) lds[wave] = carry;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int w = 0; w < nwaves; w++) {
+            uint32_t t = lds[w];
+            lds[w] = run;
+            run += t;
+        }
+        lds[nwaves] = run;
+    }
+    __syncthreads();
+    const uint32_t woff = lds[wave], total = lds[nwaves];
+#pragma unroll
+    for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
+        int b = base + r * 64 + lane;
+        if (r < rounds && b < end) out[b] = v[r] + woff;
+    }
+    if (threadIdx.x == 0) out[B] = total;
+    __syncthreads();
+    return total;
+}
+
+__device__ __forceinline__ void find_task(const uint32_t *task_start, int B, uint32_t t, uint32_t &b, uint32_t &j) {
+    uint32_t lo = 0, hi = (uint32_t)B;  // task_start[lo] <= t < task_start[hi]
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (task_start[mid] <= t) lo = mid; else hi = mid;
+    }
+    b = lo;
+    j = t - task_start[lo];
+}
+
+#endif
+
 // msm.hip
 int sum_level_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *in, uint32_t count, int L, MsmPoint *out);
 
@@ -46,6 +112,12 @@ int wide_s1_layout(kzg_ctx *ctx, hipStream_t st, const uint32_t *bucket_start, i
 int wide_level_scan(kzg_ctx *ctx, hipStream_t st, const uint32_t *in_start, uint32_t *out_start, int Btot, int L, MsmState *state,
                     uint32_t level, uint32_t in_buf, uint32_t *segsums, uint32_t *segmaxs, uint32_t *segtotal, bool apply);
 // sum (b+1) X_b over Btot = R x C buckets -> *result
+// the fold levels beyond the first FAST_LEVELS, in ONE single-block kernel that returns at once when every bucket already
+// holds one partial (the normal case): replaces ~14 no-op launches per MSM, whose queueing delays under a full GPU cost
+// 3-4 % of the batched throughput (measured).  Only adversarial inputs (few distinct digits) ever do work here.
+constexpr int FAST_LEVELS = 2;
+int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
+                  int max_level, MsmState *state);
 int wide_bucket_reduce(kzg_ctx *ctx, int lane, const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int Btot, int C,
                        const MsmState *state, MsmPoint *rows, MsmPoint *cols, MsmPoint *red0, MsmPoint *red1, MsmPoint *chunks,
                        MsmPoint *sum_scratch, MsmPoint *scratch3, MsmPoint *result);

@@ -333,6 +333,62 @@ __global__ void k_combine_shifted(const MsmPoint *a, int shift, const MsmPoint *
 
 
 // ---------------------------------------------------------------------------------------------
+// rare path of the c <= 16 pipeline: all fold levels after the first FAST_LEVELS, in one block
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
+                                                    int max_level, MsmState *st) {
+    if (st->done) return;
+    __shared__ uint32_t lds[1024];
+    __shared__ uint32_t smax;
+    int level = level0;
+    for (;;) {
+        const uint32_t *in_start = starts + (size_t)level * (B + 1);
+        uint32_t *out_start = starts + (size_t)(level + 1) * (B + 1);
+        if (threadIdx.x == 0) smax = 0;
+        __syncthreads();
+        uint32_t mx = 0;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            uint32_t cnt = in_start[b + 1] - in_start[b];
+            mx = cnt > mx ? cnt : mx;
+        }
+        atomicMax(&smax, mx);
+        __syncthreads();
+        if (smax <= 1 || level >= max_level) {
+            if (threadIdx.x == 0) {
+                st->done = smax <= 1 ? 1u : 0u;
+                st->final_level = (uint32_t)level;
+                st->final_buf = (uint32_t)(level & 1);
+                st->max_cnt = smax;
+            }
+            return;
+        }
+        const uint32_t T = block_exclusive_scan(
+            B, [&](int b) { return (in_start[b + 1] - in_start[b] + L - 1) / L; }, out_start, lds);
+        const MsmPoint *in = (level & 1) ? buf1 : buf0;
+        MsmPoint *out = (level & 1) ? buf0 : buf1;
+        for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+            uint32_t b, j;
+            find_task(out_start, B, t, b, j);
+            uint32_t s = in_start[b] + j * L;
+            uint32_t e = in_start[b + 1];
+            e = s + L < e ? s + L : e;
+            MsmPoint acc = in[s];
+            for (uint32_t k = s + 1; k < e; k++) acc = g1_add29(acc, in[k]);
+            out[t] = acc;
+        }
+        __threadfence_block();
+        __syncthreads();
+        level++;
+    }
+}
+
+int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
+                  int max_level, MsmState *state) {
+    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, 1024, 0, buf0, buf1, starts, B, L, level0, max_level, state);
+    return KZG_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers used by msm.hip's wide orchestration
 // ---------------------------------------------------------------------------------------------
 int wide_sort_pass2(kzg_ctx *ctx, hipStream_t st, const uint32_t *entries1, const MsmState *state, int nhi, uint32_t *blockcnt,
