@@ -106,7 +106,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="commitments per step (pipelined on the engine's HIP streams)")
+    ap.add_argument("--batch", type=int, default=64, help="commitments per step (pipelined on the engine's HIP streams)")
     ap.add_argument("--streams", type=int, default=16, help="HIP streams the engine pipelines a batch over (0 = engine default, 8)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks (0 = default)")
     ap.add_argument("--log-n", type=int, default=LOG_N)
