@@ -246,7 +246,7 @@ def main():
                         "kernel_ms_per_msm": {k: round(v[1] / per_msm, 4) for k, v in sorted(prof.items())}}
             # informational: the same kernel against the integer-multiply issue rate, over the whole timed region
             # (launches overlap on 8 streams, so the aggregate rate is the meaningful one)
-            mads = float(launches) * n * W * MADS_PER_ADD
+            mads = float(launches) * n * (4 if args.u64 else W) * MADS_PER_ADD  # u64-valued scalars: 4 non-zero 16-bit windows
             t_mad = mads / dt / 1e12
             roofline["valu"] = {"resource": "v_mad_u64_u32 issue", "achieved": round(t_mad, 2), "unit": "T lane-mad/s",
                                 "peak": MAD_PEAK_TLANE_S, "frac": round(t_mad / MAD_PEAK_TLANE_S, 4),
@@ -262,6 +262,19 @@ def main():
             if rc:
                 raise RuntimeError(engine.last_error())
         latency_ms = (time.perf_counter() - t1) / reps * 1e3
+        # the same kernel with nothing else on the GPU (the batched figure above divides by a duration that is stretched
+        # by the other MSMs in flight): two more single MSMs with the engine's event profiling on
+        if roofline is not None:
+            engine.prof_enable(True)
+            engine.prof_reset()
+            for _ in range(reps):
+                engine.lib.kzg_msm_g1(engine.ctx, srs.handle, 0, scal.ptr, n, scal.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
+            l2, ms2 = engine.prof_all().get("k_accum_affine", (0, 0.0))
+            engine.prof_enable(False)
+            if l2:
+                a2 = BYTES_PER_TERM * n / (ms2 / l2 / 1e3) / 1e9
+                roofline["alone"] = {"avg_kernel_ms": round(ms2 / l2, 4), "achieved": round(a2, 2), "unit": "GB/s",
+                                     "frac": round(a2 / HBM_PEAK_GBS, 5)}
 
     if rank == 0:
         value = units_per_step * args.steps / dt
