@@ -457,7 +457,7 @@ extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pf
         const void *d_raw = nullptr;
         KZG_TRY(stage_in(ctx, 0, points, count * psz, flags, &d_raw));
         KZG_TRY(decode_points(ctx, st, d_raw, count, pfmt, dec, bad));
-        KZG_TRY(points_to29(ctx, st, dec, pts, count));
+        KZG_TRY(points_to30(ctx, st, dec, pts, count));
         KZG_TRY(sum_points_run(ctx, 0, pts, count, scratch, &res));
     }
     int hbad = 0;
@@ -487,7 +487,7 @@ extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, 
     const void *d_raw = nullptr;
     KZG_TRY(stage_in(ctx, 0, points, total * psz, flags, &d_raw));
     KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, dec, bad));
-    KZG_TRY(points_to29(ctx, st, dec, pts, total));
+    KZG_TRY(points_to30(ctx, st, dec, pts, total));
     KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, tmp, d_out, ofmt));
     int hbad = 0;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));

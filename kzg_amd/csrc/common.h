@@ -12,7 +12,7 @@
 
 #include "../../include/kzg_mi355x.h"
 #include "curve.h"
-#include "curve29.h"
+#include "curve30.h"
 
 namespace kzg {
 
@@ -76,7 +76,7 @@ struct kzg_srs {
     int c = 0;           // window bits (signed digits, 2^(c-1) buckets)
     int W = 0;           // windows = ceil(256 / c); table row w holds 2^(c*w) * P_i
     kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
-    void *table29 = nullptr;         // [W][npad] G1Affine29 (2 x 14 x 29-bit limbs, 112 B): what k_accum_affine gathers
+    void *table30 = nullptr;         // [W][npad] G1Affine30 (2 x 13 x 30-bit limbs + pad, 112 B): what k_accum_affine gathers
     int device = 0;
 };
 
@@ -132,8 +132,8 @@ inline int ilog2_ceil(size_t x) {
 }
 
 // The point type the MSM pipeline computes in and hands between its kernels: extended Jacobian coordinates in
-// the unsaturated 29-bit field representation (curve29.h).  Canonical encodings are produced by emit_point.
-typedef G1Xyzz29 MsmPoint;
+// the signed 30-bit field representation (curve30.h).  Canonical encodings are produced by emit_point.
+typedef G1Xyzz30 MsmPoint;
 
 // ---- cross-TU entry points -------------------------------------------------------------------
 // msm.hip
@@ -144,8 +144,8 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
 // d_points: count points -> one point (plain sum)
 int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result);
 // conversions between the canonical saturated XYZZ form and MsmPoint (device arrays)
-int points_to29(kzg_ctx *ctx, hipStream_t st, const G1Xyzz *d_in, MsmPoint *d_out, size_t n);
-int points_from29(kzg_ctx *ctx, hipStream_t st, const MsmPoint *d_in, G1Xyzz *d_out, size_t n);
+int points_to30(kzg_ctx *ctx, hipStream_t st, const G1Xyzz *d_in, MsmPoint *d_out, size_t n);
+int points_from30(kzg_ctx *ctx, hipStream_t st, const MsmPoint *d_in, G1Xyzz *d_out, size_t n);
 int point_set_infinity(kzg_ctx *ctx, hipStream_t st, MsmPoint *d_pt);
 size_t sum_points_scratch_count(size_t count);
 // writes one point in `ofmt` (from XYZZ) to d_out (device); single thread incl. the Fq inversion

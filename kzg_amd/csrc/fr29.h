@@ -1,5 +1,5 @@
 // fr29.h -- Fr in the UNSATURATED 9 x 29-bit representation (Montgomery radix 2^261) used inside the NTT
-// kernels.  Same idea as field29.h: a product-scanning multiply whose columns (<= 18 products < 2^58) sum
+// kernels.  Same idea as field30.h (there with signed limbs): a product-scanning multiply whose columns (<= 18 products < 2^58) sum
 // in one 64-bit accumulator, so every partial product is a bare v_mad_u64_u32 (162 per multiply instead of
 // 128 mads + 128 carry folds), and lazily reduced butterflies: u + t and u - t + 2r are limb-wise adds.
 //
@@ -11,9 +11,13 @@
 // (inter-pass twiddle, d^-1 scale, or one) brings the value below 1.4 r and one conditional subtraction
 // makes it canonical before it is packed back into 8 x 32-bit words.
 #pragma once
-#include "field29.h"
+#include "field.h"
 
 namespace kzg {
+
+#include "fr29_consts.inc"
+
+constexpr uint32_t F29_MASK = (1u << 29) - 1u;
 
 constexpr int R29_N = 9;
 

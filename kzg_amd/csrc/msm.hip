@@ -6,7 +6,7 @@
 //
 //   * The SRS is resident in HBM as W = ceil(256/c) rows, row w holding the affine points
 //     2^(c*w) * P_i (built once at upload; 1.5 GiB for 2^20 points at c = 16 -- cheap in 288 GB), plus
-//     a copy of the same table in the unsaturated 29-bit representation the inner loop computes in
+//     a copy of the same table in the signed 30-bit representation the inner loop computes in
 //     (112 B per point, 1.75 GiB at 2^20).
 //     Every signed c-bit digit of every scalar therefore lands in ONE shared set of 2^(c-1)
 //     buckets: there is no per-window bucket reduction and no window-combine doubling chain.
@@ -151,10 +151,10 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
 // ---------------------------------------------------------------------------------------------
 // accumulation rounds
 // ---------------------------------------------------------------------------------------------
-// table29 entry: G1Affine29 = 2 x 14 limbs = 112 B = 7 x 16 B
-__device__ __forceinline__ G1Affine29 load_entry_point29(const uint4 *table29, uint32_t ent) {
-    const uint4 *src = table29 + (size_t)(ent & 0x7fffffffu) * 7;
-    G1Affine29 p;
+// table30 entry: G1Affine30 = 2 x 13 limbs + 8 B pad = 112 B = 7 x 16 B
+__device__ __forceinline__ G1Affine30 load_entry_point30(const uint4 *table30, uint32_t ent) {
+    const uint4 *src = table30 + (size_t)(ent & 0x7fffffffu) * 7;
+    G1Affine30 p;
     uint4 *dst = reinterpret_cast<uint4 *>(&p);
 #pragma unroll
     for (int k = 0; k < 7; k++) dst[k] = src[k];
@@ -162,12 +162,12 @@ __device__ __forceinline__ G1Affine29 load_entry_point29(const uint4 *table29, u
 }
 
 // round 1 (dominant kernel): thread s folds its E consecutive sorted entries with XYZZ mixed adds in the
-// unsaturated 29-bit field representation (curve29.h), gathering each precomputed point from the
-// resident 29-bit table (next point prefetched under the add), and writes one partial per bucket it
+// signed 30-bit field representation (curve30.h), gathering each precomputed point from the
+// resident 30-bit table (next point prefetched under the add), and writes one partial per bucket it
 // touches.  Every thread has the same amount of work,
 // so the kernel ends without a straggler round.
 __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
-                                                      const uint32_t *s1, int B, const uint4 *table29,
+                                                      const uint32_t *s1, int B, const uint4 *table30,
                                                       MsmPoint *out, const MsmState *st) {
     const uint32_t E = st->E, M = st->M;
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -187,18 +187,18 @@ __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, c
     uint32_t f_next = s1[b + 1] - (bucket_start[b + 1] + E - 1) / E;  // F[b+1]
     uint32_t pos = s + f_next;
     uint32_t ent = entries[lo];
-    G1Affine29 cur = load_entry_point29(table29, ent);
-    G1Xyzz29 acc = g1_from_affine29(cur, ent >> 31);
+    G1Affine30 cur = load_entry_point30(table30, ent);
+    G1Xyzz30 acc = g1_from_affine30(cur, ent >> 31);
     if (lo + 1 < hi) {
         ent = entries[lo + 1];
-        cur = load_entry_point29(table29, ent);
+        cur = load_entry_point30(table30, ent);
     }
     for (uint32_t k = lo + 1; k < hi; k++) {
         // `cur` / `ent` hold entry k.  mode 0: mixed add; 1: restart the accumulator from cur; 2: skip (identity point)
         const bool neg_k = (ent >> 31) != 0;
         const uint32_t ent_k = ent;
         int mode = 0;
-        Madd29Mid mid;
+        Madd30Mid mid;
         if (k == bend) {  // bucket boundary: flush and restart
             out[pos++] = acc;
             do {
@@ -211,15 +211,15 @@ __global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, c
         } else if (acc.inf) {
             mode = 1;
         }
-        if (mode == 0) mid = g1_madd29_phase1(acc, cur, neg_k);
-        if (mode == 1) acc = g1_from_affine29(cur, neg_k);
+        if (mode == 0) mid = g1_madd30_phase1(acc, cur, neg_k);
+        if (mode == 1) acc = g1_from_affine30(cur, neg_k);
         // entry k's point is dead now: start the gather of entry k+1 into the same registers; its latency
         // hides under the eight remaining multiplies of this addition
         if (k + 1 < hi) {
             ent = entries[k + 1];
-            cur = load_entry_point29(table29, ent);
+            cur = load_entry_point30(table30, ent);
         }
-        if (mode == 0) acc = g1_madd29_phase2(acc, mid, neg_k, [&]() { return load_entry_point29(table29, ent_k); });
+        if (mode == 0) acc = g1_madd30_phase2(acc, mid, neg_k, [&]() { return load_entry_point30(table30, ent_k); });
     }
     out[pos] = acc;
 }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const ui
         uint32_t e = in_start[b + 1];
         e = s + L < e ? s + L : e;
         MsmPoint acc = in[s];
-        for (uint32_t k = s + 1; k < e; k++) acc = g1_add29(acc, in[k]);
+        for (uint32_t k = s + 1; k < e; k++) acc = g1_add30(acc, in[k]);
         out[t] = acc;
     }
 }
@@ -288,17 +288,17 @@ __global__ __launch_bounds__(64) void k_bucket_reduce(const MsmPoint *buf0, cons
     MsmPoint run = MsmPoint::infinity(), acc = MsmPoint::infinity();
     for (int b = lo + CH - 1; b >= lo; b--) {
         uint32_t s = start[b];
-        if (start[b + 1] > s) run = g1_add29(run, buf[s]);
-        acc = g1_add29(acc, run);
+        if (start[b + 1] > s) run = g1_add30(run, buf[s]);
+        acc = g1_add30(acc, run);
     }
     // acc = sum (b - lo + 1) B_b ; add lo * run
     if (lo != 0 && !run.inf) {
         MsmPoint m = MsmPoint::infinity();
         for (int bit = 30; bit >= 0; bit--) {
-            m = g1_dbl29(m);
-            if ((lo >> bit) & 1) m = g1_add29(m, run);
+            m = g1_dbl30(m);
+            if ((lo >> bit) & 1) m = g1_add30(m, run);
         }
-        acc = g1_add29(acc, m);
+        acc = g1_add30(acc, m);
     }
     out[t] = acc;
 }
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(64) void k_sum_level(const MsmPoint *in, uint32_t c
     if (t >= nout) return;
     uint32_t s = t * L, e = s + L < count ? s + L : count;
     MsmPoint acc = in[s];
-    for (uint32_t k = s + 1; k < e; k++) acc = g1_add29(acc, in[k]);
+    for (uint32_t k = s + 1; k < e; k++) acc = g1_add30(acc, in[k]);
     out[t] = acc;
 }
 
@@ -334,7 +334,7 @@ __device__ bool fq_lexicographically_largest(const Fq &canon) {  // y > (q-1)/2
 __global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const G1Xyzz p = g1_xyzz_from29(pts[i * stride_pts]);
+    const G1Xyzz p = g1_xyzz_from30(pts[i * stride_pts]);
     if (fmt == KZG_G1_JACOBIAN_MONT_144) {
         G1Jacobian j = g1_to_jacobian(p);
         *reinterpret_cast<G1Jacobian *>(out + i * 144) = j;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(64) void k_sum_groups(const MsmPoint *pts, uint32_t
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
     MsmPoint acc = MsmPoint::infinity();
-    for (uint32_t i = 0; i < count; i++) acc = g1_add29(acc, pts[(size_t)g * count + i]);
+    for (uint32_t i = 0; i < count; i++) acc = g1_add30(acc, pts[(size_t)g * count + i]);
     out[g] = acc;
 }
 
@@ -387,22 +387,22 @@ int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count,
     return KZG_OK;
 }
 
-__global__ __launch_bounds__(256) void k_points_to29(const G1Xyzz *in, MsmPoint *out, size_t n) {
+__global__ __launch_bounds__(256) void k_points_to30(const G1Xyzz *in, MsmPoint *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = g1_xyzz_to29(in[i]);
+    if (i < n) out[i] = g1_xyzz_to30(in[i]);
 }
-__global__ __launch_bounds__(256) void k_points_from29(const MsmPoint *in, G1Xyzz *out, size_t n) {
+__global__ __launch_bounds__(256) void k_points_from30(const MsmPoint *in, G1Xyzz *out, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = g1_xyzz_from29(in[i]);
+    if (i < n) out[i] = g1_xyzz_from30(in[i]);
 }
 __global__ void k_point_set_infinity(MsmPoint *p) { *p = MsmPoint::infinity(); }
 
-int points_to29(kzg_ctx *ctx, hipStream_t st, const G1Xyzz *d_in, MsmPoint *d_out, size_t n) {
-    if (n) KZG_LAUNCH(ctx, st, "k_points_to29", k_points_to29, (unsigned)((n + 255) / 256), 256, 0, d_in, d_out, n);
+int points_to30(kzg_ctx *ctx, hipStream_t st, const G1Xyzz *d_in, MsmPoint *d_out, size_t n) {
+    if (n) KZG_LAUNCH(ctx, st, "k_points_to30", k_points_to30, (unsigned)((n + 255) / 256), 256, 0, d_in, d_out, n);
     return KZG_OK;
 }
-int points_from29(kzg_ctx *ctx, hipStream_t st, const MsmPoint *d_in, G1Xyzz *d_out, size_t n) {
-    if (n) KZG_LAUNCH(ctx, st, "k_points_from29", k_points_from29, (unsigned)((n + 255) / 256), 256, 0, d_in, d_out, n);
+int points_from30(kzg_ctx *ctx, hipStream_t st, const MsmPoint *d_in, G1Xyzz *d_out, size_t n) {
+    if (n) KZG_LAUNCH(ctx, st, "k_points_from30", k_points_from30, (unsigned)((n + 255) / 256), 256, 0, d_in, d_out, n);
     return KZG_OK;
 }
 int point_set_infinity(kzg_ctx *ctx, hipStream_t st, MsmPoint *d_pt) {
@@ -591,7 +591,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, start_arr(0), Btot,
-               (const uint4 *)srs->table29, bufs[0], state);
+               (const uint4 *)srs->table30, bufs[0], state);
     size_t tmax = L.T1_max;
     for (int lv = 1; lv <= L.levels + 1; lv++) {
         int in_buf = (lv - 1) & 1;
@@ -683,7 +683,7 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
-               (const uint4 *)srs->table29, bufs[0], state);
+               (const uint4 *)srs->table30, bufs[0], state);
     // fold rounds: the list of level k lives in bufs[k & 1] with per-bucket starts start_arr(k).  Two rounds of fan-in
     // LK settle every input whose buckets were split over <= 16 threads; k_fold_rest finishes the others.
     size_t tmax = L.T1_max;

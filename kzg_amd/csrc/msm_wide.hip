@@ -283,7 +283,7 @@ __global__ __launch_bounds__(64) void k_rows8(const MsmPoint *buf0, const MsmPoi
     const uint32_t *start = starts + (size_t)st->final_level * (Btot + 1);
     const MsmPoint *buf = st->final_buf ? buf1 : buf0;
     MsmPoint acc = MsmPoint::infinity();
-    for (int k = 0; k < 8; k++) acc = g1_add29(acc, final_bucket(buf, start, t * 8 + k));
+    for (int k = 0; k < 8; k++) acc = g1_add30(acc, final_bucket(buf, start, t * 8 + k));
     out[t] = acc;
 }
 
@@ -297,7 +297,7 @@ __global__ __launch_bounds__(64) void k_cols8(const MsmPoint *buf0, const MsmPoi
     const MsmPoint *buf = st->final_buf ? buf1 : buf0;
     uint32_t c = t % C, g = t / C;  // consecutive threads -> consecutive columns of the same row group (coalesced starts)
     MsmPoint acc = MsmPoint::infinity();
-    for (int k = 0; k < 8; k++) acc = g1_add29(acc, final_bucket(buf, start, (g * 8 + k) * C + c));
+    for (int k = 0; k < 8; k++) acc = g1_add30(acc, final_bucket(buf, start, (g * 8 + k) * C + c));
     out[(size_t)c * (R / 8) + g] = acc;
 }
 
@@ -309,17 +309,17 @@ __global__ __launch_bounds__(64) void k_weighted_chunks(const MsmPoint *pts, int
     int lo = t * CH, hi = lo + CH < N ? lo + CH : N;
     MsmPoint run = MsmPoint::infinity(), acc = MsmPoint::infinity();
     for (int i = hi - 1; i >= lo; i--) {
-        run = g1_add29(run, pts[i]);
-        acc = g1_add29(acc, run);
+        run = g1_add30(run, pts[i]);
+        acc = g1_add30(acc, run);
     }
     int base = lo + first_weight;  // acc = sum (i - lo + 1) pts[i]; add base * run
     if (base != 0 && !run.inf) {
         MsmPoint m = MsmPoint::infinity();
         for (int bit = 30; bit >= 0; bit--) {
-            m = g1_dbl29(m);
-            if ((base >> bit) & 1) m = g1_add29(m, run);
+            m = g1_dbl30(m);
+            if ((base >> bit) & 1) m = g1_add30(m, run);
         }
-        acc = g1_add29(acc, m);
+        acc = g1_add30(acc, m);
     }
     out[t] = acc;
 }
@@ -327,8 +327,8 @@ __global__ __launch_bounds__(64) void k_weighted_chunks(const MsmPoint *pts, int
 // result = 2^shift * a + b
 __global__ void k_combine_shifted(const MsmPoint *a, int shift, const MsmPoint *b, MsmPoint *result) {
     MsmPoint m = *a;
-    for (int k = 0; k < shift; k++) m = g1_dbl29(m);
-    *result = g1_add29(m, *b);
+    for (int k = 0; k < shift; k++) m = g1_dbl30(m);
+    *result = g1_add30(m, *b);
 }
 
 
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *bu
             uint32_t e = in_start[b + 1];
             e = s + L < e ? s + L : e;
             MsmPoint acc = in[s];
-            for (uint32_t k = s + 1; k < e; k++) acc = g1_add29(acc, in[k]);
+            for (uint32_t k = s + 1; k < e; k++) acc = g1_add30(acc, in[k]);
             out[t] = acc;
         }
         __threadfence_block();

@@ -3,7 +3,7 @@
 // points, row w = 2^(c*w) * P_i (see msm.hip for why).  Also the GPU versions of the untimed input
 // generators: setup() (src/lib.rs:38-47, G1 half) and the Lagrange basis for a known secret.
 #include "common.h"
-#include "curve29.h"
+#include "curve30.h"
 
 namespace kzg {
 
@@ -76,7 +76,7 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     s->W = (256 + s->c - 1) / s->c;
     s->device = ctx->device;
     // `table` keeps row 0 only (the points themselves, canonical saturated form: download, re-upload);
-    // the W window rows live in the 29-bit table built by srs_precompute.
+    // the W window rows live in the 30-bit table built by srs_precompute.
     hipError_t e = hipMalloc((void **)&s->table, s->npad * sizeof(G1Affine));
     if (e != hipSuccess) {
         delete s;
@@ -87,22 +87,22 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     return KZG_OK;
 }
 
-// the 29-bit rows that k_accum_affine gathers from (one thread per point, 2 multiplies)
-__global__ __launch_bounds__(256) void k_table_to29(const G1Affine *src, G1Affine29 *dst, size_t npoints) {
+// the 30-bit rows that k_accum_affine gathers from (one thread per point, 2 multiplies)
+__global__ __launch_bounds__(256) void k_table_to30(const G1Affine *src, G1Affine30 *dst, size_t npoints) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npoints) return;
-    dst[i] = g1_affine_to29(src[i]);
+    dst[i] = g1_affine_to30(src[i]);
 }
 
 // rows w = 1..W-1: row w = 2^c * row (w-1), computed in the saturated representation through two ping-pong
-// row buffers and converted row by row into the resident 29-bit table.
+// row buffers and converted row by row into the resident 30-bit table.
 int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     if (srs->n == 0) return KZG_OK;
     hipStream_t st = ctx->lanes[0].stream;
     const size_t n = srs->n;
     size_t npts = (size_t)srs->W * srs->npad;
-    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table29, npts * sizeof(G1Affine29)));
-    G1Affine29 *t29 = (G1Affine29 *)srs->table29;
+    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table30, npts * sizeof(G1Affine30)));
+    G1Affine30 *t30 = (G1Affine30 *)srs->table30;
     const size_t CHUNK = (size_t)1 << 20;
     size_t chunk = n < CHUNK ? n : CHUNK;
     G1Xyzz *tmp = nullptr;
@@ -111,7 +111,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     KZG_HIP_CHECK(ctx, hipMalloc((void **)&rows[0], n * sizeof(G1Affine)));
     KZG_HIP_CHECK(ctx, hipMalloc((void **)&rows[1], n * sizeof(G1Affine)));
     unsigned gn = (unsigned)((n + 255) / 256);
-    KZG_LAUNCH(ctx, st, "k_table_to29", k_table_to29, gn, 256, 0, srs->table, t29, n);
+    KZG_LAUNCH(ctx, st, "k_table_to30", k_table_to30, gn, 256, 0, srs->table, t30, n);
     const G1Affine *prev = srs->table;
     for (int w = 1; w < srs->W; w++) {
         G1Affine *cur = rows[w & 1];
@@ -120,7 +120,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
             KZG_LAUNCH(ctx, st, "k_dbl_c", k_dbl_c, (unsigned)((m + 255) / 256), 256, 0, prev + o, tmp, m, srs->c);
             KZG_TRY(batch_to_affine(ctx, st, tmp, cur + o, m));
         }
-        KZG_LAUNCH(ctx, st, "k_table_to29", k_table_to29, gn, 256, 0, cur, t29 + (size_t)w * srs->npad, n);
+        KZG_LAUNCH(ctx, st, "k_table_to30", k_table_to30, gn, 256, 0, cur, t30 + (size_t)w * srs->npad, n);
         prev = cur;
     }
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
@@ -523,6 +523,6 @@ extern "C" void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs) {
         for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
     }
     if (srs->table) hipFree(srs->table);
-    if (srs->table29) hipFree(srs->table29);
+    if (srs->table30) hipFree(srs->table30);
     delete srs;
 }

@@ -421,9 +421,9 @@ extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mo
     kzg_srs *s = nullptr;
     KZG_TRY(srs_alloc(ctx, d, &s));
     G1Xyzz *rows = nullptr;
-    MsmPoint *rows29 = nullptr;
+    MsmPoint *rows30 = nullptr;
     int rc = KZG_OK;
-    if (hipMalloc((void **)&rows, d * sizeof(G1Xyzz)) != hipSuccess || hipMalloc((void **)&rows29, d * sizeof(MsmPoint)) != hipSuccess)
+    if (hipMalloc((void **)&rows, d * sizeof(G1Xyzz)) != hipSuccess || hipMalloc((void **)&rows30, d * sizeof(MsmPoint)) != hipSuccess)
         rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange rows)");
     Fr omega_inv = inv(host_omega(exp));
     Fr dinv = inv(from_u64<FrParams>((uint64_t)d));
@@ -434,14 +434,14 @@ extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mo
         if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(omega_inv, (uint64_t)i), dinv, d, sc);
         MsmPoint *res = nullptr;
         if (rc == KZG_OK) rc = msm_run(ctx, 0, mono, 0, sc, d, KZG_FR_MONT_LE_32, &res);
-        if (rc == KZG_OK && hipMemcpyAsync(rows29 + i, res, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        if (rc == KZG_OK && hipMemcpyAsync(rows30 + i, res, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st) != hipSuccess)
             rc = fail(ctx, KZG_ERR_HIP, "copy");
     }
-    if (rc == KZG_OK) rc = points_from29(ctx, st, rows29, rows, d);
+    if (rc == KZG_OK) rc = points_from30(ctx, st, rows30, rows, d);
     if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, rows);
     hipStreamSynchronize(st);
     if (rows) hipFree(rows);
-    if (rows29) hipFree(rows29);
+    if (rows30) hipFree(rows30);
     if (rc != KZG_OK) {
         hipFree(s->table);
         delete s;

@@ -33,33 +33,43 @@ extern "C" {
 void hm_fq_inv_fermat(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv_fermat(x); memcpy(o, z.v, 48); }
 void hm_fr_inv_fermat(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv_fermat(x); memcpy(o, z.v, 32); }
 }
-#include "../kzg_amd/csrc/curve29.h"
+#include "../kzg_amd/csrc/curve30.h"
 extern "C" {
-// Fq29: x*R384 (48 B) -> to29 -> mul29 -> from29 -> 48 B, must equal the saturated Montgomery product
-void hm_mul29(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48);
-    Fq z = from29(mul29(to29(x), to29(y))); memcpy(o, z.v, 48); }
-void hm_roundtrip29(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = from29(to29(x)); memcpy(o, z.v, 48); }
-void hm_packunpack29(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = pack29(unpack29(x)); memcpy(o, z.v, 48); }
-// chain of n mixed additions in the 29-bit representation: acc = first; acc += pts[i] (sign bit i of `signs`)
-void hm_madd29_chain(const uint32_t *pts, int n, uint64_t signs, uint32_t *o) {
+// Fq30: x*R384 (48 B) -> to30 -> mul30 -> from30 -> 48 B, must equal the saturated Montgomery product
+void hm_mul30(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48);
+    Fq z = from30(mul30(to30(x), to30(y))); memcpy(o, z.v, 48); }
+void hm_sqr30(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = from30(sqr30(to30(x))); memcpy(o, z.v, 48); }
+void hm_roundtrip30(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = from30(to30(x)); memcpy(o, z.v, 48); }
+void hm_packunpack30(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = pack30(unpack30(x)); memcpy(o, z.v, 48); }
+// raw limb interfaces (13 x int32 each): the exact integers going in and out, for the overflow / bound tests
+void hm_mul30_raw(const int32_t *a, const int32_t *b, int32_t *o) { Fq30 x, y; memcpy(x.v, a, 52); memcpy(y.v, b, 52);
+    Fq30 z = mul30(x, y); memcpy(o, z.v, 52); }
+void hm_sqr30_raw(const int32_t *a, int32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq30 z = sqr30(x); memcpy(o, z.v, 52); }
+void hm_muladd30_raw(const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d, int32_t *o) {
+    Fq30 x, y, u, w; memcpy(x.v, a, 52); memcpy(y.v, b, 52); memcpy(u.v, c, 52); memcpy(w.v, d, 52);
+    Fq30 z = muladd30_inline(x, y, u, w); memcpy(o, z.v, 52); }
+void hm_normalize30_raw(const int32_t *a, int32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq30 z = normalize30(x); memcpy(o, z.v, 52); }
+void hm_from30_raw(const int32_t *a, uint32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq z = from30(x); memcpy(o, z.v, 48); }
+// chain of n mixed additions in the 30-bit representation: acc = first; acc += pts[i] (sign bit i of `signs`)
+void hm_madd30_chain(const uint32_t *pts, int n, uint64_t signs, uint32_t *o) {
     const G1Affine *p = (const G1Affine *)pts;
-    G1Xyzz29 acc = g1_from_affine29(g1_affine_to29(p[0]), signs & 1);
-    for (int i = 1; i < n; i++) acc = g1_madd29(acc, g1_affine_to29(p[i]), (signs >> i) & 1);
-    G1Affine r = g1_to_affine(g1_xyzz_from29(acc)); memcpy(o, &r, 96); }
+    G1Xyzz30 acc = g1_from_affine30(g1_affine_to30(p[0]), signs & 1);
+    for (int i = 1; i < n; i++) acc = g1_madd30(acc, g1_affine_to30(p[i]), (signs >> i) & 1);
+    G1Affine r = g1_to_affine(g1_xyzz_from30(acc)); memcpy(o, &r, 96); }
 }
 extern "C" {
-// general 29-bit addition / doubling on de-normalised operands built from madd29 / dbl29 chains
-void hm_add29(const uint32_t *a, const uint32_t *b, uint32_t *o) { G1Affine x, y; memcpy(&x, a, 96); memcpy(&y, b, 96);
-    G1Affine29 x29 = g1_affine_to29(x), y29 = g1_affine_to29(y);
-    // p = 2x - x (via dbl29 + madd29 of -x), q = (y + y) - y: non-trivial ZZ/ZZZ and lazy coordinates
-    G1Xyzz29 p = g1_madd29(g1_dbl29(g1_from_affine29(x29, false)), x29, true);
-    G1Xyzz29 q = g1_madd29(g1_madd29(g1_from_affine29(y29, false), y29, false), y29, true);
-    G1Affine r = g1_to_affine(g1_xyzz_from29(g1_add29(p, q))); memcpy(o, &r, 96); }
-// [k]P by double-and-add with dbl29 / add29 only (k: 8 x u32)
-void hm_mul29_scalar(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1Affine x; memcpy(&x, a, 96);
-    G1Xyzz29 base = g1_from_affine29(g1_affine_to29(x), false), acc = G1Xyzz29::infinity();
-    for (int i = 255; i >= 0; i--) { acc = g1_dbl29(acc); if ((k[i >> 5] >> (i & 31)) & 1) acc = g1_add29(acc, base); }
-    G1Affine r = g1_to_affine(g1_xyzz_from29(acc)); memcpy(o, &r, 96); }
+// general 30-bit addition / doubling on de-normalised operands built from madd30 / dbl30 chains
+void hm_add30(const uint32_t *a, const uint32_t *b, uint32_t *o) { G1Affine x, y; memcpy(&x, a, 96); memcpy(&y, b, 96);
+    G1Affine30 x30 = g1_affine_to30(x), y30 = g1_affine_to30(y);
+    // p = 2x - x (via dbl30 + madd30 of -x), q = (y + y) - y: non-trivial ZZ/ZZZ and lazy coordinates
+    G1Xyzz30 p = g1_madd30(g1_dbl30(g1_from_affine30(x30, false)), x30, true);
+    G1Xyzz30 q = g1_madd30(g1_madd30(g1_from_affine30(y30, false), y30, false), y30, true);
+    G1Affine r = g1_to_affine(g1_xyzz_from30(g1_add30(p, q))); memcpy(o, &r, 96); }
+// [k]P by double-and-add with dbl30 / add30 only (k: 8 x u32)
+void hm_mul30_scalar(const uint32_t *a, const uint32_t *k, uint32_t *o) { G1Affine x; memcpy(&x, a, 96);
+    G1Xyzz30 base = g1_from_affine30(g1_affine_to30(x), false), acc = G1Xyzz30::infinity();
+    for (int i = 255; i >= 0; i--) { acc = g1_dbl30(acc); if ((k[i >> 5] >> (i & 31)) & 1) acc = g1_add30(acc, base); }
+    G1Affine r = g1_to_affine(g1_xyzz_from30(acc)); memcpy(o, &r, 96); }
 }
 extern "C" {
 void hm_fq_inv_bgcd(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48); Fq z = inv_bgcd(x); memcpy(o, z.v, 48); }

@@ -94,23 +94,24 @@ def test_g1_ops(L):
     assert L.hm_g1_on_curve(P[:95] + bytes([P[95] ^ 1])) == 0
 
 
-def test_fq29_unsaturated_layer(L):
-    """field29.h / curve29.h (the 14 x 29-bit representation used by k_accum_affine) vs the oracle."""
-    rng = random.Random(29)
+def test_fq30_unsaturated_layer(L):
+    """field30.h / curve30.h (the signed 13 x 30-bit representation used by k_accum_affine) vs the oracle."""
+    rng = random.Random(30)
     Rq = M.FQ_MONT_R
     ri = pow(Rq, -1, M.Q)
     vals = [0, 1, M.Q - 1, M.Q - 2, (1 << 380) % M.Q] + [rng.randrange(M.Q) for _ in range(200)]
     for a in vals:
-        assert call(L.hm_packunpack29, b(a, 48)) == a
-        assert call(L.hm_roundtrip29, b(a, 48)) == a
+        assert call(L.hm_packunpack30, b(a, 48)) == a
+        assert call(L.hm_roundtrip30, b(a, 48)) == a
     for i in range(200):
         a, c = vals[i % len(vals)], vals[(7 * i + 3) % len(vals)]
-        assert call(L.hm_mul29, b(a, 48), b(c, 48)) == a * c * ri % M.Q
+        assert call(L.hm_mul30, b(a, 48), b(c, 48)) == a * c * ri % M.Q
+        assert call(L.hm_sqr30, b(a, 48)) == a * a * ri % M.Q
     G, INF = C.g1_generator(), bytes(96)
 
     def chain(ps, signs):
         o = ctypes.create_string_buffer(96)
-        L.hm_madd29_chain(b"".join(ps), len(ps), ctypes.c_uint64(signs), o)
+        L.hm_madd30_chain(b"".join(ps), len(ps), ctypes.c_uint64(signs), o)
         return o.raw
 
     def ref(ps, signs):
@@ -133,17 +134,95 @@ def test_fq29_unsaturated_layer(L):
         assert chain(ps, s) == ref(ps, s)
 
 
-def test_fq29_general_add_and_double(L):
-    """g1_add29 / g1_dbl29 (tail kernels of the MSM) on de-normalised, lazily-reduced operands."""
+def test_fq30_general_add_and_double(L):
+    """g1_add30 / g1_dbl30 (tail kernels of the MSM) on de-normalised, lazily-reduced operands."""
     rng = random.Random(31)
     G, INF = C.g1_generator(), bytes(96)
     P = C.g1_mul(G, rng.randrange(1, M.R))
     Q = C.g1_mul(G, rng.randrange(1, M.R))
     nP = C.point_to_blob(M.g1_neg(C.blob_to_point(P)))
     for a, c in [(P, Q), (P, P), (P, nP), (INF, P), (P, INF), (INF, INF), (Q, P)]:
-        assert pt(L.hm_add29, a, c) == C.g1_add(a, c)
+        assert pt(L.hm_add30, a, c) == C.g1_add(a, c)
     for k in (0, 1, 2, 3, M.R - 1, rng.randrange(M.R)):
-        assert pt(L.hm_mul29_scalar, P, b(k, 32)) == C.g1_mul(P, k)
+        assert pt(L.hm_mul30_scalar, P, b(k, 32)) == C.g1_mul(P, k)
+
+
+def test_fq30_raw_limb_bounds(L):
+    """mul30 / sqr30 / muladd30 on raw balanced limbs, including the extreme digits -2^29 and 2^29 that the
+    64-bit column accumulators must survive (26 products of 2^58 per column; the fused multiply-add sets the
+    high part aside in the five columns that hold more than 30): results are exact Montgomery quotients,
+    normalised, and inside the documented magnitude bound."""
+    import struct
+    rng = random.Random(3030)
+    N, B = 13, 30
+    R30, H = 1 << (N * B), 1 << (B - 1)
+
+    def val(l):
+        return sum(v << (B * i) for i, v in enumerate(l))
+
+    def raw(l):
+        return struct.pack("<13i", *l)
+
+    def out(fn, *args):
+        o = ctypes.create_string_buffer(52)
+        fn(*[raw(a) for a in args], o)
+        return list(struct.unpack("<13i", o.raw))
+
+    def limbs(kind):
+        if kind == "max":
+            l = [H - 1] * 12
+        elif kind == "min":
+            l = [-H] * 12
+        elif kind == "neg_of_min":          # limb-wise negation of a normalised value: +2^29 digits
+            l = [H] * 12
+        elif kind == "alt":
+            l = [(-H if i & 1 else H - 1) for i in range(12)]
+        else:
+            l = [rng.randrange(-H, H) for _ in range(12)]
+        return l + [rng.randrange(-(1 << 27), 1 << 27)]   # |value| < 2^387 ~ 80 q
+
+    def check(r, num, bound_q):
+        assert all(-H <= v < H for v in r[:12]), r                       # normalised
+        x = val(r)
+        assert (x * R30 - num) % M.Q == 0                                 # exact Montgomery quotient
+        assert abs(x) * 1000 <= M.Q * int(bound_q * 1000), (abs(x) / M.Q, bound_q)
+
+    kinds = ["max", "min", "neg_of_min", "alt", "rnd", "rnd", "rnd"]
+    qr = M.Q / R30
+    for ka in kinds:
+        for kb in kinds:
+            a, c = limbs(ka), limbs(kb)
+            A, Cv = val(a), val(c)
+            check(out(L.hm_mul30_raw, a, c), A * Cv, 0.5001 + abs(A * Cv) / M.Q / M.Q * qr)
+            e, f = limbs(kb), limbs(ka)
+            E, F = val(e), val(f)
+            check(out(L.hm_muladd30_raw, a, c, e, f), A * Cv + E * F, 0.5001 + (abs(A * Cv) + abs(E * F)) / M.Q / M.Q * qr)
+        if ka != "neg_of_min":                 # sqr30 doubles its operand: needs the normalised range
+            a = limbs(ka)
+            check(out(L.hm_sqr30_raw, a), val(a) ** 2, 0.5001 + val(a) ** 2 / M.Q / M.Q * qr)
+    # same-sign worst case for every column at once
+    a = [H] * 12 + [1 << 20]
+    check(out(L.hm_muladd30_raw, a, a, a, a), 2 * val(a) ** 2, 0.5001 + 2 * val(a) ** 2 / M.Q / M.Q * qr)
+    na = [-H] * 12 + [-(1 << 20)]
+    check(out(L.hm_muladd30_raw, a, na, a, na), 2 * val(a) * val(na), 0.5001 + 2 * val(a) ** 2 / M.Q / M.Q * qr)
+    # normalize30: any limbs below 2^31 - 2^29 in magnitude -> the unique normalised form of the same integer
+    for _ in range(50):
+        l = [rng.randrange(-3 * H + 1, 3 * H) for _ in range(12)] + [rng.randrange(-(1 << 20), 1 << 20)]
+        r = out(L.hm_normalize30_raw, l)
+        assert val(r) == val(l) and all(-H <= v < H for v in r[:12])
+    # from30 on lazy values up to 256 q in magnitude, either sign: canonical x / R30 * R384
+    Rq = M.FQ_MONT_R
+    for _ in range(50):
+        x = rng.randrange(-255 * M.Q, 255 * M.Q)
+        l, t = [], x
+        for _i in range(12):
+            d = ((t + H) % (1 << B)) - H
+            l.append(d)
+            t = (t - d) >> B
+        l.append(t)
+        o = ctypes.create_string_buffer(48)
+        L.hm_from30_raw(raw(l), o)
+        assert int.from_bytes(o.raw, "little") == x * pow(R30, -1, M.Q) * Rq % M.Q
 
 
 def test_fr29_ntt_arithmetic(L):
