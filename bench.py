@@ -34,13 +34,14 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_TERM = 128           # 32 B scalar + 96 B affine point per MSM term
-# The resource that actually binds k_accum_affine: v_mad_u64_u32 issue.  One bucket addition executes
-# 8 mul29 (392 mads) + 2 sqr29 (301) + one fused double product (588) = 3934 mads per lane (static count from the ISA);
-# tools/microbench.hip measured the chip's v_mad_u64_u32 rate: 30.9 T lane-op/s at 8 waves/SIMD, 23.2 T at the 2
-# waves/SIMD a 256-VGPR kernel can hold (profiles/r01_microbench.txt).
-MADS_PER_ADD = 8 * 392 + 2 * 301 + 588
-MAD_PEAK_TLANE_S = 30.93
-MAD_PEAK_OCC2_TLANE_S = 23.21
+# The resource that actually binds k_accum_affine: VALU issue, dominated by v_mad_i64_i32.  One bucket
+# addition executes 6 mul30 (338 mads) + 2 sqr30 (260) + one fused double product with a single reduction (507) = 3055
+# mads per lane (static count from the ISA; 4379 VALU instructions in all by SQ_INSTS_VALU).  tools/microbench.hip
+# measured the chip's 64-bit multiply-add rate: 31.5 T lane-op/s at 8 waves/SIMD, 23.7 T at the 2 waves/SIMD a
+# 215-VGPR kernel holds (profiles/r01_microbench.txt).
+MADS_PER_ADD = 6 * 338 + 2 * 260 + 507
+MAD_PEAK_TLANE_S = 31.51
+MAD_PEAK_OCC2_TLANE_S = 23.70
 TAU = 0x5EED5EED5EED5EED       # known secret for the synthetic SRS (setup(s, n), src/lib.rs:38)
 
 
@@ -109,6 +110,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="commitments per step (pipelined on the engine's HIP streams)")
     ap.add_argument("--streams", type=int, default=16, help="HIP streams the engine pipelines a batch over (0 = engine default, 8)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks (0 = default)")
+    ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (kzg_ctx_set_option), repeatable")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--window-bits", type=int, default=0, help="engine option window_bits (0 = engine default)")
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
@@ -149,6 +151,9 @@ def main():
         engine.set_option("streams", args.streams)
     if args.accum_blocks:
         engine.set_option("accum_blocks_batch", args.accum_blocks)
+    for kv in args.opt:
+        key, val = kv.split("=")
+        engine.set_option(key, int(val))
 
     def barrier():
         if dist is not None:
@@ -241,14 +246,14 @@ def main():
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                         "algorithmic_bytes_per_launch": BYTES_PER_TERM * n, "launches": launches,
                         "avg_kernel_ms": round(avg_s * 1e3, 4),
-                        "note": "binding resource is integer VALU issue (~5e4 32-bit multiply-adds per term), not HBM; "
+                        "note": "binding resource is integer VALU issue (~4.9e4 32-bit multiply-adds per term), not HBM; "
                                 "see DESIGN.md 3.2",
                         "kernel_ms_per_msm": {k: round(v[1] / per_msm, 4) for k, v in sorted(prof.items())}}
             # informational: the same kernel against the integer-multiply issue rate, over the whole timed region
             # (launches overlap on 8 streams, so the aggregate rate is the meaningful one)
             mads = float(launches) * n * (4 if args.u64 else W) * MADS_PER_ADD  # u64-valued scalars: 4 non-zero 16-bit windows
             t_mad = mads / dt / 1e12
-            roofline["valu"] = {"resource": "v_mad_u64_u32 issue", "achieved": round(t_mad, 2), "unit": "T lane-mad/s",
+            roofline["valu"] = {"resource": "v_mad_i64_i32 issue", "achieved": round(t_mad, 2), "unit": "T lane-mad/s",
                                 "peak": MAD_PEAK_TLANE_S, "frac": round(t_mad / MAD_PEAK_TLANE_S, 4),
                                 "peak_at_2_waves_per_simd": MAD_PEAK_OCC2_TLANE_S,
                                 "frac_of_occupancy_2_peak": round(t_mad / MAD_PEAK_OCC2_TLANE_S, 4),

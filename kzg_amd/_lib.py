@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libkzg_mi355x.so")
+SO_PATH = os.environ.get("KZG_LIB") or os.path.join(HERE, "libkzg_mi355x.so")  # KZG_LIB: A/B another build of the same ABI
 
 KZG_OK = 0
 KZG_ERR_POINT_NOT_ON_POLY = 1

@@ -264,8 +264,12 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
         if (value < 1 || value > 16) return fail(ctx, KZG_ERR_SHAPE, "streams must be 1..16");
         ctx->opt_streams = (int)value;
     } else if (k == "accum_blocks" || k == "accum_blocks_batch") {
-        if (value < 64 || value > 512) return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 64..512");
+        if (value != 0 && (value < 64 || value > 256 * KZG_ACCUM_WAVES))
+            return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 0 (auto) or 64..256 x waves per SIMD");
         (k == "accum_blocks" ? ctx->opt_accum_blocks : ctx->opt_accum_blocks_batch) = (int)value;
+    } else if (k == "sort_threads" || k == "sort_threads_batch") {
+        if (value != 256 && value != 512 && value != 1024) return fail(ctx, KZG_ERR_SHAPE, "sort_threads must be 256, 512 or 1024");
+        (k == "sort_threads" ? ctx->opt_sort_threads : ctx->opt_sort_threads_batch) = (int)value;
     } else if (k == "ntt_vec_log") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_vec_log must be 0..2");
         ctx->opt_ntt_vec_log = (int)value;
@@ -396,7 +400,8 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
     if (batch == 0) return KZG_OK;
     int nl = (int)std::min<size_t>(batch, (size_t)ctx->opt_streams);
     KZG_TRY(ensure_lanes(ctx, nl));
-    ctx->cur_accum_blocks = nl > 1 ? ctx->opt_accum_blocks_batch : ctx->opt_accum_blocks;
+    ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
+    ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
     size_t per = msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192;
     for (int l = 0; l < nl; l++) KZG_TRY(lane_reserve(ctx, l, per));
     uint8_t *d_out = nullptr;
@@ -425,7 +430,8 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
         if (rc == KZG_OK) rc = emit_point(ctx, l, res, d_out + b * psz, ofmt);
     }
     for (int l = 0; l < nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
-    ctx->cur_accum_blocks = ctx->opt_accum_blocks;
+    ctx->cur_accum_blocks = ctx->accum_blocks_single();
+    ctx->cur_sort_threads = ctx->opt_sort_threads;
     if (rc == KZG_OK && !out_dev) {
         hipError_t e = hipMemcpy(out, d_out, batch * psz, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));

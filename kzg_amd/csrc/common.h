@@ -43,6 +43,10 @@ struct EvalDomainTables;
 
 }  // namespace kzg
 
+#ifndef KZG_ACCUM_WAVES
+#define KZG_ACCUM_WAVES 2  // waves per SIMD k_accum_affine is compiled for (VGPR budget 512 / waves)
+#endif
+
 struct kzg_ctx {
     int device = 0;
     std::mutex mu;
@@ -50,11 +54,16 @@ struct kzg_ctx {
     std::vector<kzg::Lane> lanes;
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 8;
-    int opt_accum_blocks = 512;        // k_accum_affine grid for a single MSM: every SIMD holds its 2 waves
+    int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
-    int opt_accum_blocks_batch = 480;  // batched MSMs: leave 1/16 of the wave slots to the latency-bound tail and sort
+    int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)
-    int cur_accum_blocks = 512;        // value msm_run uses (set by the entry point)
+    int cur_accum_blocks = 256 * KZG_ACCUM_WAVES;  // value msm_run uses (set by the entry point)
+    int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
+    int opt_sort_threads_batch = 1024; // ... for batched MSMs
+    int cur_sort_threads = 1024;
+    int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
+    int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
     int num_cus = 256;
     bool attr_msm_set = false, attr_ntt_set = false, attr_wide_set = false;  // > 64 KiB dynamic-LDS opt-in done for this device
     // profiling

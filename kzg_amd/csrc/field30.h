@@ -165,9 +165,11 @@ KZG_HD Fq30 sqr30_inline(const Fq30 &a) {
     return r;
 }
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_INLINE_MUL30)
-// ONE out-of-line body per operation (operands travel in VGPR tuples; struct arguments would go through scratch):
-// a mixed addition is ~25 KB of code instead of ~100 KB.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(KZG_OOL_MUL30)
+// Optional (-DKZG_OOL_MUL30): ONE out-of-line body per operation (operands travel in VGPR tuples; struct arguments
+// would go through scratch): a mixed addition is ~25 KB of code instead of ~80 KB.  Measured slower than inlining
+// on gfx950 (k_accum_affine 2.76 vs 2.53 ms, same-box A/B: no argument shuffling, scheduling across the call
+// boundaries, 215 instead of 229 VGPRs), so the default build inlines every multiply.
 typedef int32_t i32x13 __attribute__((ext_vector_type(13)));
 __device__ __noinline__ i32x13 sqr30_ool(i32x13 a) {
     Fq30 x;

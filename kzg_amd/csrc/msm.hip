@@ -166,7 +166,7 @@ __device__ __forceinline__ G1Affine30 load_entry_point30(const uint4 *table30, u
 // resident 30-bit table (next point prefetched under the add), and writes one partial per bucket it
 // touches.  Every thread has the same amount of work,
 // so the kernel ends without a straggler round.
-__global__ __launch_bounds__(256) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
+__global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uint32_t *entries, const uint32_t *bucket_start,
                                                       const uint32_t *s1, int B, const uint4 *table30,
                                                       MsmPoint *out, const MsmState *st) {
     const uint32_t E = st->E, M = st->M;
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const ui
 // ---------------------------------------------------------------------------------------------
 // sum_b (b + 1) * bucket[b]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_bucket_reduce(const MsmPoint *buf0, const MsmPoint *buf1,
+__global__ __launch_bounds__(256) void k_bucket_reduce(const MsmPoint *buf0, const MsmPoint *buf1,
                                                       const uint32_t *starts, int B, int CH, MsmPoint *out,
                                                       const MsmState *st) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(64) void k_bucket_reduce(const MsmPoint *buf0, cons
     out[t] = acc;
 }
 
-__global__ __launch_bounds__(64) void k_sum_level(const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
+__global__ __launch_bounds__(256) void k_sum_level(const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t nout = (count + L - 1) / L;
     if (t >= nout) return;
@@ -578,11 +578,11 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     auto start_arr = [&](int level) { return starts + (size_t)level * (Btot + 1); };
 
     // pass 1: LDS counting sort by the low 15 bucket bits (hi rides in the entry word)
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist);
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B_lo + 255) / 256, 256, 0, blk_hist, G, B_lo, total);
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;
     KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B_lo, lo_start, s1_lo, state, slots);  // M, E, ntasks
-    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
+    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
                (uint32_t)srs->npad, (uint32_t)offset, entries1);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
     KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
@@ -617,7 +617,7 @@ size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) {
 
 int sum_level_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
     size_t nout = (count + L - 1) / L;
-    KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + 63) / 64), 64, 0, in, count, L, out);
+    KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + TAIL_THREADS - 1) / TAIL_THREADS), TAIL_THREADS, 0, in, count, L, out);
     return KZG_OK;
 }
 
@@ -628,7 +628,7 @@ int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, Msm
     int which = 0;
     while (count > 1) {
         size_t nout = (count + SUM_L - 1) / SUM_L;
-        KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + 63) / 64), 64, 0, in, (uint32_t)count,
+        KZG_LAUNCH(ctx, st, "k_sum_level", k_sum_level, (unsigned)((nout + TAIL_THREADS - 1) / TAIL_THREADS), TAIL_THREADS, 0, in, (uint32_t)count,
                    SUM_L, bufs[which]);
         in = bufs[which];
         which ^= 1;
@@ -672,12 +672,12 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     size_t lds_bytes = (size_t)B * 4;
     auto start_arr = [&](int level) { return starts + (size_t)level * (B + 1); };
 
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
     // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
     KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, slots);
-    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, 1024, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
+    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
     // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
@@ -700,7 +700,7 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     KZG_TRY(fold_rest_run(ctx, st, bufs[0], bufs[1], starts, B, LK, fast, L.levels, state));
     int CH = B < REDUCE_CH ? B : REDUCE_CH;
     int nchunks = B / CH;
-    KZG_LAUNCH(ctx, st, "k_bucket_reduce", k_bucket_reduce, (nchunks + 63) / 64, 64, 0, bufs[0], bufs[1], starts, B,
+    KZG_LAUNCH(ctx, st, "k_bucket_reduce", k_bucket_reduce, (nchunks + TAIL_THREADS - 1) / TAIL_THREADS, TAIL_THREADS, 0, bufs[0], bufs[1], starts, B,
                CH, chunks, state);
     MsmPoint *sum = nullptr;
     KZG_TRY(sum_points_run(ctx, lane, chunks, nchunks, sum_scratch, &sum));

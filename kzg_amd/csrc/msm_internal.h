@@ -7,7 +7,11 @@
 
 namespace kzg {
 
-constexpr uint32_t ACC_SLOTS = 256 * 8 * 64;  // resident threads of k_accum_affine: 256 CUs x 2 waves/SIMD x 4 SIMDs x 64
+constexpr uint32_t ACC_SLOTS = 256 * 4 * KZG_ACCUM_WAVES * 64;  // resident threads of k_accum_affine: 256 CUs x 4 SIMDs x waves/SIMD x 64
+// Latency-bound tail kernels run next to other MSMs' accumulation kernels (batched mode).  A block of k_accum_affine is 4
+// waves, one per SIMD of a CU, so a lone 64-thread tail block on one SIMD strands the other three SIMDs of that
+// half-CU for as long as it lives; 256-thread tail blocks take exactly one accumulation-block slot instead.
+constexpr int TAIL_THREADS = 256;
 constexpr int LK = 4;   // fan-in of the later fold rounds
 constexpr int SUM_L = 4;  // fan-in of the plain tree sum
 constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread

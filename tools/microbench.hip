@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include "../kzg_amd/csrc/curve.h"
+#include "../kzg_amd/csrc/field30.h"
 using namespace kzg;
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1);} } while (0)
@@ -45,6 +46,12 @@ __global__ __launch_bounds__(256) void k_rate(uint32_t *out, int iters, uint32_t
 #define M(c) { uint32_t lo = (uint32_t)c; asm volatile("v_add_u32 %0, %0, %1" : "+v"(lo) : "v"(a)); c = lo; }
             M(c0) M(c1) M(c2) M(c3) M(c4) M(c5) M(c6) M(c7)
 #undef M
+        } else if (OP == 8) {  // the instruction mix of mul30: mostly v_mad_i64_i32 with a few 64-bit shifts / adds and 32-bit ops
+#define M(c) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+            M(c0) M(c1) M(c2) M(c3) M(c4) M(c5)
+#undef M
+            asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(c6) : "v"(c0));
+            asm volatile("v_ashrrev_i64 %0, 30, %0" : "+v"(c7));
         } else if (OP == 7) {
 #define M(c) { uint32_t lo = (uint32_t)c; asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(lo) : "v"(a)); c = lo; }
             M(c0) M(c1) M(c2) M(c3) M(c4) M(c5) M(c6) M(c7)
@@ -62,6 +69,17 @@ __global__ __launch_bounds__(256) void k_fmul(F *out, const F *in, int iters) {
     F x = in[i], y = in[i + 1];
     for (int k = 0; k < iters; k++) { F z = mul(x, y); x = y; y = z; }
     out[i] = y;
+}
+
+// chain of dependent mul30 (the MSM multiply, inlined), seeded with normalised limbs
+__global__ __launch_bounds__(256) void k_fmul30(int32_t *out, int iters, int32_t seed) {
+    Fq30 x, y;
+    for (int i = 0; i < F30_N; i++) { x.v[i] = sext30((uint32_t)(seed * (i + 3) + threadIdx.x * 77)); y.v[i] = sext30((uint32_t)(seed * (i + 11) + blockIdx.x * 131)); }
+    x.v[F30_N - 1] >>= 12; y.v[F30_N - 1] >>= 12;
+    for (int k = 0; k < iters; k++) { Fq30 z = mul30_inline(x, y); x = y; y = z; }
+    int32_t t = 0;
+    for (int i = 0; i < F30_N; i++) t ^= y.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t;
 }
 
 __global__ __launch_bounds__(256) void k_madd(G1Xyzz *out, const G1Affine *pts, int iters) {
@@ -97,11 +115,13 @@ int main() {
     int cus = p.multiProcessorCount;
     printf("device %s, %d CUs, clock %d kHz\n", p.name, cus, p.clockRate);
     uint32_t *out; CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 8));
-    const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_fma_f64", "v_lshl_add_u64", "v_add_u32", "v_mad_u32_u24"};
+    const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_u32_u24", "v_fma_f64", "v_lshl_add_u64", "v_add_u32", "v_mad_u32_u24", "mix 6 mad_i64:2 x64"};
     int iters = 4096;
-    for (int wps = 1; wps <= 8; wps *= 2) {  // waves per SIMD = blocks of 256 threads per CU
+    const int wlist[] = {1, 2, 3, 4, 6, 8};
+    for (int wi = 0; wi < 6; wi++) {  // waves per SIMD = blocks of 256 threads per CU
+        const int wps = wlist[wi];
         dim3 grid(cus * wps), block(256);
-        double ms[8];
+        double ms[9];
         ms[0] = time_kernel(k_rate<0>, grid, block, 5, out, iters, 7u);
         ms[1] = time_kernel(k_rate<1>, grid, block, 5, out, iters, 7u);
         ms[2] = time_kernel(k_rate<2>, grid, block, 5, out, iters, 7u);
@@ -110,11 +130,20 @@ int main() {
         ms[5] = time_kernel(k_rate<5>, grid, block, 5, out, iters, 7u);
         ms[6] = time_kernel(k_rate<6>, grid, block, 5, out, iters, 7u);
         ms[7] = time_kernel(k_rate<7>, grid, block, 5, out, iters, 7u);
-        for (int o = 0; o < 8; o++) {
+        ms[8] = time_kernel(k_rate<8>, grid, block, 5, out, iters, 7u);
+        for (int o = 0; o < 9; o++) {
             double ops = (double)cus * wps * 256 * iters * 8;
             printf("waves/SIMD %d  %-16s %8.3f ms  %8.2f Tlane-op/s  (%.2f cycles/wave-instr/SIMD @2.4GHz)\n", wps, names[o], ms[o],
                    ops / ms[o] / 1e9, ms[o] * 1e-3 * 2.4e9 / ((double)iters * 8 * wps));
         }
+    }
+    for (int wi = 0; wi < 6; wi++) {
+        const int wps = wlist[wi];
+        dim3 grid(cus * wps), block(256);
+        int it = 2000;
+        double t = time_kernel(k_fmul30, grid, block, 3, (int32_t *)out, it, 12345);
+        printf("waves/SIMD %d  Fq30 mul (inline chain) %7.2f G/s (%6.0f cyc/wave-mul/SIMD)\n", wps, (double)cus * wps * 256 * it / t / 1e6,
+               t * 1e-3 * 2.4e9 / ((double)it * wps));
     }
     // field multiply / mixed add throughput
     size_t nthreads = (size_t)cus * 8 * 256;
