@@ -236,6 +236,10 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
         if (l.stream) hipStreamDestroy(l.stream);
     }
     for (auto e : ctx->event_pool) hipEventDestroy(e);
+    for (auto e : ctx->sorted_events) hipEventDestroy(e);
+    for (auto e : ctx->accum_events) hipEventDestroy(e);
+    for (auto st : ctx->accum_streams)
+        if (st) hipStreamDestroy(st);
     if (ctx->batch_out) hipFree(ctx->batch_out);
     ntt_plans_free(ctx);
     eval_tabs_free(ctx);
@@ -267,9 +271,15 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
         if (value != 0 && (value < 64 || value > 256 * KZG_ACCUM_WAVES))
             return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 0 (auto) or 64..256 x waves per SIMD");
         (k == "accum_blocks" ? ctx->opt_accum_blocks : ctx->opt_accum_blocks_batch) = (int)value;
+    } else if (k == "scan_threads" || k == "scan_threads_batch") {
+        if (value != 256 && value != 512 && value != 1024) return fail(ctx, KZG_ERR_SHAPE, "scan_threads must be 256, 512 or 1024");
+        (k == "scan_threads" ? ctx->opt_scan_threads : ctx->opt_scan_threads_batch) = (int)value;
     } else if (k == "sort_threads" || k == "sort_threads_batch") {
         if (value != 256 && value != 512 && value != 1024) return fail(ctx, KZG_ERR_SHAPE, "sort_threads must be 256, 512 or 1024");
         (k == "sort_threads" ? ctx->opt_sort_threads : ctx->opt_sort_threads_batch) = (int)value;
+    } else if (k == "accum_streams") {
+        if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
+        ctx->opt_accum_streams = (int)value;
     } else if (k == "ntt_vec_log") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_vec_log must be 0..2");
         ctx->opt_ntt_vec_log = (int)value;
@@ -402,6 +412,7 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
     KZG_TRY(ensure_lanes(ctx, nl));
     ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
     ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
+    ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
     size_t per = msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192;
     for (int l = 0; l < nl; l++) KZG_TRY(lane_reserve(ctx, l, per));
     uint8_t *d_out = nullptr;
@@ -420,18 +431,41 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
         d_out = (uint8_t *)ctx->batch_out;
     }
     int rc = KZG_OK;
-    for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
-        int l = (int)(b % nl);
-        ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
-        const void *d_sc = nullptr;
-        rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
-        MsmPoint *res = nullptr;
-        if (rc == KZG_OK) rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res);
-        if (rc == KZG_OK) rc = emit_point(ctx, l, res, d_out + b * psz, ofmt);
+    {
+        // dedicated accumulation streams only when every stream can have a hardware queue of its own (the runtime reads
+        // GPU_MAX_HW_QUEUES when it initialises; its default of 4 multiplexes the streams, and a shared queue costs more than the
+        // FIFO order gains)
+        const char *hwq = getenv("GPU_MAX_HW_QUEUES");
+        const int nas = (nl > 1 && hwq && atoi(hwq) >= nl + ctx->opt_accum_streams) ? ctx->opt_accum_streams : 0;
+        for (int i = 0; i < nas && rc == KZG_OK; i++)
+            if (!ctx->accum_streams[i] && hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking) != hipSuccess)
+                rc = fail(ctx, KZG_ERR_HIP, "hipStreamCreate");
+        while (nas && (int)ctx->sorted_events.size() < nl && rc == KZG_OK) {
+            hipEvent_t e1 = nullptr, e2 = nullptr;
+            if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
+                rc = fail(ctx, KZG_ERR_HIP, "hipEventCreate");
+            ctx->sorted_events.push_back(e1);
+            ctx->accum_events.push_back(e2);
+        }
+        for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
+            int l = (int)(b % nl);
+            ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
+            const void *d_sc = nullptr;
+            rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
+            MsmPoint *res = nullptr;
+            if (rc == KZG_OK) {
+                if (nas)
+                    rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res, ctx->accum_streams[b % nas], ctx->sorted_events[l], ctx->accum_events[l]);
+                else
+                    rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res);
+            }
+            if (rc == KZG_OK) rc = emit_point(ctx, l, res, d_out + b * psz, ofmt);
+        }
     }
     for (int l = 0; l < nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
     ctx->cur_accum_blocks = ctx->accum_blocks_single();
     ctx->cur_sort_threads = ctx->opt_sort_threads;
+    ctx->cur_scan_threads = ctx->opt_scan_threads;
     if (rc == KZG_OK && !out_dev) {
         hipError_t e = hipMemcpy(out, d_out, batch * psz, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));

@@ -59,6 +59,18 @@ struct kzg_ctx {
     int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)
     int cur_accum_blocks = 256 * KZG_ACCUM_WAVES;  // value msm_run uses (set by the entry point)
+    // kzg_msm_g1_batch: every k_accum_affine runs on one of this many dedicated streams, in submission order (0 = on its lane's
+    // stream).  With the accumulation on the lanes' own streams the lanes fall into a convoy -- all sorting, then up to nine
+    // accumulation kernels resident at once, then all in their tails -- and no accumulation kernel is resident 6 % of the time
+    // (rocprofv3 kernel trace); two FIFO streams keep exactly the next one or two queued behind the running one: +3.5 %.
+    // Needs its own hardware queues (GPU_MAX_HW_QUEUES >= lanes + 2): sharing a queue with a lane serialises them (-10 %).
+    int opt_accum_streams = 2;
+    hipStream_t accum_streams[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> sorted_events, accum_events;  // per lane
+    int opt_scan_threads = 1024;       // threads of the single-block scan kernels (k_scan_buckets, k_level_scan, k_fold_rest), single MSM
+    int opt_scan_threads_batch = 256;  // batched MSMs: a 256-thread block (<= 128 VGPRs) fits in any free accumulation-block slot,
+                                       // a 1024-thread block waits for a whole free CU (measured 4-7 ms per launch in a full pipeline)
+    int cur_scan_threads = 1024;
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
     int opt_sort_threads_batch = 1024; // ... for batched MSMs
     int cur_sort_threads = 1024;
@@ -148,8 +160,9 @@ typedef G1Xyzz30 MsmPoint;
 // msm.hip
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n);
 // d_scalars: device pointer to n scalars (sfmt); result: one device MsmPoint in the lane arena
+// accum_stream (optional): run k_accum_affine there instead of on the lane's stream, ordered by the two caller-owned events
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-            MsmPoint **d_result);
+            MsmPoint **d_result, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr, hipEvent_t accum_ev = nullptr);
 // d_points: count points -> one point (plain sum)
 int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result);
 // conversions between the canonical saturated XYZZ form and MsmPoint (device arrays)

@@ -225,26 +225,24 @@ __global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uin
 }
 
 // per-level task layout: ntask[b] = ceil(cnt[b] / L); also detects "every bucket <= 1 partial"
-__global__ __launch_bounds__(1024) void k_level_scan(const uint32_t *in_start, uint32_t *out_task_start, int B,
-                                                     int L, MsmState *st, uint32_t level, uint32_t in_buf) {
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t smax;
+__device__ __forceinline__ void level_scan_body(const uint32_t *in_start, uint32_t *out_task_start, int B, int L, MsmState *st,
+                                                uint32_t level, uint32_t in_buf, uint32_t *lds, uint32_t *smax) {
     if (st->done) return;
-    if (threadIdx.x == 0) smax = 0;
+    if (threadIdx.x == 0) *smax = 0;
     __syncthreads();
     uint32_t mx = 0;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         uint32_t cnt = in_start[b + 1] - in_start[b];
         mx = cnt > mx ? cnt : mx;
     }
-    atomicMax(&smax, mx);
+    atomicMax(smax, mx);
     __syncthreads();
-    if (smax <= 1) {
+    if (*smax <= 1) {
         if (threadIdx.x == 0) {
             st->done = 1;
             st->final_level = level;
             st->final_buf = in_buf;
-            st->max_cnt = smax;
+            st->max_cnt = *smax;
         }
         return;
     }
@@ -252,13 +250,19 @@ __global__ __launch_bounds__(1024) void k_level_scan(const uint32_t *in_start, u
         B, [&](int b) { return (in_start[b + 1] - in_start[b] + L - 1) / L; }, out_task_start, lds);
     if (threadIdx.x == 0) {
         st->ntasks = T;
-        st->max_cnt = smax;
+        st->max_cnt = *smax;
     }
 }
 
-__global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const uint32_t *in_start,
-                                                    const uint32_t *task_start, int B, int L, MsmPoint *out,
-                                                    const MsmState *st) {
+__global__ __launch_bounds__(1024) void k_level_scan(const uint32_t *in_start, uint32_t *out_task_start, int B,
+                                                     int L, MsmState *st, uint32_t level, uint32_t in_buf) {
+    __shared__ uint32_t lds[1024];
+    __shared__ uint32_t smax;
+    level_scan_body(in_start, out_task_start, B, L, st, level, in_buf, lds, &smax);
+}
+
+__device__ __forceinline__ void accum_xyzz_body(const MsmPoint *in, const uint32_t *in_start, const uint32_t *task_start, int B,
+                                                int L, MsmPoint *out, const MsmState *st) {
     if (st->done) return;
     const uint32_t T = st->ntasks;
     for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
@@ -273,12 +277,17 @@ __global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const ui
     }
 }
 
+__global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const uint32_t *in_start,
+                                                    const uint32_t *task_start, int B, int L, MsmPoint *out,
+                                                    const MsmState *st) {
+    accum_xyzz_body(in, in_start, task_start, B, L, out, st);
+}
+
 // ---------------------------------------------------------------------------------------------
 // sum_b (b + 1) * bucket[b]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_bucket_reduce(const MsmPoint *buf0, const MsmPoint *buf1,
-                                                      const uint32_t *starts, int B, int CH, MsmPoint *out,
-                                                      const MsmState *st) {
+__device__ __forceinline__ void bucket_reduce_body(const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int B, int CH,
+                                                   MsmPoint *out, const MsmState *st) {
     int t = blockIdx.x * blockDim.x + threadIdx.x;
     int nchunks = B / CH;
     if (t >= nchunks) return;
@@ -301,6 +310,12 @@ __global__ __launch_bounds__(256) void k_bucket_reduce(const MsmPoint *buf0, con
         acc = g1_add30(acc, m);
     }
     out[t] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_bucket_reduce(const MsmPoint *buf0, const MsmPoint *buf1,
+                                                      const uint32_t *starts, int B, int CH, MsmPoint *out,
+                                                      const MsmState *st) {
+    bucket_reduce_body(buf0, buf1, starts, B, CH, out, st);
 }
 
 __global__ __launch_bounds__(256) void k_sum_level(const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
@@ -331,23 +346,21 @@ __device__ bool fq_lexicographically_largest(const Fq &canon) {  // y > (q-1)/2
     return false;
 }
 
-__global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= count) return;
-    const G1Xyzz p = g1_xyzz_from30(pts[i * stride_pts]);
+// one point -> `fmt` at `o` (one thread; includes the Fq inversion of to_affine)
+__device__ void emit_one(const MsmPoint &pt, uint8_t *o, int fmt) {
+    const G1Xyzz p = g1_xyzz_from30(pt);
     if (fmt == KZG_G1_JACOBIAN_MONT_144) {
         G1Jacobian j = g1_to_jacobian(p);
-        *reinterpret_cast<G1Jacobian *>(out + i * 144) = j;
+        *reinterpret_cast<G1Jacobian *>(o) = j;
         return;
     }
     G1Affine a = g1_to_affine(p);
     if (fmt == KZG_G1_AFFINE_MONT_96) {
-        *reinterpret_cast<G1Affine *>(out + i * 96) = a;
+        *reinterpret_cast<G1Affine *>(o) = a;
         return;
     }
     Fq x = from_mont(a.x), y = from_mont(a.y);
     if (fmt == KZG_G1_ZCASH_UNCOMPRESSED_96) {
-        uint8_t *o = out + i * 96;
         if (a.is_inf()) {
             for (int k = 0; k < 96; k++) o[k] = 0;
             o[0] = 0x40;
@@ -356,7 +369,6 @@ __global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t 
             write_be48(o + 48, y);
         }
     } else {  // compressed
-        uint8_t *o = out + i * 48;
         if (a.is_inf()) {
             for (int k = 0; k < 48; k++) o[k] = 0;
             o[0] = 0xC0;
@@ -366,6 +378,16 @@ __global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t 
             if (fq_lexicographically_largest(y)) o[0] |= 0x20;
         }
     }
+}
+
+__device__ __forceinline__ size_t format_bytes_dev(int fmt) {
+    return fmt == KZG_G1_JACOBIAN_MONT_144 ? 144 : fmt == KZG_G1_ZCASH_COMPRESSED_48 ? 48 : 96;
+}
+
+__global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    emit_one(pts[i * stride_pts], out + i * format_bytes_dev(fmt), fmt);
 }
 
 // out[g] = sum_{i < count} pts[g * count + i]   (count is small: one partial per GPU)
@@ -581,7 +603,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B_lo + 255) / 256, 256, 0, blk_hist, G, B_lo, total);
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;
-    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B_lo, lo_start, s1_lo, state, slots);  // M, E, ntasks
+    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, ctx->cur_scan_threads, 0, total, B_lo, lo_start, s1_lo, state, slots);  // M, E, ntasks
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
                (uint32_t)srs->npad, (uint32_t)offset, entries1);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
@@ -638,20 +660,17 @@ int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, Msm
     return KZG_OK;
 }
 
-int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-            MsmPoint **d_result) {
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
-    if (srs->c > 16) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
-    if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
+// Stage 1 of an MSM: counting sort (on the lane's stream) + bucket accumulation (on `accum_stream`, which is the lane's stream
+// unless the batched pipeline runs every accumulation kernel on dedicated streams: then `sorted_ev` / `accum_ev` order the two).
+// Leaves the round-1 partial list (bufA), its per-bucket starts (start_arr(0)) and the state block in the lane arena at the
+// offsets of msm_layout(srs, n); *base_out = arena base.
+static int msm_stage1(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
+                      const MsmLayout &L, char **base_out, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr,
+                      hipEvent_t accum_ev = nullptr) {
     hipStream_t st = ctx->lanes[lane].stream;
-    MsmLayout L = msm_layout(srs, n ? n : 1);
     char *base = (char *)lane_alloc(ctx, lane, L.bytes);
     if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
-    MsmPoint *result = (MsmPoint *)(base + L.off_result);
-    *d_result = result;
-    if (n == 0) {
-        return point_set_infinity(ctx, st, result);
-    }
+    *base_out = base;
     if (!ctx->attr_msm_set) {  // per context (= per device): the LDS opt-in is a per-device function attribute
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
@@ -664,33 +683,54 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     uint32_t *starts = (uint32_t *)(base + L.off_starts);
     MsmState *state = (MsmState *)(base + L.off_state);
     uint32_t *entries = (uint32_t *)(base + L.off_entries);
-    MsmPoint *bufs[2] = {(MsmPoint *)(base + L.off_bufA), (MsmPoint *)(base + L.off_bufB)};
-    MsmPoint *chunks = (MsmPoint *)(base + L.off_chunks);
-    MsmPoint *sum_scratch = (MsmPoint *)(base + L.off_sum);
+    MsmPoint *bufA = (MsmPoint *)(base + L.off_bufA);
     const Fr *sc = (const Fr *)d_scalars;
     size_t per_block = (n + G - 1) / G;
     size_t lds_bytes = (size_t)B * 4;
-    auto start_arr = [&](int level) { return starts + (size_t)level * (B + 1); };
 
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
-    // start_arr(0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
+    // starts[0 .. B] (level 0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
-    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, 1024, 0, total, B, bucket_start, start_arr(0), state, slots);
+    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, ctx->cur_scan_threads, 0, total, B, bucket_start, starts, state, slots);
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
+    hipStream_t as = st;
+    if (accum_stream && accum_stream != st) {
+        KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
+        KZG_HIP_CHECK(ctx, hipStreamWaitEvent(accum_stream, sorted_ev, 0));
+        as = accum_stream;
+    }
     // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, start_arr(0), B,
-               (const uint4 *)srs->table30, bufs[0], state);
+    KZG_LAUNCH(ctx, as, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, starts, B,
+               (const uint4 *)srs->table30, bufA, state);
+    if (as != st) {
+        KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, as));
+        KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
+    }
+    return KZG_OK;
+}
+
+// The rest of one MSM on its own stream: fold the partial sums by bucket, sum_b (b+1) B_b, tree sum -> *d_result.
+static int msm_tail(kzg_ctx *ctx, int lane, const MsmLayout &L, char *base, MsmPoint **d_result) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    const int B = L.B;
+    uint32_t *starts = (uint32_t *)(base + L.off_starts);
+    MsmState *state = (MsmState *)(base + L.off_state);
+    MsmPoint *bufs[2] = {(MsmPoint *)(base + L.off_bufA), (MsmPoint *)(base + L.off_bufB)};
+    MsmPoint *chunks = (MsmPoint *)(base + L.off_chunks);
+    MsmPoint *sum_scratch = (MsmPoint *)(base + L.off_sum);
+    MsmPoint *result = (MsmPoint *)(base + L.off_result);
+    auto start_arr = [&](int level) { return starts + (size_t)level * (B + 1); };
     // fold rounds: the list of level k lives in bufs[k & 1] with per-bucket starts start_arr(k).  Two rounds of fan-in
     // LK settle every input whose buckets were split over <= 16 threads; k_fold_rest finishes the others.
     size_t tmax = L.T1_max;
     const int fast = L.levels < FAST_LEVELS ? L.levels : FAST_LEVELS;
     for (int lv = 1; lv <= fast; lv++) {
         int in_buf = (lv - 1) & 1;
-        KZG_LAUNCH(ctx, st, "k_level_scan", k_level_scan, 1, 1024, 0, start_arr(lv - 1), start_arr(lv), B, LK, state,
+        KZG_LAUNCH(ctx, st, "k_level_scan", k_level_scan, 1, ctx->cur_scan_threads, 0, start_arr(lv - 1), start_arr(lv), B, LK, state,
                    (uint32_t)(lv - 1), (uint32_t)in_buf);
         tmax = tmax / LK + B + 1;
         unsigned grid = (unsigned)((tmax + 255) / 256);
@@ -705,7 +745,25 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     MsmPoint *sum = nullptr;
     KZG_TRY(sum_points_run(ctx, lane, chunks, nchunks, sum_scratch, &sum));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(result, sum, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
+    *d_result = result;
     return KZG_OK;
+}
+
+int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
+            MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
+    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    if (srs->c > 16) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
+    if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
+    MsmLayout L = msm_layout(srs, n ? n : 1);
+    if (n == 0) {
+        char *base = (char *)lane_alloc(ctx, lane, L.bytes);
+        if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
+        *d_result = (MsmPoint *)(base + L.off_result);
+        return point_set_infinity(ctx, ctx->lanes[lane].stream, *d_result);
+    }
+    char *base = nullptr;
+    KZG_TRY(msm_stage1(ctx, lane, srs, offset, d_scalars, n, sfmt, L, &base, accum_stream, sorted_ev, accum_ev));
+    return msm_tail(ctx, lane, L, base, d_result);
 }
 
 }  // namespace kzg

@@ -335,11 +335,9 @@ __global__ void k_combine_shifted(const MsmPoint *a, int shift, const MsmPoint *
 // ---------------------------------------------------------------------------------------------
 // rare path of the c <= 16 pipeline: all fold levels after the first FAST_LEVELS, in one block
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
-                                                    int max_level, MsmState *st) {
+__device__ __forceinline__ void fold_rest_body(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0, int max_level,
+                                               MsmState *st, uint32_t *lds, uint32_t &smax) {
     if (st->done) return;
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t smax;
     int level = level0;
     for (;;) {
         const uint32_t *in_start = starts + (size_t)level * (B + 1);
@@ -382,9 +380,15 @@ __global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *bu
     }
 }
 
+__global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
+                                                    int max_level, MsmState *st) {
+    __shared__ uint32_t lds[1024];
+    __shared__ uint32_t smax;
+    fold_rest_body(buf0, buf1, starts, B, L, level0, max_level, st, lds, smax);
+}
 int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
                   int max_level, MsmState *state) {
-    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, 1024, 0, buf0, buf1, starts, B, L, level0, max_level, state);
+    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, ctx->cur_scan_threads, 0, buf0, buf1, starts, B, L, level0, max_level, state);
     return KZG_OK;
 }
 

@@ -189,6 +189,36 @@ def test_msm_batch_and_sum(engine, srs_small):
     assert engine.g1_sum([want[0], C.point_to_blob(M.g1_neg(C.blob_to_point(want[0])))]) == bytes(96)
 
 
+def test_msm_batch_pipeline_paths(engine):
+    """kzg_msm_g1_batch in its pipelined form (more MSMs than lanes, accumulation kernels on the dedicated FIFO streams,
+    256-thread single-block scans) on adversarial scalar sets that drive the rare paths: all-equal scalars (one bucket per
+    window, deep fold rounds in k_fold_rest), all-zero, u64-valued, and uniform ones -- each vector against the single-MSM
+    entry point and the known-tau identity; then the same with the dedicated streams switched off."""
+    rng = random.Random(2024)
+    n, lanes = 1 << 12, 4
+    params = kzg_amd.setup(engine, TAU, n)
+    srs = params.gs
+    vecs = [rand_scalars(rng, n) for _ in range(5)]
+    vecs += [[rng.randrange(M.R)] * n, [0] * n, rand_scalars(rng, n, "u64"), [M.R - 1] * n, [1] + [0] * (n - 1)]
+    vecs += [rand_scalars(rng, n) for _ in range(3)]                     # 13 MSMs over 4 lanes: every lane re-used 3 times
+    flat = [s for v in vecs for s in v]
+    want = [C.g1_mul(C.g1_generator(), C.poly_eval(v, TAU)) for v in vecs]
+    engine.set_option("streams", lanes)
+    try:
+        for accum_streams, scan_threads in ((2, 256), (1, 1024), (0, 256)):
+            engine.set_option("accum_streams", accum_streams)
+            engine.set_option("scan_threads_batch", scan_threads)
+            assert engine.msm_batch(srs, flat, n, len(vecs)) == want, (accum_streams, scan_threads)
+        engine.set_option("scan_threads", 256)                           # the long-segment scan path in a single MSM
+        assert [engine.msm(srs, v) for v in vecs[4:8]] == want[4:8]
+    finally:
+        engine.set_option("scan_threads", 1024)
+        engine.set_option("scan_threads_batch", 256)
+        engine.set_option("accum_streams", 2)
+        engine.set_option("streams", 8)
+    srs.free()
+
+
 def test_sharded_srs_partials_sum_to_full_commit(engine):
     """Multi-GPU data path on one GPU: 4 contiguous SRS shards (kzg_srs_setup_g1_shard), one partial MSM
     each, kzg_g1_sum of the partials == commit against the full SRS == [p(tau)]G."""

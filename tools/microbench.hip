@@ -71,6 +71,51 @@ __global__ __launch_bounds__(256) void k_fmul(F *out, const F *in, int iters) {
     out[i] = y;
 }
 
+// experiment: the same multiply with every column forced into ONE accumulator chain (inline-asm mads), i.e. without the
+// second chain + 64-bit add per column that the compiler introduces for latency
+__device__ __forceinline__ uint64_t macv(uint64_t acc, int32_t a, int32_t b) { return mac30(acc, a, b); }
+__device__ __forceinline__ uint64_t macs(uint64_t acc, int32_t a, int32_t k) { return mac30(acc, a, k); }
+#define CHAIN_BARRIER(acc) asm("" : "+v"(acc))
+__device__ __forceinline__ Fq30 mul30_chain(const Fq30 &a, const Fq30 &b) {
+    int32_t m[F30_N];
+    Fq30 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < F30_N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc = macv(acc, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = macs(acc, m[i], Fq30Consts::mod(k - i));
+        m[k] = sext30((uint32_t)acc * Fq30Consts::INV);
+        acc = macs(acc, m[k], Fq30Consts::mod(0));
+        acc = sar30(acc);
+        CHAIN_BARRIER(acc);
+    }
+#pragma unroll
+    for (int k = F30_N; k < 2 * F30_N - 1; k++) {
+#pragma unroll
+        for (int i = k - F30_N + 1; i < F30_N; i++) {
+            acc = macv(acc, a.v[i], b.v[k - i]);
+            acc = macs(acc, m[i], Fq30Consts::mod(k - i));
+        }
+        r.v[k - F30_N] = sext30((uint32_t)acc);
+        acc = sar30(acc + (uint64_t)F30_HALF);
+        CHAIN_BARRIER(acc);
+    }
+    r.v[F30_N - 1] = (int32_t)acc;
+    return r;
+}
+template <int CHAIN>
+__global__ __launch_bounds__(256) void k_fmul30x(int32_t *out, int iters, int32_t seed) {
+    Fq30 x, y;
+    for (int i = 0; i < F30_N; i++) { x.v[i] = sext30((uint32_t)(seed * (i + 3) + threadIdx.x * 77)); y.v[i] = sext30((uint32_t)(seed * (i + 11) + blockIdx.x * 131)); }
+    x.v[F30_N - 1] >>= 12; y.v[F30_N - 1] >>= 12;
+    for (int k = 0; k < iters; k++) { Fq30 z = CHAIN ? mul30_chain(x, y) : mul30_inline(x, y); x = y; y = z; }
+    int32_t t = 0;
+    for (int i = 0; i < F30_N; i++) t ^= y.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = t;
+}
+
 // chain of dependent mul30 (the MSM multiply, inlined), seeded with normalised limbs
 __global__ __launch_bounds__(256) void k_fmul30(int32_t *out, int iters, int32_t seed) {
     Fq30 x, y;
@@ -142,8 +187,10 @@ int main() {
         dim3 grid(cus * wps), block(256);
         int it = 2000;
         double t = time_kernel(k_fmul30, grid, block, 3, (int32_t *)out, it, 12345);
-        printf("waves/SIMD %d  Fq30 mul (inline chain) %7.2f G/s (%6.0f cyc/wave-mul/SIMD)\n", wps, (double)cus * wps * 256 * it / t / 1e6,
-               t * 1e-3 * 2.4e9 / ((double)it * wps));
+        double t0 = time_kernel(k_fmul30x<0>, grid, block, 3, (int32_t *)out + 64, it, 12345);
+        double t1 = time_kernel(k_fmul30x<1>, grid, block, 3, (int32_t *)out + 128, it, 12345);
+        printf("waves/SIMD %d  Fq30 mul (inline chain) %7.2f G/s (%6.0f cyc/wave-mul/SIMD)   compiler-scheduled %7.2f G/s   single-chain asm %7.2f G/s\n", wps, (double)cus * wps * 256 * it / t / 1e6,
+               t * 1e-3 * 2.4e9 / ((double)it * wps), (double)cus * wps * 256 * it / t0 / 1e6, (double)cus * wps * 256 * it / t1 / 1e6);
     }
     // field multiply / mixed add throughput
     size_t nthreads = (size_t)cus * 8 * 256;
