@@ -99,7 +99,7 @@ KZG_HD Fq30 times3_30(const Fq30 &a) {
 // dbl-2008-s-1 (a = 0): 6M + 3S.  In: |X|, |Y| < 8.  Out: |X| < 1.6, |Y| < 1.2.
 KZG_HD G1Xyzz30 g1_dbl30(const G1Xyzz30 &p) {
     if (p.inf) return p;
-    Fq30 U = times2_30(normalize30(p.y));   // < 16
+    Fq30 U = times2_30(p.y);                // < 16 (limbs of y <= 2^29 in magnitude, normalised or negated)
     Fq30 V = sqr30(U);                      // 16^2 = 256 < 300: |V| < q, so the zero test below is exact
     if (is_zero30(V)) return G1Xyzz30::infinity();  // y == 0: a point of order two
     Fq30 W = mul30(U, V);
@@ -177,7 +177,7 @@ KZG_HD G1Xyzz30 g1_madd30_phase2(const G1Xyzz30 &p, const Madd30Mid &m, bool neg
     r.zzz = mul30(p.zzz, PPP);
     r.x = sub30(sqr30(R), add2x30(PPP, Q));
     // Y3 = R (Q - X3) + (-Y1) PPP: one double-width accumulation, one reduction
-    r.y = muladd30_inline(R, sub30(Q, r.x), neg30(p.y), PPP);
+    r.y = muladd30(R, sub30(Q, r.x), neg30(p.y), PPP);
     return r;
 }
 

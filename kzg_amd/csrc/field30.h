@@ -217,10 +217,27 @@ KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) {
     for (int i = 0; i < F30_N; i++) r.v[i] = z[i];
     return r;
 }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_C_MUL30)
+// Default on the device: generated single-chain versions (tools/gen_mul30.py).  hipcc's code for the portable functions above
+// sums every column in a second accumulator and merges it with the carry by a 64-bit add (36 v_lshl_add_u64 per multiply);
+// with the products in inline-asm blocks the chain starts from the carry.  Same results bit for bit; measured +4 % batched
+// MSM throughput (same-box A/B).  -DKZG_C_MUL30 selects the portable versions.
+#include "mul30_gfx950.inc"
+KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) { return mul30_asm(a, b); }
+KZG_HD Fq30 sqr30(const Fq30 &a) { return sqr30_asm(a); }
+#define KZG_HAVE_MULADD30_ASM 1
 #else
 KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) { return mul30_inline(a, b); }
 KZG_HD Fq30 sqr30(const Fq30 &a) { return sqr30_inline(a); }
 #endif
+
+KZG_HD Fq30 muladd30(const Fq30 &a, const Fq30 &b, const Fq30 &c, const Fq30 &d) {
+#if defined(KZG_HAVE_MULADD30_ASM)
+    return muladd30_asm(a, b, c, d);
+#else
+    return muladd30_inline(a, b, c, d);
+#endif
+}
 
 KZG_HD Fq30 zero30() {
     Fq30 z;

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Generates kzg_amd/csrc/mul30_gfx950.inc: the signed 13 x 30-bit Montgomery multiply / square / fused multiply-add of
+field30.h with every column's products in ONE v_mad_i64_i32 accumulator chain (inline-asm blocks of up to 30 operands).
+
+hipcc's own code for the portable C version sums each column's products in a second accumulator and merges it with the
+carry by a 64-bit add (one v_lshl_add_u64 per column, 36 per multiply, for latency that two resident waves already hide);
+here the chain starts from the carry.  Everything that is not a multiply-add (quotient digit, shifts, digit extraction)
+stays in C between the blocks."""
+import sys
+
+N = 13
+MAX_OPS = 30
+
+
+def block(products):
+    """products: list of (x_expr, x_cons, y_expr, y_cons); one asm statement accumulating all of them into acc"""
+    ops, lines = [], []
+
+    def ref(cons, expr):
+        for i, (c, e) in enumerate(ops):
+            if e == expr and c == cons:
+                return i + 1
+        ops.append((cons, expr))
+        return len(ops)
+    for (x, xc, y, yc) in products:
+        lines.append(f"v_mad_i64_i32 %0, vcc, %{ref(xc, x)}, %{ref(yc, y)}, %0")
+    assert len(ops) + 1 <= MAX_OPS, len(ops)
+    body = "\\n\\t".join(lines)
+    ins = ", ".join(f'"{c}"({e})' for c, e in ops)
+    return f'    asm("{body}" : "+v"(acc) : {ins} : "vcc");\n'
+
+
+def emit_products(products):
+    """split a column's product list into blocks that respect the operand limit"""
+    out, cur, names = "", [], set()
+    for p in products:
+        new = {(p[1], p[0]), (p[3], p[2])}
+        if len(names | new) + 1 > MAX_OPS:
+            out += block(cur)
+            cur, names = [], set()
+        cur.append(p)
+        names |= new
+    if cur:
+        out += block(cur)
+    return out
+
+
+def q(j):
+    return f"Fq30Consts::mod({j})"
+
+
+def gen_mul():
+    s = "__device__ __forceinline__ Fq30 mul30_asm(const Fq30 &a, const Fq30 &b) {\n    int32_t m[F30_N];\n    Fq30 r;\n    uint64_t acc = 0;\n"
+    for k in range(N):
+        prods = [(f"a.v[{i}]", "v", f"b.v[{k - i}]", "v") for i in range(k + 1)]
+        prods += [(f"m[{i}]", "v", q(k - i), "s") for i in range(k)]
+        s += emit_products(prods)
+        s += f"    m[{k}] = sext30((uint32_t)acc * Fq30Consts::INV);\n    acc = sar30(mac30(acc, m[{k}], {q(0)}));\n"
+    for k in range(N, 2 * N - 1):
+        prods = []
+        for i in range(k - N + 1, N):
+            prods.append((f"a.v[{i}]", "v", f"b.v[{k - i}]", "v"))
+            prods.append((f"m[{i}]", "v", q(k - i), "s"))
+        s += emit_products(prods)
+        s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+    s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
+    return s
+
+
+def gen_sqr():
+    s = ("__device__ __forceinline__ Fq30 sqr30_asm(const Fq30 &a) {\n    int32_t m[F30_N], d[F30_N];\n    Fq30 r;\n"
+         "#pragma unroll\n    for (int i = 0; i < F30_N; i++) d[i] = a.v[i] * 2;\n    uint64_t acc = 0;\n")
+
+    def cross(k, lo):
+        p = [(f"a.v[{i}]", "v", f"d[{k - i}]", "v") for i in range(lo, N) if 2 * i < k and k - i < N]
+        if k % 2 == 0:
+            p.append((f"a.v[{k // 2}]", "v", f"a.v[{k // 2}]", "v"))
+        return p
+    for k in range(N):
+        prods = cross(k, 0) + [(f"m[{i}]", "v", q(k - i), "s") for i in range(k)]
+        s += emit_products(prods)
+        s += f"    m[{k}] = sext30((uint32_t)acc * Fq30Consts::INV);\n    acc = sar30(mac30(acc, m[{k}], {q(0)}));\n"
+    for k in range(N, 2 * N - 1):
+        prods = cross(k, k - N + 1) + [(f"m[{i}]", "v", q(k - i), "s") for i in range(k - N + 1, N)]
+        s += emit_products(prods)
+        s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+    s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
+    return s
+
+
+def gen_muladd():
+    """(a*b + c*d)/R30 with one reduction; in the columns with more than 30 products the multiple of 2^30 accumulated so far is
+    set aside before the c*d products go in (field30.h, muladd30_inline)."""
+    s = ("__device__ __forceinline__ Fq30 muladd30_asm(const Fq30 &a, const Fq30 &b, const Fq30 &c, const Fq30 &d) {\n"
+         "    int32_t m[F30_N];\n    Fq30 r;\n    uint64_t acc = 0, hi;\n")
+    for k in range(2 * N - 1):
+        lo = max(0, k - N + 1)
+        hi_i = min(k, N - 1)
+        cnt = hi_i - lo + 1
+        split = 3 * cnt > 30
+        ab = [(f"a.v[{i}]", "v", f"b.v[{k - i}]", "v") for i in range(lo, hi_i + 1)]
+        cd = [(f"c.v[{i}]", "v", f"d.v[{k - i}]", "v") for i in range(lo, hi_i + 1)]
+        mq = [(f"m[{i}]", "v", q(k - i), "s") for i in range(lo, min(k, N)) if k - i >= 1 or k >= N]
+        if k < N:
+            mq = [(f"m[{i}]", "v", q(k - i), "s") for i in range(k)]
+        else:
+            mq = [(f"m[{i}]", "v", q(k - i), "s") for i in range(k - N + 1, N)]
+        if split:
+            s += emit_products(ab + mq)
+            s += "    hi = sar30(acc);\n    acc &= (uint64_t)F30_MASK;\n"
+            s += emit_products(cd)
+        else:
+            s += emit_products(ab + mq + cd)
+        tail = " + hi" if split else ""
+        if k < N:
+            s += f"    m[{k}] = sext30((uint32_t)acc * Fq30Consts::INV);\n    acc = sar30(mac30(acc, m[{k}], {q(0)})){tail};\n"
+        else:
+            s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF){tail};\n"
+    s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
+    return s
+
+
+def main(dst):
+    out = "// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_mul() + gen_sqr() + gen_muladd()
+    open(dst, "w").write(out)
+    print("wrote", dst)
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -73,44 +73,15 @@ __global__ __launch_bounds__(256) void k_fmul(F *out, const F *in, int iters) {
 
 // experiment: the same multiply with every column forced into ONE accumulator chain (inline-asm mads), i.e. without the
 // second chain + 64-bit add per column that the compiler introduces for latency
-__device__ __forceinline__ uint64_t macv(uint64_t acc, int32_t a, int32_t b) { return mac30(acc, a, b); }
-__device__ __forceinline__ uint64_t macs(uint64_t acc, int32_t a, int32_t k) { return mac30(acc, a, k); }
-#define CHAIN_BARRIER(acc) asm("" : "+v"(acc))
-__device__ __forceinline__ Fq30 mul30_chain(const Fq30 &a, const Fq30 &b) {
-    int32_t m[F30_N];
-    Fq30 r;
-    uint64_t acc = 0;
-#pragma unroll
-    for (int k = 0; k < F30_N; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) acc = macv(acc, a.v[i], b.v[k - i]);
-#pragma unroll
-        for (int i = 0; i < k; i++) acc = macs(acc, m[i], Fq30Consts::mod(k - i));
-        m[k] = sext30((uint32_t)acc * Fq30Consts::INV);
-        acc = macs(acc, m[k], Fq30Consts::mod(0));
-        acc = sar30(acc);
-        CHAIN_BARRIER(acc);
-    }
-#pragma unroll
-    for (int k = F30_N; k < 2 * F30_N - 1; k++) {
-#pragma unroll
-        for (int i = k - F30_N + 1; i < F30_N; i++) {
-            acc = macv(acc, a.v[i], b.v[k - i]);
-            acc = macs(acc, m[i], Fq30Consts::mod(k - i));
-        }
-        r.v[k - F30_N] = sext30((uint32_t)acc);
-        acc = sar30(acc + (uint64_t)F30_HALF);
-        CHAIN_BARRIER(acc);
-    }
-    r.v[F30_N - 1] = (int32_t)acc;
-    return r;
+namespace kzg {
+#include "/tmp/gen/mul30_gfx950.inc"
 }
 template <int CHAIN>
 __global__ __launch_bounds__(256) void k_fmul30x(int32_t *out, int iters, int32_t seed) {
     Fq30 x, y;
     for (int i = 0; i < F30_N; i++) { x.v[i] = sext30((uint32_t)(seed * (i + 3) + threadIdx.x * 77)); y.v[i] = sext30((uint32_t)(seed * (i + 11) + blockIdx.x * 131)); }
     x.v[F30_N - 1] >>= 12; y.v[F30_N - 1] >>= 12;
-    for (int k = 0; k < iters; k++) { Fq30 z = CHAIN ? mul30_chain(x, y) : mul30_inline(x, y); x = y; y = z; }
+    for (int k = 0; k < iters; k++) { Fq30 z = CHAIN ? mul30_asm(x, y) : mul30_inline(x, y); x = y; y = z; }
     int32_t t = 0;
     for (int i = 0; i < F30_N; i++) t ^= y.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = t;
