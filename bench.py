@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 # One hardware queue per engine stream: 16 MSM lanes + 2 accumulation streams (the ROCm default multiplexes all streams
 # onto 4 in-order queues, which makes independent MSM lanes wait for each other's tail kernels); must be in the
 # environment before HIP initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

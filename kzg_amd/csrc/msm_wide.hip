@@ -325,7 +325,7 @@ __global__ __launch_bounds__(64) void k_weighted_chunks(const MsmPoint *pts, int
 }
 
 // result = 2^shift * a + b
-__global__ void k_combine_shifted(const MsmPoint *a, int shift, const MsmPoint *b, MsmPoint *result) {
+__global__ __launch_bounds__(64) void k_combine_shifted(const MsmPoint *a, int shift, const MsmPoint *b, MsmPoint *result) {
     MsmPoint m = *a;
     for (int k = 0; k < shift; k++) m = g1_dbl30(m);
     *result = g1_add30(m, *b);
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *bu
 }
 int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
                   int max_level, MsmState *state) {
-    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, ctx->cur_scan_threads, 0, buf0, buf1, starts, B, L, level0, max_level, state);
+    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, 1024, 0, buf0, buf1, starts, B, L, level0, max_level, state);
     return KZG_OK;
 }
 

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void k_g2_sum(const G2Jacobian *terms, size_t n
 }
 
 // out = a - b (single thread)
-__global__ void k_g2_sub(const G2Affine *a, const G2Affine *b, G2Affine *out) {
+__global__ __launch_bounds__(64) void k_g2_sub(const G2Affine *a, const G2Affine *b, G2Affine *out) {
     G2Jacobian x, y;
     G2Affine nb;
     g2_neg_affine(nb, *b);
@@ -241,7 +241,7 @@ __global__ void k_g2_sub(const G2Affine *a, const G2Affine *b, G2Affine *out) {
 }
 
 // lines[j] = stored Miller lines of pts[j], j < count <= 2
-__global__ void k_g2_lines(const G2Affine *pts, int count, Fq2 *lines) {
+__global__ __launch_bounds__(64) void k_g2_lines(const G2Affine *pts, int count, Fq2 *lines) {
     int j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= count) return;
     g2_precompute_lines(pts[j], lines + (size_t)j * 2 * MILLER_LINES);
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(64) void k_verify_eval(const Fr *xs, const Fr *ys, 
 
 // e(w, hz) == e(C - gr, h0)   (verify_eval_batched src/coeff_form.rs:144-182, verify_eval_all src/eval_form.rs:192-217);
 // hz varies per call (lines on the fly), h0 uses its stored lines
-__global__ void k_verify_finish(const G1Xyzz *C, const G1Affine *gr, const G1Xyzz *w, const G2Affine *hz, const G2Affine *h0,
+__global__ __launch_bounds__(64) void k_verify_finish(const G1Xyzz *C, const G1Affine *gr, const G1Xyzz *w, const G2Affine *hz, const G2Affine *h0,
                                 const Fq2 *lines_h0, uint8_t *ok) {
     G1Affine P[2];
     G2Affine Q[2], T[2];

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_fmul(F *out, const F *in, int iters) {
 // experiment: the same multiply with every column forced into ONE accumulator chain (inline-asm mads), i.e. without the
 // second chain + 64-bit add per column that the compiler introduces for latency
 namespace kzg {
-#include "/tmp/gen/mul30_gfx950.inc"
+#include "../kzg_amd/csrc/mul30_gfx950.inc"
 }
 template <int CHAIN>
 __global__ __launch_bounds__(256) void k_fmul30x(int32_t *out, int iters, int32_t seed) {
