@@ -335,9 +335,105 @@ __global__ __launch_bounds__(64) void k_combine_shifted(const MsmPoint *a, int s
 // ---------------------------------------------------------------------------------------------
 // rare path of the c <= 16 pipeline: all fold levels after the first FAST_LEVELS, in one block
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fold_rest_body(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0, int max_level,
-                                               MsmState *st, uint32_t *lds, uint32_t &smax) {
+// The fold levels beyond the first FAST_LEVELS, in one block.  Normal inputs: every bucket already holds one partial and the
+// kernel returns after one pass over the counts.  Otherwise the buckets that still hold several partials are few (after two
+// fan-in-4 rounds only buckets more than 16x the equal-split chunk long: the carry bucket of u64-valued scalars -- half of all
+// scalars put a digit 1 into window 4 --, or the handful of buckets of adversarial inputs), so they are compacted into a list
+// in LDS once and reduced by fan-in-L trees IN PLACE: level by level between the two partial buffers at the bucket's own
+// offset, the single result ending in slot 0 of the bucket's range in the input list, which is where k_bucket_reduce reads it.
+// No per-level pass over all 2^15 buckets (that cost 0.55 ms per level: 2.8 ms for the u64 case).  256 threads: the
+// additions need ~200 VGPRs (a 1024-thread block is capped at 128 and spills).  More than FOLD_LIST multi-partial buckets:
+// the generic level loop (scan of all buckets per level).
+constexpr int FOLD_LIST = 1024;
+__global__ __launch_bounds__(256) void k_fold_rest(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
+                                                   int max_level, MsmState *st) {
     if (st->done) return;
+    __shared__ uint32_t lds[1024];
+    __shared__ uint32_t ls[FOLD_LIST], lc[FOLD_LIST], lpre[FOLD_LIST + 1];
+    __shared__ uint32_t smax, nmulti, total;
+    const uint32_t *start0 = starts + (size_t)level0 * (B + 1);
+    if (threadIdx.x == 0) {
+        smax = 0;
+        nmulti = 0;
+    }
+    __syncthreads();
+    {
+        uint32_t mx = 0;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) {
+            uint32_t s = start0[b], cnt = start0[b + 1] - s;
+            mx = cnt > mx ? cnt : mx;
+            if (cnt > 1) {
+                uint32_t i = atomicAdd(&nmulti, 1u);
+                if (i < (uint32_t)FOLD_LIST) {
+                    ls[i] = s;
+                    lc[i] = cnt;
+                }
+            }
+        }
+        atomicMax(&smax, mx);
+    }
+    __syncthreads();
+    if (smax <= 1) {
+        if (threadIdx.x == 0) {
+            st->done = 1;
+            st->final_level = (uint32_t)level0;
+            st->final_buf = (uint32_t)(level0 & 1);
+            st->max_cnt = smax;
+        }
+        return;
+    }
+    if (nmulti <= (uint32_t)FOLD_LIST && level0 >= 1) {
+        // level0 >= 1: the other buffer held the (longer) list of the level before, so every offset used below fits it
+        const uint32_t nm = nmulti;
+        MsmPoint *X = (level0 & 1) ? buf1 : buf0, *Y = (level0 & 1) ? buf0 : buf1;
+        MsmPoint *const X0 = X;
+        for (;;) {
+            if (threadIdx.x == 0) {
+                uint32_t run = 0, mx = 0;
+                for (uint32_t i = 0; i < nm; i++) {
+                    lpre[i] = run;
+                    run += (lc[i] + L - 1) / L;
+                    mx = lc[i] > mx ? lc[i] : mx;
+                }
+                lpre[nm] = run;
+                total = run;
+                smax = mx;
+            }
+            __syncthreads();
+            if (smax <= 1) break;
+            const uint32_t T = total;
+            for (uint32_t t = threadIdx.x; t < T; t += blockDim.x) {
+                uint32_t lo = 0, hi = nm;  // lpre[lo] <= t < lpre[hi]
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if (lpre[mid] <= t) lo = mid; else hi = mid;
+                }
+                const uint32_t j = t - lpre[lo];
+                uint32_t s = ls[lo] + j * L, e = ls[lo] + lc[lo];
+                e = s + L < e ? s + L : e;
+                MsmPoint acc = X[s];
+                for (uint32_t k = s + 1; k < e; k++) acc = g1_add30(acc, X[k]);
+                Y[ls[lo] + j] = acc;
+            }
+            __threadfence_block();
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) lc[i] = (lc[i] + L - 1) / L;
+            MsmPoint *tmp = X;
+            X = Y;
+            Y = tmp;
+            __syncthreads();
+        }
+        if (X != X0)  // odd number of levels: the results sit in the other buffer
+            for (uint32_t i = threadIdx.x; i < nm; i += blockDim.x) X0[ls[i]] = X[ls[i]];
+        if (threadIdx.x == 0) {
+            st->done = 1;
+            st->final_level = (uint32_t)level0;
+            st->final_buf = (uint32_t)(level0 & 1);
+            st->max_cnt = 1;
+        }
+        return;
+    }
+    // generic level loop
     int level = level0;
     for (;;) {
         const uint32_t *in_start = starts + (size_t)level * (B + 1);
@@ -379,16 +475,9 @@ __device__ __forceinline__ void fold_rest_body(MsmPoint *buf0, MsmPoint *buf1, u
         level++;
     }
 }
-
-__global__ __launch_bounds__(1024) void k_fold_rest(MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
-                                                    int max_level, MsmState *st) {
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t smax;
-    fold_rest_body(buf0, buf1, starts, B, L, level0, max_level, st, lds, smax);
-}
 int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
                   int max_level, MsmState *state) {
-    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, 1024, 0, buf0, buf1, starts, B, L, level0, max_level, state);
+    KZG_LAUNCH(ctx, st, "k_fold_rest", k_fold_rest, 1, 256, 0, buf0, buf1, starts, B, L, level0, max_level, state);
     return KZG_OK;
 }
 
