@@ -724,8 +724,8 @@ static int msm_tail(kzg_ctx *ctx, int lane, const MsmLayout &L, char *base, MsmP
     MsmPoint *sum_scratch = (MsmPoint *)(base + L.off_sum);
     MsmPoint *result = (MsmPoint *)(base + L.off_result);
     auto start_arr = [&](int level) { return starts + (size_t)level * (B + 1); };
-    // fold rounds: the list of level k lives in bufs[k & 1] with per-bucket starts start_arr(k).  Two rounds of fan-in
-    // LK settle every input whose buckets were split over <= 16 threads; k_fold_rest finishes the others.
+    // fold rounds: the list of level k lives in bufs[k & 1] with per-bucket starts start_arr(k).  FAST_LEVELS grid-wide
+    // round(s) of fan-in LK settle every input whose buckets were split over <= LK threads; k_fold_rest finishes the others.
     size_t tmax = L.T1_max;
     const int fast = L.levels < FAST_LEVELS ? L.levels : FAST_LEVELS;
     for (int lv = 1; lv <= fast; lv++) {

@@ -12,7 +12,16 @@ constexpr uint32_t ACC_SLOTS = 256 * 4 * KZG_ACCUM_WAVES * 64;  // resident thre
 // waves, one per SIMD of a CU, so a lone 64-thread tail block on one SIMD strands the other three SIMDs of that
 // half-CU for as long as it lives; 256-thread tail blocks take exactly one accumulation-block slot instead.
 constexpr int TAIL_THREADS = 256;
-constexpr int LK = 4;   // fan-in of the later fold rounds
+#ifndef KZG_FOLD_FANIN
+#define KZG_FOLD_FANIN 8
+#endif
+#ifndef KZG_FAST_LEVELS
+#define KZG_FAST_LEVELS 1
+#endif
+// One grid-wide fold round of fan-in 8 settles every bucket that was split over <= 8 threads (uniform scalars: 4-6); the
+// single-block k_fold_rest finishes the others.  (Two rounds of fan-in 4 measured the same for uniform scalars and 4 % slower
+// for u64-valued ones, with two more launches per MSM.)
+constexpr int LK = KZG_FOLD_FANIN;   // fan-in of the fold rounds
 constexpr int SUM_L = 4;  // fan-in of the plain tree sum
 constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
 constexpr int MAX_LEVELS = 24;
@@ -178,7 +187,7 @@ int wide_level_scan(kzg_ctx *ctx, hipStream_t st, const uint32_t *in_start, uint
 // the fold levels beyond the first FAST_LEVELS, in ONE single-block kernel that returns at once when every bucket already
 // holds one partial (the normal case): replaces ~14 no-op launches per MSM, whose queueing delays under a full GPU cost
 // 3-4 % of the batched throughput (measured).  Only adversarial inputs (few distinct digits) ever do work here.
-constexpr int FAST_LEVELS = 2;
+constexpr int FAST_LEVELS = KZG_FAST_LEVELS;
 int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
                   int max_level, MsmState *state);
 int wide_bucket_reduce(kzg_ctx *ctx, int lane, const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int Btot, int C,

@@ -336,8 +336,8 @@ __global__ __launch_bounds__(64) void k_combine_shifted(const MsmPoint *a, int s
 // rare path of the c <= 16 pipeline: all fold levels after the first FAST_LEVELS, in one block
 // ---------------------------------------------------------------------------------------------
 // The fold levels beyond the first FAST_LEVELS, in one block.  Normal inputs: every bucket already holds one partial and the
-// kernel returns after one pass over the counts.  Otherwise the buckets that still hold several partials are few (after two
-// fan-in-4 rounds only buckets more than 16x the equal-split chunk long: the carry bucket of u64-valued scalars -- half of all
+// kernel returns after one pass over the counts.  Otherwise the buckets that still hold several partials are few (after the
+// grid-wide round only buckets more than LK times the equal-split chunk long: the carry bucket of u64-valued scalars -- half of all
 // scalars put a digit 1 into window 4 --, or the handful of buckets of adversarial inputs), so they are compacted into a list
 // in LDS once and reduced by fan-in-L trees IN PLACE: level by level between the two partial buffers at the bucket's own
 // offset, the single result ending in slot 0 of the bucket's range in the input list, which is where k_bucket_reduce reads it.

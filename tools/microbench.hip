@@ -71,17 +71,13 @@ __global__ __launch_bounds__(256) void k_fmul(F *out, const F *in, int iters) {
     out[i] = y;
 }
 
-// experiment: the same multiply with every column forced into ONE accumulator chain (inline-asm mads), i.e. without the
-// second chain + 64-bit add per column that the compiler introduces for latency
-namespace kzg {
-#include "../kzg_amd/csrc/mul30_gfx950.inc"
-}
+// k_fmul30x<0>: the portable C multiply as hipcc schedules it; <1>: the generated single-chain version (mul30_gfx950.inc)
 template <int CHAIN>
 __global__ __launch_bounds__(256) void k_fmul30x(int32_t *out, int iters, int32_t seed) {
     Fq30 x, y;
     for (int i = 0; i < F30_N; i++) { x.v[i] = sext30((uint32_t)(seed * (i + 3) + threadIdx.x * 77)); y.v[i] = sext30((uint32_t)(seed * (i + 11) + blockIdx.x * 131)); }
     x.v[F30_N - 1] >>= 12; y.v[F30_N - 1] >>= 12;
-    for (int k = 0; k < iters; k++) { Fq30 z = CHAIN ? mul30_asm(x, y) : mul30_inline(x, y); x = y; y = z; }
+    for (int k = 0; k < iters; k++) { Fq30 z = CHAIN ? mul30(x, y) : mul30_inline(x, y); x = y; y = z; }  // mul30 = the generated version on the device
     int32_t t = 0;
     for (int i = 0; i < F30_N; i++) t ^= y.v[i];
     out[blockIdx.x * blockDim.x + threadIdx.x] = t;
