@@ -16,11 +16,12 @@ constexpr int TAIL_THREADS = 256;
 #define KZG_FOLD_FANIN 8
 #endif
 #ifndef KZG_FAST_LEVELS
-#define KZG_FAST_LEVELS 1
+#define KZG_FAST_LEVELS 2
 #endif
-// One grid-wide fold round of fan-in 8 settles every bucket that was split over <= 8 threads (uniform scalars: 4-6); the
-// single-block k_fold_rest finishes the others.  (Two rounds of fan-in 4 measured the same for uniform scalars and 4 % slower
-// for u64-valued ones, with two more launches per MSM.)
+// Two grid-wide fold rounds of fan-in 8 settle every bucket that was split over <= 64 threads: one round for uniform scalars at
+// 2^20 (4-6 partials per bucket; the second launch pair then returns at once), two at the small sizes where a bucket is many
+// equal-split chunks long (2^16: c = 12, ~64 partials per bucket).  The single-block k_fold_rest finishes the others.
+// Same-box A/B against two rounds of fan-in 4: 2^20 equal, u64-valued +4 %, 2^16 +19 % (single commit 2.1 -> 1.4 ms).
 constexpr int LK = KZG_FOLD_FANIN;   // fan-in of the fold rounds
 constexpr int SUM_L = 4;  // fan-in of the plain tree sum
 constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
