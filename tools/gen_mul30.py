@@ -12,7 +12,7 @@ N = 13
 MAX_OPS = 30
 
 
-def block(products):
+def block(products, mnem="v_mad_i64_i32"):
     """products: list of (x_expr, x_cons, y_expr, y_cons); one asm statement accumulating all of them into acc"""
     ops, lines = [], []
 
@@ -23,25 +23,25 @@ def block(products):
         ops.append((cons, expr))
         return len(ops)
     for (x, xc, y, yc) in products:
-        lines.append(f"v_mad_i64_i32 %0, vcc, %{ref(xc, x)}, %{ref(yc, y)}, %0")
+        lines.append(f"{mnem} %0, vcc, %{ref(xc, x)}, %{ref(yc, y)}, %0")
     assert len(ops) + 1 <= MAX_OPS, len(ops)
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({e})' for c, e in ops)
     return f'    asm("{body}" : "+v"(acc) : {ins} : "vcc");\n'
 
 
-def emit_products(products):
+def emit_products(products, mnem="v_mad_i64_i32"):
     """split a column's product list into blocks that respect the operand limit"""
     out, cur, names = "", [], set()
     for p in products:
         new = {(p[1], p[0]), (p[3], p[2])}
         if len(names | new) + 1 > MAX_OPS:
-            out += block(cur)
+            out += block(cur, mnem)
             cur, names = [], set()
         cur.append(p)
         names |= new
     if cur:
-        out += block(cur)
+        out += block(cur, mnem)
     return out
 
 
@@ -120,10 +120,39 @@ def gen_muladd():
     return s
 
 
+def gen_fr29():
+    """Fr in 9 unsigned 29-bit limbs (fr29.h, the NTT kernels): same single-chain structure with v_mad_u64_u32."""
+    n = 9
+
+    def blocku(products):
+        return emit_products(products, "v_mad_u64_u32")
+
+    def qr(j):
+        return f"Fr29Consts::mod({j})"
+    s = "__device__ __forceinline__ Fr29 mul29r_asm(const Fr29 &a, const Fr29 &b) {\n    uint32_t m[R29_N];\n    Fr29 r;\n    uint64_t acc = 0;\n"
+    for k in range(n):
+        prods = [(f"a.v[{i}]", "v", f"b.v[{k - i}]", "v") for i in range(k + 1)]
+        prods += [(f"m[{i}]", "v", qr(k - i), "s") for i in range(k)]
+        s += blocku(prods)
+        s += f"    m[{k}] = ((uint32_t)acc * Fr29Consts::INV) & F29_MASK;\n    acc = (acc + (uint64_t)m[{k}] * {qr(0)}) >> 29;\n"
+    for k in range(n, 2 * n - 1):
+        prods = []
+        for i in range(k - n + 1, n):
+            prods.append((f"a.v[{i}]", "v", f"b.v[{k - i}]", "v"))
+            prods.append((f"m[{i}]", "v", qr(k - i), "s"))
+        s += blocku(prods)
+        s += f"    r.v[{k - n}] = (uint32_t)acc & F29_MASK;\n    acc >>= 29;\n"
+    s += f"    r.v[{n - 1}] = (uint32_t)acc;\n    return r;\n}}\n"
+    return s
+
+
 def main(dst):
     out = "// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_mul() + gen_sqr() + gen_muladd()
     open(dst, "w").write(out)
     print("wrote", dst)
+    if len(sys.argv) > 2:
+        open(sys.argv[2], "w").write("// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_fr29())
+        print("wrote", sys.argv[2])
 
 
 if __name__ == "__main__":
