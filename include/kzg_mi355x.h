@@ -131,6 +131,13 @@ int kzg_commit_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_
  * x, y are host scalars in sfmt.  n = polynomial.num_coeffs() >= 1. */
 int kzg_witness_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *x,
                       const void *y, int sfmt, int flags, void *out, int ofmt);
+/* Throughput form of the above ("256 independent create_witness calls sharing one SRS"): `count`
+ * openings (xs[j], ys[j]) of ONE polynomial, pipelined like kzg_msm_g1_batch -- quotient scan and MSM of opening j on lane
+ * j % streams.  out: count points in ofmt.  status (optional, count ints): 0 or KZG_ERR_POINT_NOT_ON_POLY per opening, the
+ * call then returns KZG_OK; without it the call returns KZG_ERR_POINT_NOT_ON_POLY if any opening is off the polynomial (every
+ * witness is still written).  Not a reference method: equivalent to calling create_witness count times. */
+int kzg_witness_coeff_many(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *xs, const void *ys,
+                           size_t count, int sfmt, int flags, void *out, int ofmt, int *status);
 /* KZGProver::create_witness_batched (:83-111): w = [(p - I)/Z]_1 and r = I (the interpolant through
  * (xs, ys)).  xs, ys: k host scalars.  out_r receives *out_r_len scalars (host, sfmt): k normally,
  * 2 for k == 1 (the reference returns X + (y - x), src/polynomial.rs:244-247).

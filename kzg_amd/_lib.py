@@ -69,6 +69,7 @@ def load():
         "kzg_coset_ntt_fr": (i32, [vp, vp, u32, i32, i32, i32]),
         "kzg_commit_coeff": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
         "kzg_witness_coeff": (i32, [vp, vp, vp, sz, vp, vp, i32, i32, vp, i32]),
+        "kzg_witness_coeff_many": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, ctypes.POINTER(i32)]),
         "kzg_witness_coeff_batched": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, vp, ctypes.POINTER(sz)]),
         "kzg_verify_poly_coeff": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
         "kzg_commit_eval": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),

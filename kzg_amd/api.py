@@ -563,6 +563,28 @@ class KZGProver:
             _raise(e, rc)
         return out.raw
 
+    def create_witness_many(self, polynomial, points, ofmt=L.G1_AFFINE_MONT, coeffs_device=None):
+        """Throughput form of create_witness (not a reference method): one witness per (x, y) in `points`, all for the same
+        polynomial, pipelined on the engine's lanes.  Returns (witnesses, ok) with ok[j] False where the reference would
+        return Err(PointNotOnPolynomial).  coeffs_device: a DeviceBuffer already holding the coefficients."""
+        e = self.engine
+        k = len(points)
+        n = polynomial.num_coeffs() if coeffs_device is None else coeffs_device.n
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt] * max(k, 1))
+        status = (ctypes.c_int * max(k, 1))()
+        if coeffs_device is None:
+            src, sfmt, flags = pack_scalars(polynomial.slice_coeffs()), L.FR_CANONICAL, 0
+        else:
+            src, sfmt, flags = coeffs_device.ptr, coeffs_device.sfmt, L.IN_DEVICE
+        if sfmt != L.FR_CANONICAL:
+            raise ValueError("create_witness_many takes canonical scalars")
+        rc = e.lib.kzg_witness_coeff_many(e.ctx, self.parameters.gs.handle, src, n, pack_scalars([p[0] for p in points]),
+                                          pack_scalars([p[1] for p in points]), k, sfmt, flags, out, ofmt, status)
+        if rc:
+            _raise(e, rc)
+        psz = L.POINT_BYTES[ofmt]
+        return [out.raw[j * psz:(j + 1) * psz] for j in range(k)], [status[j] == 0 for j in range(k)]
+
     def create_witness_batched(self, polynomial, xs, ys, ofmt=L.G1_AFFINE_MONT):  # :83-111
         e = self.engine
         assert len(xs) == len(ys)

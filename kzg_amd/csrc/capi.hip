@@ -398,6 +398,73 @@ extern "C" int kzg_commit_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void
     return kzg_msm_g1(ctx, lagrange, 0, evals, d, sfmt, flags, out, ofmt);
 }
 
+// ---- the batched pipeline shared by kzg_msm_g1_batch and kzg_witness_coeff_many -------------------------------------------
+// Item b runs on lane b % nl; every bucket-accumulation kernel goes to one of the dedicated FIFO streams.
+struct BatchPipe {
+    int nl = 1, nas = 0;
+    uint8_t *d_out = nullptr;
+    bool out_dev = false;
+};
+
+static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, int flags, BatchPipe *bp) {
+    bp->nl = (int)std::min<size_t>(batch, (size_t)ctx->opt_streams);
+    const int nl = bp->nl;
+    KZG_TRY(ensure_lanes(ctx, nl));
+    ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
+    ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
+    ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
+    bp->out_dev = (flags & KZG_OUT_DEVICE) != 0;
+    if (bp->out_dev) {
+        bp->d_out = (uint8_t *)out;
+    } else {
+        // grow-only device staging for the results: a hipMalloc / hipFree pair per call costs a device-wide sync
+        if (ctx->batch_out_bytes < out_bytes + 256) {
+            if (ctx->batch_out) hipFree(ctx->batch_out);
+            ctx->batch_out = nullptr;
+            ctx->batch_out_bytes = 0;
+            KZG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->batch_out, out_bytes + 256));
+            ctx->batch_out_bytes = out_bytes + 256;
+        }
+        bp->d_out = (uint8_t *)ctx->batch_out;
+    }
+    // dedicated accumulation streams only when every stream can have a hardware queue of its own (the runtime reads
+    // GPU_MAX_HW_QUEUES when it initialises; its default of 4 multiplexes the streams, and a shared queue costs more than the
+    // FIFO order gains)
+    const char *hwq = getenv("GPU_MAX_HW_QUEUES");
+    bp->nas = (nl > 1 && hwq && atoi(hwq) >= nl + ctx->opt_accum_streams) ? ctx->opt_accum_streams : 0;
+    for (int i = 0; i < bp->nas; i++)
+        if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking));
+    while (bp->nas && (int)ctx->sorted_events.size() < nl) {
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        ctx->sorted_events.push_back(e1);
+        ctx->accum_events.push_back(e2);
+    }
+    return KZG_OK;
+}
+
+static int batch_msm(kzg_ctx *ctx, const BatchPipe &bp, size_t b, int lane, const kzg_srs *srs, size_t offset, const void *d_sc,
+                     size_t n, int sfmt, MsmPoint **res) {
+    if (bp.nas)
+        return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res, ctx->accum_streams[b % bp.nas], ctx->sorted_events[lane],
+                       ctx->accum_events[lane]);
+    return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res);
+}
+
+static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_t out_bytes) {
+    for (int l = 0; l < bp.nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
+    ctx->cur_accum_blocks = ctx->accum_blocks_single();
+    ctx->cur_sort_threads = ctx->opt_sort_threads;
+    ctx->cur_scan_threads = ctx->opt_scan_threads;
+    if (rc == KZG_OK && !bp.out_dev) {
+        hipError_t e = hipMemcpy(out, bp.d_out, out_bytes, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
+    }
+    if (ctx->prof) prof_collect(ctx);
+    return rc;
+}
+
 extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n,
                                 size_t batch, int sfmt, int flags, void *out, int ofmt) {
     if (!ctx || !srs || !out || (!scalars && n && batch)) return KZG_ERR_SHAPE;
@@ -408,70 +475,74 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
     if (batch == 0) return KZG_OK;
-    int nl = (int)std::min<size_t>(batch, (size_t)ctx->opt_streams);
-    KZG_TRY(ensure_lanes(ctx, nl));
-    ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
-    ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
-    ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
+    BatchPipe bp;
+    KZG_TRY(batch_begin(ctx, batch, batch * psz, out, flags, &bp));
     size_t per = msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192;
-    for (int l = 0; l < nl; l++) KZG_TRY(lane_reserve(ctx, l, per));
-    uint8_t *d_out = nullptr;
-    bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
-    if (out_dev) {
-        d_out = (uint8_t *)out;
-    } else {
-        // grow-only device staging for the results: a hipMalloc / hipFree pair per call costs a device-wide sync
-        if (ctx->batch_out_bytes < batch * psz + 256) {
-            if (ctx->batch_out) hipFree(ctx->batch_out);
-            ctx->batch_out = nullptr;
-            ctx->batch_out_bytes = 0;
-            KZG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->batch_out, batch * psz + 256));
-            ctx->batch_out_bytes = batch * psz + 256;
-        }
-        d_out = (uint8_t *)ctx->batch_out;
-    }
     int rc = KZG_OK;
-    {
-        // dedicated accumulation streams only when every stream can have a hardware queue of its own (the runtime reads
-        // GPU_MAX_HW_QUEUES when it initialises; its default of 4 multiplexes the streams, and a shared queue costs more than the
-        // FIFO order gains)
-        const char *hwq = getenv("GPU_MAX_HW_QUEUES");
-        const int nas = (nl > 1 && hwq && atoi(hwq) >= nl + ctx->opt_accum_streams) ? ctx->opt_accum_streams : 0;
-        for (int i = 0; i < nas && rc == KZG_OK; i++)
-            if (!ctx->accum_streams[i] && hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking) != hipSuccess)
-                rc = fail(ctx, KZG_ERR_HIP, "hipStreamCreate");
-        while (nas && (int)ctx->sorted_events.size() < nl && rc == KZG_OK) {
-            hipEvent_t e1 = nullptr, e2 = nullptr;
-            if (hipEventCreateWithFlags(&e1, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&e2, hipEventDisableTiming) != hipSuccess)
-                rc = fail(ctx, KZG_ERR_HIP, "hipEventCreate");
-            ctx->sorted_events.push_back(e1);
-            ctx->accum_events.push_back(e2);
-        }
-        for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
-            int l = (int)(b % nl);
-            ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
-            const void *d_sc = nullptr;
-            rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
-            MsmPoint *res = nullptr;
-            if (rc == KZG_OK) {
-                if (nas)
-                    rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res, ctx->accum_streams[b % nas], ctx->sorted_events[l], ctx->accum_events[l]);
-                else
-                    rc = msm_run(ctx, l, srs, offset, d_sc, n, sfmt, &res);
-            }
-            if (rc == KZG_OK) rc = emit_point(ctx, l, res, d_out + b * psz, ofmt);
-        }
+    for (int l = 0; l < bp.nl && rc == KZG_OK; l++) rc = lane_reserve(ctx, l, per);
+    for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
+        int l = (int)(b % bp.nl);
+        ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
+        const void *d_sc = nullptr;
+        rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
+        MsmPoint *res = nullptr;
+        if (rc == KZG_OK) rc = batch_msm(ctx, bp, b, l, srs, offset, d_sc, n, sfmt, &res);
+        if (rc == KZG_OK) rc = emit_point(ctx, l, res, bp.d_out + b * psz, ofmt);
     }
-    for (int l = 0; l < nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
-    ctx->cur_accum_blocks = ctx->accum_blocks_single();
-    ctx->cur_sort_threads = ctx->opt_sort_threads;
-    ctx->cur_scan_threads = ctx->opt_scan_threads;
-    if (rc == KZG_OK && !out_dev) {
-        hipError_t e = hipMemcpy(out, d_out, batch * psz, hipMemcpyDeviceToHost);
-        if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
+    return batch_end(ctx, bp, rc, out, batch * psz);
+}
+
+extern "C" int kzg_witness_coeff_many(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *xs,
+                                      const void *ys, size_t count, int sfmt, int flags, void *out, int ofmt, int *status) {
+    // `count` calls of KZGProver::create_witness (src/coeff_form.rs:66-81) on ONE polynomial, pipelined: opening j computes its
+    // quotient (Horner scan) and its MSM on lane j % streams.  status[j] = 0 or KZG_ERR_POINT_NOT_ON_POLY (p(x_j) != y_j).
+    if (!ctx || !srs || !coeffs || !out || n == 0 || ((!xs || !ys) && count)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    size_t psz = point_format_bytes(ofmt);
+    if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (n - 1 > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
+    if (count == 0) return KZG_OK;
+    std::vector<Fr> xm(count);
+    for (size_t j = 0; j < count; j++) KZG_TRY(host_scalar(ctx, (const uint8_t *)xs + 32 * j, sfmt, &xm[j]));
+    BatchPipe bp;
+    KZG_TRY(batch_begin(ctx, count, count * psz, out, flags, &bp));
+    int rc = KZG_OK;
+    // shared inputs / outputs live in the arena of one extra lane: the coefficients (when they come from the host) and p(x_j)
+    const int sl = bp.nl;
+    rc = ensure_lanes(ctx, sl + 1);
+    if (rc == KZG_OK) rc = lane_reserve(ctx, sl, stage_bytes(n * 32, flags) + count * 32 + 4096);
+    const void *d_coeffs = nullptr;
+    Fr *d_px = nullptr;
+    if (rc == KZG_OK) rc = stage_in(ctx, sl, coeffs, n * 32, flags, &d_coeffs);
+    if (rc == KZG_OK && !(d_px = (Fr *)lane_alloc(ctx, sl, count * 32))) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
+    if (rc == KZG_OK && hipStreamSynchronize(ctx->lanes[sl].stream) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "stage-in of the coefficients");
+    size_t per = msm_workspace_bytes(srs, n - 1) + n * 32 + (n / 2048 + 4) * 64 + 65536;
+    for (int l = 0; l < bp.nl && rc == KZG_OK; l++) rc = lane_reserve(ctx, l, per);
+    for (size_t j = 0; j < count && rc == KZG_OK; j++) {
+        int l = (int)(j % bp.nl);
+        ctx->lanes[l].arena_used = 0;
+        Fr *dq = (Fr *)lane_alloc(ctx, l, n * 32);
+        if (!dq) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
+        if (rc == KZG_OK) rc = quotient_linear_run(ctx, l, (const Fr *)d_coeffs, n, xm[j], dq, d_px + j);
+        MsmPoint *res = nullptr;
+        if (rc == KZG_OK) rc = batch_msm(ctx, bp, j, l, srs, 0, dq, n - 1, sfmt, &res);
+        if (rc == KZG_OK) rc = emit_point(ctx, l, res, bp.d_out + j * psz, ofmt);
     }
-    if (ctx->prof) prof_collect(ctx);
-    return rc;
+    rc = batch_end(ctx, bp, rc, out, count * psz);
+    if (rc != KZG_OK) return rc;
+    std::vector<uint8_t> px(count * 32);
+    KZG_HIP_CHECK(ctx, hipMemcpy(px.data(), d_px, count * 32, hipMemcpyDeviceToHost));
+    int worst = KZG_OK;
+    for (size_t j = 0; j < count; j++) {
+        // remainder of (p - y)/(X - x) is p(x) - y: Some(_) => Err(PointNotOnPolynomial)
+        int sj = memcmp(px.data() + 32 * j, (const uint8_t *)ys + 32 * j, 32) != 0 ? KZG_ERR_POINT_NOT_ON_POLY : KZG_OK;
+        if (status) status[j] = sj;
+        if (sj) worst = sj;
+    }
+    if (worst && !status) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
+    return KZG_OK;
 }
 
 extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pfmt, int flags, void *out, int ofmt) {

@@ -1,5 +1,6 @@
 """End-to-end KZGProver / KZGProverEvalForm parity via the known-tau identities and the C
 oracle, mirroring the reference's tests (src/coeff_form.rs:271-398, src/eval_form.rs:318-483)."""
+import ctypes
 import random
 
 import pytest
@@ -86,6 +87,42 @@ def test_config1_commit_and_witness(engine, log_n):
     if log_n == 10:  # and against the oracle's long_division + Pippenger
         qb, nz = C.witness_quotient_bytes(C.scalars_to_bytes(coeffs), n, x, y)
         assert not nz and w == C.msm_g1_raw(params.gs.download(0, n - 1), qb, n - 1)
+    params.gs.free()
+
+
+@pytest.mark.parametrize("n,k", [(1 << 10, 21), (1 << 13, 5), (3, 4), (1, 3)])
+def test_create_witness_many(engine, n, k):
+    """kzg_witness_coeff_many == k calls of create_witness on the same polynomial (secondary reading):
+    each witness against the known-tau identity and the single-opening entry point; wrong y -> that opening flagged as
+    PointNotOnPolynomial while the others stay valid; device-resident coefficients give the same bytes."""
+    rng = random.Random(7000 + n + k)
+    tau = rng.getrandbits(64)
+    params = kzg_amd.setup(engine, tau, max(n, 2))
+    prover = kzg_amd.KZGProver(params)
+    coeffs = rand_scalars(rng, n)
+    p = kzg_amd.Polynomial(coeffs)
+    ptau = C.poly_eval(coeffs, tau)
+    xs = [rng.randrange(M.R) for _ in range(k)]
+    pts = [(x, C.poly_eval(coeffs, x)) for x in xs]
+    ws, ok = prover.create_witness_many(p, pts)
+    assert ok == [True] * k
+    for (x, y), w in zip(pts, ws):
+        assert w == C.g1_mul(G(), (ptau - y) * M.fr_inv(tau - x) % M.R)
+    assert ws[0] == prover.create_witness(p, pts[0])
+    bad = list(pts)
+    bad[1] = (bad[1][0], (bad[1][1] + 1) % M.R)
+    ws2, ok2 = prover.create_witness_many(p, bad)
+    assert ok2 == [j != 1 for j in range(k)] and [w for j, w in enumerate(ws2) if j != 1] == [w for j, w in enumerate(ws) if j != 1]
+    e = engine
+    rc = e.lib.kzg_witness_coeff_many(e.ctx, params.gs.handle, kzg_amd.api.pack_scalars(coeffs), n,
+                                      kzg_amd.api.pack_scalars([b[0] for b in bad]), kzg_amd.api.pack_scalars([b[1] for b in bad]), k,
+                                      L.FR_CANONICAL, 0, ctypes.create_string_buffer(96 * k), L.G1_AFFINE_MONT, None)
+    assert rc == L.KZG_ERR_POINT_NOT_ON_POLY                      # no status array: the reference's Err, for the whole call
+    buf = e.alloc_scalars(n)
+    buf.upload(kzg_amd.api.pack_scalars(coeffs))
+    ws3, ok3 = prover.create_witness_many(None, pts, coeffs_device=buf)
+    assert ws3 == ws and ok3 == ok
+    buf.free()
     params.gs.free()
 
 
