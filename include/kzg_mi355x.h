@@ -158,6 +158,10 @@ int kzg_commit_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, si
  * i >= d (the reference panics on the index). */
 int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, size_t i, int sfmt,
                      int flags, void *out, int ofmt);
+/* Throughput form: `count` openings (indices[j]) of ONE evaluation vector, pipelined like kzg_msm_g1_batch.  out: count points.
+ * Not a reference method: equivalent to calling KZGProverEvalForm::create_witness count times. */
+int kzg_witness_eval_many(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, const size_t *indices,
+                          size_t count, int sfmt, int flags, void *out, int ofmt);
 /* KZGVerifierEvalForm::verify_poly (:162-171): ifft then monomial MSM, compare. */
 int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const void *commitment, int pfmt,
                          const void *evals, size_t d, int sfmt, int flags, int *ok);

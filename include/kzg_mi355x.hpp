@@ -163,6 +163,22 @@ class KZGProver {  // src/coeff_form.rs:37-112
                                    KZG_FR_CANONICAL_LE_32, 0, out.bytes.data(), KZG_G1_AFFINE_MONT_96));
         return out;
     }
+    // Not a reference method: `xs.size()` calls of create_witness on one polynomial, pipelined on the GPU.  ok[j] == false
+    // where the reference would return Err(PointNotOnPolynomial) for opening j.
+    std::vector<KZGWitness> create_witness_many(const Polynomial &p, const std::vector<Scalar> &xs, const std::vector<Scalar> &ys,
+                                                std::vector<bool> *ok = nullptr) const {
+        if (xs.size() != ys.size()) throw ReferencePanic("assert_eq!(xs.len(), ys.len())");
+        std::vector<KZGWitness> out(xs.size());
+        std::vector<int> status(xs.size() ? xs.size() : 1, 0);
+        static_assert(sizeof(KZGWitness) == 96, "KZGWitness is the 96-byte affine encoding");
+        e_.check(kzg_witness_coeff_many(e_.ctx(), params_.gs, p.coeffs.data(), p.num_coeffs(), xs.data(), ys.data(), xs.size(),
+                                        KZG_FR_CANONICAL_LE_32, 0, out.data(), KZG_G1_AFFINE_MONT_96, status.data()));
+        if (ok) {
+            ok->assign(xs.size(), true);
+            for (size_t j = 0; j < xs.size(); j++) (*ok)[j] = status[j] == 0;
+        }
+        return out;
+    }
     KZGBatchWitness create_witness_batched(const Polynomial &p, const std::vector<Scalar> &xs,
                                            const std::vector<Scalar> &ys) const {  // :83-111
         if (xs.size() != ys.size()) throw ReferencePanic("assert_eq!(xs.len(), ys.len())");

@@ -73,6 +73,7 @@ def load():
         "kzg_witness_coeff_batched": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, vp, ctypes.POINTER(sz)]),
         "kzg_verify_poly_coeff": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
         "kzg_commit_eval": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
+        "kzg_witness_eval_many": (i32, [vp, vp, vp, sz, ctypes.POINTER(sz), sz, i32, i32, vp, i32]),
         "kzg_witness_eval": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_verify_poly_eval": (i32, [vp, vp, vp, i32, vp, sz, i32, i32, ctypes.POINTER(i32)]),
         "kzg_srs_setup_g2": (i32, [vp, vp, i32, sz, c_void_pp]),

@@ -687,6 +687,19 @@ class KZGProverEvalForm:
             _raise(e, rc)
         return out.raw
 
+    def create_witness_many(self, evals, indices, ofmt=L.G1_AFFINE_MONT):
+        """Throughput form of create_witness (not a reference method): one witness per index, same evaluation vector."""
+        e = self.engine
+        k = len(indices)
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt] * max(k, 1))
+        idx = (ctypes.c_size_t * max(k, 1))(*indices)
+        rc = e.lib.kzg_witness_eval_many(e.ctx, self.lagrange_basis_g.handle, pack_scalars(evals.coeffs), len(evals), idx, k,
+                                         L.FR_CANONICAL, 0, out, ofmt)
+        if rc:
+            _raise(e, rc)
+        psz = L.POINT_BYTES[ofmt]
+        return [out.raw[j * psz:(j + 1) * psz] for j in range(k)]
+
     def create_witness_all(self):  # :142-146: identity
         return bytes(96)
 

@@ -545,6 +545,45 @@ extern "C" int kzg_witness_coeff_many(kzg_ctx *ctx, const kzg_srs *srs, const vo
     return KZG_OK;
 }
 
+extern "C" int kzg_witness_eval_many(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, const size_t *indices,
+                                     size_t count, int sfmt, int flags, void *out, int ofmt) {
+    // `count` calls of KZGProverEvalForm::create_witness (src/eval_form.rs:124-140) on ONE evaluation vector, pipelined
+    if (!ctx || !lagrange || !evals || !out || (!indices && count)) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    size_t psz = point_format_bytes(ofmt);
+    if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
+    for (size_t j = 0; j < count; j++)
+        if (indices[j] >= d) return fail(ctx, KZG_ERR_SHAPE, "evaluation index out of range (reference: index panic)");
+    if (d > lagrange->n) return fail(ctx, KZG_ERR_SHAPE, "evaluations longer than the Lagrange SRS (reference: slice panic)");
+    uint32_t log_d = (uint32_t)ilog2_ceil(d);
+    if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
+    if (count == 0) return KZG_OK;
+    BatchPipe bp;
+    KZG_TRY(batch_begin(ctx, count, count * psz, out, flags, &bp));
+    const int sl = bp.nl;  // shared arena: the evaluations when they come from the host
+    int rc = ensure_lanes(ctx, sl + 1);
+    if (rc == KZG_OK) rc = lane_reserve(ctx, sl, stage_bytes(d * 32, flags) + 4096);
+    const void *de = nullptr;
+    if (rc == KZG_OK) rc = stage_in(ctx, sl, evals, d * 32, flags, &de);
+    if (rc == KZG_OK) rc = eval_tables_ready(ctx, sl, log_d);  // also waits for the stage-in
+    size_t per = msm_workspace_bytes(lagrange, d) + d * 32 + (d / 256 + 4) * 32 + 65536;
+    for (int l = 0; l < bp.nl && rc == KZG_OK; l++) rc = lane_reserve(ctx, l, per);
+    for (size_t j = 0; j < count && rc == KZG_OK; j++) {
+        int l = (int)(j % bp.nl);
+        ctx->lanes[l].arena_used = 0;
+        Fr *dq = (Fr *)lane_alloc(ctx, l, d * 32);
+        if (!dq) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
+        if (rc == KZG_OK) rc = quotient_eval_run(ctx, l, (const Fr *)de, log_d, indices[j], sfmt, dq);
+        MsmPoint *res = nullptr;
+        if (rc == KZG_OK) rc = batch_msm(ctx, bp, j, l, lagrange, 0, dq, d, sfmt, &res);
+        if (rc == KZG_OK) rc = emit_point(ctx, l, res, bp.d_out + j * psz, ofmt);
+    }
+    return batch_end(ctx, bp, rc, out, count * psz);
+}
+
 extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pfmt, int flags, void *out, int ofmt) {
     if (!ctx || !out || (!points && count)) return KZG_ERR_SHAPE;
     Guard g(ctx);

@@ -206,6 +206,7 @@ int batch_inverse(kzg_ctx *ctx, hipStream_t stream, const Fr *d_in, Fr *d_out, s
 // Horner machinery: eval and linear quotient. d_coeffs in Montgomery or canonical form (linear ops:
 // the result is in the same form provided x_mont is Montgomery).
 int poly_eval_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_y_out);
+int eval_tables_ready(kzg_ctx *ctx, int lane, uint32_t log_d);
 int quotient_linear_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_q_out,
                         Fr *d_px_out);
 int quotient_eval_run(kzg_ctx *ctx, int lane, const Fr *d_evals, uint32_t log_d, size_t m, int sfmt, Fr *d_q_out);

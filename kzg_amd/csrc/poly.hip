@@ -289,6 +289,14 @@ __global__ __launch_bounds__(256) void k_eval_quotient_fix(const Fr *partial, ui
     if (threadIdx.x == 0) q[m] = neg(s);
 }
 
+// builds (first use) the per-domain tables and waits for them: callers that run quotient_eval_run on several lanes at once
+int eval_tables_ready(kzg_ctx *ctx, int lane, uint32_t log_d) {
+    EvalDomainTables *tab = nullptr;
+    KZG_TRY(eval_tables(ctx, ctx->lanes[lane].stream, log_d, &tab));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lanes[lane].stream));
+    return KZG_OK;
+}
+
 int quotient_eval_run(kzg_ctx *ctx, int lane, const Fr *d_evals, uint32_t log_d, size_t m, int sfmt, Fr *d_q_out) {
     (void)sfmt;  // the map f -> q is linear with Montgomery-form constants: either input form is preserved
     hipStream_t st = ctx->lanes[lane].stream;

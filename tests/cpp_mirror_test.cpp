@@ -45,6 +45,16 @@ int main() {
     if (!verifier.verify_eval_batched(xs, cm2, bw)) return 12;
     xs[1] = Scalar::from_u64(9);
     if (verifier.verify_eval_batched(xs, cm2, bw)) return 13;
+    {   // create_witness_many == create_witness per opening; a wrong y is flagged, not thrown
+        std::vector<Scalar> mx = {Scalar::from_u64(11), Scalar::from_u64(12), Scalar::from_u64(13)}, my;
+        for (auto &x : mx) my.push_back(p2.eval(e, x));
+        my[2] = Scalar::from_u64(1);
+        std::vector<bool> ok;
+        std::vector<KZGWitness> ws = prover.create_witness_many(p2, mx, my, &ok);
+        if (ws.size() != 3 || !ok[0] || !ok[1] || ok[2]) return 14;
+        if (!(ws[0] == prover.create_witness(p2, mx[0], my[0]))) return 15;
+        if (!verifier.verify_eval(mx[1], my[1], cm2, ws[1])) return 16;
+    }
     std::printf("cpp mirror ok\n");
     return 0;
 }

@@ -160,6 +160,15 @@ def test_eval_form(engine, d):
     with pytest.raises(kzg_amd.ReferencePanic):
         prover.commit(short)  # assert!(self.d == evals.d)
     assert prover.create_witness_all() == bytes(96)
+    # throughput form: many openings of the same evaluation vector == one create_witness call each
+    idx = [0, 3, d - 1, 3, 1] + [rng.randrange(d) for _ in range(14)]
+    many = prover.create_witness_many(evals, idx)
+    assert many[1] == w and many[3] == w
+    for i2, w2 in zip(idx, many):
+        x2 = pow(prover.omega(), i2, M.R)
+        assert w2 == C.g1_mul(G(), (C.poly_eval(coeffs, tau) - evals.coeffs[i2]) * M.fr_inv(tau - x2) % M.R)
+    with pytest.raises(kzg_amd.ReferencePanic):
+        prover.create_witness_many(evals, [1, d])
     params.gs.free(); lag.free()
 
 
