@@ -330,11 +330,20 @@ def main():
                     res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(engine, params, scal, args.log_n)
                 except Exception as e:
                     res["cpu_baseline_all_cores"] = {"value": None, "sample": f"failed: {e}"}
-        print(json.dumps(res), flush=True)
+        line = json.dumps(res)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     engine.close()
+    # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's
+    # own output at exit: flush it now so that the JSON line is the last line of stdout
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":
