@@ -331,17 +331,17 @@ def main():
                 except Exception as e:
                     res["cpu_baseline_all_cores"] = {"value": None, "sample": f"failed: {e}"}
         line = json.dumps(res)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
-    engine.close()
-    # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's
-    # own output at exit: flush it now so that the JSON line is the last line of stdout
+    # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's own
+    # output when a process exits: every rank flushes it before the last barrier, so that rank 0's JSON line ends the output
     sys.stdout.flush()
     try:
         ctypes.CDLL(None).fflush(None)
     except Exception:
         pass
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    engine.close()
     if rank == 0:
         print(line, flush=True)
 
