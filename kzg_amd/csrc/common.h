@@ -95,7 +95,8 @@ struct kzg_srs {
     size_t n = 0;        // points
     size_t npad = 0;     // row stride (points)
     int c = 0;           // window bits (signed digits, 2^(c-1) buckets)
-    int W = 0;           // windows = ceil(256 / c); table row w holds 2^(c*w) * P_i
+    int W = 0;           // windows = ceil(256 / c) (15 in the c = 17 single-pass mode); table row w holds 2^(c*w) * P_i
+    bool narrow17 = false;  // c = 17: single-pass sort walking the scalars twice (half the buckets per walk), balanced scalars
     kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
     void *table30 = nullptr;         // [W][npad] G1Affine30 (2 x 13 x 30-bit limbs + pad, 112 B): what k_accum_affine gathers
     int device = 0;

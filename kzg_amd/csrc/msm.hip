@@ -47,9 +47,25 @@ __device__ __forceinline__ void load_scalar(const Fr *scalars, size_t i, int sfm
     for (int k = 0; k < 8; k++) s[k] = v.v[k];
 }
 
-// calls f(w, magnitude in [1, 2^(c-1)], negative) for every non-zero signed digit
+// calls f(w, magnitude in [1, 2^(c-1)], negative) for every non-zero signed digit.
+// balanced (the c = 17 single-pass mode, W * c = 255): a scalar with bit 254 set is replaced by r - k < 2^254 with every digit
+// sign flipped (k = -(r - k) mod r), so the top window's raw digit stays <= 2^(c-1) and nothing carries out of window W - 1.
 template <class F>
-__device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W, F f) {
+__device__ __forceinline__ void for_each_digit(const uint32_t s_in[8], int c, int W, bool balanced, F f) {
+    uint32_t s[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = s_in[k];
+    uint32_t flip = 0;
+    if (balanced && (s[7] & 0x40000000u)) {
+        uint64_t bw = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t d = (uint64_t)FrParams::mod(k) - s[k] - bw;
+            s[k] = (uint32_t)d;
+            bw = (d >> 63) & 1u;
+        }
+        flip = 1;
+    }
     uint32_t carry = 0;
     const uint32_t mask = (1u << c) - 1u;
     const uint32_t half = 1u << (c - 1);
@@ -63,7 +79,7 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
         uint32_t neg = raw > half ? 1u : 0u;
         uint32_t mag = neg ? ((1u << c) - raw) : raw;
         carry = neg;
-        if (mag) f(w, mag, neg);
+        if (mag) f(w, mag, neg ^ flip);
     }
 }
 
@@ -72,21 +88,32 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s[8], int c, int W
 // ---------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
 
+// mode 0: B u32 counters (c <= 16, or the low 15 bucket bits of the wide path); mode 2 (c = 17 single pass): B = 2^16 buckets, the
+// u32 counters of half of them fit the LDS, so the block walks its scalars twice (as k_scatter does); balanced scalars
 __global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int sfmt, int c, int W, int B,
-                                               size_t per_block, uint32_t *blk_hist) {
-    // B = number of LDS counters = sort keys of this pass: the whole magnitude (c <= 16) or its low 15 bits (wide)
-    for (int b = threadIdx.x; b < B; b += blockDim.x) lds_u32[b] = 0;
-    __syncthreads();
+                                               size_t per_block, uint32_t *blk_hist, int mode) {
+    const bool pk = mode == 2;
+    const int BH = pk ? B / 2 : B;
     size_t i0 = (size_t)blockIdx.x * per_block;
     size_t i1 = i0 + per_block < n ? i0 + per_block : n;
-    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        uint32_t s[8];
-        load_scalar(scalars, i, sfmt, s);
-        for_each_digit(s, c, W, [&](int, uint32_t mag, uint32_t) { atomicAdd(&lds_u32[(mag - 1) & (uint32_t)(B - 1)], 1u); });
-    }
-    __syncthreads();
     uint32_t *dst = blk_hist + (size_t)blockIdx.x * B;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) dst[b] = lds_u32[b];
+    for (int half = 0; half < (pk ? 2 : 1); half++) {
+        const uint32_t base = (uint32_t)half * (uint32_t)BH;
+        if (half) __syncthreads();
+        for (int b = threadIdx.x; b < BH; b += blockDim.x) lds_u32[b] = 0;
+        __syncthreads();
+        for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            uint32_t s[8];
+            load_scalar(scalars, i, sfmt, s);
+            for_each_digit(s, c, W, pk, [&](int, uint32_t mag, uint32_t) {
+                const uint32_t idx = (mag - 1) & (uint32_t)(B - 1);
+                if (pk && (idx >> 15) != (uint32_t)half) return;
+                atomicAdd(&lds_u32[idx - base], 1u);
+            });
+        }
+        __syncthreads();
+        for (int b = threadIdx.x; b < BH; b += blockDim.x) dst[base + b] = lds_u32[b];
+    }
 }
 
 // per bucket: exclusive scan over sort blocks; total[b] = bucket size
@@ -127,24 +154,35 @@ __global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t *total, in
     }
 }
 
+// mode 0: c <= 16 (u32 cursors in LDS); mode 1: wide path (sorts by the low 15 bucket bits, the high bits ride in bits 27..30 of
+// the entry word until the second pass strips them); mode 2: c = 17 single pass, 2^16 buckets: the 32-bit cursors of only half the
+// buckets fit the LDS, so the block walks its scalars twice, scattering the digits of one bucket half per walk (the digit
+// extraction is cheap next to the scattered stores; cursors kept in L2 instead cost +83 % on this kernel)
 __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, int sfmt, int c, int W, int B,
                                                   size_t per_block, const uint32_t *blk_off,
                                                   const uint32_t *bucket_start, uint32_t row_stride,
-                                                  uint32_t idx_base, uint32_t *entries) {
+                                                  uint32_t idx_base, uint32_t *entries, int mode) {
     const uint32_t *off = blk_off + (size_t)blockIdx.x * B;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) lds_u32[b] = bucket_start[b] + off[b];
-    __syncthreads();
+    const bool pk = mode == 2;
+    const int BH = pk ? B / 2 : B;  // buckets whose cursors are resident per walk
     size_t i0 = (size_t)blockIdx.x * per_block;
     size_t i1 = i0 + per_block < n ? i0 + per_block : n;
-    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
-        uint32_t s[8];
-        load_scalar(scalars, i, sfmt, s);
-        for_each_digit(s, c, W, [&](int w, uint32_t mag, uint32_t neg) {
-            uint32_t pos = atomicAdd(&lds_u32[(mag - 1) & (uint32_t)(B - 1)], 1u);
-            // wide mode (c > 16): the high bucket bits ride in bits 27..30 until the second sort pass strips them
-            entries[pos] = ((uint32_t)w * row_stride + idx_base + (uint32_t)i) | (((mag - 1) >> WIDE_LO_BITS) << WIDE_HI_SHIFT) |
-                           (neg << 31);
-        });
+    for (int half = 0; half < (pk ? 2 : 1); half++) {
+        const uint32_t base = (uint32_t)half * (uint32_t)BH;
+        if (half) __syncthreads();
+        for (int b = threadIdx.x; b < BH; b += blockDim.x) lds_u32[b] = bucket_start[base + b] + off[base + b];
+        __syncthreads();
+        for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+            uint32_t s[8];
+            load_scalar(scalars, i, sfmt, s);
+            for_each_digit(s, c, W, pk, [&](int w, uint32_t mag, uint32_t neg) {
+                const uint32_t idx = (mag - 1) & (uint32_t)(B - 1);
+                if (pk && (idx >> 15) != (uint32_t)half) return;
+                const uint32_t pos = atomicAdd(&lds_u32[idx - base], 1u);
+                const uint32_t hi = mode == 1 ? (((mag - 1) >> WIDE_LO_BITS) << WIDE_HI_SHIFT) : 0u;
+                entries[pos] = ((uint32_t)w * row_stride + idx_base + (uint32_t)i) | hi | (neg << 31);
+            });
+        }
     }
 }
 
@@ -600,12 +638,12 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     auto start_arr = [&](int level) { return starts + (size_t)level * (Btot + 1); };
 
     // pass 1: LDS counting sort by the low 15 bucket bits (hi rides in the entry word)
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist);
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, 0);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B_lo + 255) / 256, 256, 0, blk_hist, G, B_lo, total);
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;
     KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, ctx->cur_scan_threads, 0, total, B_lo, lo_start, s1_lo, state, slots);  // M, E, ntasks
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
-               (uint32_t)srs->npad, (uint32_t)offset, entries1);
+               (uint32_t)srs->npad, (uint32_t)offset, entries1, 1);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
     KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
     // equal-split layout of round 1 over the full bucket set
@@ -634,7 +672,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
 }
 
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) {
-    return srs->c > 16 ? wide_layout(srs, n ? n : 1).bytes : msm_layout(srs, n ? n : 1).bytes;
+    return (srs->c > 16 && !srs->narrow17) ? wide_layout(srs, n ? n : 1).bytes : msm_layout(srs, n ? n : 1).bytes;
 }
 
 int sum_level_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
@@ -686,15 +724,16 @@ static int msm_stage1(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset,
     MsmPoint *bufA = (MsmPoint *)(base + L.off_bufA);
     const Fr *sc = (const Fr *)d_scalars;
     size_t per_block = (n + G - 1) / G;
-    size_t lds_bytes = (size_t)B * 4;
+    const int mode = srs->narrow17 ? 2 : 0;
+    size_t lds_bytes = srs->narrow17 ? (size_t)B * 2 : (size_t)B * 4;  // c = 17: the counters / cursors of half the buckets per walk
 
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist);
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode);
     KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
     // starts[0 .. B] (level 0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
     KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, ctx->cur_scan_threads, 0, total, B, bucket_start, starts, state, slots);
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
-               bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries);
+               bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode);
     hipStream_t as = st;
     if (accum_stream && accum_stream != st) {
         KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
@@ -752,7 +791,7 @@ static int msm_tail(kzg_ctx *ctx, int lane, const MsmLayout &L, char *base, MsmP
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
     if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
-    if (srs->c > 16) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
+    if (srs->c > 16 && !srs->narrow17) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
     if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
     MsmLayout L = msm_layout(srs, n ? n : 1);
     if (n == 0) {

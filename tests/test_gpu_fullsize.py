@@ -150,7 +150,7 @@ def test_adversarial_scalars_2_16(engine, case):
 
 @pytest.mark.parametrize("n", [5, 17, 33, 100, 700, 3000, 9000, 40000])
 def test_every_window_size(engine, n):
-    """SRS sizes that select every window width c = 4 .. 14 (c = 16 is covered by the 2^20 tests)."""
+    """SRS sizes that select every window width c = 4 .. 14 (c = 17 is covered by the 2^20 tests, 16 by test_wide_windows)."""
     rng = random.Random(n)
     params = kzg_amd.setup(engine, TAU, n)
     c, W = params.gs.window_info()
@@ -161,18 +161,19 @@ def test_every_window_size(engine, n):
     params.gs.free()
 
 
-@pytest.mark.parametrize("wb", [17, 18, 19, 20])
+@pytest.mark.parametrize("wb", [16, 17, 18, 19, 20])
 def test_wide_windows(engine, wb):
-    """Window widths above 16 (option window_bits): two-pass sort, 2^(wb-1) buckets, row/column bucket reduction.  Random,
-    adversarial (one bucket, extreme digits) and u64-valued scalars at 2^16 terms, sub-ranges with an offset, and the
-    batched entry point, each against the known-tau identity."""
+    """Window widths chosen by option (window_bits): 16 (the default below 2^19 points tops out at 15) and the widths above it.  18..20: two-pass sort, 2^(wb-1) buckets, row/column bucket reduction.
+    17: single-pass sort that walks the scalars twice (half the 2^16 buckets per walk), 15 windows, scalars >= 2^254 replaced by -(r - k).
+    Random, adversarial (one bucket, extreme digits, values around 2^254 and r) and u64-valued scalars at 2^16 terms,
+    sub-ranges with an offset, and the batched entry point, each against the known-tau identity."""
     n = 1 << 16
     rng = random.Random(wb)
     engine.set_option("window_bits", wb)
     try:
         params = kzg_amd.setup(engine, TAU, n, g2_len=0)
         c, W = params.gs.window_info()
-        assert c == wb and W == -(-256 // wb)
+        assert c == wb and W == (15 if wb == 17 else -(-256 // wb))
         pw = [1]
         for _ in range(n - 1):
             pw.append(pw[-1] * TAU % R)
@@ -187,6 +188,8 @@ def test_wide_windows(engine, wb):
             "all_equal": [rng.randrange(R)] * n,
             "extreme_digits": [int(("8" + "0" * (wb // 4 - 1)) * (255 // wb), 16) % R] * n,
             "r_minus_1_and_zero": [(R - 1) * (i & 1) for i in range(n)],
+            "around_2^254": [((1 << 254) + d) % R for d in (-2, -1, 0, 1, 2, (1 << 237), -(1 << 237))] * (n // 7) + [R - 2] * (n % 7),
+            "top_window_max": [((1 << 254) - 1) - (i % 3)  for i in range(n)],
         }
         for name, sc in cases.items():
             assert engine.msm(params.gs, sc) == want(sc), (wb, name)
