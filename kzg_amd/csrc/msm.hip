@@ -4,14 +4,14 @@
 // src/eval_form.rs:118,136).  The result is the group element sum_i s_i * P_i; how it is computed
 // is free, so the structure below is chosen for the MI355X, not for the CPU the reference runs on:
 //
-//   * The SRS is resident in HBM as W = ceil(256/c) rows, row w holding the affine points
-//     2^(c*w) * P_i (built once at upload; 1.5 GiB for 2^20 points at c = 16 -- cheap in 288 GB), plus
-//     a copy of the same table in the signed 30-bit representation the inner loop computes in
-//     (112 B per point, 1.75 GiB at 2^20).
+//   * The SRS is resident in HBM as W rows (W = ceil(256/c); 15 at c = 17, the width used above 2^19 points), row w holding
+//     the affine points 2^(c*w) * P_i in the signed 30-bit representation the inner loop computes in (112 B per point,
+//     1.64 GiB for 2^20 points -- cheap in 288 GB); row 0 also in the canonical 96-byte form.
 //     Every signed c-bit digit of every scalar therefore lands in ONE shared set of 2^(c-1)
 //     buckets: there is no per-window bucket reduction and no window-combine doubling chain.
-//   * Digits -> buckets by a one-pass counting sort whose 2^(c-1)-entry histogram / cursor array
-//     lives in LDS (128 KiB of the CU's 160 KiB at c = 16): k_hist, k_scan_*, k_scatter.
+//   * Digits -> buckets by a one-pass counting sort whose histogram / cursor array lives in LDS (2^15 u32 counters = 128 KiB
+//     of the CU's 160 KiB; at c = 17 the blocks walk their scalars twice, half the 2^16 buckets per walk): k_hist,
+//     k_scan_*, k_scatter.
 //   * Bucket accumulation (k_accum_affine) is an equal split of the sorted entry list over exactly
 //     the resident thread slots (XYZZ mixed adds, points gathered from the resident table, one partial
 //     per bucket a thread touches), then partial sums are folded by key in rounds of fan-in LK
