@@ -83,6 +83,50 @@ __device__ __forceinline__ void for_each_digit(const uint32_t s_in[8], int c, in
     }
 }
 
+// The same for a window width fixed at compile time: every limb index and shift is a constant, so the digits come straight out
+// of registers (the generic version selects limbs with a chain of compares).  Used for the production width c = 17, W = 15.
+template <int C, int WN, class F>
+__device__ __forceinline__ void for_each_digit_fixed(const uint32_t s_in[8], bool balanced, F f) {
+    uint32_t s[9];
+#pragma unroll
+    for (int k = 0; k < 8; k++) s[k] = s_in[k];
+    s[8] = 0;
+    uint32_t flip = 0;
+    if (balanced && (s[7] & 0x40000000u)) {
+        uint64_t bw = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint64_t d = (uint64_t)FrParams::mod(k) - s[k] - bw;
+            s[k] = (uint32_t)d;
+            bw = (d >> 63) & 1u;
+        }
+        flip = 1;
+    }
+    uint32_t carry = 0;
+    constexpr uint32_t mask = (1u << C) - 1u;
+    constexpr uint32_t half = 1u << (C - 1);
+#pragma unroll
+    for (int w = 0; w < WN; w++) {
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int o = w * C, limb = o >> 5, sh = o & 31;
+        const uint32_t lo = s[limb], hi = s[limb + 1 > 8 ? 8 : limb + 1];
+        const uint64_t both = ((uint64_t)hi << 32) | lo;
+        const uint32_t raw = ((uint32_t)(both >> sh) & mask) + carry;
+        const uint32_t neg = raw > half ? 1u : 0u;
+        const uint32_t mag = neg ? ((1u << C) - raw) : raw;
+        carry = neg;
+        if (mag) f(w, mag, neg ^ flip);
+    }
+}
+
+// dispatch: the fixed-width version for c = 17 (W = 15, balanced), the generic one otherwise
+template <class F>
+__device__ __forceinline__ void digits_of(const uint32_t s[8], int c, int W, bool balanced, F f) {
+    if (c == 17 && W == 15) for_each_digit_fixed<17, 15>(s, balanced, f);
+    else for_each_digit(s, c, W, balanced, f);
+}
+
 // ---------------------------------------------------------------------------------------------
 // counting sort by bucket, LDS histogram / cursors
 // ---------------------------------------------------------------------------------------------
@@ -105,7 +149,7 @@ __global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int 
         for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
             uint32_t s[8];
             load_scalar(scalars, i, sfmt, s);
-            for_each_digit(s, c, W, pk, [&](int, uint32_t mag, uint32_t) {
+            digits_of(s, c, W, pk, [&](int, uint32_t mag, uint32_t) {
                 const uint32_t idx = (mag - 1) & (uint32_t)(B - 1);
                 if (pk && (idx >> 15) != (uint32_t)half) return;
                 atomicAdd(&lds_u32[idx - base], 1u);
@@ -175,7 +219,7 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
         for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
             uint32_t s[8];
             load_scalar(scalars, i, sfmt, s);
-            for_each_digit(s, c, W, pk, [&](int w, uint32_t mag, uint32_t neg) {
+            digits_of(s, c, W, pk, [&](int w, uint32_t mag, uint32_t neg) {
                 const uint32_t idx = (mag - 1) & (uint32_t)(B - 1);
                 if (pk && (idx >> 15) != (uint32_t)half) return;
                 const uint32_t pos = atomicAdd(&lds_u32[idx - base], 1u);
