@@ -24,7 +24,10 @@ constexpr int TAIL_THREADS = 256;
 // Same-box A/B against two rounds of fan-in 4: 2^20 equal, u64-valued +4 %, 2^16 +19 % (single commit 2.1 -> 1.4 ms).
 constexpr int LK = KZG_FOLD_FANIN;   // fan-in of the fold rounds
 constexpr int SUM_L = 4;  // fan-in of the plain tree sum
-constexpr int REDUCE_CH = 8;  // buckets per k_bucket_reduce thread
+#ifndef KZG_REDUCE_CH
+#define KZG_REDUCE_CH 8
+#endif
+constexpr int REDUCE_CH = KZG_REDUCE_CH;  // buckets per k_bucket_reduce thread
 constexpr int MAX_LEVELS = 24;
 // wide windows (16 < c <= 20): bucket id = hi (c - 16 bits) : lo (15 bits).  Pass 1 sorts by lo with the LDS counting sort,
 // pass 2 is a stable partition by hi; between the passes hi travels in bits 27..30 of the entry word, which limits the
