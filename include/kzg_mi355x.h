@@ -73,6 +73,7 @@ enum { KZG_IN_DEVICE = 1, KZG_OUT_DEVICE = 2 };
 
 /* ---- context ------------------------------------------------------------------------------- */
 const char *kzg_version(void);
+int kzg_device_count(void);  /* usable HIP devices (0 if none) */
 /* device: HIP device ordinal.  Fails with KZG_ERR_NO_DEVICE if no gfx950-class device is usable. */
 int kzg_ctx_create(int device, kzg_ctx **out);
 void kzg_ctx_destroy(kzg_ctx *ctx);
@@ -112,6 +113,57 @@ int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pfmt, int fla
 /* `groups` independent sums: out[g] = sum_i points[g*count + i] (batched multi-GPU combine). */
 int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t groups, int pfmt, int flags, void *out,
                      int ofmt);
+
+/* ---- multi-GPU: the SRS sharded over up to 8 GPUs, partial commitments combined over RCCL / xGMI ---------------------
+ * (north star: "MSM shards the SRS across up to 8 GPUs with an RCCL all-reduce of partial bucket sums"; the seam is the
+ * multi_exp call of KZGProver::commit, src/coeff_form.rs:59-64, and of create_witness, :66-81.)
+ * A kzg_mctx is a group of `world` GPUs (ranks).  Rank r holds the contiguous SRS range kzg_shard_range(n, r, world) resident
+ * and reduces the matching scalar slice of every polynomial to ONE partial point on its GPU; the 144-byte Jacobian partials are
+ * exchanged with one ncclAllGather and every rank adds them locally (EC addition is not an RCCL reduction op, so the
+ * "all-reduce" is all-gather + local sum).  Two ways to form the group:
+ *   - one host process driving n GPUs: kzg_mctx_create(devices, n)   (ncclCommInitAll; one host thread per device per call);
+ *   - one process per GPU:  rank 0 calls kzg_mctx_unique_id, the host distributes the 128 bytes by any means (MPI, a TCP
+ *     store, torch.distributed), every rank calls kzg_mctx_create_rank(device, rank, world, id)   (ncclCommInitRank).
+ * RCCL (librccl.so.1) is loaded on first use; a group of one GPU needs no RCCL unless option "always_gather" is set.
+ * Every entry point below is collective in the one-process-per-GPU mode: all ranks call it with the same arguments. */
+typedef struct kzg_mctx kzg_mctx;
+typedef struct kzg_msrs kzg_msrs;   /* an SRS sharded contiguously over the group */
+enum { KZG_UNIQUE_ID_BYTES = 128 };
+int kzg_mctx_create(const int *devices, int n, kzg_mctx **out);
+int kzg_mctx_unique_id(void *id_out);
+int kzg_mctx_create_rank(int device, int rank, int world, const void *unique_id, kzg_mctx **out);
+void kzg_mctx_destroy(kzg_mctx *m);
+const char *kzg_mctx_last_error(kzg_mctx *m);
+int kzg_mctx_world(const kzg_mctx *m);        /* ranks in the group */
+int kzg_mctx_local_count(const kzg_mctx *m);  /* GPUs this process drives (n, or 1 in the per-process mode) */
+int kzg_mctx_rank(const kzg_mctx *m, int local_index);          /* global rank of a local GPU */
+kzg_ctx *kzg_mctx_ctx(kzg_mctx *m, int local_index);            /* its single-GPU context (NTT, scans, device memory) */
+/* options: "always_gather" (run the collective even in a group of one), plus every kzg_ctx_set_option key (applied to all) */
+int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value);
+/* rank r of `world` holds terms [lo, hi) of n: the first n % world ranks get one extra.  Host-only helper. */
+int kzg_shard_range(size_t n, int rank, int world, size_t *lo, size_t *hi);
+/* setup(s, n), G1 half, sharded: rank r generates gs[lo_r .. hi_r) on its GPU (src/lib.rs:38-47). */
+int kzg_srs_setup_g1_sharded(kzg_mctx *m, const void *s, int sfmt, size_t n, kzg_msrs **out);
+/* KZGParams.gs supplied by the caller: `pts` is the WHOLE vector (n points, host); every rank uploads its own range. */
+int kzg_srs_upload_g1_sharded(kzg_mctx *m, const void *pts, size_t n, int pfmt, kzg_msrs **out);
+size_t kzg_msrs_len(const kzg_msrs *srs);
+const kzg_srs *kzg_msrs_shard(const kzg_msrs *srs, int local_index, size_t *first);  /* the resident shard and its first index */
+void kzg_msrs_free(kzg_mctx *m, kzg_msrs *srs);
+/* KZGProver::commit over the group (src/coeff_form.rs:59-64).  coeffs: the whole polynomial (n scalars, host), every rank
+ * reads its slice; with KZG_IN_DEVICE `coeffs` is instead an array of kzg_mctx_local_count() device pointers, entry i
+ * pointing at local GPU i's slice ([hi - lo] scalars, resident in that GPU's HBM).  out: one point (host), on every rank.
+ * KZG_ERR_SHAPE if n > kzg_msrs_len (the slice index panic). */
+int kzg_commit_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, int sfmt, int flags, void *out,
+                             int ofmt);
+/* `batch` polynomials of n coefficients each (host: contiguous, stride n * 32 B; KZG_IN_DEVICE: per local GPU a
+ * [batch][hi - lo] array of slices).  One all-gather of batch x 144 B per rank for the whole batch.  out: batch points. */
+int kzg_commit_coeff_sharded_batch(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, size_t batch, int sfmt,
+                                   int flags, void *out, int ofmt);
+/* KZGProver::create_witness over the group (src/coeff_form.rs:66-81): every rank computes the quotient (p - y)/(X - x) on its
+ * GPU (a replicated O(n) scan) and reduces its own slice of it; host-resident coefficients only.
+ * KZG_ERR_POINT_NOT_ON_POLY iff p(x) != y. */
+int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *x, const void *y,
+                              int sfmt, void *out, int ofmt);
 
 /* ---- NTT: EvaluationDomain::fft / ifft (src/ft.rs:111-140; best_fft :274-288) --------------- */
 /* EvaluationDomain::compute_omega (src/ft.rs:55-76): m = next pow2 >= d, exp = log2 m, omega.

@@ -234,6 +234,72 @@ class KZGVerifier {  // src/coeff_form.rs:114-183; the pairing checks run on the
     const Engine &e_;
 };
 
+// ---- multi-GPU: KZGParams.gs sharded over a group of GPUs, KZGProver::commit / create_witness over the group ----
+// (the seam is the multi_exp call, src/coeff_form.rs:61,78; partial points are combined over RCCL inside the library)
+class DeviceGroup {
+  public:
+    explicit DeviceGroup(const std::vector<int> &devices) {  // one process drives all GPUs
+        if (int rc = kzg_mctx_create(devices.data(), (int)devices.size(), &m_)) throw EngineError("kzg_mctx_create failed: " + std::to_string(rc));
+    }
+    DeviceGroup(int device, int rank, int world, const void *unique_id) {  // one process per GPU
+        if (int rc = kzg_mctx_create_rank(device, rank, world, unique_id, &m_)) throw EngineError("kzg_mctx_create_rank failed: " + std::to_string(rc));
+    }
+    ~DeviceGroup() { kzg_mctx_destroy(m_); }
+    DeviceGroup(const DeviceGroup &) = delete;
+    DeviceGroup &operator=(const DeviceGroup &) = delete;
+    kzg_mctx *handle() const { return m_; }
+    int world() const { return kzg_mctx_world(m_); }
+    void check(int rc) const {
+        if (rc == KZG_OK) return;
+        std::string msg = kzg_mctx_last_error(m_);
+        if (rc == KZG_ERR_POINT_NOT_ON_POLY) throw KZGError(KZGError::PointNotOnPolynomial, "point not on polynomial!");
+        if (rc == KZG_ERR_SHAPE) throw ReferencePanic(msg);
+        throw EngineError("kzg_mi355x error " + std::to_string(rc) + ": " + msg);
+    }
+
+  private:
+    kzg_mctx *m_ = nullptr;
+};
+
+struct ShardedParams {  // KZGParams.gs held as one contiguous shard per GPU
+    const DeviceGroup *group = nullptr;
+    kzg_msrs *gs = nullptr;
+    ShardedParams() = default;
+    ShardedParams(const ShardedParams &) = delete;
+    ShardedParams &operator=(const ShardedParams &) = delete;
+    ShardedParams(ShardedParams &&o) noexcept : group(o.group), gs(o.gs) { o.gs = nullptr; }
+    ~ShardedParams() { if (gs) kzg_msrs_free(group->handle(), gs); }
+    size_t len() const { return kzg_msrs_len(gs); }
+};
+
+inline ShardedParams setup_sharded(const DeviceGroup &g, const Scalar &s, size_t num_coeffs) {  // src/lib.rs:38-47
+    ShardedParams p;
+    p.group = &g;
+    g.check(kzg_srs_setup_g1_sharded(g.handle(), s.le.data(), KZG_FR_CANONICAL_LE_32, num_coeffs, &p.gs));
+    return p;
+}
+
+class ShardedKZGProver {  // KZGProver (src/coeff_form.rs:37-81) with the SRS spread over the group
+  public:
+    explicit ShardedKZGProver(const ShardedParams &params) : params_(params), g_(*params.group) {}
+    KZGCommitment commit(const Polynomial &p) const {  // :59-64
+        G1Affine out;
+        g_.check(kzg_commit_coeff_sharded(g_.handle(), params_.gs, p.coeffs.data(), p.num_coeffs(), KZG_FR_CANONICAL_LE_32, 0,
+                                          out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+    KZGWitness create_witness(const Polynomial &p, const Scalar &x, const Scalar &y) const {  // :66-81
+        G1Affine out;
+        g_.check(kzg_witness_coeff_sharded(g_.handle(), params_.gs, p.coeffs.data(), p.num_coeffs(), x.le.data(), y.le.data(),
+                                           KZG_FR_CANONICAL_LE_32, out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+
+  private:
+    const ShardedParams &params_;
+    const DeviceGroup &g_;
+};
+
 class KZGProverEvalForm {  // src/eval_form.rs:39-147
   public:
     KZGProverEvalForm(const KZGParams &params, const kzg_srs *lagrange_basis_g)  // :88-100

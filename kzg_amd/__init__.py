@@ -7,8 +7,8 @@ reference's prover surface used by tests/ and bench.py.  There is no CPU fallbac
 from ._lib import (FR_CANONICAL, FR_MONT, G1_AFFINE_MONT, G1_JACOBIAN_MONT, G1_ZCASH_COMPRESSED,
                    G1_ZCASH_UNCOMPRESSED, G2_AFFINE_MONT, G2_COMPRESSED, G2_JACOBIAN_MONT, G2_UNCOMPRESSED, IN_DEVICE,
                    OUT_DEVICE, SO_PATH, load)
-from .api import (DeviceBuffer, Engine, EngineError, EvaluationDomain, KZGBatchWitness, KZGError, KZGParams,
+from .api import (DeviceBuffer, DeviceGroup, Engine, EngineError, EvaluationDomain, KZGBatchWitness, KZGError, KZGParams,
                   KZGProver, KZGProverEvalForm, KZGVerifier, KZGVerifierEvalForm, PointNotOnPolynomial, Polynomial,
-                  PolynomialDegreeTooLarge, ReferencePanic, Srs, SrsG2, compute_lagrange_basis, compute_lagrange_basis_g2, compute_omega,
+                  PolynomialDegreeTooLarge, ReferencePanic, ShardedSrs, Srs, SrsG2, compute_lagrange_basis, compute_lagrange_basis_g2, compute_omega,
                   pack_scalars, setup, setup_g2, setup_lagrange, setup_lagrange_g2, setup_shard, splitmix_scalar,
                   unpack_scalars)

@@ -4,7 +4,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.environ.get("KZG_LIB") or os.path.join(HERE, "libkzg_mi355x.so")  # KZG_LIB: A/B another build of the same ABI
+SO_PATH = os.path.join(HERE, "libkzg_mi355x.so")
 
 KZG_OK = 0
 KZG_ERR_POINT_NOT_ON_POLY = 1
@@ -33,19 +33,21 @@ _lib = None
 c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 
 
-def load():
-    """Load the shared library (building it in-tree first if hipcc is available and it is stale)."""
+def load(path=None):
+    """Load the shared library.  `path` (tools/ab_libs.py only) selects another build of the same ABI for A/B runs."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(SO_PATH):
+    so = path or SO_PATH
+    if not os.path.exists(so):
         raise ImportError(
-            f"{SO_PATH} not found: build it with `python -m kzg_amd.build` (hipcc --offload-arch=gfx950). "
+            f"{so} not found: build it with `python -m kzg_amd.build` (hipcc --offload-arch=gfx950). "
             "kzg_amd has no CPU fallback.")
-    L = ctypes.CDLL(SO_PATH)
+    L = ctypes.CDLL(so)
     sz, i32, u32, u64, vp = ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p
     sig = {
         "kzg_version": (ctypes.c_char_p, []),
+        "kzg_device_count": (i32, []),
         "kzg_ctx_create": (i32, [i32, c_void_pp]),
         "kzg_ctx_destroy": (None, [vp]),
         "kzg_last_error": (ctypes.c_char_p, [vp]),
@@ -64,6 +66,25 @@ def load():
         "kzg_msm_g1_batch": (i32, [vp, vp, sz, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_g1_sum": (i32, [vp, vp, sz, i32, i32, vp, i32]),
         "kzg_g1_sum_batch": (i32, [vp, vp, sz, sz, i32, i32, vp, i32]),
+        "kzg_mctx_create": (i32, [ctypes.POINTER(i32), i32, c_void_pp]),
+        "kzg_mctx_unique_id": (i32, [vp]),
+        "kzg_mctx_create_rank": (i32, [i32, i32, i32, vp, c_void_pp]),
+        "kzg_mctx_destroy": (None, [vp]),
+        "kzg_mctx_last_error": (ctypes.c_char_p, [vp]),
+        "kzg_mctx_world": (i32, [vp]),
+        "kzg_mctx_local_count": (i32, [vp]),
+        "kzg_mctx_rank": (i32, [vp, i32]),
+        "kzg_mctx_ctx": (vp, [vp, i32]),
+        "kzg_mctx_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
+        "kzg_shard_range": (i32, [sz, i32, i32, ctypes.POINTER(sz), ctypes.POINTER(sz)]),
+        "kzg_srs_setup_g1_sharded": (i32, [vp, vp, i32, sz, c_void_pp]),
+        "kzg_srs_upload_g1_sharded": (i32, [vp, vp, sz, i32, c_void_pp]),
+        "kzg_msrs_len": (sz, [vp]),
+        "kzg_msrs_shard": (vp, [vp, i32, ctypes.POINTER(sz)]),
+        "kzg_msrs_free": (None, [vp, vp]),
+        "kzg_commit_coeff_sharded": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
+        "kzg_commit_coeff_sharded_batch": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
+        "kzg_witness_coeff_sharded": (i32, [vp, vp, vp, sz, vp, vp, i32, vp, i32]),
         "kzg_compute_omega": (i32, [sz, ctypes.POINTER(sz), ctypes.POINTER(u32), vp, i32]),
         "kzg_ntt_fr": (i32, [vp, vp, u32, i32, i32]),
         "kzg_coset_ntt_fr": (i32, [vp, vp, u32, i32, i32, i32]),

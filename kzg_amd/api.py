@@ -128,9 +128,9 @@ class Engine:
         self.device = device
 
     def close(self):
-        if self.ctx:
+        if self.ctx and not getattr(self, "_borrowed", False):
             self.lib.kzg_ctx_destroy(self.ctx)
-            self.ctx = None
+        self.ctx = None
 
     def last_error(self):
         return (self.lib.kzg_last_error(self.ctx) or b"").decode()
@@ -457,6 +457,144 @@ def compute_lagrange_basis_g2(params):
     if rc:
         _raise(e, rc)
     return SrsG2(e, h)
+
+
+class ShardedSrs:
+    """An SRS sharded contiguously over a DeviceGroup (kzg_msrs)."""
+
+    def __init__(self, group, handle):
+        self.group, self.handle = group, handle
+
+    def __len__(self):
+        return self.group.lib.kzg_msrs_len(self.handle)
+
+    def shard(self, local_index=0):
+        """(Srs view of the resident shard of local GPU `local_index`, index of its first point); owned by this object."""
+        first = ctypes.c_size_t()
+        h = self.group.lib.kzg_msrs_shard(self.handle, local_index, ctypes.byref(first))
+        return Srs(self.group.engine(local_index), ctypes.c_void_p(h)), first.value
+
+    def free(self):
+        if self.handle:
+            self.group.lib.kzg_msrs_free(self.group.handle, self.handle)
+            self.handle = None
+
+
+class DeviceGroup:
+    """kzg_mctx: a group of GPUs holding a sharded SRS; partial commitments are combined over RCCL inside the library.
+    DeviceGroup(devices=[0, 1, ...]) -- one process drives all of them;
+    DeviceGroup.for_rank(device, rank, world, unique_id) -- one process per GPU (unique_id from DeviceGroup.unique_id()
+    on rank 0, distributed by the host)."""
+
+    def __init__(self, devices=(0,), _handle=None):
+        self.lib = L.load()
+        if _handle is None:
+            arr = (ctypes.c_int * len(devices))(*devices)
+            h = ctypes.c_void_p()
+            rc = self.lib.kzg_mctx_create(arr, len(devices), ctypes.byref(h))
+            if rc:
+                raise EngineError(f"kzg_mctx_create({list(devices)}) failed with {rc} (kzg_amd has no CPU fallback)")
+            _handle = h
+        self.handle = _handle
+        self._engines = {}
+
+    @staticmethod
+    def unique_id():
+        lib = L.load()
+        buf = ctypes.create_string_buffer(128)
+        rc = lib.kzg_mctx_unique_id(buf)
+        if rc:
+            raise EngineError(f"kzg_mctx_unique_id failed with {rc} (RCCL not loadable?)")
+        return buf.raw
+
+    @staticmethod
+    def for_rank(device, rank, world, unique_id):
+        lib = L.load()
+        h = ctypes.c_void_p()
+        rc = lib.kzg_mctx_create_rank(device, rank, world, unique_id, ctypes.byref(h))
+        if rc:
+            raise EngineError(f"kzg_mctx_create_rank(device={device}, rank={rank}/{world}) failed with {rc}")
+        return DeviceGroup(_handle=h)
+
+    def last_error(self):
+        return (self.lib.kzg_mctx_last_error(self.handle) or b"").decode()
+
+    def _check(self, rc):
+        if rc:
+            _raise(self, rc)
+
+    @property
+    def world(self):
+        return self.lib.kzg_mctx_world(self.handle)
+
+    @property
+    def local_count(self):
+        return self.lib.kzg_mctx_local_count(self.handle)
+
+    def rank(self, local_index=0):
+        return self.lib.kzg_mctx_rank(self.handle, local_index)
+
+    def engine(self, local_index=0):
+        """The single-GPU Engine of a local GPU (borrowed: closed with the group)."""
+        if local_index not in self._engines:
+            e = Engine.__new__(Engine)
+            e.lib = self.lib
+            e.ctx = ctypes.c_void_p(self.lib.kzg_mctx_ctx(self.handle, local_index))
+            e.device = None
+            e._borrowed = True
+            self._engines[local_index] = e
+        return self._engines[local_index]
+
+    def set_option(self, key, value):
+        self._check(self.lib.kzg_mctx_set_option(self.handle, key.encode(), value))
+
+    def setup(self, s, n):
+        """setup(s, n).gs sharded over the group (src/lib.rs:38-47)."""
+        h = ctypes.c_void_p()
+        self._check(self.lib.kzg_srs_setup_g1_sharded(self.handle, (s % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, n,
+                                                      ctypes.byref(h)))
+        return ShardedSrs(self, h)
+
+    def upload(self, blob, n, pfmt=L.G1_AFFINE_MONT):
+        assert len(blob) == n * L.POINT_BYTES[pfmt]
+        h = ctypes.c_void_p()
+        self._check(self.lib.kzg_srs_upload_g1_sharded(self.handle, blob, n, pfmt, ctypes.byref(h)))
+        return ShardedSrs(self, h)
+
+    def commit(self, srs, coeffs, ofmt=L.G1_AFFINE_MONT):
+        """KZGProver::commit over the group; coeffs: ints / canonical blob (host)."""
+        blob = pack_scalars(coeffs)
+        return self.commit_batch(srs, blob, len(blob) // 32, 1, ofmt=ofmt)[0]
+
+    def commit_batch(self, srs, coeffs, n, batch, ofmt=L.G1_AFFINE_MONT, sfmt=L.FR_CANONICAL):
+        """coeffs: host blob of batch * n scalars, or a list of DeviceBuffer (one per local GPU, [batch][shard] slices)."""
+        psz = L.POINT_BYTES[ofmt]
+        out = ctypes.create_string_buffer(psz * max(batch, 1))
+        if isinstance(coeffs, (list, tuple)) and coeffs and isinstance(coeffs[0], DeviceBuffer):
+            ptrs = (ctypes.c_void_p * len(coeffs))(*[c.ptr.value for c in coeffs])
+            rc = self.lib.kzg_commit_coeff_sharded_batch(self.handle, srs.handle, ptrs, n, batch, coeffs[0].sfmt, L.IN_DEVICE, out, ofmt)
+        else:
+            blob = pack_scalars(coeffs)
+            assert len(blob) == 32 * n * batch
+            rc = self.lib.kzg_commit_coeff_sharded_batch(self.handle, srs.handle, blob, n, batch, sfmt, 0, out, ofmt)
+        self._check(rc)
+        return [out.raw[i * psz:(i + 1) * psz] for i in range(batch)]
+
+    def create_witness(self, srs, coeffs, point, ofmt=L.G1_AFFINE_MONT):
+        blob = pack_scalars(coeffs)
+        x, y = point
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        self._check(self.lib.kzg_witness_coeff_sharded(self.handle, srs.handle, blob, len(blob) // 32,
+                                                       (x % R_MODULUS).to_bytes(32, "little"), (y % R_MODULUS).to_bytes(32, "little"),
+                                                       L.FR_CANONICAL, out, ofmt))
+        return out.raw
+
+    def close(self):
+        if self.handle:
+            self.lib.kzg_mctx_destroy(self.handle)
+            self.handle = None
+            for e in self._engines.values():
+                e.ctx = None
 
 
 class Polynomial:

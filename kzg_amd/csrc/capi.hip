@@ -199,6 +199,12 @@ using namespace kzg;
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *kzg_version(void) { return "kzg-mi355x 0.1.0 (gfx950)"; }
 
+extern "C" int kzg_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 0) return 0;
+    return count;
+}
+
 extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
     if (!out) return KZG_ERR_SHAPE;
     int count = 0;
@@ -366,7 +372,7 @@ static int msm_locked(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const voi
                       void *out, int ofmt) {
     KZG_TRY(check_sfmt(ctx, sfmt));
     if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
     const void *d_sc = nullptr;
     KZG_TRY(stage_in(ctx, 0, scalars, n * 32, flags, &d_sc));
@@ -465,15 +471,17 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
     return rc;
 }
 
-extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n,
-                                size_t batch, int sfmt, int flags, void *out, int ofmt) {
-    if (!ctx || !srs || !out || (!scalars && n && batch)) return KZG_ERR_SHAPE;
+namespace kzg {
+// kzg_msm_g1_batch with an explicit distance between consecutive scalar vectors (the sharded commit hands every device the
+// slice [lo, hi) of each polynomial: stride = whole-polynomial bytes, n = hi - lo)
+int msm_batch_strided(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, size_t batch,
+                      size_t stride_bytes, int sfmt, int flags, void *out, int ofmt) {
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     size_t psz = point_format_bytes(ofmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
     if (batch == 0) return KZG_OK;
     BatchPipe bp;
     KZG_TRY(batch_begin(ctx, batch, batch * psz, out, flags, &bp));
@@ -484,12 +492,20 @@ extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset,
         int l = (int)(b % bp.nl);
         ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
         const void *d_sc = nullptr;
-        rc = stage_in(ctx, l, (const uint8_t *)scalars + b * n * 32, n * 32, flags, &d_sc);
+        rc = stage_in(ctx, l, (const uint8_t *)scalars + b * stride_bytes, n * 32, flags, &d_sc);
         MsmPoint *res = nullptr;
         if (rc == KZG_OK) rc = batch_msm(ctx, bp, b, l, srs, offset, d_sc, n, sfmt, &res);
         if (rc == KZG_OK) rc = emit_point(ctx, l, res, bp.d_out + b * psz, ofmt);
     }
     return batch_end(ctx, bp, rc, out, batch * psz);
+}
+}  // namespace kzg
+
+extern "C" int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n,
+                                size_t batch, int sfmt, int flags, void *out, int ofmt) {
+    if (!ctx || !srs || !out || (!scalars && n && batch)) return KZG_ERR_SHAPE;
+    if (n > SIZE_MAX / 32) return KZG_ERR_SHAPE;
+    return msm_batch_strided(ctx, srs, offset, scalars, n, batch, n * 32, sfmt, flags, out, ofmt);
 }
 
 extern "C" int kzg_witness_coeff_many(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, const void *xs,
@@ -617,13 +633,14 @@ extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pf
     return KZG_OK;
 }
 
-extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t groups, int pfmt, int flags,
-                                void *out, int ofmt) {
-    if (!ctx || !out || !points || count == 0 || groups == 0) return KZG_ERR_SHAPE;
+namespace kzg {
+int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t groups, size_t gstride, size_t istride, int pfmt,
+                         int flags, void *out, int ofmt) {
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t psz = point_format_bytes(pfmt), osz = point_format_bytes(ofmt);
     if (!psz || !osz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
+    if (count > (1u << 20) || groups > (1u << 24)) return fail(ctx, KZG_ERR_SHAPE, "kzg_g1_sum_batch: count <= 2^20, groups <= 2^24");
     size_t total = count * groups;
     KZG_TRY(lane_reserve(ctx, 0, stage_bytes(total * psz, flags) + total * sizeof(G1Xyzz) + (total + groups + 4) * sizeof(MsmPoint) + groups * 144 + 65536));
     hipStream_t st = ctx->lanes[0].stream;
@@ -638,7 +655,7 @@ extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, 
     KZG_TRY(stage_in(ctx, 0, points, total * psz, flags, &d_raw));
     KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, dec, bad));
     KZG_TRY(points_to30(ctx, st, dec, pts, total));
-    KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, tmp, d_out, ofmt));
+    KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, gstride, istride, tmp, d_out, ofmt));
     int hbad = 0;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
     if (!(flags & KZG_OUT_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, groups * osz, hipMemcpyDeviceToHost, st));
@@ -646,6 +663,13 @@ extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, 
     if (ctx->prof) prof_collect(ctx);
     if (hbad) return fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode or is not on the curve");
     return KZG_OK;
+}
+}  // namespace kzg
+
+extern "C" int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t groups, int pfmt, int flags,
+                                void *out, int ofmt) {
+    if (!ctx || !out || !points || count == 0 || groups == 0) return KZG_ERR_SHAPE;
+    return g1_sum_batch_strided(ctx, points, count, groups, count, 1, pfmt, flags, out, ofmt);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -174,8 +174,16 @@ size_t sum_points_scratch_count(size_t count);
 // writes one point in `ofmt` (from XYZZ) to d_out (device); single thread incl. the Fq inversion
 int emit_point(kzg_ctx *ctx, int lane, const MsmPoint *d_point, void *d_out, int ofmt);
 size_t point_format_bytes(int fmt);
-int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count, size_t groups, MsmPoint *d_tmp, void *d_out,
-                    int ofmt);
+// out[g] = sum_i pts[g * gstride + i * istride], written in ofmt
+int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count, size_t groups, size_t gstride, size_t istride,
+                    MsmPoint *d_tmp, void *d_out, int ofmt);
+
+// capi.hip
+int msm_batch_strided(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, size_t batch,
+                      size_t stride_bytes, int sfmt, int flags, void *out, int ofmt);
+// out[g] = sum_i points[g * gstride + i * istride] (strides in points); points in pfmt, host or device per flags
+int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t groups, size_t gstride, size_t istride, int pfmt,
+                         int flags, void *out, int ofmt);
 
 // srs.hip
 int srs_choose_window(kzg_ctx *ctx, size_t n);

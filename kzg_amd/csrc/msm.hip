@@ -472,20 +472,21 @@ __global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t 
     emit_one(pts[i * stride_pts], out + i * format_bytes_dev(fmt), fmt);
 }
 
-// out[g] = sum_{i < count} pts[g * count + i]   (count is small: one partial per GPU)
-__global__ __launch_bounds__(64) void k_sum_groups(const MsmPoint *pts, uint32_t count, uint32_t groups, MsmPoint *out) {
+// out[g] = sum_{i < count} pts[g * gstride + i * istride]   (count is small: one partial per GPU)
+__global__ __launch_bounds__(64) void k_sum_groups(const MsmPoint *pts, uint32_t count, uint32_t groups, size_t gstride,
+                                                   size_t istride, MsmPoint *out) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= groups) return;
     MsmPoint acc = MsmPoint::infinity();
-    for (uint32_t i = 0; i < count; i++) acc = g1_add30(acc, pts[(size_t)g * count + i]);
+    for (uint32_t i = 0; i < count; i++) acc = g1_add30(acc, pts[(size_t)g * gstride + (size_t)i * istride]);
     out[g] = acc;
 }
 
-int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count, size_t groups, MsmPoint *d_tmp, void *d_out,
-                    int ofmt) {
+int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count, size_t groups, size_t gstride, size_t istride,
+                    MsmPoint *d_tmp, void *d_out, int ofmt) {
     hipStream_t st = ctx->lanes[lane].stream;
     KZG_LAUNCH(ctx, st, "k_sum_groups", k_sum_groups, (unsigned)((groups + 63) / 64), 64, 0, d_pts, (uint32_t)count,
-               (uint32_t)groups, d_tmp);
+               (uint32_t)groups, gstride, istride, d_tmp);
     KZG_LAUNCH(ctx, st, "k_emit_points", k_emit_points, (unsigned)((groups + 63) / 64), 64, 0, d_tmp, groups, (size_t)1,
                (uint8_t *)d_out, ofmt);
     return KZG_OK;
@@ -834,7 +835,7 @@ static int msm_tail(kzg_ctx *ctx, int lane, const MsmLayout &L, char *base, MsmP
 
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if (srs->c > 16 && !srs->narrow17) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
     if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
     MsmLayout L = msm_layout(srs, n ? n : 1);

@@ -468,7 +468,7 @@ extern "C" int kzg_srs_download_g2(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t o
     if (!ctx || !srs || (!out && n)) return KZG_ERR_SHAPE;
     Lock g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "SRS download range out of bounds");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "SRS download range out of bounds");
     size_t psz = g2_format_bytes(pfmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G2 point format");
     if (!n) return KZG_OK;
@@ -558,7 +558,7 @@ extern "C" int kzg_msm_g2(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t offset, co
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     size_t psz = g2_format_bytes(ofmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G2 point format");
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     KZG_TRY(lane_reserve(ctx, 0, n * 32 + (n + 64) * sizeof(G2Jacobian) + 8192));
     hipStream_t st = ctx->lanes[0].stream;
     Fr *ds = (Fr *)lane_alloc(ctx, 0, n * 32 + 32);
@@ -670,7 +670,7 @@ extern "C" int kzg_verify_eval_batched(kzg_ctx *ctx, const kzg_srs *gs, const kz
     if (!psz || pfmt == KZG_G1_JACOBIAN_MONT_144) return fail(ctx, KZG_ERR_SHAPE, "commitment / witness are affine (G1Affine)");
     if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no points (reference: op_tree over an empty set panics)");
     if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "batched verification is limited to 4096 points");
-    if (k + 1 > hs->n) return fail(ctx, KZG_ERR_SHAPE, "z longer than hs (reference: slice index panic)");
+    if (k >= hs->n) return fail(ctx, KZG_ERR_SHAPE, "z longer than hs (reference: slice index panic)");
     if (r_len > gs->n) return fail(ctx, KZG_ERR_SHAPE, "witness.r longer than gs (reference: slice index panic)");
     KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(gs, r_len) + (k + 2) * (3 * 32 + sizeof(G2Jacobian)) + 64 * sizeof(G2Jacobian) +
                                      r_len * 32 + 65536));

@@ -503,7 +503,7 @@ extern "C" int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offs
     if (!ctx || !srs || (!out && n)) return KZG_ERR_SHAPE;
     std::lock_guard<std::mutex> g(ctx->mu);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    if (offset + n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "SRS download range out of bounds");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "SRS download range out of bounds");
     if (n == 0) return KZG_OK;
     if (pfmt != KZG_G1_AFFINE_MONT_96) return fail(ctx, KZG_ERR_SHAPE, "SRS download supports KZG_G1_AFFINE_MONT_96 only");
     hipStream_t st = ctx->lanes[0].stream;

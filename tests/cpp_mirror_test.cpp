@@ -55,6 +55,25 @@ int main() {
         if (!(ws[0] == prover.create_witness(p2, mx[0], my[0]))) return 15;
         if (!verifier.verify_eval(mx[1], my[1], cm2, ws[1])) return 16;
     }
+    {   // the multi-GPU prover over every visible GPU (a group of one on the test box): same commitment / witness as one GPU
+        int ndev = kzg_device_count();
+        if (ndev < 1) return 20;
+        std::vector<int> devs;
+        for (int i = 0; i < ndev && i < 8; i++) devs.push_back(i);
+        DeviceGroup group(devs);
+        if (kzg_mctx_set_option(group.handle(), "always_gather", 1)) return 21;  // exercise the RCCL exchange even alone
+        ShardedParams sp = setup_sharded(group, Scalar::from_u64(0x1234567), 13);
+        ShardedKZGProver sprover(sp);
+        if (!(sprover.commit(p2) == cm2)) return 22;
+        Scalar x5 = Scalar::from_u64(5), y5 = p2.eval(e, x5);
+        if (!(sprover.create_witness(p2, x5, y5) == prover.create_witness(p2, x5, y5))) return 23;
+        try {
+            sprover.create_witness(p2, x5, Scalar::from_u64(1));
+            return 24;
+        } catch (const KZGError &err) {
+            if (err.kind != KZGError::PointNotOnPolynomial) return 25;
+        }
+    }
     std::printf("cpp mirror ok\n");
     return 0;
 }

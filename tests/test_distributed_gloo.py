@@ -1,6 +1,8 @@
-"""N>1 data path on CPU: world_size-2 torch.distributed (gloo), contiguous SRS shards, one partial point
-per rank, all_gather of 96-byte partials, local sum -- kzg_amd.distributed.ShardedCommitter with the
-oracle standing in for the per-rank GPU operations (tests may use the oracle; the product never does)."""
+"""N>1 protocol on CPU: world_size-2 torch.distributed (gloo), contiguous SRS shards (kzg_shard_range), one partial point
+per rank and polynomial, all_gather laid out [world][batch], per-polynomial sums -- kzg_amd.distributed.ProtocolModel with the
+oracle standing in for the per-rank GPU operations (tests may use the oracle; the product never does).  The product's own
+exchange (kzg_amd/csrc/mgpu.hip, RCCL) is exercised on the GPU by tests/test_gpu_mgpu.py; this test pins the partition rule,
+the gathered layout and the unique-id hand-off it relies on."""
 import os
 import random
 import socket
@@ -9,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from kzg_amd.distributed import ShardedCommitter, shard_range
+from kzg_amd.distributed import ProtocolModel, broadcast_unique_id, shard_range
 from oracle import c_oracle as C
 from oracle import kzg_model as M
 
@@ -35,19 +37,21 @@ def _worker(rank, world, port, n, tau, seed, q):
     def local_msm(polys, batch):
         return torch.frombuffer(bytearray(b"".join(C.msm_g1(shard, sc) for sc in polys)), dtype=torch.uint8)
 
-    def local_sum(grouped, batch):
-        raw = bytes(grouped.numpy().tobytes())
-        per = len(raw) // batch
+    def local_sum(gathered, nranks, batch):
+        raw = bytes(gathered.numpy().tobytes())      # [world][batch][96], as ncclAllGather leaves it
         res = []
         for b in range(batch):
             acc = bytes(96)
-            for i in range(0, per, 96):
-                acc = C.g1_add(acc, raw[b * per + i: b * per + i + 96])
+            for w in range(nranks):                   # = k_sum_groups with gstride 1, istride batch
+                acc = C.g1_add(acc, raw[96 * (w * batch + b): 96 * (w * batch + b + 1)])
             res.append(acc)
         return res
 
-    committer = ShardedCommitter(dist, rank, world, local_msm, local_sum)
-    # a batch of two polynomials: p and 3*p (tests the [world][batch] -> [batch][world] regrouping)
+    # the 128-byte communicator id travels from rank 0 to everyone over the process group
+    uid = broadcast_unique_id(dist, rank, lambda: bytes(range(128)))
+    assert uid == bytes(range(128))
+    committer = ProtocolModel(dist, rank, world, local_msm, local_sum)
+    # a batch of two polynomials: p and 3*p (distinguishes the [world][batch] layout from its transpose)
     got = committer.commit_batch([coeffs[lo:hi], [3 * c % M.R for c in coeffs[lo:hi]]], 2)
     q.put((rank, got))
     dist.barrier()
@@ -55,7 +59,7 @@ def _worker(rank, world, port, n, tau, seed, q):
 
 
 def test_shard_range_partitions():
-    for n in (0, 1, 7, 1000, 1 << 20):
+    for n in (0, 1, 7, 1000, 1 << 20, (1 << 24) + 5):
         for world in (1, 2, 3, 8):
             rs = [shard_range(n, r, world) for r in range(world)]
             assert rs[0][0] == 0 and rs[-1][1] == n
