@@ -6,44 +6,52 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N = 1 : workload = BASELINE configs[1] "degree-2^20 coeff_form commit (G1 Pippenger MSM) on 1xMI355X".
-        One step = one batch of `--batch` independent commitments pipelined on the engine's HIP
-        streams (kzg_msm_g1_batch); value = commitments / second.
-N > 1 : the SRS is sharded contiguously, 2^20 terms per rank (polynomial of N*2^20 coefficients, the
-        shape of configs[4]); each step every rank reduces its shard on its GPU, the 96-byte partials
-        are all-gathered over RCCL/xGMI and summed locally.  value = (terms processed by all ranks /
-        2^20) per second, i.e. degree-2^20-equivalent commitments/s (weak scaling, no work skipped).
+        One step = one batch of `--batch` independent commitments pipelined on the engine's HIP streams
+        (kzg_msm_g1_batch); value = commitments / second.
+N > 1 : one process per GPU; the data path is the C ABI's device group (kzg_mctx_create_rank / kzg_commit_coeff_sharded_batch,
+        kzg_amd/csrc/mgpu.hip): SRS sharded contiguously, one partial point per rank and polynomial, ONE ncclAllGather of the
+        144-byte partials inside the library, local sums.  torch.distributed only carries the RCCL unique id and the barriers.
+          default (= --strong) : the SAME metric -- degree-2^20 commitments/s, each commitment's 2^20 terms sharded N ways
+                                 (2^20 / N per rank); "scaling": "strong".
+          --config5            : BASELINE configs[4] -- 2^21 terms per rank (degree 2^24 at N = 8); value = commitments/s of
+                                 that N * 2^21-coefficient polynomial, msm_terms_per_sec beside it; "scaling": "weak".
+          --replicas           : full SRS on every GPU, different polynomials per GPU, no data-path collective.
 
-The JSON line also carries `roofline` for the dominant kernel (k_accum_affine; HIP-event time measured
-on the engine's stream inside this process) and `cpu_baseline` (the oracle's single-threaded C
-Pippenger on a bounded sample, rank 0, N = 1 only).  The oracle is never on the measured path.
+The JSON line carries `roofline` for the dominant kernel (k_accum_affine; HIP-event times measured on the engine's streams
+inside this process), `paths` (the other BASELINE configs, timed after the timed region) and `cpu_baseline` (the oracle's
+single-threaded C Pippenger, rank 0, N = 1 only; worker processes are started BEFORE the GPU is initialised).
+The oracle is never on the measured path.
 """
 import argparse
 import ctypes
 import json
 import os
+import statistics
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# One hardware queue per engine stream: 16 MSM lanes + 2 accumulation streams (the ROCm default multiplexes all streams
-# onto 4 in-order queues, which makes independent MSM lanes wait for each other's tail kernels); must be in the
-# environment before HIP initialises.
+# One hardware queue per engine stream (16 MSM lanes + 2 accumulation streams; the ROCm default multiplexes all streams onto 4
+# in-order queues); must be in the environment before HIP initialises.  profiles/ records the cost of leaving it unset.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 BYTES_PER_TERM = 128           # SURVEY 8(d): 32 B scalar + 96 B affine point per MSM term
-# The resource that actually binds k_accum_affine (DESIGN.md 3.2): VALU issue, dominated by v_mad_i64_i32.  One bucket
-# addition executes 6 mul30 (338 mads) + 2 sqr30 (260) + one fused double product with a single reduction (507) = 3055
-# mads per lane (static count from the ISA; 4379 VALU instructions in all by SQ_INSTS_VALU).  tools/microbench.hip
-# measured the chip's 64-bit multiply-add rate: 31.5 T lane-op/s at 8 waves/SIMD, 23.7 T at the 2 waves/SIMD a
-# 215-VGPR kernel holds (profiles/r01_microbench.txt).
+NTT_BYTES_PER_ELEM = 64        # SURVEY 8(d): one read + one write of a 32-byte Fr
+# The resource that binds k_accum_affine (DESIGN.md 3.2): VALU issue, dominated by v_mad_i64_i32.  One bucket addition
+# executes 6 mul30 (338 mads) + 2 sqr30 (260) + one fused double product with a single reduction (507) = 3055 mads per lane
+# (static count from the ISA).  tools/microbench.hip measured the chip's 64-bit multiply-add issue rate: 31.5 T lane-op/s at
+# 8 waves/SIMD, 23.7 T at the 2 waves/SIMD a 200-VGPR kernel holds (profiles/r01_microbench.txt).
 MADS_PER_ADD = 6 * 338 + 2 * 260 + 507
 MAD_PEAK_TLANE_S = 31.51
 MAD_PEAK_OCC2_TLANE_S = 23.70
+FR_MUL_PEAK_G_S = 111.0        # measured Fr (9 x 29-bit) multiplies per second of the NTT's multiply (DESIGN.md 3.3)
 TAU = 0x5EED5EED5EED5EED       # known secret for the synthetic SRS (setup(s, n), src/lib.rs:38)
+SEED = 1
 
 
 def g1_adds_per_msm(n, c, W):
@@ -51,56 +59,237 @@ def g1_adds_per_msm(n, c, W):
     return n * W + 2 * (1 << (c - 1))
 
 
-def cpu_baseline(engine, params, scal, log_n):
-    """Oracle C Pippenger (single thread, like the reference's multi_exp) on one whole polynomial of the timed
-    workload: the first min(2^log_n, 2^20) coefficients of batch entry 0, same SRS (about 20 s of CPU at 2^20)."""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: worker processes (spawned before HIP initialises; they never touch the GPU)
+# ---------------------------------------------------------------------------------------------------------------------
+def _cpu_worker_init(native_path):
     from oracle import c_oracle as C
-    n = 1 << min(log_n, 20)
-    pts = params.gs.download(0, n)
-    sc = scal.download(n)
-    if scal.sfmt != 1:  # the oracle takes canonical little-endian scalars
-        raise RuntimeError("cpu_baseline expects canonical scalars")
+    if native_path:
+        try:
+            C.use_library(native_path)
+        except Exception:
+            pass
+    C.lib()
+
+
+def _cpu_worker_msm(args):
+    """One oracle Pippenger over terms [lo, hi) of the shared sample file; returns (seconds, 96-byte result)."""
+    path, n, lo, hi = args
+    from oracle import c_oracle as C
+    with open(path, "rb") as f:
+        f.seek(96 * lo)
+        pts = f.read(96 * (hi - lo))
+        f.seek(96 * n + 32 * lo)
+        sc = f.read(32 * (hi - lo))
     t0 = time.perf_counter()
-    out = C.msm_g1_raw(pts, sc, n)
-    dt = time.perf_counter() - t0
-    ok = engine.msm(params.gs, scal, n=n) == out   # the baseline run doubles as a parity check
-    terms_per_s = n / dt
-    return {"value": terms_per_s / (1 << log_n), "unit": "commitments/s",
-            "cores": 1, "kind": "port",
-            "sample": f"one 2^{min(log_n, 20)}-term MSM = polynomial 0 of the timed batch, same SRS, {dt:.2f} s, "
-                      f"{terms_per_s:.0f} terms/s; matches GPU result: {ok}"}
+    out = C.msm_g1_raw(pts, sc, hi - lo)
+    return time.perf_counter() - t0, out
 
 
-def _cpu_chunk(args):
-    pts, sc, n = args
-    from oracle import c_oracle as C
-    return C.msm_g1_raw(pts, sc, n)
+def _cpu_worker_ping(_):
+    return os.getpid()
 
 
-def cpu_baseline_all_cores(engine, params, scal, log_n):
-    """The same oracle MSM split into one contiguous chunk per host core (processes), partial points added at the end."""
-    import multiprocessing as mp
-    from oracle import c_oracle as C
-    n = 1 << min(log_n, 20)
-    # chunks below ~2^15 terms make the bucket method inefficient (measured: 256 chunks of 4096 take 2.75 s, 5x the
-    # per-term cost), so at most n / 2^15 worker processes are used
-    cores = max(1, min(os.cpu_count() or 1, n >> 15))
-    pts = params.gs.download(0, n)
-    sc = scal.download(n)
-    per = (n + cores - 1) // cores
-    chunks = [(pts[96 * i:96 * min(i + per, n)], sc[32 * i:32 * min(i + per, n)], min(i + per, n) - i) for i in range(0, n, per)]
-    with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(_cpu_chunk, chunks[:1])  # warm the workers (library load)
-        t0 = time.perf_counter()
-        parts = pool.map(_cpu_chunk, chunks)
-        acc = parts[0]
-        for p_ in parts[1:]:
-            acc = C.g1_add(acc, p_)
-        dt = time.perf_counter() - t0
-    ok = engine.msm(params.gs, scal, n=n) == acc
-    return {"value": n / dt / (1 << log_n), "unit": "commitments/s", "cores": cores, "kind": "port",
-            "sample": f"one 2^{min(log_n, 20)}-term MSM in {len(chunks)} chunks over {cores} processes, {dt:.2f} s; "
-                      f"matches GPU result: {ok}"}
+class CpuBaseline:
+    """Pool of oracle workers.  start() must run before anything initialises HIP (no fork of a GPU process)."""
+
+    def __init__(self):
+        self.pool = None
+        self.workers = 0
+        self.native = None
+
+    def start(self):
+        import multiprocessing as mp
+        from concurrent.futures import ProcessPoolExecutor
+        from oracle import c_oracle as C
+        C.build()
+        self.native = C.build_native()
+        self.workers = max(1, min(os.cpu_count() or 1, 128))
+        self.pool = ProcessPoolExecutor(self.workers, mp_context=mp.get_context("spawn"), initializer=_cpu_worker_init,
+                                        initargs=(self.native,))
+        list(self.pool.map(_cpu_worker_ping, range(self.workers)))  # all workers up (and the library loaded) before HIP
+
+    def run(self, pts, sc, n, log_n, gpu_result):
+        """pts / sc: the first 2^min(log_n, 20) SRS points and coefficients of polynomial 0 of the timed batch."""
+        fd, path = tempfile.mkstemp(prefix="kzg_cpu_sample_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            with os.fdopen(fd, "wb") as f:
+                f.write(pts)
+                f.write(sc)
+            scale = n / float(1 << log_n)
+            # (i) single core, like the reference's multi_exp: three samples of the whole MSM on three cores at once
+            r1 = list(self.pool.map(_cpu_worker_msm, [(path, n, 0, n)] * 3))
+            t_med = statistics.median(t for t, _ in r1)
+            ok1 = all(o == gpu_result for _, o in r1)
+            single = {"value": round(scale / t_med, 5), "unit": "commitments/s", "cores": 1, "kind": "port",
+                      "build": "gcc -O3 -march=native" if self.native else "gcc -O2 (portable)",
+                      "samples_s": [round(t, 2) for t, _ in r1],
+                      "sample": f"one whole 2^{n.bit_length() - 1}-term MSM = polynomial 0 of the timed batch, same SRS; median of 3 "
+                                f"single-threaded runs ({t_med:.2f} s, {n / t_med:.0f} terms/s); matches GPU result: {ok1}"}
+            # (ii) all cores: every worker commits to the same polynomial once, concurrently (one commitment per core at a
+            # time is how a host would use a single-threaded multi_exp)
+            w = self.workers
+            t0 = time.perf_counter()
+            r2 = list(self.pool.map(_cpu_worker_msm, [(path, n, 0, n)] * w))
+            wall = time.perf_counter() - t0
+            ok2 = all(o == gpu_result for _, o in r2)
+            allc = {"value": round(w * scale / wall, 4), "unit": "commitments/s", "cores": w, "kind": "port",
+                    "sample": f"{w} concurrent whole 2^{n.bit_length() - 1}-term MSMs, one per worker process "
+                              f"(os.cpu_count() = {os.cpu_count()}), wall {wall:.2f} s, slowest worker "
+                              f"{max(t for t, _ in r2):.2f} s; all match the GPU result: {ok2}"}
+            return single, allc
+        finally:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+
+    def close(self):
+        if self.pool:
+            self.pool.shutdown(wait=False, cancel_futures=True)
+            self.pool = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def view(kzg_amd, buf, first, n):
+    v = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    v.engine, v.n, v.sfmt, v.ptr = buf.engine, n, buf.sfmt, ctypes.c_void_p(buf.ptr.value + 32 * first)
+    return v
+
+
+def timeit(f, reps=3, warm=1):
+    for _ in range(warm):
+        f()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        f()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0):
+    """The other BASELINE configs at degree 2^log_n, inputs resident in HBM, each result checked by an identity that needs no
+    oracle (eval-form == coeff-form, witness_eval == witness_coeff at omega^m); outside the timed region."""
+    t_start = time.perf_counter()
+    lib, ctx, srs = engine.lib, engine.ctx, params.gs
+    R = kzg_amd.api.R_MODULUS
+    res = {"log_n": log_n}
+    out = ctypes.create_string_buffer(96)
+    coeffs = view(kzg_amd, scal, 0, n)          # polynomial 0 of the timed batch
+
+    def b32(v):
+        return (v % R).to_bytes(32, "little")
+
+    def commit():
+        assert lib.kzg_commit_coeff(ctx, srs.handle, coeffs.ptr, n, coeffs.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
+    res["commit_coeff_ms"] = round(timeit(commit), 3)
+    commitment = out.raw
+    host_coeffs = coeffs.download()
+
+    def commit_host():
+        assert lib.kzg_commit_coeff(ctx, srs.handle, host_coeffs, n, coeffs.sfmt, 0, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
+    res["commit_host_resident_ms"] = round(timeit(commit_host), 3)       # + one 32 n-byte PCIe copy; never `value`
+    assert out.raw == commitment
+    # config 3: NTT then Lagrange-SRS MSM
+    lag = kzg_amd.setup_lagrange(engine, TAU, n)
+    ev = engine.alloc_scalars(n)
+    ev.upload(host_coeffs)
+    engine.prof_enable(True)
+    engine.prof_reset()
+
+    def ntt():
+        assert lib.kzg_ntt_fr(ctx, ev.ptr, log_n, 0, L.IN_DEVICE) == 0, engine.last_error()
+    reps = 5
+    ntt_ms = timeit(ntt, reps=reps, warm=1)
+    prof = engine.prof_all()
+    engine.prof_enable(False)
+    kern_ms = sum(v[1] for k, v in prof.items() if k.startswith("k_ntt")) / (reps + 1)
+    res["ntt_2e%d_ms" % log_n] = round(ntt_ms, 4)
+    nbytes = NTT_BYTES_PER_ELEM * n
+    fr_muls = (n // 2) * log_n
+    res["ntt_roofline"] = {
+        "bound": "valu", "kernels": {k: round(v[1] / (reps + 1), 4) for k, v in sorted(prof.items()) if k.startswith("k_ntt")},
+        "kernel_ms": round(kern_ms, 4), "achieved": round(fr_muls / (kern_ms / 1e3) / 1e9, 2), "peak": FR_MUL_PEAK_G_S,
+        "unit": "G Fr-mul/s ((n/2) log n butterflies)", "frac": round(fr_muls / (kern_ms / 1e3) / 1e9 / FR_MUL_PEAK_G_S, 4),
+        "hbm": {"bound": "hbm", "achieved": round(nbytes / (kern_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(nbytes / (kern_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": nbytes}}
+    ev.upload(host_coeffs)
+    ntt()
+
+    def commit_eval():
+        assert lib.kzg_commit_eval(ctx, lag.handle, ev.ptr, n, ev.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
+    res["commit_eval_ms"] = round(timeit(commit_eval), 3)
+    res["commit_eval_equals_commit_coeff"] = bool(out.raw == commitment)
+    # config 4, single opening and batched k = 256
+    x = kzg_amd.splitmix_scalar(99, 0)
+    y = engine.poly_eval(coeffs, x)
+
+    def witness():
+        rc = lib.kzg_witness_coeff(ctx, srs.handle, coeffs.ptr, n, b32(x), b32(y), coeffs.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+        assert rc == 0, engine.last_error()
+    res["witness_coeff_ms"] = round(timeit(witness), 3)
+    m = 12345 % n
+    xm = pow(kzg_amd.compute_omega(n)[2], m, R)
+    ym = engine.poly_eval(coeffs, xm)
+    rc = lib.kzg_witness_coeff(ctx, srs.handle, coeffs.ptr, n, b32(xm), b32(ym), coeffs.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    w_coeff = out.raw
+
+    def witness_eval():
+        assert lib.kzg_witness_eval(ctx, lag.handle, ev.ptr, n, m, ev.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
+    res["witness_eval_ms"] = round(timeit(witness_eval), 3)
+    res["witness_eval_equals_witness_coeff"] = bool(rc == 0 and out.raw == w_coeff)
+    k = 256 if n > 512 else 4
+    xs = [kzg_amd.splitmix_scalar(7, i) for i in range(k)]
+    ys = [engine.poly_eval(coeffs, v) for v in xs]
+    xb, yb = kzg_amd.pack_scalars(xs), kzg_amd.pack_scalars(ys)
+    rbuf, rlen = ctypes.create_string_buffer(32 * k), ctypes.c_size_t()
+
+    def batched():
+        rc = lib.kzg_witness_coeff_batched(ctx, srs.handle, coeffs.ptr, n, xb, yb, k, coeffs.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT,
+                                           rbuf, ctypes.byref(rlen))
+        assert rc == 0, engine.last_error()
+    res["witness_batched_k%d_ms" % k] = round(timeit(batched, reps=2), 3)
+    if time.perf_counter() - t_start < budget_s * 0.5:
+        outs = ctypes.create_string_buffer(96 * k)
+        st = (ctypes.c_int * k)()
+
+        def witness_many():
+            rc = lib.kzg_witness_coeff_many(ctx, srs.handle, coeffs.ptr, n, xb, yb, k, coeffs.sfmt, L.IN_DEVICE, outs, L.G1_AFFINE_MONT, st)
+            assert rc == 0, engine.last_error()
+        t_many = timeit(witness_many, reps=1, warm=1)
+        res["witness_many_k%d_per_s" % k] = round(k / t_many * 1e3, 1)
+        res["witness_many_all_on_poly"] = all(v == 0 for v in st)
+    ev.free()
+    lag.free()
+    return res
+
+
+def measure_spots(kzg_amd, L, engine, budget_ok):
+    """2^16 and 2^24 spot values of the same metric (sweep 2^16 - 2^24), full-width scalars."""
+    res = {}
+    for log_m, batch in ((16, 64), (24, 2)):
+        if not budget_ok():
+            break
+        m = 1 << log_m
+        p = kzg_amd.setup(engine, TAU, m, g2_len=0)
+        sc = engine.alloc_scalars(m * batch).fill_random(SEED + 77)
+        out = ctypes.create_string_buffer(96 * batch)
+
+        def step():
+            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, p.gs.handle, 0, sc.ptr, m, batch, sc.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == 0, engine.last_error()
+        ms = timeit(step, reps=3 if log_m == 16 else 2)
+        c, W = p.gs.window_info()
+        res["commit_2e%d" % log_m] = {"commitments_per_s": round(batch / ms * 1e3, 2), "batch": batch, "window_bits": c, "windows": W,
+                                      "hbm_frac": round(BYTES_PER_TERM * m * batch / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}
+        one = ctypes.create_string_buffer(96)
+
+        def single():
+            rc = engine.lib.kzg_msm_g1(engine.ctx, p.gs.handle, 0, sc.ptr, m, sc.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
+            assert rc == 0, engine.last_error()
+        res["commit_2e%d" % log_m]["single_commit_latency_ms"] = round(timeit(single, reps=2), 3)
+        sc.free()
+        p.gs.free()
+    return res
 
 
 def main():
@@ -109,35 +298,44 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="commitments per step (pipelined on the engine's HIP streams)")
-    ap.add_argument("--streams", type=int, default=16, help="HIP streams the engine pipelines a batch over (0 = engine default, 8)")
-    ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks (0 = default)")
+    ap.add_argument("--streams", type=int, default=16, help="HIP streams the engine pipelines a batch over (0 = engine default)")
+    ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks_batch (0 = default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (kzg_ctx_set_option), repeatable")
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--window-bits", type=int, default=0, help="engine option window_bits (0 = engine default)")
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-paths", action="store_true", help="skip the `paths` measurements after the timed region")
+    ap.add_argument("--strong", action="store_true", help="N>1 (default there): one degree-2^log_n commitment sharded N ways")
+    ap.add_argument("--config5", action="store_true", help="N>1: BASELINE configs[4], 2^21 terms per rank (degree 2^24 at N = 8)")
+    ap.add_argument("--weak", action="store_true", help="N>1: 2^log_n terms per rank (degree N * 2^log_n)")
     ap.add_argument("--sharded", action="store_true",
-                    help="use the N>1 code path (process group, sharded SRS, RCCL all_gather) even at world size 1")
-    ap.add_argument("--check", action="store_true", help="verify the timed result against [p(tau)]G (known-tau identity)")
+                    help="use the device-group code path (sharded SRS, RCCL all-gather inside the library) even at world size 1")
+    ap.add_argument("--check", action="store_true", help="verify EVERY commitment of the last step against [p(tau)]G")
     ap.add_argument("--replicas", action="store_true",
-                    help="N>1 only: data-parallel replicas (full SRS on every GPU, different polynomials per GPU, no "
-                         "collective in the data path) instead of the sharded-SRS mode (SURVEY 8e, throughput alternative)")
-    ap.add_argument("--cpu-all-cores", action="store_true",
-                    help="also time the oracle MSM split over all host cores (extra field cpu_baseline_all_cores)")
+                    help="N>1 only: data-parallel replicas (full SRS on every GPU, different polynomials per GPU, no collective)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    n = 1 << args.log_n
+    sharded = (world > 1 and not args.replicas) or args.sharded
+
+    cpu = None
+    if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
+        try:
+            cpu = CpuBaseline()
+            cpu.start()          # before torch / HIP: the workers are spawned from a process that has not touched the GPU
+        except Exception as e:   # the baseline must never take the bench line down
+            cpu = None
+            cpu_err = str(e)
 
     import torch
     import kzg_amd
     from kzg_amd import _lib as L
 
     dist = None
-    sharded = (world > 1 and not args.replicas) or args.sharded
-    if sharded or world > 1:
+    if world > 1 or sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
@@ -145,7 +343,31 @@ def main():
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-    engine = kzg_amd.Engine(local_rank)
+
+    # ---- which polynomial, which slice of it this rank holds -------------------------------------------------
+    if not sharded:
+        mode = "single" if world == 1 else "replicas"
+        n_poly = 1 << args.log_n
+        lo, hi = 0, n_poly
+    else:
+        from kzg_amd.distributed import group_from_torch, shard_range
+        if args.config5:
+            mode, n_poly = "config5", world << 21
+        elif args.weak:
+            mode, n_poly = "weak", world << args.log_n
+        else:
+            mode, n_poly = "strong", 1 << args.log_n
+        lo, hi = shard_range(n_poly, rank, world)
+    n_local = hi - lo
+
+    group = None
+    if sharded:
+        group = group_from_torch(dist, local_rank, rank, world)
+        if world == 1:
+            group.set_option("always_gather", 1)     # --sharded at N = 1 exercises the RCCL exchange
+        engine = group.engine(0)
+    else:
+        engine = kzg_amd.Engine(local_rank)
     if args.window_bits:
         engine.set_option("window_bits", args.window_bits)
     if args.streams:
@@ -162,33 +384,41 @@ def main():
         torch.cuda.synchronize()
 
     # ---- inputs, resident in HBM before the timed region -----------------------------------------
-    if not sharded:
-        params = kzg_amd.setup(engine, TAU, n, g2_len=0)                       # gs[i] = [tau^i]G
-        srs = params.gs
-        scal = engine.alloc_scalars(n * args.batch).fill_random(1 + 1000 * rank, u64_valued=args.u64)
+    # polynomial b of the batch = elements of the counter stream seeded SEED + 1000 b (replicas: + 10^6 rank); a rank holds
+    # coefficients [lo, hi) of each, laid out [batch][hi - lo]
+    def poly_seed(b):
+        return SEED + 1000 * b + (1_000_000 * rank if mode == "replicas" else 0)
+
+    scal = engine.alloc_scalars(max(n_local, 1) * args.batch)
+    for b in range(args.batch):
+        view(kzg_amd, scal, b * n_local, n_local).fill_random(poly_seed(b) + 4 * lo, u64_valued=args.u64)
+    if sharded:
+        msrs = group.setup(TAU, n_poly)                          # rank r generates gs[lo_r, hi_r) on its GPU
+        srs, first = msrs.shard(0)
+        assert first == lo and len(srs) == n_local
+        params = None
     else:
-        # rank r holds the contiguous shard gs[r*n .. (r+1)*n) = [tau^(r*n + i)]G of setup(tau, world*n)
-        params = kzg_amd.KZGParams(kzg_amd.setup_shard(engine, TAU, rank * n, n))
+        params = kzg_amd.setup(engine, TAU, n_poly, g2_len=0)    # gs[i] = [tau^i]G
         srs = params.gs
-        scal = engine.alloc_scalars(n * args.batch).fill_random(1 + 1000 * rank, u64_valued=args.u64)
     c, W = srs.window_info()
     out = ctypes.create_string_buffer(96 * max(args.batch, 1))
 
-    last = {}
     if not sharded:
         def step():
-            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, srs.handle, 0, scal.ptr, n, args.batch, scal.sfmt,
+            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, srs.handle, 0, scal.ptr, n_poly, args.batch, scal.sfmt,
                                              L.IN_DEVICE, out, L.G1_AFFINE_MONT)
             if rc:
                 raise RuntimeError(engine.last_error())
         units_per_step = world * args.batch   # replicas: every rank commits its own batch
     else:
-        from kzg_amd.distributed import ShardedCommitter
-        committer = ShardedCommitter.for_engine(engine, srs, dist, rank, world, max_batch=args.batch, always_gather=True)
+        ptrs = (ctypes.c_void_p * 1)(scal.ptr.value)
 
         def step():
-            last["commitments"] = committer.commit_batch(scal, args.batch)
-        units_per_step = world * args.batch   # world * n terms per polynomial = `world` degree-2^20 equivalents each
+            rc = group.lib.kzg_commit_coeff_sharded_batch(group.handle, msrs.handle, ptrs, n_poly, args.batch, scal.sfmt,
+                                                          L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            if rc:
+                raise RuntimeError(group.last_error())
+        units_per_step = args.batch           # every commitment involves all ranks
 
     for _ in range(args.warmup):
         step()
@@ -208,22 +438,18 @@ def main():
 
     check = None
     if args.check:
-        # known-tau identity: commitment == [p(tau)]G.  p(tau) = sum_r tau^(r*n) * p_r(tau) from per-rank GPU Horner
-        # evaluations; the single scalar multiplication of G is done by the oracle (checker only, outside the timing).
+        # known-tau identity for EVERY commitment of the last step: C_b == [p_b(tau)]G, p_b(tau) = sum_r tau^(lo_r) p_{b,r}(tau)
+        # from per-rank GPU Horner evaluations; the scalar multiplications of G are done by the oracle (checker only).
         from oracle import c_oracle as C
         R = kzg_amd.api.R_MODULUS
-        mine = pow(TAU, rank * n, R) * engine.poly_eval(scal, TAU, n=n) % R if sharded else None  # polynomial 0 of the batch
-        if sharded:
-            vals = [None] * world
-            if world > 1:
-                dist.all_gather_object(vals, mine)
-            else:
-                vals = [mine]
-            want = C.g1_mul(C.g1_generator(), sum(vals) % R)
-            check = bool(last.get("commitments", [None])[0] == want)
-        else:
-            want = C.g1_mul(C.g1_generator(), engine.poly_eval(scal, TAU, n=n))
-            check = bool(out.raw[:96] == want)
+        mine = [pow(TAU, lo, R) * engine.poly_eval(view(kzg_amd, scal, b * n_local, n_local), TAU) % R if n_local else 0
+                for b in range(args.batch)]
+        if sharded and world > 1:
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+            mine = [sum(v[b] for v in allv) % R for b in range(args.batch)]
+        G = C.g1_generator()
+        check = all(out.raw[96 * b: 96 * b + 96] == C.g1_mul(G, mine[b]) for b in range(args.batch))
 
     # ---- roofline of the dominant kernel: HIP events recorded on the engine's streams over the timed region ----
     roofline = None
@@ -234,56 +460,71 @@ def main():
         launches, total_ms = prof.get("k_accum_affine", (0, 0.0))
         if launches:
             avg_s = total_ms / launches / 1e3
-            achieved = BYTES_PER_TERM * n / avg_s / 1e9
+            adds_per_launch = n_local * (4 if args.u64 else W)   # u64-valued scalars: 4 non-zero 16/17-bit windows
+            mads_per_launch = float(adds_per_launch) * MADS_PER_ADD
             traffic = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
+            if os.path.exists(tpath) and n_local == (1 << 20) and not args.u64:
                 try:
                     traffic = json.load(open(tpath)).get("k_accum_affine_bytes_per_launch")
                 except Exception:
                     traffic = None
-            per_msm = launches  # one k_accum_affine launch per MSM
-            roofline = {"bound": "hbm", "kernel": "k_accum_affine", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": BYTES_PER_TERM * n, "launches": launches,
-                        "avg_kernel_ms": round(avg_s * 1e3, 4),
-                        "note": "binding resource is integer VALU issue (~4.9e4 32-bit multiply-adds per term), not HBM; "
-                                "see DESIGN.md 3.2",
-                        "kernel_ms_per_msm": {k: round(v[1] / per_msm, 4) for k, v in sorted(prof.items())}}
-            # informational: the same kernel against the integer-multiply issue rate, over the whole timed region
-            # (launches overlap on 8 streams, so the aggregate rate is the meaningful one)
-            mads = float(launches) * n * (4 if args.u64 else W) * MADS_PER_ADD  # u64-valued scalars: 4 non-zero 16-bit windows
-            t_mad = mads / dt / 1e12
-            roofline["valu"] = {"resource": "v_mad_i64_i32 issue", "achieved": round(t_mad, 2), "unit": "T lane-mad/s",
-                                "peak": MAD_PEAK_TLANE_S, "frac": round(t_mad / MAD_PEAK_TLANE_S, 4),
-                                "peak_at_2_waves_per_simd": MAD_PEAK_OCC2_TLANE_S,
-                                "frac_of_occupancy_2_peak": round(t_mad / MAD_PEAK_OCC2_TLANE_S, 4),
-                                "mads_per_bucket_add": MADS_PER_ADD}
-        # single-commit latency (one MSM alone on the GPU), outside the timed region
+            t_mad = launches * mads_per_launch / dt / 1e12       # over the whole timed region (launches overlap on streams)
+            hbm_achieved = BYTES_PER_TERM * n_local / avg_s / 1e9
+            roofline = {
+                "bound": "valu", "kernel": "k_accum_affine", "resource": "v_mad_i64_i32 issue (integer VALU)",
+                "achieved": round(t_mad, 2), "peak": MAD_PEAK_TLANE_S, "unit": "T lane-mad/s", "frac": round(t_mad / MAD_PEAK_TLANE_S, 4),
+                "traffic": traffic,
+                "derivation": "launches x terms x windows x %d mads per bucket addition (6 mul30 x 338 + 2 sqr30 x 260 + 1 fused "
+                              "muladd 507; 13 x 30-bit signed limbs) / wall time of the timed region; peak = measured "
+                              "v_mad_i64_i32 issue rate of the chip (tools/microbench.hip, profiles/r01_microbench.txt)" % MADS_PER_ADD,
+                "peak_at_2_waves_per_simd": MAD_PEAK_OCC2_TLANE_S, "frac_of_occupancy_2_peak": round(t_mad / MAD_PEAK_OCC2_TLANE_S, 4),
+                "mads_per_bucket_add": MADS_PER_ADD, "launches": launches, "avg_kernel_ms": round(avg_s * 1e3, 4),
+                "hbm": {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(hbm_achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": BYTES_PER_TERM * n_local,
+                        "note": "128 B per term / in-situ kernel duration (two accumulation kernels share the GPU in the batched "
+                                "pipeline); the kernel is VALU-bound, see DESIGN.md 3.2"},
+                "kernel_ms_per_msm": {k: round(v[1] / launches, 4) for k, v in sorted(prof.items())}}
+        # single-commit latency (one MSM alone on the GPU = what a blocking KZGProver::commit call sees), outside the timed region
         one = ctypes.create_string_buffer(96)
-        reps = 2
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            rc = engine.lib.kzg_msm_g1(engine.ctx, srs.handle, 0, scal.ptr, n, scal.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
-            if rc:
-                raise RuntimeError(engine.last_error())
-        latency_ms = (time.perf_counter() - t1) / reps * 1e3
-        # the same kernel with nothing else on the GPU (the batched figure above divides by a duration that is stretched
-        # by the other MSMs in flight): two more single MSMs with the engine's event profiling on
-        if roofline is not None:
-            engine.prof_enable(True)
-            engine.prof_reset()
-            for _ in range(reps):
-                engine.lib.kzg_msm_g1(engine.ctx, srs.handle, 0, scal.ptr, n, scal.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
-            l2, ms2 = engine.prof_all().get("k_accum_affine", (0, 0.0))
-            engine.prof_enable(False)
-            if l2:
-                a2 = BYTES_PER_TERM * n / (ms2 / l2 / 1e3) / 1e9
-                roofline["alone"] = {"avg_kernel_ms": round(ms2 / l2, 4), "achieved": round(a2, 2), "unit": "GB/s",
-                                     "frac": round(a2 / HBM_PEAK_GBS, 5)}
+        if not sharded:
+            def single():
+                rc = engine.lib.kzg_msm_g1(engine.ctx, srs.handle, 0, scal.ptr, n_poly, scal.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
+                if rc:
+                    raise RuntimeError(engine.last_error())
+            latency_ms = timeit(single, reps=4, warm=1)
+            if roofline is not None:
+                engine.prof_enable(True)
+                engine.prof_reset()
+                for _ in range(3):
+                    single()
+                pa = engine.prof_all()
+                engine.prof_enable(False)
+                l2, ms2 = pa.get("k_accum_affine", (0, 0.0))
+                if l2:
+                    k_s = ms2 / l2 / 1e3
+                    roofline["alone"] = {"avg_kernel_ms": round(ms2 / l2, 4),
+                                         "valu_frac": round(mads_per_launch / k_s / 1e12 / MAD_PEAK_TLANE_S, 4),
+                                         "hbm_gbs": round(BYTES_PER_TERM * n_local / k_s / 1e9, 2),
+                                         "hbm_frac": round(BYTES_PER_TERM * n_local / k_s / 1e9 / HBM_PEAK_GBS, 5),
+                                         "kernel_ms_single_msm": {k: round(v[1] / l2, 4) for k, v in sorted(pa.items())}}
 
     if rank == 0:
         value = units_per_step * args.steps / dt
+        workloads = {
+            "single": "degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step" % (args.log_n, args.batch),
+            "replicas": "degree-2^%d coeff_form commit, %d data-parallel replicas (full SRS per GPU, batch of %d per rank and step, "
+                        "no data-path collective)" % (args.log_n, world, args.batch),
+            "strong": "degree-2^%d coeff_form commit, every commitment's terms and the SRS sharded %d ways (%d terms per rank), batch "
+                      "of %d per step, one RCCL all-gather of the 144-B partials inside the library + local sums (strong scaling)"
+                      % (args.log_n, world, n_local, args.batch),
+            "config5": "degree-%d (= %d x 2^21) coeff_form commit, SRS sharded 2^21 terms per rank over %d GPUs (BASELINE configs[4] is "
+                       "N = 8: degree 2^24), batch of %d per step, RCCL all-gather of the partials inside the library"
+                       % (n_poly, world, world, args.batch),
+            "weak": "degree-%d (= %d x 2^%d) coeff_form commit, SRS sharded 2^%d terms per rank, batch of %d per step, RCCL "
+                    "all-gather of the partials inside the library" % (n_poly, world, args.log_n, args.log_n, args.batch),
+        }
         res = {
             "metric": "commitments/sec + MSM G1-adds/sec at degree 2^20, 1/2/4/8 MI355X",
             "value": round(value, 3),
@@ -293,44 +534,50 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if mode == "strong" else "weak",
             "vs_baseline": None,
             "dtype": "u32 limbs (Fq 381-bit / Fr 255-bit Montgomery integer arithmetic)",
             "data": "synthetic",
             "config": {
-                "workload": (("degree-2^%d coeff_form commit (G1 Pippenger MSM) on 1xMI355X, batch of %d per step"
-                              % (args.log_n, args.batch)) if world == 1 else
-                             ("degree-2^%d coeff_form commit, %d data-parallel replicas (full SRS per GPU, batch of %d per "
-                              "rank and step, no data-path collective)" % (args.log_n, world, args.batch))) if not sharded else
-                            ("degree-%d*2^%d coeff_form commit, SRS sharded 2^%d terms per rank over %d GPUs, batch of %d "
-                             "per step, one RCCL all_gather of the 144-B Jacobian partials + local sums"
-                             % (world, args.log_n, args.log_n, world, args.batch)),
-                "scalars": "u64-valued Fr" if args.u64 else "uniform full-width Fr (SplitMix64 counter stream, seed 1)",
-                "terms_per_rank": n, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",
+                "workload": workloads[mode], "mode": mode, "polynomial_coefficients": n_poly,
+                "scalars": "u64-valued Fr" if args.u64 else "uniform full-width Fr (SplitMix64 counter stream)",
+                "terms_per_rank": n_local, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",
                 "inputs_resident_in_hbm": True,
             },
-            "g1_adds_per_sec": round(value * g1_adds_per_msm(n, c, W), 1),
-            "msm_terms_per_sec": round(value * n, 1),
+            "g1_adds_per_sec": round(value * (world if mode != "replicas" else 1) * g1_adds_per_msm(n_local, c, W), 1),
+            "msm_terms_per_sec": round(value * n_poly, 1),
+            "parity_pin": "fr-literal+known-tau",   # G1 layer: no literal vector in the reference
             "single_commit_latency_ms": None if latency_ms is None else round(latency_ms, 4),
+            "blocking_commit_per_s": None if latency_ms is None else round(1e3 / latency_ms, 2),
         }
         if check is not None:
-            res["result_matches_known_tau"] = check
-        if world > 1:
-            res["unit_note"] = "N>1: value = (terms processed by all ranks / 2^20) per second (degree-2^20 equivalents)"
+            res["all_results_match_known_tau"] = check
         if roofline:
             res["roofline"] = roofline
-        if world == 1 and not sharded and not args.no_cpu_baseline:
+        t_extra = time.perf_counter()
+        if mode == "single" and not args.no_paths:
             try:
-                res["cpu_baseline"] = cpu_baseline(engine, params, scal, args.log_n)
-            except Exception as e:  # the baseline must never take the bench line down
-                res["cpu_baseline"] = {"value": None, "unit": "commitments/s", "cores": 1, "kind": "port",
-                                       "sample": f"failed: {e}"}
-            if args.cpu_all_cores:
+                res["paths"] = measure_paths(kzg_amd, L, engine, params, scal, n_poly, args.log_n)
+                if args.log_n == 20 and not args.u64:
+                    res["paths"].update(measure_spots(kzg_amd, L, engine, lambda: time.perf_counter() - t_extra < 45.0))
+            except Exception as e:
+                res["paths"] = {"error": str(e)}
+        if mode == "single" and not args.no_cpu_baseline:
+            if cpu is not None:
                 try:
-                    res["cpu_baseline_all_cores"] = cpu_baseline_all_cores(engine, params, scal, args.log_n)
+                    n_s = 1 << min(args.log_n, 20)
+                    pts = params.gs.download(0, n_s)
+                    sc = view(kzg_amd, scal, 0, n_s).download()
+                    gpu_res = engine.msm(params.gs, view(kzg_amd, scal, 0, n_s), n=n_s)
+                    res["cpu_baseline"], res["cpu_baseline_all_cores"] = cpu.run(pts, sc, n_s, args.log_n, gpu_res)
                 except Exception as e:
-                    res["cpu_baseline_all_cores"] = {"value": None, "sample": f"failed: {e}"}
+                    res["cpu_baseline"] = {"value": None, "unit": "commitments/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+            else:
+                res["cpu_baseline"] = {"value": None, "unit": "commitments/s", "cores": 1, "kind": "port",
+                                       "sample": "failed to start the worker pool: " + locals().get("cpu_err", "?")}
         line = json.dumps(res)
+    if cpu is not None:
+        cpu.close()
     # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's own
     # output when a process exits: every rank flushes it before the last barrier, so that rank 0's JSON line ends the output
     sys.stdout.flush()
@@ -340,8 +587,14 @@ def main():
         pass
     if dist is not None:
         dist.barrier()
+    scal.free()
+    if group is not None:
+        msrs.free()
+        group.close()
+    else:
+        engine.close()
+    if dist is not None:
         dist.destroy_process_group()
-    engine.close()
     if rank == 0:
         print(line, flush=True)
 

@@ -14,11 +14,11 @@
 //     k_scan_*, k_scatter.
 //   * Bucket accumulation (k_accum_affine) is an equal split of the sorted entry list over exactly
 //     the resident thread slots (XYZZ mixed adds, points gathered from the resident table, one partial
-//     per bucket a thread touches), then partial sums are folded by key in rounds of fan-in LK
-//     (k_accum_xyzz) until every bucket holds one point.  No atomics, no
-//     unbounded per-thread chain, so adversarial inputs (all-equal scalars) stay bounded.
-//   * sum_b (b+1) * B_b by chunked running sums + small scalar-muls (k_bucket_reduce), a plain
-//     tree sum (k_sum_level), and one Fq inversion for the affine result (k_emit_point).
+//     per bucket a thread touches).  No atomics, no unbounded per-thread chain, so adversarial inputs (all-equal
+//     scalars) stay bounded.
+//   * msm_tail.hip: the partial sums are folded into one point per bucket by lane groups, sum_b (b+1) * B_b by row /
+//     column sums + bit-sliced weighted sums (depth ~35 additions), and one Fq inversion for the affine result
+//     (k_emit_points).
 //
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
 #include "msm_internal.h"
@@ -160,42 +160,121 @@ __global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int 
     }
 }
 
-// per bucket: exclusive scan over sort blocks; total[b] = bucket size
-__global__ void k_scan_blocks(uint32_t *blk_hist, int G, int B, uint32_t *total) {
-    int b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= B) return;
-    uint32_t run = 0;
-    for (int g = 0; g < G; g++) {
-        uint32_t t = blk_hist[(size_t)g * B + b];
-        blk_hist[(size_t)g * B + b] = run;
-        run += t;
+// ---- bucket starts and the round-1 layout, in two multi-block kernels (no single-block pass over all buckets) ----
+// k_scan_a: block j owns the 256 buckets [256 j, 256 j + 256).  Per bucket: exclusive scan over the sort blocks' counts (in
+// place), total[b] = bucket size; then the block-local exclusive scan local[b] of the totals and the block aggregate agg[j].
+constexpr int SCAN_SEG = 256;
+__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *lds, uint32_t *total_out) {
+    // exclusive scan of one value per thread over a 256-thread block (4 waves): wave shuffles + one LDS pass
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    total[b] = run;
+    if (lane == 63) lds[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        uint32_t t = lds[w];
+        if (w < wave) woff += t;
+        tot += t;
+    }
+    __syncthreads();
+    *total_out = tot;
+    return incl - v + woff;
 }
 
-// bucket_start[] from total[]; then the round-1 layout.  Round 1 is an EQUAL SPLIT: thread s folds
-// the sorted entries [s*E, (s+1)*E), E = ceil(M / slots), and emits one partial per (thread, bucket) run.
-// Run starts are the multiples of E and the non-empty bucket starts, so the partial list is ordered by
+__global__ __launch_bounds__(SCAN_SEG) void k_scan_a(uint32_t *blk_hist, int G, int B, uint32_t *total, uint32_t *local, uint32_t *agg,
+                                                     uint32_t *ready) {
+    __shared__ uint32_t lds[4];
+    if (threadIdx.x == 0) ready[blockIdx.x] = 0;  // k_scan_b's chained flag counts
+    const int b = blockIdx.x * SCAN_SEG + threadIdx.x;
+    uint32_t run = 0;
+    if (b < B) {
+        for (int g = 0; g < G; g++) {
+            uint32_t t = blk_hist[(size_t)g * B + b];
+            blk_hist[(size_t)g * B + b] = run;
+            run += t;
+        }
+        total[b] = run;
+    }
+    uint32_t tot;
+    uint32_t ex = block_scan_256(run, lds, &tot);
+    if (b < B) local[b] = ex;
+    if (threadIdx.x == 0) agg[blockIdx.x] = tot;
+}
+
+// k_scan_b: every block scans the (<= 256) block aggregates itself -> M, the equal-split chunk E, its own bucket starts.
+// Round 1 is an EQUAL SPLIT: thread s folds the sorted entries [s*E, (s+1)*E), E = ceil(M / slots), and emits one partial per
+// (thread, bucket) run.  Run starts are the multiples of E and the non-empty bucket starts, so the partial list is ordered by
 // bucket and bucket b's partials are [S1[b], S1[b+1]) with
 //     S1[b] = ceil(start[b] / E) + #{non-empty b' < b : start[b'] mod E != 0}.
-__global__ __launch_bounds__(1024) void k_scan_buckets(const uint32_t *total, int B, uint32_t *bucket_start,
-                                                       uint32_t *s1, MsmState *st, uint32_t slots) {
-    __shared__ uint32_t lds[1024];
-    uint32_t M = block_exclusive_scan(B, [&](int b) { return total[b]; }, bucket_start, lds);
+// The count over the preceding blocks is a chained scan: block j publishes its own count in ready[j] (count << 1 | 1, one
+// relaxed atomic word) and thread t < j of block j waits for ready[t].  Blocks are dispatched in order, so a block only ever
+// waits for blocks that are already running or done (the forward-progress assumption of every decoupled look-back scan).
+__device__ __forceinline__ uint32_t mod_u32(uint32_t x, uint32_t e, double rcp_e) {
+    uint32_t q = (uint32_t)((double)x * rcp_e);
+    uint32_t r = x - q * e;          // q is floor(x / e) or one off in either direction
+    if ((int32_t)r < 0) r += e;
+    if (r >= e) r -= e;
+    return r;
+}
+
+__global__ __launch_bounds__(SCAN_SEG) void k_scan_b(const uint32_t *total, const uint32_t *local, const uint32_t *agg, int B, int NB,
+                                                     uint32_t *bucket_start, uint32_t *s1, MsmState *st, uint32_t slots, uint32_t *ready) {
+    __shared__ uint32_t lds[4];
+    __shared__ uint32_t my_prefix;
+    uint32_t M;
+    {
+        uint32_t v = (int)threadIdx.x < NB ? agg[threadIdx.x] : 0u;
+        uint32_t ex = block_scan_256(v, lds, &M);
+        if (threadIdx.x == blockIdx.x) my_prefix = ex;
+    }
+    __syncthreads();
     uint32_t E = (M + slots - 1) / slots;
     if (E < 8) E = 8;
-    block_exclusive_scan(
-        B, [&](int b) { return (total[b] != 0 && (bucket_start[b] % E) != 0) ? 1u : 0u; }, s1, lds);
-    for (int b = threadIdx.x; b <= B; b += blockDim.x) s1[b] += (bucket_start[b] + E - 1) / E;
-    if (threadIdx.x == 0) {
+    const double rcp_e = 1.0 / (double)E;
+    const int b = blockIdx.x * SCAN_SEG + threadIdx.x;
+    uint32_t start = 0, f = 0;
+    if (b < B) {
+        start = my_prefix + local[b];
+        f = (total[b] != 0 && mod_u32(start, E, rcp_e) != 0) ? 1u : 0u;
+    }
+    uint32_t ftot;
+    const uint32_t fex = block_scan_256(f, lds, &ftot);
+    if (threadIdx.x == 0) __hip_atomic_store(&ready[blockIdx.x], (ftot << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prev = 0;
+    if (threadIdx.x < blockIdx.x) {
+        uint32_t w;
+        while (((w = __hip_atomic_load(&ready[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u) == 0) __builtin_amdgcn_s_sleep(1);
+        prev = w >> 1;
+    }
+    uint32_t before;
+    block_scan_256(prev, lds, &before);
+    if (b < B) {
+        bucket_start[b] = start;
+        s1[b] = before + fex + (start + E - 1) / E;
+    }
+    if (blockIdx.x == (unsigned)NB - 1 && threadIdx.x == 0) {
+        bucket_start[B] = M;
+        s1[B] = before + ftot + (M + E - 1) / E;
         st->M = M;
         st->E = E;
         st->ntasks = (M + E - 1) / E;
-        st->done = 0;
-        st->final_level = 0;
-        st->final_buf = 0;
-        st->max_cnt = 0;
+        st->ovf_tasks = 0;
     }
+}
+
+static int scan_run(kzg_ctx *ctx, hipStream_t st, uint32_t *blk_hist, int G, int B, uint32_t *total, uint32_t *local, uint32_t *agg,
+                    uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots) {
+    const int NB = (B + SCAN_SEG - 1) / SCAN_SEG;  // <= 256 (B <= 2^16)
+    uint32_t *ready = agg + SCAN_SEG;
+    KZG_LAUNCH(ctx, st, "k_scan_a", k_scan_a, NB, SCAN_SEG, 0, blk_hist, G, B, total, local, agg, ready);
+    KZG_LAUNCH(ctx, st, "k_scan_b", k_scan_b, NB, SCAN_SEG, 0, total, local, agg, B, NB, bucket_start, s1, state, slots, ready);
+    return KZG_OK;
 }
 
 // mode 0: c <= 16 (u32 cursors in LDS); mode 1: wide path (sorts by the low 15 bucket bits, the high bits ride in bits 27..30 of
@@ -304,100 +383,6 @@ __global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uin
         if (mode == 0) acc = g1_madd30_phase2(acc, mid, neg_k, [&]() { return load_entry_point30(table30, ent_k); });
     }
     out[pos] = acc;
-}
-
-// per-level task layout: ntask[b] = ceil(cnt[b] / L); also detects "every bucket <= 1 partial"
-__device__ __forceinline__ void level_scan_body(const uint32_t *in_start, uint32_t *out_task_start, int B, int L, MsmState *st,
-                                                uint32_t level, uint32_t in_buf, uint32_t *lds, uint32_t *smax) {
-    if (st->done) return;
-    if (threadIdx.x == 0) *smax = 0;
-    __syncthreads();
-    uint32_t mx = 0;
-    for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        uint32_t cnt = in_start[b + 1] - in_start[b];
-        mx = cnt > mx ? cnt : mx;
-    }
-    atomicMax(smax, mx);
-    __syncthreads();
-    if (*smax <= 1) {
-        if (threadIdx.x == 0) {
-            st->done = 1;
-            st->final_level = level;
-            st->final_buf = in_buf;
-            st->max_cnt = *smax;
-        }
-        return;
-    }
-    uint32_t T = block_exclusive_scan(
-        B, [&](int b) { return (in_start[b + 1] - in_start[b] + L - 1) / L; }, out_task_start, lds);
-    if (threadIdx.x == 0) {
-        st->ntasks = T;
-        st->max_cnt = *smax;
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_level_scan(const uint32_t *in_start, uint32_t *out_task_start, int B,
-                                                     int L, MsmState *st, uint32_t level, uint32_t in_buf) {
-    __shared__ uint32_t lds[1024];
-    __shared__ uint32_t smax;
-    level_scan_body(in_start, out_task_start, B, L, st, level, in_buf, lds, &smax);
-}
-
-__device__ __forceinline__ void accum_xyzz_body(const MsmPoint *in, const uint32_t *in_start, const uint32_t *task_start, int B,
-                                                int L, MsmPoint *out, const MsmState *st) {
-    if (st->done) return;
-    const uint32_t T = st->ntasks;
-    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < T; t += gridDim.x * blockDim.x) {
-        uint32_t b, j;
-        find_task(task_start, B, t, b, j);
-        uint32_t s = in_start[b] + j * L;
-        uint32_t e = in_start[b + 1];
-        e = s + L < e ? s + L : e;
-        MsmPoint acc = in[s];
-        for (uint32_t k = s + 1; k < e; k++) acc = g1_add30(acc, in[k]);
-        out[t] = acc;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_accum_xyzz(const MsmPoint *in, const uint32_t *in_start,
-                                                    const uint32_t *task_start, int B, int L, MsmPoint *out,
-                                                    const MsmState *st) {
-    accum_xyzz_body(in, in_start, task_start, B, L, out, st);
-}
-
-// ---------------------------------------------------------------------------------------------
-// sum_b (b + 1) * bucket[b]
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bucket_reduce_body(const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int B, int CH,
-                                                   MsmPoint *out, const MsmState *st) {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    int nchunks = B / CH;
-    if (t >= nchunks) return;
-    const uint32_t *start = starts + (size_t)st->final_level * (B + 1);
-    const MsmPoint *buf = st->final_buf ? buf1 : buf0;
-    int lo = t * CH;
-    MsmPoint run = MsmPoint::infinity(), acc = MsmPoint::infinity();
-    for (int b = lo + CH - 1; b >= lo; b--) {
-        uint32_t s = start[b];
-        if (start[b + 1] > s) run = g1_add30(run, buf[s]);
-        acc = g1_add30(acc, run);
-    }
-    // acc = sum (b - lo + 1) B_b ; add lo * run
-    if (lo != 0 && !run.inf) {
-        MsmPoint m = MsmPoint::infinity();
-        for (int bit = 30; bit >= 0; bit--) {
-            m = g1_dbl30(m);
-            if ((lo >> bit) & 1) m = g1_add30(m, run);
-        }
-        acc = g1_add30(acc, m);
-    }
-    out[t] = acc;
-}
-
-__global__ __launch_bounds__(256) void k_bucket_reduce(const MsmPoint *buf0, const MsmPoint *buf1,
-                                                      const uint32_t *starts, int B, int CH, MsmPoint *out,
-                                                      const MsmState *st) {
-    bucket_reduce_body(buf0, buf1, starts, B, CH, out, st);
 }
 
 __global__ __launch_bounds__(256) void k_sum_level(const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {
@@ -543,24 +528,14 @@ static int sort_blocks(size_t n) {
     return (int)g;
 }
 
-static int worst_case_levels(size_t M) {  // fold rounds after round 1 until one partial per bucket
-    size_t c = M / 8 + 1;  // round 1 leaves at most ceil(M / E) partials in one bucket, E >= 8
-    if (c > ACC_SLOTS) c = ACC_SLOTS;
-    int lv = 0;
-    while (c > 1) {
-        c = (c + LK - 1) / LK;
-        lv++;
-    }
-    return lv;
-}
-
 size_t sum_points_scratch_count(size_t count) { return (count + SUM_L - 1) / SUM_L + 64; }
 
 struct MsmLayout {
-    int B, G, levels;
+    int B, G;
     size_t M_max, T1_max;
-    size_t off_blk_hist, off_total, off_bucket_start, off_starts, off_state, off_entries, off_bufA, off_bufB,
-        off_chunks, off_sum, off_result, bytes;
+    size_t off_blk_hist, off_total, off_local, off_agg, off_bucket_start, off_s1, off_state, off_entries, off_bufA, off_bufB, off_tail,
+        bytes;
+    TailLayout tail;
 };
 
 static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
@@ -569,8 +544,6 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.G = sort_blocks(n);
     L.M_max = n * (size_t)srs->W;
     L.T1_max = (size_t)ACC_SLOTS + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
-    L.levels = worst_case_levels(L.M_max);
-    if (L.levels > MAX_LEVELS) L.levels = MAX_LEVELS;
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t r = o;
@@ -579,28 +552,27 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     };
     L.off_blk_hist = take((size_t)L.G * L.B * 4);
     L.off_total = take((size_t)L.B * 4);
+    L.off_local = take((size_t)L.B * 4);
+    L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
     L.off_bucket_start = take((size_t)(L.B + 1) * 4);
-    L.off_starts = take((size_t)(L.levels + 2) * (L.B + 1) * 4);
+    L.off_s1 = take((size_t)(L.B + 1) * 4);
     L.off_state = take(sizeof(MsmState));
     L.off_entries = take(L.M_max * 4 + 16);
     L.off_bufA = take(L.T1_max * sizeof(MsmPoint));
-    size_t t2 = L.T1_max / LK + L.B + 1;
-    L.off_bufB = take(t2 * sizeof(MsmPoint));
-    int nchunks = L.B / (L.B < REDUCE_CH ? L.B : REDUCE_CH);
-    L.off_chunks = take((size_t)nchunks * sizeof(MsmPoint));
-    L.off_sum = take(sum_points_scratch_count(nchunks) * 2 * sizeof(MsmPoint));
-    L.off_result = take(sizeof(MsmPoint));
+    L.off_bufB = take(L.T1_max * sizeof(MsmPoint));  // slice sums of overflowing buckets, at the bucket's own offsets
+    L.tail = tail_layout(L.B, L.T1_max);
+    L.off_tail = take(L.tail.bytes);
     L.bytes = o;
     return L;
 }
 
 // ---- wide mode layout / orchestration ----
 struct WideLayout {
-    int B_lo, nhi, Btot, G, levels, C, R;
+    int B_lo, nhi, Btot, G;
     size_t M_max, T1_max;
-    size_t off_blk_hist, off_total, off_lo_start, off_s1_lo, off_state, off_entries1, off_entries2, off_bucket_start, off_starts,
-        off_blockcnt, off_binbase, off_segsums, off_segmaxs, off_segtotal, off_bufA, off_bufB, off_rows, off_cols, off_red, off_chunks,
-        off_sum, off_result, bytes;
+    size_t off_blk_hist, off_total, off_local, off_agg, off_lo_start, off_s1_lo, off_state, off_entries1, off_entries2, off_bucket_start, off_s1,
+        off_blockcnt, off_binbase, off_segsums, off_segmaxs, off_segtotal, off_bufA, off_bufB, off_tail, bytes;
+    TailLayout tail;
 };
 
 static WideLayout wide_layout(const kzg_srs *srs, size_t n) {
@@ -608,13 +580,9 @@ static WideLayout wide_layout(const kzg_srs *srs, size_t n) {
     L.B_lo = 1 << WIDE_LO_BITS;
     L.nhi = 1 << (srs->c - 1 - WIDE_LO_BITS);
     L.Btot = L.nhi * L.B_lo;
-    L.C = 512;
-    L.R = L.Btot / L.C;
     L.G = sort_blocks(n);
     L.M_max = n * (size_t)srs->W;
     L.T1_max = (size_t)ACC_SLOTS + L.Btot + 1;
-    L.levels = worst_case_levels(L.M_max);
-    if (L.levels > MAX_LEVELS) L.levels = MAX_LEVELS;
     size_t o = 0;
     auto take = [&](size_t bytes) {
         size_t r = o;
@@ -623,42 +591,46 @@ static WideLayout wide_layout(const kzg_srs *srs, size_t n) {
     };
     L.off_blk_hist = take((size_t)L.G * L.B_lo * 4);
     L.off_total = take((size_t)L.B_lo * 4);
+    L.off_local = take((size_t)L.B_lo * 4);
+    L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
     L.off_lo_start = take((size_t)(L.B_lo + 1) * 4);
     L.off_s1_lo = take((size_t)(L.B_lo + 1) * 4);
     L.off_state = take(sizeof(MsmState));
     L.off_entries1 = take(L.M_max * 4 + 16);
     L.off_entries2 = take(L.M_max * 4 + 16);
     L.off_bucket_start = take((size_t)(L.Btot + 1) * 4);
-    L.off_starts = take((size_t)(L.levels + 2) * (L.Btot + 1) * 4);
+    L.off_s1 = take((size_t)(L.Btot + 1) * 4);
     L.off_blockcnt = take(16 * HI_BLOCKS * 4);
     L.off_binbase = take(16 * HI_BLOCKS * 4);
     L.off_segsums = take(256 * 4);
     L.off_segmaxs = take(256 * 4);
     L.off_segtotal = take(256);
     L.off_bufA = take(L.T1_max * sizeof(MsmPoint));
-    L.off_bufB = take((L.T1_max / LK + L.Btot + 1) * sizeof(MsmPoint));
-    L.off_rows = take((size_t)(L.Btot / 8) * sizeof(MsmPoint));
-    L.off_cols = take((size_t)(L.Btot / 8) * sizeof(MsmPoint));
-    L.off_red = take((size_t)(L.Btot / 64 + 64) * 2 * sizeof(MsmPoint));
-    size_t nch = (size_t)(L.R + L.C) / REDUCE_CH + 8;
-    L.off_chunks = take(nch * sizeof(MsmPoint));
-    L.off_sum = take(sum_points_scratch_count(nch) * 2 * sizeof(MsmPoint));
-    L.off_result = take(4 * sizeof(MsmPoint));
+    L.off_bufB = take(L.T1_max * sizeof(MsmPoint));
+    L.tail = tail_layout(L.Btot, L.T1_max);
+    L.off_tail = take(L.tail.bytes);
     L.bytes = o;
     return L;
+}
+
+// round-1 partials the equal split is expected to emit (one per thread that gets work + one per bucket boundary inside a chunk)
+static size_t expected_partials(size_t M_max, uint32_t slots, int B) {
+    size_t thr = M_max / 8 + 1 < (size_t)slots ? M_max / 8 + 1 : (size_t)slots;
+    return thr + (size_t)B;
 }
 
 static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
                         MsmPoint **d_result) {
     if ((uint64_t)srs->W * srs->npad >= (1ull << WIDE_HI_SHIFT))
-        return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the wide-window entry encoding");
+        return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the wide-window entry encoding (window_bits 18..20: W * n < 2^27)");
     hipStream_t st = ctx->lanes[lane].stream;
     WideLayout L = wide_layout(srs, n ? n : 1);
     char *base = (char *)lane_alloc(ctx, lane, L.bytes);
     if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
-    MsmPoint *result = (MsmPoint *)(base + L.off_result);
-    *d_result = result;
-    if (n == 0) return point_set_infinity(ctx, st, result);
+    if (n == 0) {
+        *d_result = (MsmPoint *)(base + L.off_tail + L.tail.off_result);
+        return point_set_infinity(ctx, st, *d_result);
+    }
     if (!ctx->attr_msm_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
@@ -669,51 +641,32 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     uint32_t *lo_start = (uint32_t *)(base + L.off_lo_start), *s1_lo = (uint32_t *)(base + L.off_s1_lo);
     MsmState *state = (MsmState *)(base + L.off_state);
     uint32_t *entries1 = (uint32_t *)(base + L.off_entries1), *entries2 = (uint32_t *)(base + L.off_entries2);
-    uint32_t *bucket_start = (uint32_t *)(base + L.off_bucket_start), *starts = (uint32_t *)(base + L.off_starts);
+    uint32_t *bucket_start = (uint32_t *)(base + L.off_bucket_start), *s1 = (uint32_t *)(base + L.off_s1);
     uint32_t *blockcnt = (uint32_t *)(base + L.off_blockcnt), *binbase = (uint32_t *)(base + L.off_binbase);
     uint32_t *segsums = (uint32_t *)(base + L.off_segsums), *segmaxs = (uint32_t *)(base + L.off_segmaxs);
     uint32_t *segtotal = (uint32_t *)(base + L.off_segtotal);
-    MsmPoint *bufs[2] = {(MsmPoint *)(base + L.off_bufA), (MsmPoint *)(base + L.off_bufB)};
-    MsmPoint *rows = (MsmPoint *)(base + L.off_rows), *cols = (MsmPoint *)(base + L.off_cols);
-    MsmPoint *red[2] = {(MsmPoint *)(base + L.off_red), (MsmPoint *)(base + L.off_red) + (Btot / 64 + 64)};
-    MsmPoint *chunks = (MsmPoint *)(base + L.off_chunks), *sum_scratch = (MsmPoint *)(base + L.off_sum);
+    MsmPoint *bufA = (MsmPoint *)(base + L.off_bufA), *bufB = (MsmPoint *)(base + L.off_bufB);
     const Fr *sc = (const Fr *)d_scalars;
     size_t per_block = (n + G - 1) / G;
     size_t lds_bytes = (size_t)B_lo * 4;
-    auto start_arr = [&](int level) { return starts + (size_t)level * (Btot + 1); };
 
     // pass 1: LDS counting sort by the low 15 bucket bits (hi rides in the entry word)
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, 0);
-    KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B_lo + 255) / 256, 256, 0, blk_hist, G, B_lo, total);
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;
-    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, ctx->cur_scan_threads, 0, total, B_lo, lo_start, s1_lo, state, slots);  // M, E, ntasks
+    KZG_TRY(scan_run(ctx, st, blk_hist, G, B_lo, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), lo_start, s1_lo,
+                     state, slots));  // M, E, ntasks
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
                (uint32_t)srs->npad, (uint32_t)offset, entries1, 1);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
     KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
     // equal-split layout of round 1 over the full bucket set
-    KZG_TRY(wide_s1_layout(ctx, st, bucket_start, Btot, state, segsums, segmaxs, segtotal, start_arr(0)));
+    KZG_TRY(wide_s1_layout(ctx, st, bucket_start, Btot, state, segsums, segmaxs, segtotal, s1));
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, start_arr(0), Btot,
-               (const uint4 *)srs->table30, bufs[0], state);
-    size_t tmax = L.T1_max;
-    for (int lv = 1; lv <= L.levels + 1; lv++) {
-        int in_buf = (lv - 1) & 1;
-        const bool last = lv == L.levels + 1;  // the last scan only certifies done
-        KZG_TRY(wide_level_scan(ctx, st, start_arr(lv - 1), last ? nullptr : start_arr(lv), Btot, LK, state, (uint32_t)(lv - 1),
-                                (uint32_t)in_buf, segsums, segmaxs, segtotal, !last));
-        if (last) break;
-        tmax = tmax / LK + Btot + 1;
-        unsigned grid = (unsigned)((tmax + 255) / 256);
-        if (grid > 8192) grid = 8192;  // grid-stride loop inside
-        KZG_LAUNCH(ctx, st, "k_accum_xyzz", k_accum_xyzz, grid, 256, 0, bufs[in_buf], start_arr(lv - 1), start_arr(lv), Btot, LK,
-                   bufs[in_buf ^ 1], state);
-    }
-    // sum (b+1) X_b over Btot = R x C buckets
-    KZG_TRY(wide_bucket_reduce(ctx, lane, bufs[0], bufs[1], starts, Btot, L.C, state, rows, cols, red[0], red[1], chunks, sum_scratch,
-                               result + 1, result));
-    return KZG_OK;
+    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, s1, Btot,
+               (const uint4 *)srs->table30, bufA, state);
+    return msm_tail_run(ctx, st, bufA, bufB, s1, Btot, expected_partials(L.M_max, slots, Btot), state, base + L.off_tail, L.tail,
+                        d_result);
 }
 
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) {
@@ -743,17 +696,18 @@ int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, Msm
     return KZG_OK;
 }
 
-// Stage 1 of an MSM: counting sort (on the lane's stream) + bucket accumulation (on `accum_stream`, which is the lane's stream
-// unless the batched pipeline runs every accumulation kernel on dedicated streams: then `sorted_ev` / `accum_ev` order the two).
-// Leaves the round-1 partial list (bufA), its per-bucket starts (start_arr(0)) and the state block in the lane arena at the
-// offsets of msm_layout(srs, n); *base_out = arena base.
-static int msm_stage1(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-                      const MsmLayout &L, char **base_out, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr,
-                      hipEvent_t accum_ev = nullptr) {
+// One MSM on the lane's stream: counting sort, bucket accumulation (on `accum_stream` when the batched pipeline runs every
+// accumulation kernel on dedicated streams: then `sorted_ev` / `accum_ev` order the two), tail (msm_tail.hip).
+static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
+                          MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
     hipStream_t st = ctx->lanes[lane].stream;
+    MsmLayout L = msm_layout(srs, n ? n : 1);
     char *base = (char *)lane_alloc(ctx, lane, L.bytes);
     if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
-    *base_out = base;
+    if (n == 0) {
+        *d_result = (MsmPoint *)(base + L.off_tail + L.tail.off_result);
+        return point_set_infinity(ctx, st, *d_result);
+    }
     if (!ctx->attr_msm_set) {  // per context (= per device): the LDS opt-in is a per-device function attribute
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
@@ -763,20 +717,20 @@ static int msm_stage1(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset,
     uint32_t *blk_hist = (uint32_t *)(base + L.off_blk_hist);
     uint32_t *total = (uint32_t *)(base + L.off_total);
     uint32_t *bucket_start = (uint32_t *)(base + L.off_bucket_start);
-    uint32_t *starts = (uint32_t *)(base + L.off_starts);
+    uint32_t *s1 = (uint32_t *)(base + L.off_s1);
     MsmState *state = (MsmState *)(base + L.off_state);
     uint32_t *entries = (uint32_t *)(base + L.off_entries);
-    MsmPoint *bufA = (MsmPoint *)(base + L.off_bufA);
+    MsmPoint *bufA = (MsmPoint *)(base + L.off_bufA), *bufB = (MsmPoint *)(base + L.off_bufB);
     const Fr *sc = (const Fr *)d_scalars;
     size_t per_block = (n + G - 1) / G;
     const int mode = srs->narrow17 ? 2 : 0;
     size_t lds_bytes = srs->narrow17 ? (size_t)B * 2 : (size_t)B * 4;  // c = 17: the counters / cursors of half the buckets per walk
 
     KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode);
-    KZG_LAUNCH(ctx, st, "k_scan_blocks", k_scan_blocks, (B + 255) / 256, 256, 0, blk_hist, G, B, total);
-    // starts[0 .. B] (level 0) = task layout of round 1 = per-bucket start offsets of the round-1 output list
+    // s1[0 .. B] = per-bucket start offsets of the round-1 output list
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
-    KZG_LAUNCH(ctx, st, "k_scan_buckets", k_scan_buckets, 1, ctx->cur_scan_threads, 0, total, B, bucket_start, starts, state, slots);
+    KZG_TRY(scan_run(ctx, st, blk_hist, G, B, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), bucket_start, s1,
+                     state, slots));
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode);
     hipStream_t as = st;
@@ -788,66 +742,22 @@ static int msm_stage1(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset,
     // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
     size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    KZG_LAUNCH(ctx, as, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, starts, B,
+    KZG_LAUNCH(ctx, as, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
                (const uint4 *)srs->table30, bufA, state);
     if (as != st) {
         KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, as));
         KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
     }
-    return KZG_OK;
-}
-
-// The rest of one MSM on its own stream: fold the partial sums by bucket, sum_b (b+1) B_b, tree sum -> *d_result.
-static int msm_tail(kzg_ctx *ctx, int lane, const MsmLayout &L, char *base, MsmPoint **d_result) {
-    hipStream_t st = ctx->lanes[lane].stream;
-    const int B = L.B;
-    uint32_t *starts = (uint32_t *)(base + L.off_starts);
-    MsmState *state = (MsmState *)(base + L.off_state);
-    MsmPoint *bufs[2] = {(MsmPoint *)(base + L.off_bufA), (MsmPoint *)(base + L.off_bufB)};
-    MsmPoint *chunks = (MsmPoint *)(base + L.off_chunks);
-    MsmPoint *sum_scratch = (MsmPoint *)(base + L.off_sum);
-    MsmPoint *result = (MsmPoint *)(base + L.off_result);
-    auto start_arr = [&](int level) { return starts + (size_t)level * (B + 1); };
-    // fold rounds: the list of level k lives in bufs[k & 1] with per-bucket starts start_arr(k).  FAST_LEVELS grid-wide
-    // round(s) of fan-in LK settle every input whose buckets were split over <= LK threads; k_fold_rest finishes the others.
-    size_t tmax = L.T1_max;
-    const int fast = L.levels < FAST_LEVELS ? L.levels : FAST_LEVELS;
-    for (int lv = 1; lv <= fast; lv++) {
-        int in_buf = (lv - 1) & 1;
-        KZG_LAUNCH(ctx, st, "k_level_scan", k_level_scan, 1, ctx->cur_scan_threads, 0, start_arr(lv - 1), start_arr(lv), B, LK, state,
-                   (uint32_t)(lv - 1), (uint32_t)in_buf);
-        tmax = tmax / LK + B + 1;
-        unsigned grid = (unsigned)((tmax + 255) / 256);
-        KZG_LAUNCH(ctx, st, "k_accum_xyzz", k_accum_xyzz, grid, 256, 0, bufs[in_buf], start_arr(lv - 1), start_arr(lv),
-                   B, LK, bufs[in_buf ^ 1], state);
-    }
-    KZG_TRY(fold_rest_run(ctx, st, bufs[0], bufs[1], starts, B, LK, fast, L.levels, state));
-    int CH = B < REDUCE_CH ? B : REDUCE_CH;
-    int nchunks = B / CH;
-    KZG_LAUNCH(ctx, st, "k_bucket_reduce", k_bucket_reduce, (nchunks + TAIL_THREADS - 1) / TAIL_THREADS, TAIL_THREADS, 0, bufs[0], bufs[1], starts, B,
-               CH, chunks, state);
-    MsmPoint *sum = nullptr;
-    KZG_TRY(sum_points_run(ctx, lane, chunks, nchunks, sum_scratch, &sum));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(result, sum, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
-    *d_result = result;
-    return KZG_OK;
+    return msm_tail_run(ctx, st, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, d_result);
 }
 
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if (srs->c > 16 && !srs->narrow17) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
-    if ((uint64_t)srs->W * srs->npad >= (1ull << 31)) return fail(ctx, KZG_ERR_SHAPE, "SRS too large for 31-bit entry index");
-    MsmLayout L = msm_layout(srs, n ? n : 1);
-    if (n == 0) {
-        char *base = (char *)lane_alloc(ctx, lane, L.bytes);
-        if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
-        *d_result = (MsmPoint *)(base + L.off_result);
-        return point_set_infinity(ctx, ctx->lanes[lane].stream, *d_result);
-    }
-    char *base = nullptr;
-    KZG_TRY(msm_stage1(ctx, lane, srs, offset, d_scalars, n, sfmt, L, &base, accum_stream, sorted_ev, accum_ev));
-    return msm_tail(ctx, lane, L, base, d_result);
+    if ((uint64_t)srs->W * srs->npad >= (1ull << 31))
+        return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (windows * points < 2^31)");
+    return msm_run_narrow(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result, accum_stream, sorted_ev, accum_ev);
 }
 
 }  // namespace kzg

@@ -12,23 +12,7 @@ constexpr uint32_t ACC_SLOTS = 256 * 4 * KZG_ACCUM_WAVES * 64;  // resident thre
 // waves, one per SIMD of a CU, so a lone 64-thread tail block on one SIMD strands the other three SIMDs of that
 // half-CU for as long as it lives; 256-thread tail blocks take exactly one accumulation-block slot instead.
 constexpr int TAIL_THREADS = 256;
-#ifndef KZG_FOLD_FANIN
-#define KZG_FOLD_FANIN 8
-#endif
-#ifndef KZG_FAST_LEVELS
-#define KZG_FAST_LEVELS 2
-#endif
-// Two grid-wide fold rounds of fan-in 8 settle every bucket that was split over <= 64 threads: one round for uniform scalars at
-// 2^20 (4-6 partials per bucket; the second launch pair then returns at once), two at the small sizes where a bucket is many
-// equal-split chunks long (2^16: c = 12, ~64 partials per bucket).  The single-block k_fold_rest finishes the others.
-// Same-box A/B against two rounds of fan-in 4: 2^20 equal, u64-valued +4 %, 2^16 +19 % (single commit 2.1 -> 1.4 ms).
-constexpr int LK = KZG_FOLD_FANIN;   // fan-in of the fold rounds
 constexpr int SUM_L = 4;  // fan-in of the plain tree sum
-#ifndef KZG_REDUCE_CH
-#define KZG_REDUCE_CH 8
-#endif
-constexpr int REDUCE_CH = KZG_REDUCE_CH;  // buckets per k_bucket_reduce thread
-constexpr int MAX_LEVELS = 24;
 // wide windows (16 < c <= 20): bucket id = hi (c - 16 bits) : lo (15 bits).  Pass 1 sorts by lo with the LDS counting sort,
 // pass 2 is a stable partition by hi; between the passes hi travels in bits 27..30 of the entry word, which limits the
 // wide mode to W * npad < 2^27 table rows (n <= 2^22 at W = 13).
@@ -38,13 +22,10 @@ constexpr uint32_t WIDE_HI_MASK = 0xfu << WIDE_HI_SHIFT;
 
 struct MsmState {
     uint32_t M;            // sorted entries
-    uint32_t ntasks;       // tasks of the level being run
-    uint32_t done;         // every bucket holds <= 1 partial
-    uint32_t final_level;  // index of the start[] array describing the final partial list
-    uint32_t final_buf;    // which ping-pong buffer holds it
-    uint32_t max_cnt;
+    uint32_t ntasks;       // threads of round 1 that get work: ceil(M / E)
+    uint32_t reserved[4];
     uint32_t E;            // sorted entries per round-1 thread (equal split)
-    uint32_t pad[1];
+    uint32_t ovf_tasks;    // slices of buckets with too many partials for k_fold_dense (msm_tail.hip); zeroed by k_scan_buckets
 };
 
 
@@ -184,18 +165,12 @@ int wide_sort_pass2(kzg_ctx *ctx, hipStream_t st, const uint32_t *entries1, cons
                     uint32_t *binbase, const uint32_t *lo_start, int B_lo, uint32_t *entries2, uint32_t *bucket_start);
 int wide_s1_layout(kzg_ctx *ctx, hipStream_t st, const uint32_t *bucket_start, int Btot, MsmState *state, uint32_t *segsums,
                    uint32_t *segmaxs, uint32_t *segtotal, uint32_t *s1_out);
-// one fold level: task counts ceil(partials / L) per bucket, `done` detection; apply = also write out_start
-int wide_level_scan(kzg_ctx *ctx, hipStream_t st, const uint32_t *in_start, uint32_t *out_start, int Btot, int L, MsmState *state,
-                    uint32_t level, uint32_t in_buf, uint32_t *segsums, uint32_t *segmaxs, uint32_t *segtotal, bool apply);
-// sum (b+1) X_b over Btot = R x C buckets -> *result
-// the fold levels beyond the first FAST_LEVELS, in ONE single-block kernel that returns at once when every bucket already
-// holds one partial (the normal case): replaces ~14 no-op launches per MSM, whose queueing delays under a full GPU cost
-// 3-4 % of the batched throughput (measured).  Only adversarial inputs (few distinct digits) ever do work here.
-constexpr int FAST_LEVELS = KZG_FAST_LEVELS;
-int fold_rest_run(kzg_ctx *ctx, hipStream_t st, MsmPoint *buf0, MsmPoint *buf1, uint32_t *starts, int B, int L, int level0,
-                  int max_level, MsmState *state);
-int wide_bucket_reduce(kzg_ctx *ctx, int lane, const MsmPoint *buf0, const MsmPoint *buf1, const uint32_t *starts, int Btot, int C,
-                       const MsmState *state, MsmPoint *rows, MsmPoint *cols, MsmPoint *red0, MsmPoint *red1, MsmPoint *chunks,
-                       MsmPoint *sum_scratch, MsmPoint *scratch3, MsmPoint *result);
+// msm_tail.hip: everything after the bucket accumulation (fold to one point per bucket, sum (b+1) B_b)
+struct TailLayout {
+    size_t off_dense, off_rows, off_cols, off_Q, off_tasks, off_arrive, off_result, bytes;
+};
+TailLayout tail_layout(int B, size_t T1_max);
+int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
+                 size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result);
 
 }  // namespace kzg

@@ -1,0 +1,227 @@
+// msm_tail.hip -- everything of an MSM after the bucket accumulation kernel: fold the per-thread partial sums into ONE point
+// per bucket (a dense array), then sum_b (b + 1) B_b and the final point.  Shared by the narrow (c <= 17) and the wide
+// (18 <= c <= 20) pipelines of msm.hip.  Own translation unit: these kernels are latency-bound (a few waves, every
+// instruction executed once), and what suits them is not what suits k_accum_affine.
+//
+// Latency, not work, is what this stage costs (one XYZZ addition is ~6300 instructions = ~10 us for a lone wave), so every
+// kernel here is organised for DEPTH: lanes of a wave cooperate through shuffles, partial results are combined by butterfly
+// reductions, and the weighted sum is decomposed so that no thread ever runs a long chain:
+//
+//   k_fold_dense     bucket b's partials (a contiguous run of the round-1 list) are summed by a group of G lanes -- strided
+//                    sequential sums of <= 8, then log2 G butterfly steps -- into dense[b].  G is chosen on the host from the
+//                    expected partials per bucket; a bucket with more than 8 G partials is handed to
+//   k_fold_overflow  as slices of 512 partials, one wave per slice; the wave that completes a bucket's last slice (atomic
+//                    arrival counter, no spinning) adds the slice sums.  Returns at once when there is no such bucket, which is
+//                    the normal case; skewed inputs (the carry bucket of u64-valued scalars, all-equal scalars) stay bounded:
+//                    depth <= 8 + 6 + ceil(slices / 64) + 6 additions.
+//   k_rc_sums        with b = r C + c:  sum_b (b+1) B_b = C sum_r r Row_r + sum_c (c+1) Col_c.  One wave per row sum and one
+//                    per column sum: C/64 (R/64) sequential additions per lane + 6 butterfly steps.
+//   k_weighted_bits  sum_i i X_i = sum_j 2^j (sum_{i : bit j of i} X_i): one wave per bit of the row index, per bit of the
+//                    column index, and one for the plain total of the columns (the "+1").
+//   k_reduce_final   <= 21 lanes: lane i doubles its masked sum shift_i times, a 32-lane butterfly adds them up.
+//
+// For c = 17 (256 x 256 buckets): 3 + 9 + 8 + 15 ~ 35 additions deep, against 43 (8-bucket running sums + a 31-step
+// scalar multiplication per chunk) + 21 (seven tree-sum launches) + two fold rounds before.
+#include "msm_internal.h"
+
+namespace kzg {
+
+constexpr int FOLD_SEQ = 8;     // sequential additions per lane in k_fold_dense before a bucket counts as overflowing
+constexpr int OVF_SLICE = 512;  // partials per overflow task (one wave: 8 per lane + butterfly)
+
+__device__ __forceinline__ MsmPoint shfl_xor_point(const MsmPoint &p, int mask) {
+    MsmPoint r;
+#pragma unroll
+    for (int i = 0; i < F30_N; i++) {
+        r.x.v[i] = __shfl_xor(p.x.v[i], mask, 64);
+        r.y.v[i] = __shfl_xor(p.y.v[i], mask, 64);
+        r.zz.v[i] = __shfl_xor(p.zz.v[i], mask, 64);
+        r.zzz.v[i] = __shfl_xor(p.zzz.v[i], mask, 64);
+    }
+    r.inf = (uint32_t)__shfl_xor((int)p.inf, mask, 64);
+    r.pad[0] = r.pad[1] = r.pad[2] = 0;
+    return r;
+}
+
+// sum over `width` consecutive lanes (a power of two); every lane of the group ends with the total
+template <int WIDTH>
+__device__ __forceinline__ MsmPoint butterfly_sum(MsmPoint acc) {
+#pragma nounroll
+    for (int off = WIDTH / 2; off >= 1; off >>= 1) acc = g1_add30(acc, shfl_xor_point(acc, off));
+    return acc;
+}
+
+// sum of p[lo .. hi) by one wave; every lane returns the total
+__device__ __forceinline__ MsmPoint wave_sum(const MsmPoint *p, uint32_t lo, uint32_t hi, int lane) {
+    MsmPoint acc = MsmPoint::infinity();
+    for (uint32_t k = lo + (uint32_t)lane; k < hi; k += 64) acc = g1_add30(acc, p[k]);
+    return butterfly_sum<64>(acc);
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void k_fold_dense(const MsmPoint *part, const uint32_t *s1, int B, MsmPoint *dense, MsmState *st,
+                                                    uint32_t *tasks, uint32_t *arrive) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = gid / G, g = gid % G;
+    if (b >= (uint32_t)B) return;
+    const uint32_t s = s1[b], cnt = s1[b + 1] - s;
+    if (cnt > (uint32_t)(FOLD_SEQ * G)) {  // uniform over the group
+        if (g == 0) {
+            const uint32_t nsl = (cnt + OVF_SLICE - 1) / OVF_SLICE;
+            const uint32_t base = atomicAdd(&st->ovf_tasks, nsl);
+            for (uint32_t k = 0; k < nsl; k++) tasks[base + k] = (b << 12) | k;
+            arrive[b] = 0;
+        }
+        return;
+    }
+    MsmPoint acc = MsmPoint::infinity();
+    for (uint32_t k = g; k < cnt; k += G) acc = g1_add30(acc, part[s + k]);
+    acc = butterfly_sum<G>(acc);
+    if (g == 0) dense[b] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_fold_overflow(const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, MsmPoint *dense,
+                                                       const MsmState *st, const uint32_t *tasks, uint32_t *arrive) {
+    const uint32_t T = st->ovf_tasks;
+    if (T == 0) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t t = wave; t < T; t += nwaves) {
+        const uint32_t e = tasks[t], b = e >> 12, sl = e & 0xfffu;
+        const uint32_t s0 = s1[b], cnt = s1[b + 1] - s0, nsl = (cnt + OVF_SLICE - 1) / OVF_SLICE;
+        const uint32_t lo = s0 + sl * OVF_SLICE, end = s0 + cnt, hi = lo + OVF_SLICE < end ? lo + OVF_SLICE : end;
+        MsmPoint acc = wave_sum(part, lo, hi, lane);
+        if (nsl == 1) {
+            if (lane == 0) dense[b] = acc;
+            continue;
+        }
+        // slice sums go to the bucket's own offsets in the scratch list (nsl <= cnt); the last wave to arrive adds them
+        if (lane == 0) scratch[s0 + sl] = acc;
+        __threadfence();
+        uint32_t old = 0;
+        if (lane == 0) old = atomicAdd(&arrive[b], 1u);
+        old = (uint32_t)__shfl((int)old, 0, 64);
+        if (old == nsl - 1) {
+            __threadfence();
+            acc = wave_sum(scratch, s0, s0 + nsl, lane);
+            if (lane == 0) dense[b] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
+    const int lane = threadIdx.x & 63;
+    const int wv = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wv >= Rn + Cn) return;
+    MsmPoint acc = MsmPoint::infinity();
+    if (wv < Rn) {
+        const MsmPoint *row = dense + (size_t)wv * Cn;
+        for (int c = lane; c < Cn; c += 64) acc = g1_add30(acc, row[c]);
+    } else {
+        const MsmPoint *col = dense + (wv - Rn);
+        for (int r = lane; r < Rn; r += 64) acc = g1_add30(acc, col[(size_t)r * Cn]);
+    }
+    acc = butterfly_sum<64>(acc);
+    if (lane == 0) (wv < Rn ? rows[wv] : cols[wv - Rn]) = acc;
+}
+
+// Q[j] (j < lr): sum of rows whose index has bit j set; Q[lr + j] (j < lc): the same for the columns; Q[lr + lc]: all columns
+__global__ __launch_bounds__(256) void k_weighted_bits(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
+    const int lane = threadIdx.x & 63;
+    const int wv = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    if (wv > lr + lc) return;
+    const MsmPoint *X = wv < lr ? rows : cols;
+    const int size = wv < lr ? (1 << lr) : (1 << lc);
+    const int j = wv < lr ? wv : (wv < lr + lc ? wv - lr : -1);
+    MsmPoint acc = MsmPoint::infinity();
+    if (j >= 0) {
+        for (int t = lane; t < size / 2; t += 64) {
+            const int i = ((t >> j) << (j + 1)) | (1 << j) | (t & ((1 << j) - 1));
+            acc = g1_add30(acc, X[i]);
+        }
+    } else {
+        for (int i = lane; i < size; i += 64) acc = g1_add30(acc, X[i]);
+    }
+    acc = butterfly_sum<64>(acc);
+    if (lane == 0) Q[wv] = acc;
+}
+
+// result = sum_{j < lr} 2^(j + lc) Q[j] + sum_{j < lc} 2^j Q[lr + j] + Q[lr + lc]        (lr + lc + 1 <= 32 lanes)
+__global__ __launch_bounds__(64) void k_reduce_final(const MsmPoint *Q, int lr, int lc, MsmPoint *result) {
+    const int lane = threadIdx.x;
+    const int cnt = lr + lc + 1;
+    MsmPoint p = lane < cnt ? Q[lane] : MsmPoint::infinity();
+    const int shift = lane < lr ? lane + lc : (lane < lr + lc ? lane - lr : 0);
+    const int maxshift = lr > 0 ? lr + lc - 1 : (lc > 0 ? lc - 1 : 0);
+    for (int k = 0; k < maxshift; k++)
+        if (k < shift && lane < cnt) p = g1_dbl30(p);
+    p = butterfly_sum<32>(p);
+    if (lane == 0) *result = p;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+void tail_shape(int B, int *Rn, int *Cn, int *lr, int *lc) {
+    int lb = 0;
+    while ((1 << lb) < B) lb++;
+    *lc = (lb + 1) / 2;
+    *lr = lb - *lc;
+    *Cn = 1 << *lc;
+    *Rn = 1 << *lr;
+}
+
+TailLayout tail_layout(int B, size_t T1_max) {
+    TailLayout L;
+    size_t o = 0;
+    auto take = [&](size_t bytes) {
+        size_t r = o;
+        o = align_up(o + bytes, 256);
+        return r;
+    };
+    int Rn, Cn, lr, lc;
+    tail_shape(B, &Rn, &Cn, &lr, &lc);
+    L.off_dense = take((size_t)B * sizeof(MsmPoint));
+    L.off_rows = take((size_t)Rn * sizeof(MsmPoint));
+    L.off_cols = take((size_t)Cn * sizeof(MsmPoint));
+    L.off_Q = take(32 * sizeof(MsmPoint));
+    L.off_tasks = take((T1_max / OVF_SLICE + (size_t)B + 64) * 4);
+    L.off_arrive = take((size_t)B * 4);
+    L.off_result = take(sizeof(MsmPoint));
+    L.bytes = o;
+    return L;
+}
+
+// part: the round-1 partial list (ordered by bucket, bucket b = [s1[b], s1[b+1])); scratch: a list of the same capacity;
+// expected_partials: how many partials round 1 is expected to emit (chooses the lane-group width of the fold)
+int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
+                 size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result) {
+    MsmPoint *dense = (MsmPoint *)(tail_base + L.off_dense), *rows = (MsmPoint *)(tail_base + L.off_rows);
+    MsmPoint *cols = (MsmPoint *)(tail_base + L.off_cols), *Q = (MsmPoint *)(tail_base + L.off_Q);
+    uint32_t *tasks = (uint32_t *)(tail_base + L.off_tasks), *arrive = (uint32_t *)(tail_base + L.off_arrive);
+    MsmPoint *result = (MsmPoint *)(tail_base + L.off_result);
+    int Rn, Cn, lr, lc;
+    tail_shape(B, &Rn, &Cn, &lr, &lc);
+    // lane-group width: twice the expected partials per bucket still fit FOLD_SEQ sequential additions per lane 4 times over
+    size_t avg = expected_partials / (size_t)B + 1;
+    int G = 1;
+    while (G < 64 && (size_t)G * 2 < avg) G *= 2;
+    const unsigned grid = (unsigned)(((size_t)B * G + TAIL_THREADS - 1) / TAIL_THREADS);
+#define KZG_FOLD(GG)                                                                                                      \
+    case GG:                                                                                                              \
+        KZG_LAUNCH(ctx, st, "k_fold_dense", k_fold_dense<GG>, grid, TAIL_THREADS, 0, part, s1, B, dense, state, tasks, arrive); \
+        break;
+    switch (G) {
+        KZG_FOLD(1) KZG_FOLD(2) KZG_FOLD(4) KZG_FOLD(8) KZG_FOLD(16) KZG_FOLD(32) KZG_FOLD(64)
+    }
+#undef KZG_FOLD
+    KZG_LAUNCH(ctx, st, "k_fold_overflow", k_fold_overflow, 256, TAIL_THREADS, 0, part, scratch, s1, dense, state, tasks, arrive);
+    const int wpb = TAIL_THREADS / 64;
+    KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums, (Rn + Cn + wpb - 1) / wpb, TAIL_THREADS, 0, dense, Rn, Cn, rows, cols);
+    KZG_LAUNCH(ctx, st, "k_weighted_bits", k_weighted_bits, (lr + lc + 1 + wpb - 1) / wpb, TAIL_THREADS, 0, rows, cols, lr, lc, Q);
+    KZG_LAUNCH(ctx, st, "k_reduce_final", k_reduce_final, 1, 64, 0, Q, lr, lc, result);
+    *d_result = result;
+    return KZG_OK;
+}
+
+}  // namespace kzg

@@ -21,17 +21,44 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """bench.py's cpu_baseline leg only: the same source compiled for the host it runs on (-O3 -march=native, mulx/adx),
+    into a temp directory (the committed recipe builds the portable -O2 library, which must run on any box).  Returns the
+    path, or None when no compiler is available."""
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), "libkzg_oracle_native_%d.so" % os.getuid())
+    src = os.path.join(_HERE, "kzg_oracle.c")
+    try:
+        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-Wno-unused-function", "-o", out + ".tmp", src])
+            os.replace(out + ".tmp", out)
+        return out
+    except Exception:
+        return None
+
+
+def use_library(path):
+    """Load `path` instead of the portable build (bench.py's cpu_baseline workers)."""
+    global _lib
+    _lib = None
+    _lib = _bind(ctypes.CDLL(path))
+
+
+def _bind(l):
+    l.orc_compute_omega.restype = ctypes.c_int
+    l.orc_poly_long_division.restype = ctypes.c_int
+    l.orc_witness_quotient.restype = ctypes.c_int
+    l.orc_g1_on_curve.restype = ctypes.c_int
+    return l
+
+
 _lib = None
 
 
 def lib():
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(build())
-        _lib.orc_compute_omega.restype = ctypes.c_int
-        _lib.orc_poly_long_division.restype = ctypes.c_int
-        _lib.orc_witness_quotient.restype = ctypes.c_int
-        _lib.orc_g1_on_curve.restype = ctypes.c_int
+        _lib = _bind(ctypes.CDLL(build()))
     return _lib
 
 

@@ -202,3 +202,65 @@ def test_wide_windows(engine, wb):
         params.gs.free()
     finally:
         engine.set_option("window_bits", 0)
+
+
+def _view(engine, buf, first, n):
+    """A DeviceBuffer view of buf[first, first + n) (no ownership)."""
+    v = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    v.engine, v.n, v.sfmt, v.ptr = engine, n, buf.sfmt, ctypes.c_void_p(buf.ptr.value + 32 * first)
+    return v
+
+
+def test_config5_2_24_sharded_8_ways_and_whole(engine):
+    """configs[4]: degree-2^24 coeff-form commit with the SRS sharded contiguously over 8 ranks, 2^21 terms each.
+    The test box has one GPU, so the 8 shards (kzg_shard_range + kzg_srs_setup_g1_shard: c = 17, 15 window rows, 3.5 GiB each)
+    are built and reduced one after the other on it, exactly as rank r would; the 8 Jacobian partials are added as the
+    group's combine step does (kzg_g1_sum_batch over the [world][batch] layout) and must equal
+      * [p(tau)]G with p(tau) = sum_r tau^(r 2^21) p_r(tau)  (known-tau identity, per-shard Horner evaluations), and
+      * the commitment of the same 2^24 coefficients against the whole SRS resident on ONE GPU (26 GiB)."""
+    from kzg_amd.distributed import shard_range
+    n, world = 1 << 24, 8
+    buf = engine.alloc_scalars(n).fill_random(2024)
+    parts, ptau = [], 0
+    for r in range(world):
+        lo, hi = shard_range(n, r, world)
+        assert hi - lo == 1 << 21
+        shard = kzg_amd.setup_shard(engine, TAU, lo, hi - lo)
+        assert shard.window_info() == (17, 15)
+        view = _view(engine, buf, lo, hi - lo)
+        out = ctypes.create_string_buffer(144)
+        rc = engine.lib.kzg_msm_g1(engine.ctx, shard.handle, 0, view.ptr, hi - lo, buf.sfmt, L.IN_DEVICE, out, L.G1_JACOBIAN_MONT)
+        assert rc == 0, engine.last_error()
+        parts.append(out.raw)
+        ptau = (ptau + pow(TAU, lo, R) * engine.poly_eval(view, TAU)) % R
+        shard.free()
+    want = C.g1_mul(C.g1_generator(), ptau)
+    out = ctypes.create_string_buffer(96)
+    rc = engine.lib.kzg_g1_sum_batch(engine.ctx, b"".join(parts), world, 1, L.G1_JACOBIAN_MONT, 0, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and out.raw == want
+    # the whole SRS on one GPU
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    assert params.gs.window_info() == (17, 15)
+    assert _msm_dev(engine, params.gs, buf, n) == want
+    params.gs.free()
+    buf.free()
+
+
+def test_config4_secondary_witness_many_2_20_k256(engine, big):
+    """configs[3], secondary reading: 256 independent create_witness calls on one degree-2^20 polynomial sharing one SRS,
+    through the pipelined kzg_witness_coeff_many; every witness against the known-tau identity, one wrong y flagged."""
+    n, params, _ = big
+    k = 256
+    buf = engine.alloc_scalars(n).fill_random(41)
+    ptau = engine.poly_eval(buf, TAU)
+    xs = [kzg_amd.splitmix_scalar(4242, i) for i in range(k)]
+    ys = [engine.poly_eval(buf, x) for x in xs]
+    ys[100] = (ys[100] + 1) % R
+    prover = kzg_amd.KZGProver(params)
+    ws, ok = prover.create_witness_many(None, list(zip(xs, ys)), coeffs_device=buf)
+    assert ok == [j != 100 for j in range(k)]
+    G = C.g1_generator()
+    for j in range(k):
+        yj = ys[j] if j != 100 else (ys[j] - 1) % R
+        assert ws[j] == C.g1_mul(G, (ptau - yj) * pow(TAU - xs[j], -1, R) % R), j
+    buf.free()
