@@ -93,8 +93,10 @@ int kzg_srs_setup_g1_shard(kzg_ctx *ctx, const void *s, int sfmt, size_t first, 
 /* Lagrange-basis SRS for a known secret: L_i(s) G, i < d, d a power of two.  Same group elements
  * as compute_lagrange_basis(&setup(s, d)).0 (src/eval_form.rs:254-280), in O(d) not O(d^3). */
 int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *s, int sfmt, size_t d, kzg_srs **out);
-/* compute_lagrange_basis (src/eval_form.rs:254-280), G1 half, from the monomial SRS alone
- * (no secret): inverse group-NTT of gs.  gs length must be a power of two. */
+/* compute_lagrange_basis (src/eval_form.rs:254-280), G1 half, from the monomial SRS alone (no secret): the inverse
+ * group-NTT of gs, L_i = (1/d) sum_j w^(-ij) gs[j] (radix-2 over G1 points, one 255-bit scalar multiplication per
+ * butterfly: ~0.7 s at d = 2^20).  d = len(gs) must be a power of two (KZG_ERR_SHAPE otherwise, the reference's assert)
+ * and at most 2^24. */
 int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *monomial, kzg_srs **out);
 int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, size_t n, void *out, int pfmt);
 size_t kzg_srs_len(const kzg_srs *srs);

@@ -402,51 +402,3 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     *out_r_len = k;
     return KZG_OK;
 }
-
-// compute_lagrange_basis (src/eval_form.rs:254-280), G1 half.  The reference builds each l_i by d-1
-// polynomial multiplications (O(d^3) field work) and commits to it; l_i has the closed form
-// l_i(X) = (1/d) sum_j w^(-ij) X^j, so row i is one MSM of the monomial SRS with scalars w^(-ij)/d.
-// O(d) MSMs of size d: meant for the sizes the reference can handle; large Lagrange SRSs come from
-// kzg_srs_setup_lagrange_g1 (known secret) or a ceremony file via kzg_srs_upload_g1.
-extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mono, kzg_srs **out) {
-    if (!ctx || !mono || !out) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
-    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    size_t d = mono->n;
-    if (d == 0 || (d & (d - 1))) return fail(ctx, KZG_ERR_SHAPE, "assert!(d & (d - 1) == 0) (src/eval_form.rs:255-256)");
-    uint32_t exp = (uint32_t)ilog2_ceil(d);
-    if (exp >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
-    if (d > ((size_t)1 << 14)) return fail(ctx, KZG_ERR_SHAPE, "compute_lagrange_basis from the monomial SRS is limited to d <= 2^14; use kzg_srs_setup_lagrange_g1 or upload the basis");
-    hipStream_t st = ctx->lanes[0].stream;
-    kzg_srs *s = nullptr;
-    KZG_TRY(srs_alloc(ctx, d, &s));
-    G1Xyzz *rows = nullptr;
-    MsmPoint *rows30 = nullptr;
-    int rc = KZG_OK;
-    if (hipMalloc((void **)&rows, d * sizeof(G1Xyzz)) != hipSuccess || hipMalloc((void **)&rows30, d * sizeof(MsmPoint)) != hipSuccess)
-        rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(lagrange rows)");
-    Fr omega_inv = inv(host_omega(exp));
-    Fr dinv = inv(from_u64<FrParams>((uint64_t)d));
-    for (size_t i = 0; i < d && rc == KZG_OK; i++) {
-        rc = lane_reserve(ctx, 0, msm_workspace_bytes(mono, d) + d * 32 + 65536);
-        Fr *sc = rc == KZG_OK ? (Fr *)lane_alloc(ctx, 0, d * 32) : nullptr;
-        if (rc == KZG_OK && !sc) rc = fail(ctx, KZG_ERR_ALLOC, "workspace");
-        if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(omega_inv, (uint64_t)i), dinv, d, sc);
-        MsmPoint *res = nullptr;
-        if (rc == KZG_OK) rc = msm_run(ctx, 0, mono, 0, sc, d, KZG_FR_MONT_LE_32, &res);
-        if (rc == KZG_OK && hipMemcpyAsync(rows30 + i, res, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            rc = fail(ctx, KZG_ERR_HIP, "copy");
-    }
-    if (rc == KZG_OK) rc = points_from30(ctx, st, rows30, rows, d);
-    if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, rows);
-    hipStreamSynchronize(st);
-    if (rows) hipFree(rows);
-    if (rows30) hipFree(rows30);
-    if (rc != KZG_OK) {
-        hipFree(s->table);
-        delete s;
-        return rc;
-    }
-    *out = s;
-    return KZG_OK;
-}

@@ -246,6 +246,23 @@ def test_config5_2_24_sharded_8_ways_and_whole(engine):
     buf.free()
 
 
+def test_compute_lagrange_basis_2_20_without_tau(engine, big):
+    """f1: compute_lagrange_basis at production size from the monomial SRS alone (what a ceremony SRS allows): the inverse
+    group-NTT of gs equals the known-tau closed form point for point, and commits eval-form data to the coeff-form commitment."""
+    n, params, lag = big
+    got = kzg_amd.compute_lagrange_basis(params)
+    assert len(got) == n
+    step = 1 << 14                                   # 64 windows of 2^14 points: 96 MiB compared piecewise
+    for off in range(0, n, step):
+        assert got.download(off, step) == lag.download(off, step), off
+    buf = engine.alloc_scalars(n).fill_random(77)
+    c1 = _msm_dev(engine, params.gs, buf, n)
+    engine.ntt(buf, 20)
+    assert _msm_dev(engine, got, buf, n) == c1
+    buf.free()
+    got.free()
+
+
 def test_config4_secondary_witness_many_2_20_k256(engine, big):
     """configs[3], secondary reading: 256 independent create_witness calls on one degree-2^20 polynomial sharing one SRS,
     through the pipelined kzg_witness_coeff_many; every witness against the known-tau identity, one wrong y flagged."""
