@@ -13,6 +13,12 @@
  *   - a kzg_ctx is bound to one GPU and is thread-safe (calls on one ctx serialise on an internal
  *     mutex; use one ctx per host thread for concurrency).  There is NO CPU fallback: without a
  *     usable HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
+ *   - points entering through kzg_srs_upload_g1/g2, the verifier entry points and kzg_pairing_check are validated the way
+ *     blstrs' G1Affine / G2Affine deserialisation validates them upstream, in EVERY format: coordinates < q, on the curve,
+ *     in the r-torsion subgroup ([r]P == O); failure -> KZG_ERR_BAD_POINT.  Option "trusted_points" = 1 skips the subgroup
+ *     test (never the on-curve test).  kzg_g1_sum[_batch] checks coordinates and the curve equation only.
+ *   - scalars in KZG_FR_CANONICAL_LE_32 that are >= r are taken mod r (single host scalars such as x, y, tau must be < r:
+ *     KZG_ERR_SHAPE).
  *   - `flags` says where buffers live: scalars/points in host memory (default) or already resident
  *     in this GPU's HBM (KZG_IN_DEVICE), result written to host (default) or device (KZG_OUT_DEVICE).
  *
@@ -39,6 +45,19 @@
 extern "C" {
 #endif
 
+/* Limits (each returns KZG_ERR_SHAPE with a message in kzg_last_error; tests/test_gpu_validation.py):
+ *   NTT / coset NTT / verify_poly_eval      log_n <= 24                      (two LDS passes of <= 2^12 points)
+ *   kzg_witness_coeff_batched,
+ *   kzg_verify_eval_batched                 k <= 4096 opening points          (single-workgroup interpolation kernels)
+ *   kzg_srs_lagrange_from_monomial_g1       d <= 2^24;  _g2: d <= 1024
+ *   MSM                                     table rows x points < 2^31       (the sorted entry is a 31-bit table index + sign);
+ *                                           window_bits 18..20 (option): windows x points < 2^27
+ *   kzg_g1_sum_batch                        count <= 2^20, groups <= 2^24
+ *   kzg_commit_coeff_sharded_batch          batch <= 2^20
+ * SRS footprint in HBM: points x (96 + rows x 112) bytes, rows = windows = ceil(256 / c) with c chosen from the size
+ * (c = 17, 15 windows above 2^19 points: 1.64 GiB at 2^20, 26.4 GiB at 2^24; kzg_srs_footprint computes it).  A host that
+ * keeps many SRSs resident can trade speed for memory with option "window_rows" = r < windows: only r table rows are kept and
+ * every MSM takes ceil(windows / r) passes over its scalars plus a doubling chain of c x r x (passes - 1) doublings. */
 typedef struct kzg_ctx kzg_ctx;
 typedef struct kzg_srs kzg_srs;
 typedef struct kzg_srs_g2 kzg_srs_g2; /* the G2 half of KZGParams (hs) or a G2 Lagrange basis */
@@ -79,7 +98,9 @@ int kzg_ctx_create(int device, kzg_ctx **out);
 void kzg_ctx_destroy(kzg_ctx *ctx);
 const char *kzg_last_error(kzg_ctx *ctx);
 int kzg_sync(kzg_ctx *ctx);
-/* tunables: "window_bits" (0 = auto), "streams" (batch pipelining depth) */
+/* tunables: "window_bits" (0 = auto, 4..20), "window_rows" (0 = one table row per window; applies to SRSs created afterwards),
+ * "trusted_points" (0 / 1), "streams" (1..16: batch pipelining depth), "accum_streams" (0..4), "accum_blocks[_batch]",
+ * "sort_threads[_batch]", "ntt_vec_log"; unknown keys -> KZG_ERR_SHAPE */
 int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value);
 
 /* ---- SRS (KZGParams.gs, src/lib.rs:14-19; lagrange_basis_g, src/eval_form.rs:40-46) --------- */
@@ -100,6 +121,8 @@ int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *s, int sfmt, size_t d, k
 int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *monomial, kzg_srs **out);
 int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, size_t n, void *out, int pfmt);
 size_t kzg_srs_len(const kzg_srs *srs);
+/* HBM bytes an SRS of n points occupies under the given options (0 = engine defaults); host-only helper */
+int kzg_srs_footprint(size_t n, int window_bits, int window_rows, size_t *bytes);
 void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs);
 
 /* ---- MSM: G1Projective::multi_exp(&gs[offset..offset+n], scalars) --------------------------- */
@@ -291,6 +314,7 @@ int kzg_prof_get(kzg_ctx *ctx, const char *kernel, uint64_t *launches, double *t
 int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen);
 /* number of window bits and windows the engine chose for this SRS (for G1-adds accounting) */
 int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows);
+int kzg_srs_table_rows(const kzg_srs *srs);   /* resident table rows (= windows unless option window_rows) */
 
 /* ---- unit-test hooks (device arithmetic exercised directly; used by tests/ only) -------------- */
 int kzg_test_fr_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery */

@@ -60,6 +60,8 @@ def load(path=None):
         "kzg_srs_lagrange_from_monomial_g1": (i32, [vp, vp, c_void_pp]),
         "kzg_srs_download_g1": (i32, [vp, vp, sz, sz, vp, i32]),
         "kzg_srs_len": (sz, [vp]),
+        "kzg_srs_footprint": (i32, [sz, i32, i32, ctypes.POINTER(sz)]),
+        "kzg_srs_table_rows": (i32, [vp]),
         "kzg_srs_free": (None, [vp, vp]),
         "kzg_srs_window_info": (i32, [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]),
         "kzg_msm_g1": (i32, [vp, vp, sz, vp, sz, i32, i32, vp, i32]),

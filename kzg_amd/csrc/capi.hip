@@ -155,6 +155,8 @@ static int check_sfmt(kzg_ctx *ctx, int sfmt) {
 }
 
 static bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+// element counts whose byte sizes cannot overflow the arena arithmetic (2^40 Fr elements = 32 TiB: far beyond any device)
+static bool count_ok(size_t n) { return n <= ((size_t)1 << 40); }
 
 // ---------------------------------------------------------------------------------------------
 // device unit-test kernels
@@ -253,7 +255,17 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
     delete ctx;
 }
 
-extern "C" const char *kzg_last_error(kzg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+extern "C" const char *kzg_last_error(kzg_ctx *ctx) {
+    // copied under the context's lock into a per-thread buffer: another thread failing on the same context cannot
+    // invalidate the returned pointer (it stays valid until this thread's next kzg_last_error call)
+    if (!ctx) return "null context";
+    static thread_local std::string tl_err;
+    {
+        Guard g(ctx);
+        tl_err = ctx->err;
+    }
+    return tl_err.c_str();
+}
 
 extern "C" int kzg_sync(kzg_ctx *ctx) {
     if (!ctx) return KZG_ERR_SHAPE;
@@ -286,6 +298,11 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_streams") {
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
+    } else if (k == "window_rows") {
+        if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "window_rows must be 0 (one table row per window) or 1..64");
+        ctx->opt_window_rows = (int)value;
+    } else if (k == "trusted_points") {
+        ctx->opt_trusted_points = value != 0;
     } else if (k == "ntt_vec_log") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_vec_log must be 0..2");
         ctx->opt_ntt_vec_log = (int)value;
@@ -622,7 +639,7 @@ extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pf
     } else {
         const void *d_raw = nullptr;
         KZG_TRY(stage_in(ctx, 0, points, count * psz, flags, &d_raw));
-        KZG_TRY(decode_points(ctx, st, d_raw, count, pfmt, dec, bad));
+        KZG_TRY(decode_points(ctx, st, d_raw, count, pfmt, dec, bad, POINTS_ON_CURVE));
         KZG_TRY(points_to30(ctx, st, dec, pts, count));
         KZG_TRY(sum_points_run(ctx, 0, pts, count, scratch, &res));
     }
@@ -635,7 +652,7 @@ extern "C" int kzg_g1_sum(kzg_ctx *ctx, const void *points, size_t count, int pf
 
 namespace kzg {
 int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t groups, size_t gstride, size_t istride, int pfmt,
-                         int flags, void *out, int ofmt) {
+                         int flags, void *out, int ofmt, int level) {
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t psz = point_format_bytes(pfmt), osz = point_format_bytes(ofmt);
@@ -653,7 +670,7 @@ int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t 
     KZG_HIP_CHECK(ctx, hipMemsetAsync(bad, 0, sizeof(int), st));
     const void *d_raw = nullptr;
     KZG_TRY(stage_in(ctx, 0, points, total * psz, flags, &d_raw));
-    KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, dec, bad));
+    KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, dec, bad, level));
     KZG_TRY(points_to30(ctx, st, dec, pts, total));
     KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, gstride, istride, tmp, d_out, ofmt));
     int hbad = 0;
@@ -695,6 +712,7 @@ extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse,
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^24 are not supported (two LDS passes of <= 2^12 points each)");
     size_t n = (size_t)1 << log_n;
     KZG_TRY(lane_reserve(ctx, 0, n * 32 + stage_bytes(n * 32, flags) + 8192));
     hipStream_t st = ctx->lanes[0].stream;
@@ -711,7 +729,7 @@ extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse,
 // Fr polynomial helpers
 // ---------------------------------------------------------------------------------------------
 extern "C" int kzg_poly_eval(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, int sfmt, int flags, void *y_out) {
-    if (!ctx || !coeffs || !x || !y_out || n == 0) return KZG_ERR_SHAPE;
+    if (!ctx || !coeffs || !x || !y_out || n == 0 || !count_ok(n)) return KZG_ERR_SHAPE;
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
@@ -732,7 +750,7 @@ extern "C" int kzg_poly_eval(kzg_ctx *ctx, const void *coeffs, size_t n, const v
 
 extern "C" int kzg_quotient_linear(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, const void *y, int sfmt,
                                    int flags, void *q_out) {
-    if (!ctx || !coeffs || !x || !y || n == 0 || (!q_out && n > 1)) return KZG_ERR_SHAPE;
+    if (!ctx || !coeffs || !x || !y || n == 0 || (!q_out && n > 1) || !count_ok(n)) return KZG_ERR_SHAPE;
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));

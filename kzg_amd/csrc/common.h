@@ -55,6 +55,8 @@ struct kzg_ctx {
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 8;
     int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
+    int opt_window_rows = 0;           // 0 = every window has its table row; r > 0: keep r rows (low-memory SRS, multi-pass MSM)
+    int opt_trusted_points = 0;        // 1: caller vouches for its points (skip the subgroup check of uploads / verifier inputs)
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
     int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)
@@ -96,6 +98,7 @@ struct kzg_srs {
     size_t npad = 0;     // row stride (points)
     int c = 0;           // window bits (signed digits, 2^(c-1) buckets)
     int W = 0;           // windows = ceil(256 / c) (15 in the c = 17 single-pass mode); table row w holds 2^(c*w) * P_i
+    int rows = 0;        // table rows resident (= W unless option window_rows asked for fewer: then an MSM takes ceil(W / rows) passes)
     bool narrow17 = false;  // c = 17: single-pass sort walking the scalars twice (half the buckets per walk), balanced scalars
     kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
     void *table30 = nullptr;         // [W][npad] G1Affine30 (2 x 13 x 30-bit limbs + pad, 112 B): what k_accum_affine gathers
@@ -103,6 +106,12 @@ struct kzg_srs {
 };
 
 namespace kzg {
+
+// validation of decoded points (what blstrs' G1Affine / G2Affine deserialisation enforces upstream):
+//   POINTS_TRUSTED   nothing (the engine's own intermediate results)
+//   POINTS_ON_CURVE  limbs canonical (< q) and on the curve
+//   POINTS_SUBGROUP  + in the r-torsion subgroup ([r]P == O)
+enum { POINTS_TRUSTED = 0, POINTS_ON_CURVE = 1, POINTS_SUBGROUP = 2 };
 
 #define KZG_HIP_CHECK(ctx, expr)                                                                   \
     do {                                                                                           \
@@ -146,6 +155,7 @@ void prof_collect(kzg_ctx *ctx);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(block), (shmem), (stream), __VA_ARGS__);         \
     } while (0)
 
+inline int untrusted_level(const kzg_ctx *ctx) { return ctx->opt_trusted_points ? POINTS_ON_CURVE : POINTS_SUBGROUP; }
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 inline int ilog2_ceil(size_t x) {
     int l = 0;
@@ -183,15 +193,18 @@ int msm_batch_strided(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const voi
                       size_t stride_bytes, int sfmt, int flags, void *out, int ofmt);
 // out[g] = sum_i points[g * gstride + i * istride] (strides in points); points in pfmt, host or device per flags
 int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t groups, size_t gstride, size_t istride, int pfmt,
-                         int flags, void *out, int ofmt);
+                         int flags, void *out, int ofmt, int level = POINTS_ON_CURVE);
 
 // srs.hip
-int srs_choose_window(kzg_ctx *ctx, size_t n);
+int srs_choose_window(int opt_window_bits, size_t n);
+void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c, int *W, int *rows, bool *narrow17);
 int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out);
 int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz);  // batch-affine row 0 then precompute rows
 int srs_precompute(kzg_ctx *ctx, kzg_srs *srs);                              // rows 1..W-1 from row 0
 int batch_to_affine(kzg_ctx *ctx, hipStream_t stream, const G1Xyzz *d_in, G1Affine *d_out, size_t n);
-int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad);
+int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad,
+                  int level = POINTS_SUBGROUP);
+
 int fixed_base_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_scalars_mont, size_t n, G1Xyzz *d_out);
 int powers_run(kzg_ctx *ctx, hipStream_t st, const Fr &base_mont, size_t first, size_t n, Fr *d_out);  // base^(first+i)
 int lagrange_scalars_run(kzg_ctx *ctx, hipStream_t st, const Fr &tau_mont, size_t d, Fr *d_out);      // L_i(tau)

@@ -376,7 +376,8 @@ static int mctx_combine(kzg_mctx *m, size_t batch, void *out, int ofmt) {
         src = m->d_gath[0];  // [world][batch] partials; the sum below runs on the same stream, after the collective
         count = (size_t)m->world;
     }
-    int rc = g1_sum_batch_strided(m->ctxs[0], src, count, batch, 1, batch, KZG_G1_JACOBIAN_MONT_144, KZG_IN_DEVICE, out, ofmt);
+    int rc = g1_sum_batch_strided(m->ctxs[0], src, count, batch, 1, batch, KZG_G1_JACOBIAN_MONT_144, KZG_IN_DEVICE, out, ofmt,
+                                  POINTS_TRUSTED);  // the group's own partial sums
     if (rc != KZG_OK) return mfail_ctx(m, 0, rc);
     return KZG_OK;
 }

@@ -40,9 +40,30 @@ __device__ __forceinline__ uint32_t sel8(const uint32_t s[8], int idx) {
     return r;
 }
 
+// The digit extraction needs the canonical value.  Montgomery input: from_mont() returns it.  Canonical input is taken mod r
+// (a 256-bit value is < 2.3 r: at most two subtractions), so that a caller's non-canonical scalar gives the same group element
+// at every window width -- the balanced c = 17 recoding (r - k) and the 15 x 17-bit window split both assume k < r.
 __device__ __forceinline__ void load_scalar(const Fr *scalars, size_t i, int sfmt, uint32_t s[8]) {
     Fr v = scalars[i];
-    if (sfmt == KZG_FR_MONT_LE_32) v = from_mont(v);
+    if (sfmt == KZG_FR_MONT_LE_32) {
+        v = from_mont(v);
+    } else {
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {
+            uint32_t d[8];
+            uint64_t bw = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint64_t t = (uint64_t)v.v[k] - FrParams::mod(k) - bw;
+                d[k] = (uint32_t)t;
+                bw = (t >> 63) & 1u;
+            }
+            if (!bw) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) v.v[k] = d[k];
+            }
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; k++) s[k] = v.v[k];
 }
@@ -134,8 +155,9 @@ extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
 
 // mode 0: B u32 counters (c <= 16, or the low 15 bucket bits of the wide path); mode 2 (c = 17 single pass): B = 2^16 buckets, the
 // u32 counters of half of them fit the LDS, so the block walks its scalars twice (as k_scatter does); balanced scalars
+// [w_lo, w_hi): the windows of this pass (all of them unless the SRS keeps fewer table rows than windows, option window_rows)
 __global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int sfmt, int c, int W, int B,
-                                               size_t per_block, uint32_t *blk_hist, int mode) {
+                                               size_t per_block, uint32_t *blk_hist, int mode, int w_lo, int w_hi) {
     const bool pk = mode == 2;
     const int BH = pk ? B / 2 : B;
     size_t i0 = (size_t)blockIdx.x * per_block;
@@ -149,7 +171,8 @@ __global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int 
         for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
             uint32_t s[8];
             load_scalar(scalars, i, sfmt, s);
-            digits_of(s, c, W, pk, [&](int, uint32_t mag, uint32_t) {
+            digits_of(s, c, W, pk, [&](int w, uint32_t mag, uint32_t) {
+                if (w < w_lo || w >= w_hi) return;
                 const uint32_t idx = (mag - 1) & (uint32_t)(B - 1);
                 if (pk && (idx >> 15) != (uint32_t)half) return;
                 atomicAdd(&lds_u32[idx - base], 1u);
@@ -284,7 +307,7 @@ static int scan_run(kzg_ctx *ctx, hipStream_t st, uint32_t *blk_hist, int G, int
 __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, int sfmt, int c, int W, int B,
                                                   size_t per_block, const uint32_t *blk_off,
                                                   const uint32_t *bucket_start, uint32_t row_stride,
-                                                  uint32_t idx_base, uint32_t *entries, int mode) {
+                                                  uint32_t idx_base, uint32_t *entries, int mode, int w_lo, int w_hi) {
     const uint32_t *off = blk_off + (size_t)blockIdx.x * B;
     const bool pk = mode == 2;
     const int BH = pk ? B / 2 : B;  // buckets whose cursors are resident per walk
@@ -299,11 +322,12 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
             uint32_t s[8];
             load_scalar(scalars, i, sfmt, s);
             digits_of(s, c, W, pk, [&](int w, uint32_t mag, uint32_t neg) {
+                if (w < w_lo || w >= w_hi) return;
                 const uint32_t idx = (mag - 1) & (uint32_t)(B - 1);
                 if (pk && (idx >> 15) != (uint32_t)half) return;
                 const uint32_t pos = atomicAdd(&lds_u32[idx - base], 1u);
                 const uint32_t hi = mode == 1 ? (((mag - 1) >> WIDE_LO_BITS) << WIDE_HI_SHIFT) : 0u;
-                entries[pos] = ((uint32_t)w * row_stride + idx_base + (uint32_t)i) | hi | (neg << 31);
+                entries[pos] = ((uint32_t)(w - w_lo) * row_stride + idx_base + (uint32_t)i) | hi | (neg << 31);
             });
         }
     }
@@ -534,7 +558,7 @@ struct MsmLayout {
     int B, G;
     size_t M_max, T1_max;
     size_t off_blk_hist, off_total, off_local, off_agg, off_bucket_start, off_s1, off_state, off_entries, off_bufA, off_bufB, off_tail,
-        bytes;
+        off_pass, bytes;
     TailLayout tail;
 };
 
@@ -542,7 +566,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     MsmLayout L;
     L.B = 1 << (srs->c - 1);
     L.G = sort_blocks(n);
-    L.M_max = n * (size_t)srs->W;
+    L.M_max = n * (size_t)srs->rows;  // entries of one pass
     L.T1_max = (size_t)ACC_SLOTS + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -562,6 +586,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.off_bufB = take(L.T1_max * sizeof(MsmPoint));  // slice sums of overflowing buckets, at the bucket's own offsets
     L.tail = tail_layout(L.B, L.T1_max);
     L.off_tail = take(L.tail.bytes);
+    L.off_pass = take(((size_t)(srs->W + srs->rows - 1) / srs->rows + 1) * sizeof(MsmPoint));
     L.bytes = o;
     return L;
 }
@@ -651,12 +676,12 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     size_t lds_bytes = (size_t)B_lo * 4;
 
     // pass 1: LDS counting sort by the low 15 bucket bits (hi rides in the entry word)
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, 0);
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, 0, 0, W);
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;
     KZG_TRY(scan_run(ctx, st, blk_hist, G, B_lo, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), lo_start, s1_lo,
                      state, slots));  // M, E, ntasks
     KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
-               (uint32_t)srs->npad, (uint32_t)offset, entries1, 1);
+               (uint32_t)srs->npad, (uint32_t)offset, entries1, 1, 0, W);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
     KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
     // equal-split layout of round 1 over the full bucket set
@@ -696,6 +721,17 @@ int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, Msm
     return KZG_OK;
 }
 
+// result = sum_p 2^(shift p) S_p  (Horner from the top pass down: shift doublings + one addition per pass)
+__global__ __launch_bounds__(64) void k_combine_passes(const MsmPoint *S, int passes, int shift, MsmPoint *result) {
+    if (threadIdx.x != 0) return;
+    MsmPoint acc = S[passes - 1];
+    for (int p = passes - 2; p >= 0; p--) {
+        for (int k = 0; k < shift; k++) acc = g1_dbl30(acc);
+        acc = g1_add30(acc, S[p]);
+    }
+    *result = acc;
+}
+
 // One MSM on the lane's stream: counting sort, bucket accumulation (on `accum_stream` when the batched pipeline runs every
 // accumulation kernel on dedicated streams: then `sorted_ev` / `accum_ev` order the two), tail (msm_tail.hip).
 static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
@@ -726,37 +762,54 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     const int mode = srs->narrow17 ? 2 : 0;
     size_t lds_bytes = srs->narrow17 ? (size_t)B * 2 : (size_t)B * 4;  // c = 17: the counters / cursors of half the buckets per walk
 
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode);
-    // s1[0 .. B] = per-bucket start offsets of the round-1 output list
+    // One pass per `rows` windows: the table holds rows 0 .. rows-1 (2^(c w') P), so pass p reduces the digits of windows
+    // [p rows, (p+1) rows) to S_p = sum_i (sum_{w'} d_{i, p rows + w'} 2^(c w')) P_i and the result is sum_p 2^(c rows p) S_p.
+    // rows == W (the default): one pass, no doubling chain.
+    const int rows = srs->rows, passes = (W + rows - 1) / rows;
+    MsmPoint *pass_res = (MsmPoint *)(base + L.off_pass);
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
-    KZG_TRY(scan_run(ctx, st, blk_hist, G, B, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), bucket_start, s1,
-                     state, slots));
-    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
-               bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode);
-    hipStream_t as = st;
-    if (accum_stream && accum_stream != st) {
-        KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
-        KZG_HIP_CHECK(ctx, hipStreamWaitEvent(accum_stream, sorted_ev, 0));
-        as = accum_stream;
+    for (int p = 0; p < passes; p++) {
+        const int w_lo = p * rows, w_hi = (p + 1) * rows < W ? (p + 1) * rows : W;
+        KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode, w_lo, w_hi);
+        // s1[0 .. B] = per-bucket start offsets of the round-1 output list
+        KZG_TRY(scan_run(ctx, st, blk_hist, G, B, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), bucket_start, s1,
+                         state, slots));
+        KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
+                   bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode, w_lo, w_hi);
+        hipStream_t as = st;
+        if (accum_stream && accum_stream != st) {
+            KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
+            KZG_HIP_CHECK(ctx, hipStreamWaitEvent(accum_stream, sorted_ev, 0));
+            as = accum_stream;
+        }
+        // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
+        size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
+        unsigned grid1 = (unsigned)((thr1 + 255) / 256);
+        KZG_LAUNCH(ctx, as, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
+                   (const uint4 *)srs->table30, bufA, state);
+        if (as != st) {
+            KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, as));
+            KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
+        }
+        MsmPoint *res = nullptr;
+        KZG_TRY(msm_tail_run(ctx, st, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, &res));
+        if (passes == 1) {
+            *d_result = res;
+            return KZG_OK;
+        }
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(pass_res + p, res, sizeof(MsmPoint), hipMemcpyDeviceToDevice, st));
     }
-    // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
-    size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
-    unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    KZG_LAUNCH(ctx, as, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
-               (const uint4 *)srs->table30, bufA, state);
-    if (as != st) {
-        KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, as));
-        KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
-    }
-    return msm_tail_run(ctx, st, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, d_result);
+    KZG_LAUNCH(ctx, st, "k_combine_passes", k_combine_passes, 1, 64, 0, pass_res, passes, c * rows, pass_res + passes);
+    *d_result = pass_res + passes;
+    return KZG_OK;
 }
 
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if (srs->c > 16 && !srs->narrow17) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
-    if ((uint64_t)srs->W * srs->npad >= (1ull << 31))
-        return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (windows * points < 2^31)");
+    if ((uint64_t)srs->rows * srs->npad >= (1ull << 31))
+        return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (table rows * points < 2^31)");
     return msm_run_narrow(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result, accum_stream, sorted_ev, accum_ev);
 }
 

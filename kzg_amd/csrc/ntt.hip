@@ -292,7 +292,7 @@ void ntt_plans_free(kzg_ctx *ctx) {
 
 int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
-    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^24 are not implemented yet");
+    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^24 are not supported (two LDS passes of <= 2^12 points each)");
     hipStream_t st = ctx->lanes[lane].stream;
     NttPlan *p = nullptr;
     KZG_TRY(ntt_plan(ctx, st, log_n, inverse, &p));

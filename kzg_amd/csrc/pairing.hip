@@ -81,16 +81,33 @@ static __device__ __noinline__ bool f2_sqrt(Fq2 &r, const Fq2 &a) {
     return t == a;
 }
 
-__global__ __launch_bounds__(64) void k_g2_decode(const uint8_t *src, size_t n, int fmt, G2Affine *out, int *bad) {
+static __device__ bool f2_canonical(const Fq2 &a) { return is_canonical(a.c0) && is_canonical(a.c1); }
+
+// [r]Q == O: membership in G2 (the twist has a large cofactor; G2Affine deserialisation checks this upstream)
+static __device__ __noinline__ bool g2_in_subgroup(const G2Affine &a) {
+    if (a.is_inf()) return true;
+    uint32_t k[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[i] = FrParams::mod(i);
+    G2Jacobian r;
+    g2_scalar_mul(r, a, k);
+    return r.z.is_zero();
+}
+
+// level: POINTS_TRUSTED / POINTS_ON_CURVE / POINTS_SUBGROUP (common.h)
+__global__ __launch_bounds__(64) void k_g2_decode(const uint8_t *src, size_t n, int fmt, G2Affine *out, int *bad, int level) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     G2Affine a;
     bool ok = true;
     if (fmt == KZG_G2_AFFINE_MONT_192) {
         a = *reinterpret_cast<const G2Affine *>(src + i * 192);
+        if (level >= POINTS_ON_CURVE) ok = f2_canonical(a.x) && f2_canonical(a.y) && g2_on_curve(a);
     } else if (fmt == KZG_G2_JACOBIAN_MONT_288) {
         G2Jacobian j = *reinterpret_cast<const G2Jacobian *>(src + i * 288);
+        if (level >= POINTS_ON_CURVE) ok = f2_canonical(j.x) && f2_canonical(j.y) && f2_canonical(j.z);
         g2_to_affine(a, j);
+        if (level >= POINTS_ON_CURVE) ok = ok && g2_on_curve(a);
     } else if (fmt == KZG_G2_ZCASH_UNCOMPRESSED_192) {
         const uint8_t *p = src + i * 192;
         if (p[0] & 0x80) ok = false;
@@ -124,6 +141,7 @@ __global__ __launch_bounds__(64) void k_g2_decode(const uint8_t *src, size_t n, 
             if (f2_lex_largest(a.y) != ((p[0] & 0x20) != 0)) f2_neg(a.y, a.y);
         }
     }
+    if (ok && level >= POINTS_SUBGROUP) ok = g2_in_subgroup(a);
     if (!ok) {
         atomicOr(bad, 1);
         a.x = Fq2::zero();
@@ -368,7 +386,7 @@ int g1_inputs(kzg_ctx *ctx, const void *host, size_t count, int pfmt, G1Xyzz **d
     G1Xyzz *pts = (G1Xyzz *)lane_alloc(ctx, 0, count * sizeof(G1Xyzz));
     if (!raw || !pts) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(raw, host, count * psz, hipMemcpyHostToDevice, st));
-    KZG_TRY(decode_points(ctx, st, raw, count, pfmt, pts, d_bad));
+    KZG_TRY(decode_points(ctx, st, raw, count, pfmt, pts, d_bad, untrusted_level(ctx)));
     *d_out = pts;
     return KZG_OK;
 }
@@ -381,7 +399,7 @@ int fetch_ok(kzg_ctx *ctx, const uint8_t *d_ok, const int *d_bad, size_t count, 
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin + 64, d_ok, count, hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->prof) prof_collect(ctx);
-    if (*(int *)pin) return fail(ctx, KZG_ERR_BAD_POINT, "an input point failed to decode / is not on the curve");
+    if (*(int *)pin) return fail(ctx, KZG_ERR_BAD_POINT, "an input point failed to decode, is not on the curve or not in the r-torsion subgroup");
     memcpy(ok, pin + 64, count);
     return KZG_OK;
 }
@@ -443,10 +461,10 @@ extern "C" int kzg_srs_upload_g2(kzg_ctx *ctx, const void *pts, size_t n, int pf
     if (rc == KZG_OK && n) {
         hipMemsetAsync(bad, 0, sizeof(int), st);
         hipMemcpyAsync(raw, pts, n * psz, hipMemcpyHostToDevice, st);
-        KZG_LAUNCH(ctx, st, "k_g2_decode", k_g2_decode, (unsigned)((n + 63) / 64), 64, 0, raw, n, pfmt, s->pts, bad);
+        KZG_LAUNCH(ctx, st, "k_g2_decode", k_g2_decode, (unsigned)((n + 63) / 64), 64, 0, raw, n, pfmt, s->pts, bad, untrusted_level(ctx));
         hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
         if (hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "G2 decode failed");
-        if (rc == KZG_OK && hbad) rc = fail(ctx, KZG_ERR_BAD_POINT, "a G2 point failed to decode / is not on the curve");
+        if (rc == KZG_OK && hbad) rc = fail(ctx, KZG_ERR_BAD_POINT, "a G2 point failed to decode, is not on the twist or not in the r-torsion subgroup");
     }
     if (rc == KZG_OK) {
         rc = g2_make_lines(ctx, st, s);
@@ -600,7 +618,7 @@ extern "C" int kzg_pairing_check(kzg_ctx *ctx, const void *g1_points, int pfmt1,
     G1Xyzz *p = nullptr;
     KZG_TRY(g1_inputs(ctx, g1_points, total, pfmt1, &p, bad));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(raw2, g2_points, total * p2, hipMemcpyHostToDevice, st));
-    KZG_LAUNCH(ctx, st, "k_g2_decode", k_g2_decode, (unsigned)((total + 63) / 64), 64, 0, raw2, total, pfmt2, q, bad);
+    KZG_LAUNCH(ctx, st, "k_g2_decode", k_g2_decode, (unsigned)((total + 63) / 64), 64, 0, raw2, total, pfmt2, q, bad, untrusted_level(ctx));
     KZG_LAUNCH(ctx, st, "k_pairing_check", k_pairing_check, (unsigned)((checks + 63) / 64), 64, 0, p, q, (int)pairs_per_check, checks, d_ok);
     return fetch_ok(ctx, d_ok, bad, checks, ok);
 }

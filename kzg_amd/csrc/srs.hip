@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void k_dbl_c(const G1Affine *in, G1Xyzz *out, 
     out[i] = p;
 }
 
-int srs_choose_window(kzg_ctx *ctx, size_t n) {
-    int c = ctx->opt_window_bits;
+int srs_choose_window(int opt_window_bits, size_t n) {
+    int c = opt_window_bits;
     if (c == 0) {
         int l = ilog2_ceil(n ? n : 1);
         c = l - 4;
@@ -65,24 +65,35 @@ int srs_choose_window(kzg_ctx *ctx, size_t n) {
     // walks its scalars twice (measured +2.6 % batched throughput at 2^20 against c = 16); 18..20 use the two-pass ("wide")
     // sort of msm.hip and are only taken when asked for (option window_bits)
     if (c > 20) c = 20;
-    if (ctx->opt_window_bits == 0 && c >= 16) c = 17;  // l - 4 >= 16 <=> n > 2^19
+    if (opt_window_bits == 0 && c >= 16) c = 17;  // l - 4 >= 16 <=> n > 2^19
     return c;
+}
+
+// window bits, windows, resident table rows for an SRS of n points under the given options
+void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c_out, int *W_out, int *rows_out, bool *narrow17_out) {
+    int c = srs_choose_window(opt_window_bits, n);
+    int W = (256 + c - 1) / c;
+    // c = 17: 255 = 15 x 17, and a scalar k >= 2^254 is replaced by -(r - k) (all digit signs flipped), so the top window never
+    // carries out: 15 windows instead of 16.  2^16 buckets: the counting sort walks its scalars twice, half the buckets per walk
+    // (the u32 LDS counters of 2^15 buckets are what fits a CU).
+    bool narrow17 = c == 17;
+    if (narrow17) W = 15;
+    int rows = W;
+    if (opt_window_rows > 0 && opt_window_rows < W && c <= 17) rows = opt_window_rows;  // the wide path keeps every row
+    *c_out = c;
+    *W_out = W;
+    *rows_out = rows;
+    *narrow17_out = narrow17;
 }
 
 int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     kzg_srs *s = new kzg_srs();
     s->n = n;
     s->npad = n ? n : 1;
-    s->c = srs_choose_window(ctx, n);
-    s->W = (256 + s->c - 1) / s->c;
-    // c = 17: 255 = 15 x 17, and a scalar k >= 2^254 is replaced by -(r - k) (all digit signs flipped), so the top window never
-    // carries out: 15 windows instead of 16.  2^16 buckets: the counting sort walks its scalars twice, half the buckets per walk
-    // (the u32 LDS counters of 2^15 buckets are what fits a CU).
-    s->narrow17 = s->c == 17;
-    if (s->narrow17) s->W = 15;
+    srs_shape(ctx->opt_window_bits, ctx->opt_window_rows, n, &s->c, &s->W, &s->rows, &s->narrow17);
     s->device = ctx->device;
     // `table` keeps row 0 only (the points themselves, canonical saturated form: download, re-upload);
-    // the W window rows live in the 30-bit table built by srs_precompute.
+    // the window rows live in the 30-bit table built by srs_precompute.
     hipError_t e = hipMalloc((void **)&s->table, s->npad * sizeof(G1Affine));
     if (e != hipSuccess) {
         delete s;
@@ -106,7 +117,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     if (srs->n == 0) return KZG_OK;
     hipStream_t st = ctx->lanes[0].stream;
     const size_t n = srs->n;
-    size_t npts = (size_t)srs->W * srs->npad;
+    size_t npts = (size_t)srs->rows * srs->npad;
     KZG_HIP_CHECK(ctx, hipMalloc(&srs->table30, npts * sizeof(G1Affine30)));
     G1Affine30 *t30 = (G1Affine30 *)srs->table30;
     const size_t CHUNK = (size_t)1 << 20;
@@ -119,7 +130,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     unsigned gn = (unsigned)((n + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_table_to30", k_table_to30, gn, 256, 0, srs->table, t30, n);
     const G1Affine *prev = srs->table;
-    for (int w = 1; w < srs->W; w++) {
+    for (int w = 1; w < srs->rows; w++) {
         G1Affine *cur = rows[w & 1];
         for (size_t o = 0; o < n; o += chunk) {
             size_t m = n - o < chunk ? n - o : chunk;
@@ -181,17 +192,52 @@ __device__ bool fq_gt_half(const Fq &canon) {
     return false;
 }
 
-// any input point format -> XYZZ; *bad |= 1 on a decode / on-curve failure
-__global__ __launch_bounds__(256) void k_decode_points(const uint8_t *src, size_t n, int fmt, G1Xyzz *out, int *bad) {
+// [r]P == O: membership in the prime-order subgroup G1 (what G1Affine deserialisation checks upstream; the curve has cofactor
+// (z - 1)^2 / 3, and everything downstream -- the MSM's r - k trick, the verifier's rewritten pairing equation -- is only valid
+// for r-torsion points)
+__device__ bool g1_in_subgroup(const G1Xyzz &p) {
+    if (p.is_inf()) return true;
+    G1Xyzz acc = G1Xyzz::inf();
+    for (int i = 254; i >= 0; i--) {
+        acc = g1_dbl(acc);
+        uint32_t limb = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) limb = (k == (i >> 5)) ? FrParams::mod(k) : limb;
+        if ((limb >> (i & 31)) & 1) acc = g1_add(acc, p);
+    }
+    return acc.is_inf();
+}
+
+// any input point format -> XYZZ; *bad |= 1 on a decode / canonical-limb / on-curve / subgroup failure (per `level`)
+__global__ __launch_bounds__(256) void k_decode_points(const uint8_t *src, size_t n, int fmt, G1Xyzz *out, int *bad, int level) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    if (fmt == KZG_G1_AFFINE_MONT_96) {
-        out[i] = G1Xyzz::from_affine(*reinterpret_cast<const G1Affine *>(src + i * 96));
-        return;
-    }
-    if (fmt == KZG_G1_JACOBIAN_MONT_144) {
-        G1Jacobian j = *reinterpret_cast<const G1Jacobian *>(src + i * 144);
-        out[i] = g1_from_jacobian(j);
+    if (fmt == KZG_G1_AFFINE_MONT_96 || fmt == KZG_G1_JACOBIAN_MONT_144) {
+        G1Xyzz p;
+        bool ok = true;
+        if (fmt == KZG_G1_AFFINE_MONT_96) {
+            const G1Affine a = *reinterpret_cast<const G1Affine *>(src + i * 96);
+            if (level >= POINTS_ON_CURVE) ok = is_canonical(a.x) && is_canonical(a.y) && g1_on_curve(a);
+            p = G1Xyzz::from_affine(a);
+        } else {
+            const G1Jacobian j = *reinterpret_cast<const G1Jacobian *>(src + i * 144);
+            if (level >= POINTS_ON_CURVE) {
+                ok = is_canonical(j.x) && is_canonical(j.y) && is_canonical(j.z);
+                if (ok && !j.z.is_zero()) {  // Y^2 = X^3 + 4 Z^6
+                    const Fq z2 = sqr(j.z), z6 = mul(sqr(z2), z2);
+                    Fq four_z6 = add(z6, z6);
+                    four_z6 = add(four_z6, four_z6);
+                    ok = sqr(j.y) == add(mul(sqr(j.x), j.x), four_z6);
+                }
+            }
+            p = g1_from_jacobian(j);
+        }
+        if (ok && level >= POINTS_SUBGROUP) ok = g1_in_subgroup(p);
+        if (!ok) {
+            atomicOr(bad, 1);
+            p = G1Xyzz::inf();
+        }
+        out[i] = p;
         return;
     }
     G1Affine a;
@@ -225,17 +271,19 @@ __global__ __launch_bounds__(256) void k_decode_points(const uint8_t *src, size_
             a.y = y;
         }
     }
+    G1Xyzz p = G1Xyzz::from_affine(a);
+    if (ok && level >= POINTS_SUBGROUP) ok = g1_in_subgroup(p);
     if (!ok) {
         atomicOr(bad, 1);
-        a = G1Affine::inf();
+        p = G1Xyzz::inf();
     }
-    out[i] = G1Xyzz::from_affine(a);
+    out[i] = p;
 }
 
-int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad) {
+int decode_points(kzg_ctx *ctx, hipStream_t st, const void *d_raw, size_t n, int fmt, G1Xyzz *d_out, int *d_bad, int level) {
     if (!n) return KZG_OK;
     KZG_LAUNCH(ctx, st, "k_decode_points", k_decode_points, (unsigned)((n + 255) / 256), 256, 0, (const uint8_t *)d_raw, n,
-               fmt, d_out, d_bad);
+               fmt, d_out, d_bad, level);
     return KZG_OK;
 }
 
@@ -361,31 +409,28 @@ extern "C" int kzg_srs_upload_g1(kzg_ctx *ctx, const void *pts, size_t n, int pf
     hipStream_t st = ctx->lanes[0].stream;
     int rc = KZG_OK;
     if (n) {
-        if (pfmt == KZG_G1_AFFINE_MONT_96) {
-            hipError_t e = hipMemcpyAsync(s->table, pts, n * 96, hipMemcpyHostToDevice, st);
-            if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
-            if (rc == KZG_OK) rc = srs_precompute(ctx, s);
+        // every format goes through the decoder: canonical limbs, on the curve, in the subgroup (option trusted_points = 1
+        // skips the subgroup test), as G1Affine / G1Projective deserialisation guarantees upstream
+        uint8_t *raw = nullptr;
+        G1Xyzz *tmp = nullptr;
+        int *bad = nullptr;
+        int hbad = 0;
+        if (hipMalloc((void **)&raw, n * psz) != hipSuccess || hipMalloc((void **)&tmp, n * sizeof(G1Xyzz)) != hipSuccess ||
+            hipMalloc((void **)&bad, sizeof(int)) != hipSuccess) {
+            rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(decode staging)");
         } else {
-            uint8_t *raw = nullptr;
-            G1Xyzz *tmp = nullptr;
-            int *bad = nullptr;
-            int hbad = 0;
-            if (hipMalloc((void **)&raw, n * psz) != hipSuccess || hipMalloc((void **)&tmp, n * sizeof(G1Xyzz)) != hipSuccess ||
-                hipMalloc((void **)&bad, sizeof(int)) != hipSuccess) {
-                rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(decode staging)");
-            } else {
-                hipMemcpyAsync(raw, pts, n * psz, hipMemcpyHostToDevice, st);
-                hipMemsetAsync(bad, 0, sizeof(int), st);
-                KZG_LAUNCH(ctx, st, "k_decode_points", k_decode_points, (unsigned)((n + 255) / 256), 256, 0, raw, n, pfmt, tmp, bad);
-                hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
-                hipStreamSynchronize(st);
-                if (hbad) rc = fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode or is not on the curve");
-                if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, tmp);
-            }
-            if (raw) hipFree(raw);
-            if (tmp) hipFree(tmp);
-            if (bad) hipFree(bad);
+            hipMemcpyAsync(raw, pts, n * psz, hipMemcpyHostToDevice, st);
+            hipMemsetAsync(bad, 0, sizeof(int), st);
+            rc = decode_points(ctx, st, raw, n, pfmt, tmp, bad, untrusted_level(ctx));
+            hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st);
+            hipStreamSynchronize(st);
+            if (rc == KZG_OK && hbad)
+                rc = fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode, is not on the curve or not in the r-torsion subgroup");
+            if (rc == KZG_OK) rc = srs_finish_from_xyzz(ctx, s, tmp);
         }
+        if (raw) hipFree(raw);
+        if (tmp) hipFree(tmp);
+        if (bad) hipFree(bad);
     }
     if (rc != KZG_OK) {
         hipFree(s->table);
@@ -513,6 +558,18 @@ extern "C" int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offs
 }
 
 extern "C" size_t kzg_srs_len(const kzg_srs *srs) { return srs ? srs->n : 0; }
+
+extern "C" int kzg_srs_footprint(size_t n, int window_bits, int window_rows, size_t *bytes) {
+    if (!bytes || (window_bits != 0 && (window_bits < 4 || window_bits > 20)) || window_rows < 0) return KZG_ERR_SHAPE;
+    int c, W, rows;
+    bool n17;
+    srs_shape(window_bits, window_rows, n, &c, &W, &rows, &n17);
+    const size_t npad = n ? n : 1;
+    *bytes = npad * (sizeof(G1Affine) + (size_t)rows * sizeof(G1Affine30));
+    return KZG_OK;
+}
+
+extern "C" int kzg_srs_table_rows(const kzg_srs *srs) { return srs ? srs->rows : 0; }
 
 extern "C" int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows) {
     if (!srs) return KZG_ERR_SHAPE;

@@ -282,7 +282,7 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no opening points (the reference recurses without bound on an empty slice)");
-    if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "more than 4096 opening points is not supported");
+    if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "create_witness_batched supports at most 4096 opening points (single-workgroup interpolation kernels)");
     const int to_m = sfmt == KZG_FR_CANONICAL_LE_32;
     hipStream_t st = ctx->lanes[0].stream;
 
