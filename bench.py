@@ -34,9 +34,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# One hardware queue per engine stream (16 MSM lanes + 2 accumulation streams; the ROCm default multiplexes all streams onto 4
-# in-order queues); must be in the environment before HIP initialises.  profiles/ records the cost of leaving it unset.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+# No GPU_MAX_HW_QUEUES here: the library asks for its hardware queues itself when it is loaded and measures what it got
+# (capi.hip: kzg_default_hw_queues, probe_queues; profiles/r02_hw_queues.txt has the numbers for 4 / 8 / 18 queues).
 
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec

@@ -201,6 +201,13 @@ using namespace kzg;
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *kzg_version(void) { return "kzg-mi355x 0.1.0 (gfx950)"; }
 
+// The batched pipeline wants one hardware queue per stream (16 lanes + 2 accumulation streams); the HIP runtime sizes its queue
+// pool from GPU_MAX_HW_QUEUES (default 4) when it initialises, i.e. at the first HIP call of the process.  A host that links or
+// loads this library before touching HIP therefore gets the right pool without exporting anything: the variable is set here, at
+// load time, unless the host has already chosen a value.  (A host that initialises HIP first keeps the runtime's 4 queues; the
+// pipeline then measures what it has -- probe_queues() -- and narrows itself, at ~4 % lower batched throughput.)
+__attribute__((constructor)) static void kzg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+
 extern "C" int kzg_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 0) return 0;
@@ -298,6 +305,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_streams") {
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
+    } else if (k == "hw_queues") {
+        if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "hw_queues must be 0 (GPU_MAX_HW_QUEUES or the ROCm default of 4) or 1..64");
+        ctx->opt_hw_queues = (int)value;
     } else if (k == "window_rows") {
         if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "window_rows must be 0 (one table row per window) or 1..64");
         ctx->opt_window_rows = (int)value;
@@ -423,6 +433,62 @@ extern "C" int kzg_commit_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void
 
 // ---- the batched pipeline shared by kzg_msm_g1_batch and kzg_witness_coeff_many -------------------------------------------
 // Item b runs on lane b % nl; every bucket-accumulation kernel goes to one of the dedicated FIFO streams.
+// Which of the context's streams sit on hardware queues of their own?  The runtime multiplexes streams onto its queue pool
+// (GPU_MAX_HW_QUEUES, default 4, minus whatever the rest of the process uses; the assignment is not a plain round robin), and
+// two streams on one queue run their kernels strictly one after the other.  Measured, once per context: a 0.3 ms spin kernel
+// goes to one stream and a time-stamp kernel to every stream not yet classified -- a stamp taken after the spin ended waited
+// behind it, i.e. shares its queue.  The streams are then re-ordered so that the first `probed_queues` of them (lanes first,
+// then accumulation streams) are pairwise on different queues.
+__global__ void k_probe_spin(unsigned long long ticks, unsigned long long *out) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+    *out = wall_clock64();
+}
+__global__ void k_probe_mark(unsigned long long *out) { *out = wall_clock64(); }
+
+static int probe_queues(kzg_ctx *ctx, int nl, int nas) {
+    std::vector<hipStream_t *> ss;
+    for (int l = 0; l < nl; l++) ss.push_back(&ctx->lanes[l].stream);
+    for (int i = 0; i < nas; i++) ss.push_back(&ctx->accum_streams[i]);
+    const size_t K = ss.size();
+    unsigned long long *d = nullptr;
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&d, K * sizeof(unsigned long long)));
+    std::vector<int> cls(K, -1);
+    std::vector<unsigned long long> h(K);
+    int ncls = 0;
+    for (size_t s0 = 0; s0 < K; s0++) {
+        if (cls[s0] != -1) continue;
+        cls[s0] = ncls;
+        hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, *ss[s0], 30000ull, d + s0);  // wall_clock64: 100 MHz
+        for (size_t t = s0 + 1; t < K; t++)
+            if (cls[t] == -1) hipLaunchKernelGGL(k_probe_mark, dim3(1), dim3(1), 0, *ss[t], d + t);
+        for (size_t t = s0; t < K; t++) KZG_HIP_CHECK(ctx, hipStreamSynchronize(*ss[t]));
+        KZG_HIP_CHECK(ctx, hipMemcpy(h.data(), d, K * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t t = s0 + 1; t < K; t++)
+            if (cls[t] == -1 && h[t] >= h[s0]) cls[t] = ncls;
+        ncls++;
+    }
+    hipFree(d);
+    // one representative per queue first, the sharers after them
+    std::vector<hipStream_t> order;
+    std::vector<bool> seen(ncls, false);
+    for (size_t t = 0; t < K; t++)
+        if (!seen[cls[t]]) {
+            seen[cls[t]] = true;
+            order.push_back(*ss[t]);
+        }
+    std::vector<bool> seen2(ncls, false);
+    for (size_t t = 0; t < K; t++) {
+        if (seen2[cls[t]]) order.push_back(*ss[t]);
+        seen2[cls[t]] = true;
+    }
+    ctx->probed_queues = ncls;
+    ctx->probed_order = order;
+    if (getenv("KZG_DEBUG")) fprintf(stderr, "kzg: probe_queues: %zu streams on %d hardware queues\n", K, ncls);
+    return KZG_OK;
+}
+
 struct BatchPipe {
     int nl = 1, nas = 0;
     uint8_t *d_out = nullptr;
@@ -431,8 +497,7 @@ struct BatchPipe {
 
 static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, int flags, BatchPipe *bp) {
     bp->nl = (int)std::min<size_t>(batch, (size_t)ctx->opt_streams);
-    const int nl = bp->nl;
-    KZG_TRY(ensure_lanes(ctx, nl));
+    int nl = bp->nl;
     ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
     ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
     ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
@@ -450,13 +515,60 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
         }
         bp->d_out = (uint8_t *)ctx->batch_out;
     }
-    // dedicated accumulation streams only when every stream can have a hardware queue of its own (the runtime reads
-    // GPU_MAX_HW_QUEUES when it initialises; its default of 4 multiplexes the streams, and a shared queue costs more than the
-    // FIFO order gains)
-    const char *hwq = getenv("GPU_MAX_HW_QUEUES");
-    bp->nas = (nl > 1 && hwq && atoi(hwq) >= nl + ctx->opt_accum_streams) ? ctx->opt_accum_streams : 0;
-    for (int i = 0; i < bp->nas; i++)
-        if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking));
+    // Every stream must map to a hardware queue of its own (streams that share a queue serialise: a lane's tail kernels would
+    // wait behind another lane's accumulation).  How many queues the process really has is MEASURED once per context
+    // (probe_queues), so the plan does not depend on what the host exported before HIP initialised; with fewer queues than
+    // lanes + accumulation streams the pipeline is narrowed to fit (measured on 4 queues: 3 lanes + 1 accumulation stream
+    // 392/s, 2 + 2: 330/s, 4 + 0: 383/s, against 405/s with 18 queues; profiles/r02_hw_queues.txt).
+    bp->nas = nl > 1 ? ctx->opt_accum_streams : 0;
+    if (nl > 1) {
+        KZG_TRY(ensure_lanes(ctx, nl));
+        for (int i = 0; i < bp->nas; i++)
+            if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking));
+        int queues = ctx->opt_hw_queues;
+        if (queues <= 0) {
+            if (ctx->probed_queues == 0 || ctx->probed_lanes < nl || ctx->probed_accum < bp->nas) {
+                KZG_TRY(probe_queues(ctx, nl, bp->nas));
+                ctx->probed_lanes = nl;
+                ctx->probed_accum = bp->nas;
+            }
+            queues = ctx->probed_queues;
+        }
+        if (nl + bp->nas > queues) {
+            if (queues >= 4) {  // measured (tools/plan_matrix.sh): Q = 4: 3 + 1 best; Q = 8: 6 + 2; Q = 12: 10 + 2; "many + 1" loses 10 %
+                bp->nas = bp->nas ? (queues >= 6 && bp->nas >= 2 ? 2 : 1) : 0;
+                bp->nl = queues - bp->nas;
+            } else {
+                bp->nas = 0;
+                bp->nl = queues > 0 ? queues : 1;
+            }
+            if (bp->nl > nl) bp->nl = nl;
+        }
+        if (const char *pl = getenv("KZG_PLAN")) {  // debugging aid: "lanes,accum"
+            int a = 0, b2 = 0;
+            if (sscanf(pl, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= nl && b2 >= 0 && b2 <= ctx->opt_accum_streams) {
+                bp->nl = a;
+                bp->nas = b2;
+            }
+        }
+        // hand the probed streams out so that the ones this plan uses are on different queues: lanes first, accumulation
+        // streams next; the others stay parked in the remaining probed slots
+        if (ctx->opt_hw_queues <= 0 && (int)ctx->probed_order.size() == ctx->probed_lanes + ctx->probed_accum &&
+            bp->nl <= ctx->probed_lanes && bp->nas <= ctx->probed_accum) {
+            for (auto &l : ctx->lanes) KZG_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+            size_t r = 0;
+            for (int l = 0; l < bp->nl; l++) ctx->lanes[l].stream = ctx->probed_order[r++];
+            for (int i = 0; i < bp->nas; i++) ctx->accum_streams[i] = ctx->probed_order[r++];
+            for (int l = bp->nl; l < ctx->probed_lanes; l++) ctx->lanes[l].stream = ctx->probed_order[r++];
+            for (int i = bp->nas; i < ctx->probed_accum; i++) ctx->accum_streams[i] = ctx->probed_order[r++];
+        }
+    }
+    nl = bp->nl;
+    if (getenv("KZG_DEBUG")) fprintf(stderr, "kzg: batch plan: %d lanes + %d accumulation streams\n", bp->nl, bp->nas);
+    KZG_TRY(ensure_lanes(ctx, nl));
+    ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
+    ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
+    ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
     while (bp->nas && (int)ctx->sorted_events.size() < nl) {
         hipEvent_t e1 = nullptr, e2 = nullptr;
         KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));

@@ -55,6 +55,10 @@ struct kzg_ctx {
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 8;
     int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
+    int opt_hw_queues = 0;             // hardware queues to plan the batched pipeline for (0 = measure: probe_queues in capi.hip)
+    int probed_queues = 0;             // hardware queues the probed streams were found on (0 = not measured yet)
+    int probed_lanes = 0, probed_accum = 0;  // which streams that measurement covered: lanes [0, probed_lanes), accumulation streams
+    std::vector<hipStream_t> probed_order;  // the probed streams, one per queue first
     int opt_window_rows = 0;           // 0 = every window has its table row; r > 0: keep r rows (low-memory SRS, multi-pass MSM)
     int opt_trusted_points = 0;        // 1: caller vouches for its points (skip the subgroup check of uploads / verifier inputs)
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
