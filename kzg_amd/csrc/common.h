@@ -105,7 +105,7 @@ struct kzg_srs {
     int rows = 0;        // table rows resident (= W unless option window_rows asked for fewer: then an MSM takes ceil(W / rows) passes)
     bool narrow17 = false;  // c = 17: single-pass sort walking the scalars twice (half the buckets per walk), balanced scalars
     kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
-    void *table30 = nullptr;         // [W][npad] G1Affine30 (2 x 13 x 30-bit limbs + pad, 112 B): what k_accum_affine gathers
+    void *table30 = nullptr;         // [W][npad] G1Affine30 (2 x 13 x 30-bit limbs + pad, KZG_ROW_BYTES = 128 B): what k_accum_affine gathers
     int device = 0;
 };
 

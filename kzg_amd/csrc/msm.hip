@@ -336,9 +336,10 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
 // ---------------------------------------------------------------------------------------------
 // accumulation rounds
 // ---------------------------------------------------------------------------------------------
-// table30 entry: G1Affine30 = 2 x 13 limbs + 8 B pad = 112 B = 7 x 16 B
+// table30 entry: G1Affine30 = 2 x 13 limbs + pad = KZG_ROW_BYTES (112 B = 7 x 16 B by default); the 7 x 16 B that hold the
+// coordinates are what gets loaded
 __device__ __forceinline__ G1Affine30 load_entry_point30(const uint4 *table30, uint32_t ent) {
-    const uint4 *src = table30 + (size_t)(ent & 0x7fffffffu) * 7;
+    const uint4 *src = table30 + (size_t)(ent & 0x7fffffffu) * (KZG_ROW_BYTES / 16);
     G1Affine30 p;
     uint4 *dst = reinterpret_cast<uint4 *>(&p);
 #pragma unroll

@@ -191,8 +191,8 @@ def test_documented_limits_return_shape_errors(engine):
     # the footprint query agrees with the formula in the header
     nbytes = ctypes.c_size_t()
     assert lib.kzg_srs_footprint(1 << 20, 0, 0, ctypes.byref(nbytes)) == 0
-    assert nbytes.value == (1 << 20) * (96 + 15 * 112)
-    assert lib.kzg_srs_footprint(1 << 20, 0, 4, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 4 * 112)
+    assert nbytes.value == (1 << 20) * (96 + 15 * 128)
+    assert lib.kzg_srs_footprint(1 << 20, 0, 4, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 4 * 128)
     params.gs.free()
 
 
