@@ -8,9 +8,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkzg_mi355x.so")
 SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip", "msm_wide.hip", "msm_tail.hip", "mgpu.hip", "gfft.hip"]
-# per-file extra flags.  msm_tail.hip: latency-bound kernels whose every instruction runs once per wave; with the field
-# multiplies out of line an XYZZ addition is ~25 KB of code instead of ~80 KB and stays in the instruction cache.
-EXTRA_FLAGS = {"msm_tail.hip": ["-DKZG_OOL_MUL30"]}
+# per-file extra flags (none at present; out-of-line multiplies for the tail kernels were measured: no gain)
+EXTRA_FLAGS = {}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

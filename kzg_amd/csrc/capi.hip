@@ -305,6 +305,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_streams") {
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
+    } else if (k == "tail_quads") {
+        ctx->opt_tail_quads = value != 0;
+        ctx->cur_tail_quads = ctx->opt_tail_quads;
     } else if (k == "hw_queues") {
         if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "hw_queues must be 0 (GPU_MAX_HW_QUEUES or the ROCm default of 4) or 1..64");
         ctx->opt_hw_queues = (int)value;
@@ -569,6 +572,7 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
     ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
     ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
     ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
+    ctx->cur_tail_quads = nl > 1 ? 0 : ctx->opt_tail_quads;
     while (bp->nas && (int)ctx->sorted_events.size() < nl) {
         hipEvent_t e1 = nullptr, e2 = nullptr;
         KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -592,6 +596,7 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
     ctx->cur_accum_blocks = ctx->accum_blocks_single();
     ctx->cur_sort_threads = ctx->opt_sort_threads;
     ctx->cur_scan_threads = ctx->opt_scan_threads;
+    ctx->cur_tail_quads = ctx->opt_tail_quads;
     if (rc == KZG_OK && !bp.out_dev) {
         hipError_t e = hipMemcpy(out, bp.d_out, out_bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
