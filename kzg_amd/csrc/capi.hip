@@ -297,8 +297,7 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
             return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 0 (auto) or 64..256 x waves per SIMD");
         (k == "accum_blocks" ? ctx->opt_accum_blocks : ctx->opt_accum_blocks_batch) = (int)value;
     } else if (k == "scan_threads" || k == "scan_threads_batch") {
-        if (value != 256 && value != 512 && value != 1024) return fail(ctx, KZG_ERR_SHAPE, "scan_threads must be 256, 512 or 1024");
-        (k == "scan_threads" ? ctx->opt_scan_threads : ctx->opt_scan_threads_batch) = (int)value;
+        // accepted for compatibility: the bucket scans are multi-block kernels now (k_scan_a / k_scan_b)
     } else if (k == "sort_threads" || k == "sort_threads_batch") {
         if (value != 256 && value != 512 && value != 1024) return fail(ctx, KZG_ERR_SHAPE, "sort_threads must be 256, 512 or 1024");
         (k == "sort_threads" ? ctx->opt_sort_threads : ctx->opt_sort_threads_batch) = (int)value;
@@ -503,7 +502,6 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
     int nl = bp->nl;
     ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
     ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
-    ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
     bp->out_dev = (flags & KZG_OUT_DEVICE) != 0;
     if (bp->out_dev) {
         bp->d_out = (uint8_t *)out;
@@ -571,7 +569,6 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
     KZG_TRY(ensure_lanes(ctx, nl));
     ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
     ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
-    ctx->cur_scan_threads = nl > 1 ? ctx->opt_scan_threads_batch : ctx->opt_scan_threads;
     ctx->cur_tail_quads = nl > 1 ? 0 : ctx->opt_tail_quads;
     while (bp->nas && (int)ctx->sorted_events.size() < nl) {
         hipEvent_t e1 = nullptr, e2 = nullptr;
@@ -595,7 +592,6 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
     for (int l = 0; l < bp.nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
     ctx->cur_accum_blocks = ctx->accum_blocks_single();
     ctx->cur_sort_threads = ctx->opt_sort_threads;
-    ctx->cur_scan_threads = ctx->opt_scan_threads;
     ctx->cur_tail_quads = ctx->opt_tail_quads;
     if (rc == KZG_OK && !bp.out_dev) {
         hipError_t e = hipMemcpy(out, bp.d_out, out_bytes, hipMemcpyDeviceToHost);

@@ -75,10 +75,6 @@ struct kzg_ctx {
     int opt_accum_streams = 2;
     hipStream_t accum_streams[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> sorted_events, accum_events;  // per lane
-    int opt_scan_threads = 1024;       // threads of the single-block scan kernels (k_scan_buckets, k_level_scan, k_fold_rest), single MSM
-    int opt_scan_threads_batch = 256;  // batched MSMs: a 256-thread block (<= 128 VGPRs) fits in any free accumulation-block slot,
-                                       // a 1024-thread block waits for a whole free CU (measured 4-7 ms per launch in a full pipeline)
-    int cur_scan_threads = 1024;
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
     int opt_sort_threads_batch = 1024; // ... for batched MSMs
     int cur_sort_threads = 1024;

@@ -1,7 +1,7 @@
-// msm_internal.h -- declarations shared by msm.hip (the c <= 16 pipeline and all orchestration) and msm_wide.hip (the
-// kernels only the wide-window path uses; kept in their own translation unit so that they do not perturb the code
-// generation of the hot kernels: a same-box A/B showed k_accum_affine 2.5 % and k_bucket_reduce 13 % slower with
-// everything in one TU).
+// msm_internal.h -- declarations shared by msm.hip (sort, bucket accumulation, all orchestration), msm_wide.hip (the
+// kernels only the wide-window path uses) and msm_tail.hip (everything after the accumulation).  Separate translation units
+// so that they do not perturb the code generation of the hot kernel: a same-box A/B showed k_accum_affine 2.5 % slower with
+// everything in one TU.
 #pragma once
 #include "common.h"
 
@@ -28,131 +28,6 @@ struct MsmState {
     uint32_t ovf_tasks;    // slices of buckets with too many partials for k_fold_dense (msm_tail.hip); zeroed by k_scan_buckets
 };
 
-
-#if defined(__HIPCC__)
-// Single-block exclusive scan over `B` per-bucket values produced by f(b); writes out[0..B] and returns the
-// total.  Each wave owns a contiguous segment and walks it in rounds of 64 consecutive buckets, so every
-// global access is a coalesced 256-B row.  Two code paths:
-//   * the segment fits SCAN_MAX_ROUNDS rounds (1024 threads at B = 2^15): all rounds are loaded into registers first
-//     (their latencies overlap), scanned with wave shuffles and a running carry, one LDS pass combines the waves;
-//   * longer segments (the 256-thread launches of the batched mode, where a block must fit beside resident accumulation
-//     blocks instead of waiting for a whole free CU): two passes over the segment in batches of SCAN_BATCH rounds --
-//     wave totals first, then the scan proper with the wave offset known; f is evaluated twice.
-constexpr int SCAN_MAX_ROUNDS = 32;  // 1024 threads x 32 rounds = 2^15 buckets (c <= 16)
-constexpr int SCAN_BATCH = 8;
-template <class F>
-__device__ __forceinline__ uint32_t block_exclusive_scan(int B, F f, uint32_t *out, uint32_t *lds) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int seg = (B + nwaves - 1) / nwaves;          // buckets per wave
-    const int rounds = (seg + 63) >> 6;
-    const int base = wave * seg;
-    const int end = base + seg < B ? base + seg : B;
-    if (rounds <= SCAN_MAX_ROUNDS) {
-        uint32_t v[SCAN_MAX_ROUNDS];
-#pragma unroll
-        for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
-            int b = base + r * 64 + lane;
-            v[r] = (r < rounds && b < end) ? f(b) : 0u;
-        }
-        uint32_t carry = 0;
-#pragma unroll
-        for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
-            uint32_t x = v[r], incl = x;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            v[r] = incl - x + carry;
-            carry += __shfl(incl, 63, 64);
-        }
-        if (lane == 0) lds[wave] = carry;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t run = 0;
-            for (int w = 0; w < nwaves; w++) {
-                uint32_t t = lds[w];
-                lds[w] = run;
-                run += t;
-            }
-            lds[nwaves] = run;
-        }
-        __syncthreads();
-        const uint32_t woff = lds[wave], total = lds[nwaves];
-#pragma unroll
-        for (int r = 0; r < SCAN_MAX_ROUNDS; r++) {
-            int b = base + r * 64 + lane;
-            if (r < rounds && b < end) out[b] = v[r] + woff;
-        }
-        if (threadIdx.x == 0) out[B] = total;
-        __syncthreads();
-        return total;
-    }
-    // long segments: pass 1, wave totals
-    uint32_t mine = 0;
-    for (int r0 = 0; r0 < rounds; r0 += SCAN_BATCH) {
-        uint32_t x[SCAN_BATCH];
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) {
-            int b = base + (r0 + j) * 64 + lane;
-            x[j] = (r0 + j < rounds && b < end) ? f(b) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) mine += x[j];
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) mine += __shfl_xor(mine, off, 64);
-    if (lane == 0) lds[wave] = mine;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (int w = 0; w < nwaves; w++) {
-            uint32_t t = lds[w];
-            lds[w] = run;
-            run += t;
-        }
-        lds[nwaves] = run;
-    }
-    __syncthreads();
-    uint32_t carry = lds[wave];
-    const uint32_t total = lds[nwaves];
-    // pass 2: the scan proper
-    for (int r0 = 0; r0 < rounds; r0 += SCAN_BATCH) {
-        uint32_t x[SCAN_BATCH];
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) {
-            int b = base + (r0 + j) * 64 + lane;
-            x[j] = (r0 + j < rounds && b < end) ? f(b) : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < SCAN_BATCH; j++) {
-            uint32_t incl = x[j];
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                uint32_t t = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += t;
-            }
-            int b = base + (r0 + j) * 64 + lane;
-            if (r0 + j < rounds && b < end) out[b] = incl - x[j] + carry;
-            carry += __shfl(incl, 63, 64);
-        }
-    }
-    if (threadIdx.x == 0) out[B] = total;
-    __syncthreads();
-    return total;
-}
-
-__device__ __forceinline__ void find_task(const uint32_t *task_start, int B, uint32_t t, uint32_t &b, uint32_t &j) {
-    uint32_t lo = 0, hi = (uint32_t)B;  // task_start[lo] <= t < task_start[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (task_start[mid] <= t) lo = mid; else hi = mid;
-    }
-    b = lo;
-    j = t - task_start[lo];
-}
-
-#endif
 
 // msm.hip
 int sum_level_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *in, uint32_t count, int L, MsmPoint *out);

@@ -190,10 +190,11 @@ def test_msm_batch_and_sum(engine, srs_small):
 
 
 def test_msm_batch_pipeline_paths(engine):
-    """kzg_msm_g1_batch in its pipelined form (more MSMs than lanes, accumulation kernels on the dedicated FIFO streams,
-    256-thread single-block scans) on adversarial scalar sets that drive the rare paths: all-equal scalars (one bucket per
-    window, deep fold rounds in k_fold_rest), all-zero, u64-valued, and uniform ones -- each vector against the single-MSM
-    entry point and the known-tau identity; then the same with the dedicated streams switched off."""
+    """kzg_msm_g1_batch in its pipelined form (more MSMs than lanes, accumulation kernels on the dedicated FIFO streams) on
+    adversarial scalar sets that drive the rare paths: all-equal scalars (one bucket per window: the overflow slices of
+    k_fold_overflow and their last-arrival sums), all-zero, u64-valued, and uniform ones -- each vector against the known-tau
+    identity; under every pipeline plan the queue planner can choose (18 / 4 / 3 / 1 hardware queues assumed, accumulation
+    streams on and off) and with the latency-mode tail kernels on and off for single MSMs."""
     rng = random.Random(2024)
     n, lanes = 1 << 12, 4
     params = kzg_amd.setup(engine, TAU, n)
@@ -205,15 +206,16 @@ def test_msm_batch_pipeline_paths(engine):
     want = [C.g1_mul(C.g1_generator(), C.poly_eval(v, TAU)) for v in vecs]
     engine.set_option("streams", lanes)
     try:
-        for accum_streams, scan_threads in ((2, 256), (1, 1024), (0, 256)):
+        for accum_streams, hw_queues in ((2, 0), (1, 0), (0, 0), (2, 4), (2, 3), (2, 1), (1, 5)):
             engine.set_option("accum_streams", accum_streams)
-            engine.set_option("scan_threads_batch", scan_threads)
-            assert engine.msm_batch(srs, flat, n, len(vecs)) == want, (accum_streams, scan_threads)
-        engine.set_option("scan_threads", 256)                           # the long-segment scan path in a single MSM
-        assert [engine.msm(srs, v) for v in vecs[4:8]] == want[4:8]
+            engine.set_option("hw_queues", hw_queues)
+            assert engine.msm_batch(srs, flat, n, len(vecs)) == want, (accum_streams, hw_queues)
+        for quads in (0, 1):
+            engine.set_option("tail_quads", quads)
+            assert [engine.msm(srs, v) for v in vecs[4:10]] == want[4:10], quads
     finally:
-        engine.set_option("scan_threads", 1024)
-        engine.set_option("scan_threads_batch", 256)
+        engine.set_option("tail_quads", 1)
+        engine.set_option("hw_queues", 0)
         engine.set_option("accum_streams", 2)
         engine.set_option("streams", 8)
     srs.free()
