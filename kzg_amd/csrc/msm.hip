@@ -375,10 +375,16 @@ __global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uin
     uint32_t ent = entries[lo];
     G1Affine30 cur = load_entry_point30(table30, ent);
     G1Xyzz30 acc = g1_from_affine30(cur, ent >> 31);
+    // the entry words run one step ahead of the gathers (ent_next = entry k+1 while entry k is being added), so a gather's address
+    // never waits for the load of its own index
+    uint32_t ent_next = 0;
     if (lo + 1 < hi) {
         ent = entries[lo + 1];
         cur = load_entry_point30(table30, ent);
     }
+#ifndef KZG_NO_ENTRY_LOOKAHEAD
+    if (lo + 2 < hi) ent_next = entries[lo + 2];
+#endif
     for (uint32_t k = lo + 1; k < hi; k++) {
         // `cur` / `ent` hold entry k.  mode 0: mixed add; 1: restart the accumulator from cur; 2: skip (identity point)
         const bool neg_k = (ent >> 31) != 0;
@@ -402,7 +408,12 @@ __global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uin
         // entry k's point is dead now: start the gather of entry k+1 into the same registers; its latency
         // hides under the eight remaining multiplies of this addition
         if (k + 1 < hi) {
+#ifndef KZG_NO_ENTRY_LOOKAHEAD
+            ent = ent_next;
+            if (k + 2 < hi) ent_next = entries[k + 2];
+#else
             ent = entries[k + 1];
+#endif
             cur = load_entry_point30(table30, ent);
         }
         if (mode == 0) acc = g1_madd30_phase2(acc, mid, neg_k, [&]() { return load_entry_point30(table30, ent_k); });

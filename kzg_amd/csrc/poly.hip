@@ -237,14 +237,23 @@ static int eval_tables(kzg_ctx *ctx, hipStream_t st, uint32_t log_d, EvalDomainT
     EvalDomainTables *t = new EvalDomainTables();
     t->d = d;
     Fr *tmp = nullptr;
-    KZG_HIP_CHECK(ctx, hipMalloc((void **)&t->pw, d * sizeof(Fr)));
-    KZG_HIP_CHECK(ctx, hipMalloc((void **)&t->inv1, d * sizeof(Fr)));
-    KZG_HIP_CHECK(ctx, hipMalloc((void **)&tmp, d * sizeof(Fr)));
-    KZG_TRY(pow_table(ctx, st, host_omega(log_d), Fr::one(), d, t->pw));
-    KZG_LAUNCH(ctx, st, "k_sub_one", k_sub_one, (unsigned)((d + 255) / 256), 256, 0, t->pw, tmp, d);
-    KZG_TRY(batch_inverse(ctx, st, tmp, t->inv1, d));
-    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    KZG_HIP_CHECK(ctx, hipFree(tmp));
+    int rc = KZG_OK;
+    if (hipMalloc((void **)&t->pw, d * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&t->inv1, d * sizeof(Fr)) != hipSuccess ||
+        hipMalloc((void **)&tmp, d * sizeof(Fr)) != hipSuccess)
+        rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(evaluation-domain tables)");
+    if (rc == KZG_OK) rc = pow_table(ctx, st, host_omega(log_d), Fr::one(), d, t->pw);
+    if (rc == KZG_OK) {
+        KZG_LAUNCH(ctx, st, "k_sub_one", k_sub_one, (unsigned)((d + 255) / 256), 256, 0, t->pw, tmp, d);
+        rc = batch_inverse(ctx, st, tmp, t->inv1, d);
+    }
+    if (rc == KZG_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "evaluation-domain tables");
+    if (tmp) hipFree(tmp);
+    if (rc != KZG_OK) {  // nothing half-built stays behind
+        if (t->pw) hipFree(t->pw);
+        if (t->inv1) hipFree(t->inv1);
+        delete t;
+        return rc;
+    }
     ctx->eval_tabs[log_d] = t;
     *out = t;
     return KZG_OK;

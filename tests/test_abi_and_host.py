@@ -66,3 +66,24 @@ def test_polynomial_and_domain_host_mirror():
     e = kzg_amd.EvaluationDomain.from_coeffs([1, 2, 3])   # zero-pads to 2^k (src/ft.rs:94-109)
     assert e.d == 4 and e.exp == 2 and len(e) == 4 and e.coeffs == [1, 2, 3, 0]
     assert kzg_amd.splitmix_scalar(1, 0) < kzg_amd.api.R_MODULUS
+
+
+def test_host_only_helpers_shard_range_and_footprint():
+    """kzg_shard_range / kzg_srs_footprint are pure host functions: usable (and tested) without a GPU."""
+    import kzg_amd
+    from kzg_amd.distributed import shard_range
+    lib = kzg_amd.load()
+    assert shard_range(1 << 24, 3, 8) == (3 << 21, 4 << 21)             # configs[4]: 2^21 terms per rank
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    lo, hi = ctypes.c_size_t(), ctypes.c_size_t()
+    assert lib.kzg_shard_range(10, 4, 4, ctypes.byref(lo), ctypes.byref(hi)) == 3   # KZG_ERR_SHAPE: rank out of range
+    nbytes = ctypes.c_size_t()
+    assert lib.kzg_srs_footprint(1 << 20, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 15 * 128)
+    assert lib.kzg_srs_footprint(1 << 24, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 24) * (96 + 15 * 128)
+    assert lib.kzg_srs_footprint(1 << 16, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 16) * (96 + 22 * 128)  # c = 12
+    assert lib.kzg_srs_footprint(1 << 20, 0, 3, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 3 * 128)
+    assert lib.kzg_srs_footprint(1 << 20, 99, 0, ctypes.byref(nbytes)) == 3
+    # no GPU needed either: forming a group of zero devices, duplicate devices
+    h = ctypes.c_void_p()
+    arr = (ctypes.c_int * 2)(0, 0)
+    assert lib.kzg_mctx_create(arr, 2, ctypes.byref(h)) == 3 and lib.kzg_mctx_create(arr, 0, ctypes.byref(h)) == 3
