@@ -23,7 +23,9 @@ e = kzg_amd.Engine(0)
 TAU = rng.getrandbits(64)
 t_end = time.time() + budget
 fails = 0
-cases = {"msm": 0, "msm_batch": 0, "ntt": 0, "witness": 0, "witness_batched": 0, "eval_form": 0}
+cases = {"msm": 0, "msm_batch": 0, "ntt": 0, "witness": 0, "witness_batched": 0, "eval_form": 0, "group": 0, "lagrange_intt": 0}
+group = kzg_amd.DeviceGroup([0])
+group.set_option("always_gather", 1)
 
 
 def rand_scalar(kind):
@@ -40,6 +42,11 @@ def rand_scalar(kind):
 while time.time() < t_end:
     wb = rng.choice([0, 0, 0, 4, 7, 9, 12, 13, 16, 17, 18, 19, 20])
     e.set_option("window_bits", wb)
+    rows = rng.choice([0, 0, 0, 1, 2, 3, 5, 11])            # low-memory SRS: multi-pass MSM
+    e.set_option("window_rows", rows)
+    e.set_option("tail_quads", rng.randrange(2))             # latency-mode tail kernels on / off
+    e.set_option("hw_queues", rng.choice([0, 0, 1, 3, 4, 6]))  # pipeline plans
+    e.set_option("streams", rng.choice([1, 2, 4, 8]))
     nmax = rng.choice([1, 2, 5, 33, 257, 1000, 4097, 20000, 70000])
     params = kzg_amd.setup(e, TAU, nmax, g2_len=0)
     srs_blob = params.gs.download()
@@ -51,12 +58,15 @@ while time.time() < t_end:
         sc = [rand_scalar(kind if rng.random() < 0.8 else rng.randrange(4)) for _ in range(n)]
         if n and rng.random() < 0.2:
             sc = [sc[0]] * n  # all equal: one bucket per window
+        elif n and rng.random() < 0.2:
+            pool = [rand_scalar(0) for _ in range(rng.randrange(1, 6))]  # a handful of huge buckets: the overflow slices
+            sc = [rng.choice(pool) for _ in range(n)]
         want = C.msm_g1(srs_blob[96 * off:96 * (off + n)], sc) if n else bytes(96)
         got = e.msm(params.gs, sc, offset=off) if n else e.msm(params.gs, [], n=0, offset=off)
         cases["msm"] += 1
         if got != want:
             fails += 1
-            print("MSM MISMATCH", dict(window_bits=wb, nmax=nmax, n=n, off=off, kind=kind, seed=seed), flush=True)
+            print("MSM MISMATCH", dict(window_bits=wb, rows=rows, nmax=nmax, n=n, off=off, kind=kind, seed=seed), flush=True)
     if nmax >= 33:
         n = rng.randrange(1, min(nmax, 3000) + 1)
         batch = rng.randrange(1, 12)
@@ -117,6 +127,26 @@ while time.time() < t_end:
             except kzg_amd.PointNotOnPolynomial:
                 pass
     params.gs.free()
+    e.set_option("window_rows", 0)
+    # device group (one GPU, RCCL all-gather forced on): commit and witness over the group
+    n = rng.choice([1, 7, 300, 5000])
+    gsrs = group.setup(TAU, n)
+    coeffs = [rand_scalar(rng.randrange(4)) for _ in range(rng.randrange(1, n + 1))]
+    cases["group"] += 1
+    if group.commit(gsrs, coeffs) != C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU)):
+        fails += 1
+        print("GROUP COMMIT MISMATCH", dict(n=n, m=len(coeffs), seed=seed), flush=True)
+    gsrs.free()
+    # compute_lagrange_basis from the monomial SRS alone (group iNTT) == the known-tau closed form
+    if rng.random() < 0.3:
+        d = 1 << rng.randrange(0, 12)
+        pm = kzg_amd.setup(e, TAU, d, g2_len=0)
+        a, b = kzg_amd.compute_lagrange_basis(pm), kzg_amd.setup_lagrange(e, TAU, d)
+        cases["lagrange_intt"] += 1
+        if a.download() != b.download():
+            fails += 1
+            print("LAGRANGE iNTT MISMATCH", dict(d=d, seed=seed), flush=True)
+        pm.gs.free(); a.free(); b.free()
     # eval form: commit(fft(p)) == [p(tau)]G, witness at index m == coeff-form witness at omega^m
     log_d = rng.randrange(0, 11)
     d = 1 << log_d
@@ -148,5 +178,6 @@ while time.time() < t_end:
         fails += 1
         print("NTT MISMATCH", dict(log_n=log_n, seed=seed), flush=True)
 e.set_option("window_bits", 0)
+group.close()
 print("fuzz done", cases, "failures:", fails, flush=True)
 sys.exit(1 if fails else 0)
