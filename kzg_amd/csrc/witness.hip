@@ -140,6 +140,57 @@ __global__ __launch_bounds__(256) void k_bary_colsum(const Fr *rows, uint32_t k,
     if (threadIdx.x == 0) out[j] = sh[0];
 }
 
+// ---- the same interpolation building blocks with logarithmic depth (k sequential Fr multiplies are ~0.3 ms at k = 256) ----
+// out[b] = prod_{j < k, j != skip} (pt_b - xs[j]).  mode 0: pt_b = pts[b], nothing skipped (Z evaluated on a 2^m-th-roots domain);
+// mode 1: pt_b = xs[b], j = b skipped (the barycentric denominators Z'(x_b)).  One block per b, tree product through LDS.
+__global__ __launch_bounds__(256) void k_prod_diff(const Fr *pts, const Fr *xs, uint32_t k, int mode, Fr *out) {
+    __shared__ Fr sh[256];
+    const uint32_t b = blockIdx.x;
+    const Fr p = mode ? xs[b] : pts[b];
+    Fr acc = Fr::one();
+    for (uint32_t j = threadIdx.x; j < k; j += blockDim.x)
+        if (!(mode && j == b)) acc = mul(acc, sub(p, xs[j]));
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = mul(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[b] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void k_inverse_each(const Fr *in, Fr *out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i].is_zero() ? Fr::zero() : inv(in[i]);
+}
+
+// rows[j * k + i] = c_i q_{i,j}, q_i = Z / (X - x_i) (q_{i,j} = sum_{m > j} z_m x_i^(m-j-1)), c_i = y_i / Z'(x_i): the synthetic
+// division of k_bary_rows cut into chunks of CH coefficients.  One block per i, one thread per chunk c of the index range [0, k]:
+// local Horner value of the chunk (CH steps), suffix Horner over the chunks above (<= (k+1)/CH steps, X = x_i^CH) = the carry
+// entering the chunk, then the chunk's CH quotient coefficients: depth ~3 sqrt(k) instead of k.
+__global__ __launch_bounds__(128) void k_bary_rows_chunked(const Fr *xs, const Fr *ys, const Fr *den_inv, const Fr *z, uint32_t k,
+                                                           uint32_t CH, uint32_t nch, Fr *rows) {
+    __shared__ Fr B[128];
+    const uint32_t i = blockIdx.x, c = threadIdx.x;
+    const Fr xi = xs[i];
+    const Fr ci = mul(ys[i], den_inv[i]);
+    const uint32_t lo = c * CH, hi = lo + CH < k + 1 ? lo + CH : k + 1;  // coefficients z[lo, hi) of this chunk
+    Fr bv = Fr::zero();
+    if (c < nch)
+        for (uint32_t m = hi; m-- > lo;) bv = add(mul(bv, xi), z[m]);
+    B[c] = bv;
+    __syncthreads();
+    if (c >= nch) return;
+    const Fr X = pow_u64(xi, (uint64_t)CH);
+    Fr carry = Fr::zero();  // U_c = sum_{c' > c} B_c' X^(c'-c-1): the value of the coefficients above this chunk at x_i
+    for (uint32_t cc = nch; cc-- > c + 1;) carry = add(mul(carry, X), B[cc]);
+    // quotient coefficients j in [lo, hi) /\ [0, k): q_{hi-1} = carry, q_{j-1} = z_j + x_i q_j
+    for (uint32_t j = hi; j-- > lo;) {
+        if (j < k) rows[(size_t)j * k + i] = mul(ci, carry);
+        carry = add(z[j], mul(xi, carry));
+    }
+}
+
 // flag |= 1 if any of v[0..n) is zero
 __global__ __launch_bounds__(256) void k_any_zero(const Fr *v, size_t n, int *flag) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -326,7 +377,7 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     size_t N = (size_t)1 << log_N;
     size_t nq = small_poly ? 0 : n - k;
     if (nq > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
-    size_t need = msm_workspace_bytes(srs, nq ? nq : 1) + 12 * N * 32 + (size_t)k * k * 32 + 16 * (k + 2) * 32 + (1 << 20);
+    size_t need = msm_workspace_bytes(srs, nq ? nq : 1) + 12 * N * 32 + (size_t)k * k * 32 + 64 * (k + 2) * 32 + (2 << 20);
     KZG_TRY(lane_reserve(ctx, 0, need));
     Fr *dx = (Fr *)lane_alloc(ctx, 0, k * 32), *dy = (Fr *)lane_alloc(ctx, 0, k * 32);
     Fr *z0 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32);
@@ -345,11 +396,28 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(fr_convert(ctx, st, dy, k, 1));
     }
     // interpolant
-    KZG_LAUNCH(ctx, st, "k_vanishing_poly", k_vanishing_poly, 1, 1024, 0, dx, (uint32_t)k, z0, z1);
-    KZG_LAUNCH(ctx, st, "k_bary_den", k_bary_den, gridfor(k), 256, 0, dx, (uint32_t)k, den);
+    // Z = prod (X - x_i): its values on the M-th roots of unity (M = 2^m > k), one tree product per value, then one small iNTT;
+    // Z'(x_i) the same way; the interpolant by chunked synthetic divisions.  Everything here is log- or sqrt-depth in k.
+    {
+        const uint32_t log_M = (uint32_t)ilog2_ceil(k + 1);
+        const size_t Mz = (size_t)1 << log_M;
+        Fr *zev = (Fr *)lane_alloc(ctx, 0, Mz * 32), *wpow = (Fr *)lane_alloc(ctx, 0, Mz * 32);
+        if (!zev || !wpow) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+        KZG_TRY(pow_table(ctx, st, host_omega(log_M), Fr::one(), Mz, wpow));
+        KZG_LAUNCH(ctx, st, "k_prod_diff", k_prod_diff, (unsigned)Mz, 256, 0, wpow, dx, (uint32_t)k, 0, zev);
+        KZG_TRY(ntt_run(ctx, 0, zev, log_M, 1));
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(z0, zev, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
+    }
+    KZG_LAUNCH(ctx, st, "k_prod_diff", k_prod_diff, (unsigned)k, 256, 0, dx, dx, (uint32_t)k, 1, den);
     KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(k), 256, 0, den, k, flag);  // duplicate x_i
-    KZG_TRY(batch_inverse(ctx, st, den, deni, k));
-    KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows, gridfor(k), 256, 0, dx, dy, deni, z0, (uint32_t)k, rows);
+    KZG_LAUNCH(ctx, st, "k_inverse_each", k_inverse_each, gridfor(k), 256, 0, den, deni, k);
+    {
+        uint32_t CH = 1;
+        while ((uint64_t)CH * CH * 4 <= k) CH *= 2;             // CH = 2^floor(log2(k) / 2): 16 at k = 256, 64 at 4096
+        const uint32_t nch = (uint32_t)((k + 1 + CH - 1) / CH);  // <= 65
+        KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, nch <= 64 ? 64 : 128, 0, dx, dy, deni, z0, (uint32_t)k, CH, nch,
+                   rows);
+    }
     KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, rows, (uint32_t)k, I);
     // numerator and divisor on the coset g*H
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
