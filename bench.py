@@ -354,13 +354,32 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
 
+    # ---- the device group first (it decides the mode: if the group cannot be formed on this node the run degrades to
+    # data-parallel replicas and says so, instead of producing no number at all)
+    group, group_note = None, None
+    if sharded:
+        from kzg_amd.distributed import group_from_torch, shard_range
+        ok = 1
+        try:
+            group = group_from_torch(dist, local_rank, rank, world)
+        except Exception as e:  # noqa: BLE001
+            ok, group_note = 0, f"device group could not be formed ({e}); fell back to replicas"
+        if world > 1:           # all ranks agree on the outcome
+            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            ok = int(t.item())
+        if not ok:
+            if group is not None:
+                group.close()
+            group, sharded = None, False
+            group_note = group_note or "device group could not be formed on another rank; fell back to replicas"
+
     # ---- which polynomial, which slice of it this rank holds -------------------------------------------------
     if not sharded:
         mode = "single" if world == 1 else "replicas"
         n_poly = 1 << args.log_n
         lo, hi = 0, n_poly
     else:
-        from kzg_amd.distributed import group_from_torch, shard_range
         if args.config5:
             mode, n_poly = "config5", world << 21
         elif args.weak:
@@ -370,9 +389,7 @@ def main():
         lo, hi = shard_range(n_poly, rank, world)
     n_local = hi - lo
 
-    group = None
     if sharded:
-        group = group_from_torch(dist, local_rank, rank, world)
         if world == 1:
             group.set_option("always_gather", 1)     # --sharded at N = 1 exercises the RCCL exchange
         engine = group.engine(0)
@@ -554,6 +571,7 @@ def main():
                 "terms_per_rank": n_local, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",
                 "inputs_resident_in_hbm": True,
             },
+            **({"note": group_note} if group_note else {}),
             "g1_adds_per_sec": round(value * (world if mode != "replicas" else 1) * g1_adds_per_msm(n_local, c, W), 1),
             "msm_terms_per_sec": round(value * n_poly, 1),
             "parity_pin": "fr-literal+known-tau",   # G1 layer: no literal vector in the reference
