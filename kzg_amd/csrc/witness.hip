@@ -20,32 +20,32 @@ namespace kzg {
 // ---------------------------------------------------------------------------------------------
 // distribute_powers: v[i] *= g^i   (src/ft.rs:142-166)
 // ---------------------------------------------------------------------------------------------
-constexpr int DP_E = 8;
-__global__ __launch_bounds__(256) void k_distribute_powers(Fr *data, size_t n, Fr g, Fr scale) {
+constexpr int DP_E = 32;  // elements per thread: one g^t by square-and-multiply (~30 multiplies) amortised over 32
+// thread t scales elements t, t + T, t + 2T, ... (T = number of threads: coalesced) with a running g^(t + jT)
+__global__ __launch_bounds__(256) void k_distribute_powers(Fr *data, size_t n, Fr g, Fr gT, size_t T) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t i0 = t * DP_E;
-    if (i0 >= n) return;
-    Fr u = mul(scale, pow_u64(g, (uint64_t)i0));
-#pragma unroll
-    for (int k = 0; k < DP_E; k++) {
-        if (i0 + k < n) {
-            data[i0 + k] = mul(data[i0 + k], u);
-            u = mul(u, g);
-        }
+    if (t >= T || t >= n) return;
+    Fr u = pow_u64(g, (uint64_t)t);
+    for (size_t i = t; i < n; i += T) {
+        data[i] = mul(data[i], u);
+        u = mul(u, gT);
     }
 }
 
 static void distribute_powers(kzg_ctx *ctx, hipStream_t st, Fr *d, size_t n, const Fr &g) {
-    size_t threads = (n + DP_E - 1) / DP_E;
-    KZG_LAUNCH(ctx, st, "k_distribute_powers", k_distribute_powers, (unsigned)((threads + 255) / 256), 256, 0, d, n, g, Fr::one());
+    if (!n) return;
+    size_t T = (n + DP_E - 1) / DP_E;
+    T = (T + 255) / 256 * 256;
+    KZG_LAUNCH(ctx, st, "k_distribute_powers", k_distribute_powers, (unsigned)(T / 256), 256, 0, d, n, g, pow_u64(g, (uint64_t)T), T);
 }
 
-// coset_fft: distribute_powers(g) then fft; icoset_fft: ifft then distribute_powers(g^-1)
-static int coset_ntt_run(kzg_ctx *ctx, int lane, Fr *d, uint32_t log_n, int inverse, const Fr &g) {
+// coset_fft: distribute_powers(g) then fft; icoset_fft: ifft then distribute_powers(g^-1).
+// nnz (forward only): the caller knows that d[nnz ..) is zero -- a zero-padded short polynomial -- so only d[0, nnz) is scaled
+static int coset_ntt_run(kzg_ctx *ctx, int lane, Fr *d, uint32_t log_n, int inverse, const Fr &g, size_t nnz = (size_t)-1) {
     hipStream_t st = ctx->lanes[lane].stream;
     size_t n = (size_t)1 << log_n;
     if (!inverse) {
-        distribute_powers(ctx, st, d, n, g);
+        distribute_powers(ctx, st, d, nnz < n ? nnz : n, g);
         return ntt_run(ctx, lane, d, log_n, 0);
     }
     KZG_TRY(ntt_run(ctx, lane, d, log_n, 1));
@@ -208,10 +208,15 @@ __global__ __launch_bounds__(256) void k_any_diff(const Fr *a, const Fr *b, size
     if (i < n && a[i] != b[i]) atomicOr(flag, 2);
 }
 
-// a[i] = (a[i] - b[i]) * cinv[i]
-__global__ __launch_bounds__(256) void k_sub_mul(Fr *a, const Fr *b, const Fr *cinv, size_t n) {
+// a[i] *= cinv[i]
+__global__ __launch_bounds__(256) void k_mul_inplace(Fr *a, const Fr *cinv, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] = mul(sub(a[i], b[i]), cinv[i]);
+    if (i < n) a[i] = mul(a[i], cinv[i]);
+}
+// a[j] -= b[j], j < k   (p - I in coefficient form: I has k coefficients)
+__global__ __launch_bounds__(256) void k_sub_prefix(Fr *a, const Fr *b, size_t k) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < k) a[i] = sub(a[i], b[i]);
 }
 
 // dst[0..n) = src[0..m) zero-extended, converted to Montgomery form if `to_m`
@@ -422,10 +427,10 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     // numerator and divisor on the coset g*H
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, pin, n, A, N, to_m);
-    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, I, k, Bv, N, 0);
     MsmPoint *res = nullptr;
     int hflag = 0;
     if (small_poly) {
+        KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, I, k, Bv, N, 0);
         // deg I <= k-1 and deg p <= n-1 <= k-1: the quotient is zero and the division is exact iff p == I
         KZG_LAUNCH(ctx, st, "k_any_diff", k_any_diff, gridfor(N), 256, 0, A, Bv, N, flag);
         KZG_TRY(msm_run(ctx, 0, srs, 0, A, 0, KZG_FR_MONT_LE_32, &res));  // identity
@@ -446,12 +451,14 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
             if (attempt > k) return fail(ctx, KZG_ERR_INTERNAL, "no usable coset shift");
             gsh = mul(gsh, g1);
         }
-        KZG_TRY(coset_ntt_run(ctx, 0, Cv, log_N, 0, gsh));
+        // (p - I) in coefficient form, then TWO forward coset NTTs (numerator, Z) and one inverse; Z and the numerator's
+        // zero padding are not scaled
+        KZG_LAUNCH(ctx, st, "k_sub_prefix", k_sub_prefix, gridfor(k), 256, 0, A, I, k);
+        KZG_TRY(coset_ntt_run(ctx, 0, Cv, log_N, 0, gsh, k + 1));
         KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(N), 256, 0, Cv, N, flag);
-        KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 0, gsh));
-        KZG_TRY(coset_ntt_run(ctx, 0, Bv, log_N, 0, gsh));
+        KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 0, gsh, n > k ? n : k));
         KZG_TRY(batch_inverse(ctx, st, Cv, Ci, N));
-        KZG_LAUNCH(ctx, st, "k_sub_mul", k_sub_mul, gridfor(N), 256, 0, A, Bv, Ci, N);
+        KZG_LAUNCH(ctx, st, "k_mul_inplace", k_mul_inplace, gridfor(N), 256, 0, A, Ci, N);
         KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 1, gsh));
         // exact division <=> deg q <= N-1-k <=> the top k coefficients vanish
         KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);
