@@ -57,15 +57,19 @@ __global__ __launch_bounds__(256) void k_dbl_c(const G1Affine *in, G1Xyzz *out, 
 int srs_choose_window(int opt_window_bits, size_t n) {
     int c = opt_window_bits;
     if (c == 0) {
-        int l = ilog2_ceil(n ? n : 1);
-        c = l - 4;
+        // Measured (tools/window_sweep*.sh, batch 64 and single latency, profiles/r02_window_sweep.txt): with the depth-organised
+        // tail the bucket count is cheap, so wide windows pay much earlier than the old "log2 n - 4": 17 bits (15 windows, the
+        // balanced-scalar mode) from 2^17 points on -- +7 % at 2^17, +20 % at 2^18, +13 % at 2^19 over 13 / 14 / 15 bits.
+        // Widths whose TOP window holds only a few significant bits of a 255-bit scalar (255 - c (W - 1) <= 3: c = 9, 11, 12,
+        // 14, 15) are avoided: every scalar then lands in the same handful of buckets of that window, which the fold handles
+        // through its overflow path (correct, but a 0.2 ms serial stage).  c = 8, 10, 13, 16, 17 have 7, 5, 8, 15, 17 bits there.
+        const int l = ilog2_ceil(n ? n : 1);
+        c = l >= 17 ? 17 : l >= 14 ? 13 : l >= 12 ? 10 : 8;
     }
     if (c < 4) c = 4;
-    // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17 from 2^20 points on: same pipeline, 15 windows, the sort
-    // walks its scalars twice (measured +2.6 % batched throughput at 2^20 against c = 16); 18..20 use the two-pass ("wide")
-    // sort of msm.hip and are only taken when asked for (option window_bits)
+    // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17: same pipeline, 15 windows, the sort walks its scalars
+    // twice; 18..20 use the two-pass ("wide") sort of msm.hip and are only taken when asked for (option window_bits)
     if (c > 20) c = 20;
-    if (opt_window_bits == 0 && c >= 16) c = 17;  // l - 4 >= 16 <=> n > 2^19
     return c;
 }
 

@@ -80,7 +80,7 @@ def test_host_only_helpers_shard_range_and_footprint():
     nbytes = ctypes.c_size_t()
     assert lib.kzg_srs_footprint(1 << 20, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 15 * 128)
     assert lib.kzg_srs_footprint(1 << 24, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 24) * (96 + 15 * 128)
-    assert lib.kzg_srs_footprint(1 << 16, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 16) * (96 + 22 * 128)  # c = 12
+    assert lib.kzg_srs_footprint(1 << 16, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 16) * (96 + 20 * 128)  # c = 13
     assert lib.kzg_srs_footprint(1 << 20, 0, 3, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 3 * 128)
     assert lib.kzg_srs_footprint(1 << 20, 99, 0, ctypes.byref(nbytes)) == 3
     # no GPU needed either: forming a group of zero devices, duplicate devices

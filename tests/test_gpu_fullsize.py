@@ -148,16 +148,34 @@ def test_adversarial_scalars_2_16(engine, case):
     params.gs.free()
 
 
-@pytest.mark.parametrize("n", [5, 17, 33, 100, 700, 3000, 9000, 40000])
-def test_every_window_size(engine, n):
-    """SRS sizes that select every window width c = 4 .. 14 (c = 17 is covered by the 2^20 tests, 16 by test_wide_windows)."""
+@pytest.mark.parametrize("c", [4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15])
+def test_every_window_size(engine, c):
+    """Every window width of the single-pass pipeline (c = 4 .. 15; 16 .. 20 in test_wide_windows), chosen by option, at a size
+    where each has many partials per bucket; full-width, u64-valued and all-equal scalars (widths whose top window holds only
+    a few bits -- 9, 11, 12, 14, 15 -- put every scalar into a handful of buckets there: the fold's overflow slices)."""
+    n = 3000 + 97 * c
+    rng = random.Random(c)
+    engine.set_option("window_bits", c)
+    try:
+        params = kzg_amd.setup(engine, TAU, n)
+        cc, W = params.gs.window_info()
+        assert cc == c and W == -(-256 // c)
+        for sc in (rand_scalars(rng, n), rand_scalars(rng, n, "u64"), [rng.randrange(R)] * n):
+            assert engine.msm(params.gs, sc) == C.g1_mul(C.g1_generator(), C.poly_eval(sc, TAU)), c
+        params.gs.free()
+    finally:
+        engine.set_option("window_bits", 0)
+
+
+@pytest.mark.parametrize("n", [5, 300, 3000, 9000, 40000, 140000])
+def test_default_window_choice(engine, n):
+    """The widths the engine picks by itself (8, 10, 13, 17 by size) give the right commitment."""
     rng = random.Random(n)
     params = kzg_amd.setup(engine, TAU, n)
     c, W = params.gs.window_info()
-    assert W == -(-256 // c)
+    assert c in (8, 10, 13, 17) and W == (15 if c == 17 else -(-256 // c))
     sc = rand_scalars(rng, n)
-    got = engine.msm(params.gs, sc)
-    assert got == C.g1_mul(C.g1_generator(), C.poly_eval(sc, TAU))
+    assert engine.msm(params.gs, sc) == C.g1_mul(C.g1_generator(), C.poly_eval(sc, TAU))
     params.gs.free()
 
 
