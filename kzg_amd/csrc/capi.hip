@@ -536,7 +536,7 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
             queues = ctx->probed_queues;
         }
         if (nl + bp->nas > queues) {
-            if (queues >= 4) {  // measured (tools/plan_matrix.sh): Q = 4: 3 + 1 best; Q = 8: 6 + 2; Q = 12: 10 + 2; "many + 1" loses 10 %
+            if (queues >= 4) {  // measured (profiles/r02_hw_queues.txt): Q = 4: 3 + 1 best; Q = 8: 6 + 2; Q = 12: 10 + 2; "many + 1" loses 10 %
                 bp->nas = bp->nas ? (queues >= 6 && bp->nas >= 2 ? 2 : 1) : 0;
                 bp->nl = queues - bp->nas;
             } else {
@@ -544,13 +544,6 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
                 bp->nl = queues > 0 ? queues : 1;
             }
             if (bp->nl > nl) bp->nl = nl;
-        }
-        if (const char *pl = getenv("KZG_PLAN")) {  // debugging aid: "lanes,accum"
-            int a = 0, b2 = 0;
-            if (sscanf(pl, "%d,%d", &a, &b2) == 2 && a >= 1 && a <= nl && b2 >= 0 && b2 <= ctx->opt_accum_streams) {
-                bp->nl = a;
-                bp->nas = b2;
-            }
         }
         // hand the probed streams out so that the ones this plan uses are on different queues: lanes first, accumulation
         // streams next; the others stay parked in the remaining probed slots
