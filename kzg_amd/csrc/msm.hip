@@ -4,7 +4,7 @@
 // src/eval_form.rs:118,136).  The result is the group element sum_i s_i * P_i; how it is computed
 // is free, so the structure below is chosen for the MI355X, not for the CPU the reference runs on:
 //
-//   * The SRS is resident in HBM as W rows (W = ceil(256/c); 15 at c = 17, the width used above 2^19 points), row w holding
+//   * The SRS is resident in HBM as W rows (W = ceil(256/c); 15 at c = 17, the width used from 2^17 points on), row w holding
 //     the affine points 2^(c*w) * P_i in the signed 30-bit representation the inner loop computes in (112 B per point,
 //     1.64 GiB for 2^20 points -- cheap in 288 GB); row 0 also in the canonical 96-byte form.
 //     Every signed c-bit digit of every scalar therefore lands in ONE shared set of 2^(c-1)
