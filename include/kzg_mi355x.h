@@ -200,6 +200,15 @@ int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int flags)
 /* coset_fft / icoset_fft (src/ft.rs:168-178): distribute_powers(g = 7) then fft; ifft then g^-i. */
 int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int sfmt, int flags);
 
+/* EvaluationDomain::z (src/ft.rs:182-187): tau^d - 1.  Host-only helper. */
+int kzg_domain_z(size_t d, const void *tau, int sfmt, void *out);
+/* EvaluationDomain::divide_by_z_on_coset (src/ft.rs:192-217): data[i] *= 1 / (7^d - 1), d = 2^log_n. */
+int kzg_divide_by_z_on_coset(kzg_ctx *ctx, void *data, uint32_t log_n, int sfmt, int flags);
+/* EvaluationDomain::mul_assign / sub_assign (src/ft.rs:220-271): a[i] *= b[i] / a[i] -= b[i], n elements each
+ * (KZG_IN_DEVICE: both resident). */
+int kzg_fr_vec_mul(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags);
+int kzg_fr_vec_sub(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags);
+
 /* ---- coefficient form (src/coeff_form.rs) ---------------------------------------------------- */
 /* KZGProver::commit (:59-64).  coeffs[0..n) = polynomial.slice_coeffs(); KZG_ERR_SHAPE if n > SRS. */
 int kzg_commit_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, int sfmt, int flags,

@@ -138,6 +138,20 @@ struct EvaluationDomain {  // src/ft.rs:17-25
     void ifft(const Engine &e) { e.check(kzg_ntt_fr(e.ctx(), coeffs.data(), exp, 1, 0)); }  // :115-140
     void coset_fft(const Engine &e) { e.check(kzg_coset_ntt_fr(e.ctx(), coeffs.data(), exp, 0, KZG_FR_CANONICAL_LE_32, 0)); }
     void icoset_fft(const Engine &e) { e.check(kzg_coset_ntt_fr(e.ctx(), coeffs.data(), exp, 1, KZG_FR_CANONICAL_LE_32, 0)); }
+    Scalar z(const Scalar &tau) const {  // :182-187
+        Scalar out;
+        if (kzg_domain_z(coeffs.size(), tau.le.data(), KZG_FR_CANONICAL_LE_32, out.le.data())) throw ReferencePanic("z");
+        return out;
+    }
+    void divide_by_z_on_coset(const Engine &e) { e.check(kzg_divide_by_z_on_coset(e.ctx(), coeffs.data(), exp, KZG_FR_CANONICAL_LE_32, 0)); }
+    void mul_assign(const Engine &e, const EvaluationDomain &o) {  // :220-244
+        if (o.coeffs.size() != coeffs.size()) throw ReferencePanic("assert_eq!(self.coeffs.len(), other.coeffs.len())");
+        e.check(kzg_fr_vec_mul(e.ctx(), coeffs.data(), o.coeffs.data(), coeffs.size(), KZG_FR_CANONICAL_LE_32, 0));
+    }
+    void sub_assign(const Engine &e, const EvaluationDomain &o) {  // :247-271
+        if (o.coeffs.size() != coeffs.size()) throw ReferencePanic("assert_eq!(self.coeffs.len(), other.coeffs.len())");
+        e.check(kzg_fr_vec_sub(e.ctx(), coeffs.data(), o.coeffs.data(), coeffs.size(), KZG_FR_CANONICAL_LE_32, 0));
+    }
 };
 
 struct KZGBatchWitness {  // src/coeff_form.rs:12-35

@@ -90,6 +90,10 @@ def load(path=None):
         "kzg_compute_omega": (i32, [sz, ctypes.POINTER(sz), ctypes.POINTER(u32), vp, i32]),
         "kzg_ntt_fr": (i32, [vp, vp, u32, i32, i32]),
         "kzg_coset_ntt_fr": (i32, [vp, vp, u32, i32, i32, i32]),
+        "kzg_domain_z": (i32, [sz, vp, i32, vp]),
+        "kzg_divide_by_z_on_coset": (i32, [vp, vp, u32, i32, i32]),
+        "kzg_fr_vec_mul": (i32, [vp, vp, vp, sz, i32, i32]),
+        "kzg_fr_vec_sub": (i32, [vp, vp, vp, sz, i32, i32]),
         "kzg_commit_coeff": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
         "kzg_witness_coeff": (i32, [vp, vp, vp, sz, vp, vp, i32, i32, vp, i32]),
         "kzg_witness_coeff_many": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, ctypes.POINTER(i32)]),

@@ -658,6 +658,34 @@ class EvaluationDomain:
     def icoset_fft(self, engine):  # :173-178
         self.coeffs = engine.coset_ntt(self.coeffs, self.exp, inverse=True)
 
+    def z(self, tau):  # :182-187
+        out = ctypes.create_string_buffer(32)
+        rc = L.load().kzg_domain_z(len(self.coeffs), (tau % R_MODULUS).to_bytes(32, "little"), L.FR_CANONICAL, out)
+        if rc:
+            _raise(None, rc)
+        return int.from_bytes(out.raw, "little")
+
+    def _vec(self, engine, fn, other=None):
+        buf = ctypes.create_string_buffer(pack_scalars(self.coeffs), 32 * len(self.coeffs))
+        if other is None:
+            rc = fn(engine.ctx, buf, self.exp, L.FR_CANONICAL, 0)
+        else:
+            if len(other.coeffs) != len(self.coeffs):
+                raise ReferencePanic("assert_eq!(self.coeffs.len(), other.coeffs.len())")
+            rc = fn(engine.ctx, buf, pack_scalars(other.coeffs), len(self.coeffs), L.FR_CANONICAL, 0)
+        if rc:
+            _raise(engine, rc)
+        self.coeffs = unpack_scalars(buf.raw)
+
+    def divide_by_z_on_coset(self, engine):  # :192-217
+        self._vec(engine, engine.lib.kzg_divide_by_z_on_coset)
+
+    def mul_assign(self, engine, other):  # :220-244
+        self._vec(engine, engine.lib.kzg_fr_vec_mul, other)
+
+    def sub_assign(self, engine, other):  # :247-271
+        self._vec(engine, engine.lib.kzg_fr_vec_sub, other)
+
 
 class KZGBatchWitness:
     """src/coeff_form.rs:12-35"""

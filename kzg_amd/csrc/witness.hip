@@ -477,3 +477,91 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     *out_r_len = k;
     return KZG_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// the remaining EvaluationDomain operations (src/ft.rs:180-271): z, divide_by_z_on_coset, mul_assign, sub_assign
+// ---------------------------------------------------------------------------------------------
+namespace kzg {
+__global__ __launch_bounds__(256) void k_scale_fr(Fr *a, Fr s, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] = mul(a[i], s);
+}
+// a[i] = a[i] * b[i] (op 0) or a[i] - b[i] (op 1).  Montgomery form only when multiplying: a product of two canonical values
+// would carry a stray 2^-256, so canonical operands are converted on the fly
+__global__ __launch_bounds__(256) void k_vec_op(Fr *a, const Fr *b, size_t n, int op, int canonical) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (op == 1) {
+        a[i] = sub(a[i], b[i]);
+    } else {
+        a[i] = canonical ? mul(a[i], to_mont(b[i])) : mul(a[i], b[i]);
+    }
+}
+}  // namespace kzg
+
+extern "C" int kzg_domain_z(size_t d, const void *tau, int sfmt, void *out) {
+    // EvaluationDomain::z (src/ft.rs:182-187): tau^d - 1.  Host-only.
+    if (!tau || !out) return KZG_ERR_SHAPE;
+    Fr t;
+    memcpy(t.v, tau, 32);
+    if (sfmt == KZG_FR_CANONICAL_LE_32) {
+        if (!is_canonical(t)) return KZG_ERR_SHAPE;
+        t = to_mont(t);
+    } else if (sfmt != KZG_FR_MONT_LE_32) {
+        return KZG_ERR_SHAPE;
+    }
+    Fr z = sub(pow_u64(t, (uint64_t)d), Fr::one());
+    if (sfmt == KZG_FR_CANONICAL_LE_32) z = from_mont(z);
+    memcpy(out, z.v, 32);
+    return KZG_OK;
+}
+
+static int vec_entry(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags, int op, const Fr *scale) {
+    std::lock_guard<std::mutex> g(ctx->mu);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
+    if (n > ((size_t)1 << 40)) return fail(ctx, KZG_ERR_SHAPE, "vector too long");
+    if (n == 0) return KZG_OK;
+    hipStream_t st = ctx->lanes[0].stream;
+    const bool dev = (flags & KZG_IN_DEVICE) != 0;
+    KZG_TRY(lane_reserve(ctx, 0, dev ? 4096 : 2 * n * 32 + 8192));
+    Fr *da = (Fr *)a, *db = (Fr *)b;
+    if (!dev) {
+        da = (Fr *)lane_alloc(ctx, 0, n * 32);
+        db = b ? (Fr *)lane_alloc(ctx, 0, n * 32) : nullptr;
+        if (!da || (b && !db)) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, st));
+        if (b) KZG_HIP_CHECK(ctx, hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, st));
+    }
+    if (scale) KZG_LAUNCH(ctx, st, "k_scale_fr", k_scale_fr, gridfor(n), 256, 0, da, *scale, n);
+    else KZG_LAUNCH(ctx, st, "k_vec_op", k_vec_op, gridfor(n), 256, 0, da, db, n, op, sfmt == KZG_FR_CANONICAL_LE_32);
+    if (!dev) KZG_HIP_CHECK(ctx, hipMemcpyAsync(a, da, n * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (ctx->prof) prof_collect(ctx);
+    return KZG_OK;
+}
+
+extern "C" int kzg_divide_by_z_on_coset(kzg_ctx *ctx, void *data, uint32_t log_n, int sfmt, int flags) {
+    // EvaluationDomain::divide_by_z_on_coset (src/ft.rs:192-217): every value times 1 / (g^d - 1), g = 7, d = 2^log_n.
+    // A multiplication by a Montgomery-form constant preserves whichever form the data is in.
+    if (!ctx || !data) return KZG_ERR_SHAPE;
+    if (log_n >= FR_TWO_ADICITY) {
+        std::lock_guard<std::mutex> g(ctx->mu);
+        return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    }
+    const size_t d = (size_t)1 << log_n;
+    const Fr zi = inv(sub(pow_u64(from_u64<FrParams>(FR_MULT_GENERATOR), (uint64_t)d), Fr::one()));
+    return vec_entry(ctx, data, nullptr, d, sfmt, flags, 0, &zi);
+}
+
+extern "C" int kzg_fr_vec_mul(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags) {
+    // EvaluationDomain::mul_assign (src/ft.rs:220-244); the length assert is the caller's (both vectors have n elements)
+    if (!ctx || (n && (!a || !b))) return KZG_ERR_SHAPE;
+    return vec_entry(ctx, a, b, n, sfmt, flags, 0, nullptr);
+}
+
+extern "C" int kzg_fr_vec_sub(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags) {
+    // EvaluationDomain::sub_assign (src/ft.rs:247-271)
+    if (!ctx || (n && (!a || !b))) return KZG_ERR_SHAPE;
+    return vec_entry(ctx, a, b, n, sfmt, flags, 1, nullptr);
+}

@@ -151,3 +151,51 @@ def test_fft_mul_polynomial_arith(engine):
     got, want = pa.best_mul(engine, pb), left.fft_mul(right)   # the reference keeps the zero-padded 2^k vector;
     assert got.degree == want.degree == 256                     # PartialEq = degree + zipped prefix (:29-40)
     assert got.slice_coeffs() == want.slice_coeffs()
+
+
+def test_evaluation_domain_remaining_ops(engine):
+    """EvaluationDomain::z / divide_by_z_on_coset / mul_assign / sub_assign (src/ft.rs:180-271) against the model, and the
+    workflow they exist for: with a = b * Z_H + c on the domain H, (coset values of a - c) / Z on the coset are b's coset values."""
+    rng = random.Random(31)
+    for log_n in (0, 3, 8, 13):
+        n = 1 << log_n
+        xs, ys = [rng.randrange(M.R) for _ in range(n)], [rng.randrange(M.R) for _ in range(n)]
+        for op in ("mul_assign", "sub_assign"):
+            e, o = kzg_amd.EvaluationDomain.from_coeffs(xs), kzg_amd.EvaluationDomain.from_coeffs(ys)
+            m, mo = M.EvaluationDomain.from_coeffs(xs), M.EvaluationDomain.from_coeffs(ys)
+            getattr(e, op)(engine, o)
+            getattr(m, op)(mo)
+            assert e.coeffs == m.coeffs, (op, log_n)
+        e, m = kzg_amd.EvaluationDomain.from_coeffs(xs), M.EvaluationDomain.from_coeffs(xs)
+        e.divide_by_z_on_coset(engine)
+        m.divide_by_z_on_coset()
+        assert e.coeffs == m.coeffs
+        tau = rng.randrange(M.R)
+        assert e.z(tau) == m.z(tau) == (pow(tau, n, M.R) - 1) % M.R
+    with pytest.raises(kzg_amd.ReferencePanic):     # assert_eq!(self.coeffs.len(), other.coeffs.len())
+        kzg_amd.EvaluationDomain.from_coeffs([1, 2]).mul_assign(engine, kzg_amd.EvaluationDomain.from_coeffs([1, 2, 3]))
+    # quotient by the vanishing polynomial of H through the coset: a(X) = b(X) (X^d - 1) + c(X), deg b, deg c < d
+    d = 64
+    b = [rng.randrange(M.R) for _ in range(d)]
+    c = [rng.randrange(M.R) for _ in range(d)]
+    a = [(c[i] - b[i]) % M.R for i in range(d)] + b            # b X^d - b + c
+    A = kzg_amd.EvaluationDomain.from_coeffs(a)                 # size 2d
+    Cc = kzg_amd.EvaluationDomain.from_coeffs(c + [0] * d)
+    A.coset_fft(engine)
+    Cc.coset_fft(engine)
+    A.sub_assign(engine, Cc)
+    # on the coset of the size-2d domain, X^d - 1 takes the values g^d w^(jd) - 1 = +-g^d - 1: divide pointwise
+    g, w = 7, kzg_amd.compute_omega(2 * d)[2]
+    A.coeffs = [v * pow((pow(g, d, M.R) * pow(w, j * d, M.R) - 1) % M.R, -1, M.R) % M.R for j, v in enumerate(A.coeffs)]
+    A.icoset_fft(engine)
+    assert A.coeffs == b + [0] * d
+    # device-resident vectors keep their form (Montgomery in, Montgomery out)
+    n = 1 << 10
+    xs, ys = [rng.randrange(M.R) for _ in range(n)], [rng.randrange(M.R) for _ in range(n)]
+    Rm = (1 << 256) % M.R
+    da = engine.alloc_scalars(n, kzg_amd.FR_MONT).upload(kzg_amd.pack_scalars([x * Rm % M.R for x in xs]))
+    db = engine.alloc_scalars(n, kzg_amd.FR_MONT).upload(kzg_amd.pack_scalars([y * Rm % M.R for y in ys]))
+    rc = engine.lib.kzg_fr_vec_mul(engine.ctx, da.ptr, db.ptr, n, kzg_amd.FR_MONT, kzg_amd.IN_DEVICE)
+    assert rc == 0
+    assert kzg_amd.unpack_scalars(da.download()) == [x * y % M.R * Rm % M.R for x, y in zip(xs, ys)]
+    da.free(); db.free()
