@@ -177,7 +177,8 @@ void kzg_msrs_free(kzg_mctx *m, kzg_msrs *srs);
 /* KZGProver::commit over the group (src/coeff_form.rs:59-64).  coeffs: the whole polynomial (n scalars, host), every rank
  * reads its slice; with KZG_IN_DEVICE `coeffs` is instead an array of kzg_mctx_local_count() device pointers, entry i
  * pointing at local GPU i's slice ([hi - lo] scalars, resident in that GPU's HBM).  out: one point (host), on every rank.
- * KZG_ERR_SHAPE if n > kzg_msrs_len (the slice index panic). */
+ * KZG_ERR_SHAPE if n > kzg_msrs_len (the slice index panic).  (This is the sharded multi_exp: with a Lagrange-basis SRS
+ * uploaded through kzg_srs_upload_g1_sharded it is KZGProverEvalForm::commit, src/eval_form.rs:114-122, as well.) */
 int kzg_commit_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, int sfmt, int flags, void *out,
                              int ofmt);
 /* `batch` polynomials of n coefficients each (host: contiguous, stride n * 32 B; KZG_IN_DEVICE: per local GPU a
