@@ -304,6 +304,8 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_streams") {
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
+    } else if (k == "sort_single_pass") {
+        ctx->opt_sort_single = value != 0;
     } else if (k == "tail_quads") {
         ctx->opt_tail_quads = value != 0;
         ctx->cur_tail_quads = ctx->opt_tail_quads;

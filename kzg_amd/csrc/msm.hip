@@ -334,6 +334,265 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// two-level counting sort for the production width (c = 17, 2^16 buckets = 1024 bins of 64)
+// ---------------------------------------------------------------------------------------------
+// The single-pass scatter above writes every 4-byte entry to its own 32-byte sector: 256 producer blocks x 2^16 buckets leave
+// about one entry per (block, bucket), so the stores are 8x write-amplified (PMC: 504 MB written for 63 MB of entries) and the
+// per-(block, bucket) counters are another 2 x 64 MB.  Two levels keep every store stream sequential:
+//   level 1  k_bin_hist / k_bin_scan / k_bin_scatter: by the high 10 bucket bits.  Each sort block appends (entry, low 6 bits)
+//            records to 1024 runs of ~30-60 records; a run's stores hit consecutive addresses and merge in the L2.
+//   level 2  k_bin_sort: one block per bin counts its 64 buckets in LDS, then places the bin's records: all stores of a block
+//            land in the bin's own <= few-hundred-KB range.
+// The bucket sizes come out of level 2 (total[]), bin_base[] is the exclusive scan of the bin sizes = the bucket starts of every
+// 64th bucket, so k_scan_b needs no cross-block pass for the starts.
+constexpr int BIN_SHIFT = 6, BIN_BUCKETS = 1 << BIN_SHIFT, NBINS = 1024;
+
+__global__ __launch_bounds__(1024) void k_bin_hist(const Fr *scalars, size_t n, int sfmt, size_t per_block, uint32_t *blk_bins,
+                                                   int w_lo, int w_hi) {
+    __shared__ uint32_t h[NBINS];
+    for (int b = threadIdx.x; b < NBINS; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    size_t i0 = (size_t)blockIdx.x * per_block;
+    size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint32_t s[8];
+        load_scalar(scalars, i, sfmt, s);
+        for_each_digit_fixed<17, 15>(s, true, [&](int w, uint32_t mag, uint32_t) {
+            if (w < w_lo || w >= w_hi) return;
+            atomicAdd(&h[(mag - 1) >> BIN_SHIFT], 1u);
+        });
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NBINS; b += blockDim.x) blk_bins[(size_t)blockIdx.x * NBINS + b] = h[b];
+}
+
+// exclusive scan of one value per thread over a 1024-thread block; *total_out = the block sum
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *wsum /* 16 words of LDS */, uint32_t *total_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t u = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += u;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) {
+        uint32_t u = wsum[w];
+        if (w < wave) woff += u;
+        tot += u;
+    }
+    __syncthreads();
+    *total_out = tot;
+    return incl - v + woff;
+}
+
+// per bin: exclusive scan over the sort blocks' counts (in place) and the bin size.  Block q owns bins [64 q, 64 q + 64); its 16
+// waves each take a slice of the sort blocks (<= 32 counters per thread, loaded in one batch), the slices are chained through LDS.
+constexpr int BIN_SCAN_SLICES = 16, BIN_SCAN_MAXG = 32;
+__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *blk_bins, int G, uint32_t *bin_total, uint32_t *ready) {
+    __shared__ uint32_t part[BIN_SCAN_SLICES][64];
+    if (blockIdx.x == 0 && threadIdx.x < SCAN_SEG) ready[threadIdx.x] = 0;  // k_scan_b's chained flag counts
+    const int binl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int bin = blockIdx.x * 64 + binl;
+    const int gs = (G + BIN_SCAN_SLICES - 1) / BIN_SCAN_SLICES;  // <= BIN_SCAN_MAXG (G <= 512)
+    const int g0 = slice * gs;
+    uint32_t v[BIN_SCAN_MAXG];
+#pragma unroll
+    for (int k = 0; k < BIN_SCAN_MAXG; k++) v[k] = (k < gs && g0 + k < G) ? blk_bins[(size_t)(g0 + k) * NBINS + bin] : 0u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < BIN_SCAN_MAXG; k++) {
+        const uint32_t t = v[k];
+        v[k] = sum;
+        sum += t;
+    }
+    part[slice][binl] = sum;
+    __syncthreads();
+    uint32_t pre = 0, tot = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < BIN_SCAN_SLICES; s2++) {
+        const uint32_t t = part[s2][binl];
+        if (s2 < slice) pre += t;
+        tot += t;
+    }
+#pragma unroll
+    for (int k = 0; k < BIN_SCAN_MAXG; k++)
+        if (k < gs && g0 + k < G) blk_bins[(size_t)(g0 + k) * NBINS + bin] = pre + v[k];
+    if (slice == 0) bin_total[bin] = tot;
+}
+
+// Level 1.  A block takes its scalars in chunks of 1024 (one per thread).  Per chunk the <= 15 K records are first sorted by bin
+// inside the LDS (count -> scan -> place, one packed word per record), then written out in that order: a wave's 64 stores
+// cover ~4 runs of ~15 consecutive records instead of 64 unrelated addresses, so the L2 sees ~7x fewer write requests.
+// packed word: bin (10) | low 6 bucket bits (6) | sign (1) | window - w_lo (4) | thread = scalar index in the chunk (10)
+constexpr int BIN_SCATTER_LDS = (3 * NBINS + 16 + 15 * 1024) * 4;
+__global__ __launch_bounds__(1024) void k_bin_scatter(const Fr *scalars, size_t n, int sfmt, size_t per_block, const uint32_t *blk_off,
+                                                      const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
+                                                      uint32_t idx_base, uint2 *rec, int w_lo, int w_hi) {
+    uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS, *stage = wsum + 16;
+    const uint32_t tid = threadIdx.x;
+    {   // bin_base = exclusive scan of the bin sizes (every block computes it; block 0 publishes it for the later kernels)
+        uint32_t tot;
+        const uint32_t ex = block_scan_1024(bin_total[tid], wsum, &tot);
+        cur[tid] = ex + blk_off[(size_t)blockIdx.x * NBINS + tid];
+        if (blockIdx.x == 0) {
+            bin_base[tid] = ex;
+            if (tid == 0) bin_base[NBINS] = tot;
+        }
+    }
+    const size_t i0 = (size_t)blockIdx.x * per_block;
+    const size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t c0 = i0; c0 < i1; c0 += 1024) {
+        cnt[tid] = 0;
+        __syncthreads();
+        uint32_t pk[15], rk[15];
+#pragma unroll
+        for (int w = 0; w < 15; w++) pk[w] = 0xffffffffu;
+        if (c0 + tid < i1) {
+            uint32_t s[8];
+            load_scalar(scalars, c0 + tid, sfmt, s);
+            for_each_digit_fixed<17, 15>(s, true, [&](int w, uint32_t mag, uint32_t neg) {
+                if (w < w_lo || w >= w_hi) return;
+                const uint32_t idx = mag - 1, bin = idx >> BIN_SHIFT;
+                rk[w] = atomicAdd(&cnt[bin], 1u);
+                pk[w] = bin | ((idx & (BIN_BUCKETS - 1)) << 10) | (neg << 16) | ((uint32_t)(w - w_lo) << 17) | (tid << 21);
+            });
+        }
+        __syncthreads();
+        uint32_t tot;
+        off[tid] = block_scan_1024(cnt[tid], wsum, &tot);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 15; w++)
+            if (pk[w] != 0xffffffffu) stage[off[pk[w] & (NBINS - 1)] + rk[w]] = pk[w];
+        __syncthreads();
+        const uint32_t ebase = idx_base + (uint32_t)c0;
+        for (uint32_t p = tid; p < tot; p += 1024) {
+            const uint32_t v = stage[p], bin = v & (NBINS - 1);
+            const uint32_t entry = (((v >> 17) & 15u) * row_stride + ebase + (v >> 21)) | (((v >> 16) & 1u) << 31);
+            rec[cur[bin] + p - off[bin]] = make_uint2(entry, (v >> 10) & (BIN_BUCKETS - 1));
+        }
+        __syncthreads();
+        cur[tid] += cnt[tid];
+    }
+}
+
+// Level 2.  block = bin: bucket sizes -> total[], then the records -> entries[] in bucket order (order inside a bucket is
+// arbitrary, as before), again chunk-sorted in LDS first so that each bucket's share of a chunk is one run of stores.
+constexpr int BIN_SORT_THREADS = 256, BIN_SORT_UNROLL = 8, BIN_SORT_CHUNK = BIN_SORT_THREADS * BIN_SORT_UNROLL;
+__global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const uint2 *rec, const uint32_t *bin_base, uint32_t *entries,
+                                                               uint32_t *total) {
+    __shared__ uint32_t h[BIN_BUCKETS], cur[BIN_BUCKETS], off[BIN_BUCKETS];
+    __shared__ uint2 stage[BIN_SORT_CHUNK];
+    const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
+    if (threadIdx.x < BIN_BUCKETS) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t base = r0 + threadIdx.x; base < r1; base += BIN_SORT_CHUNK) {
+        uint32_t lo[BIN_SORT_UNROLL];
+#pragma unroll
+        for (int k = 0; k < BIN_SORT_UNROLL; k++) {
+            const uint32_t r = base + (uint32_t)k * BIN_SORT_THREADS;
+            lo[k] = r < r1 ? rec[r].y : 0xffffffffu;
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_SORT_UNROLL; k++)
+            if (lo[k] != 0xffffffffu) atomicAdd(&h[lo[k]], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < BIN_BUCKETS) {  // one wave
+        const uint32_t v = h[threadIdx.x];
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t u = __shfl_up(incl, o, 64);
+            if ((int)threadIdx.x >= o) incl += u;
+        }
+        total[(size_t)blockIdx.x * BIN_BUCKETS + threadIdx.x] = v;
+        cur[threadIdx.x] = r0 + incl - v;
+    }
+    for (uint32_t c0 = r0; c0 < r1; c0 += BIN_SORT_CHUNK) {
+        if (threadIdx.x < BIN_BUCKETS) h[threadIdx.x] = 0;
+        __syncthreads();
+        uint2 e[BIN_SORT_UNROLL];
+        uint32_t rk[BIN_SORT_UNROLL];
+#pragma unroll
+        for (int k = 0; k < BIN_SORT_UNROLL; k++) {
+            const uint32_t r = c0 + threadIdx.x + (uint32_t)k * BIN_SORT_THREADS;
+            e[k] = r < r1 ? rec[r] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int k = 0; k < BIN_SORT_UNROLL; k++)
+            if (e[k].y != 0xffffffffu) rk[k] = atomicAdd(&h[e[k].y], 1u);
+        __syncthreads();
+        if (threadIdx.x < BIN_BUCKETS) {
+            const uint32_t v = h[threadIdx.x];
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                uint32_t u = __shfl_up(incl, o, 64);
+                if ((int)threadIdx.x >= o) incl += u;
+            }
+            off[threadIdx.x] = incl - v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BIN_SORT_UNROLL; k++)
+            if (e[k].y != 0xffffffffu) stage[off[e[k].y] + rk[k]] = e[k];
+        __syncthreads();
+        const uint32_t m = r1 - c0 < (uint32_t)BIN_SORT_CHUNK ? r1 - c0 : (uint32_t)BIN_SORT_CHUNK;
+        for (uint32_t p = threadIdx.x; p < m; p += BIN_SORT_THREADS) {
+            const uint2 v = stage[p];
+            entries[cur[v.y] + p - off[v.y]] = v.x;
+        }
+        __syncthreads();
+        if (threadIdx.x < BIN_BUCKETS) cur[threadIdx.x] += h[threadIdx.x];
+    }
+}
+
+// k_scan_b for the two-level sort: block j's first bucket starts at bin_base[4 j], M = bin_base[NBINS]
+__global__ __launch_bounds__(SCAN_SEG) void k_scan_b_bins(const uint32_t *total, const uint32_t *bin_base, int B, int NB,
+                                                          uint32_t *bucket_start, uint32_t *s1, MsmState *st, uint32_t slots,
+                                                          uint32_t *ready) {
+    __shared__ uint32_t lds[4];
+    const uint32_t M = bin_base[NBINS];
+    const uint32_t my_prefix = bin_base[blockIdx.x * (SCAN_SEG / BIN_BUCKETS)];
+    uint32_t E = (M + slots - 1) / slots;
+    if (E < 8) E = 8;
+    const double rcp_e = 1.0 / (double)E;
+    const int b = blockIdx.x * SCAN_SEG + threadIdx.x;
+    const uint32_t cnt = b < B ? total[b] : 0u;
+    uint32_t btot;
+    const uint32_t start = my_prefix + block_scan_256(cnt, lds, &btot);
+    const uint32_t f = (cnt != 0 && mod_u32(start, E, rcp_e) != 0) ? 1u : 0u;
+    uint32_t ftot;
+    const uint32_t fex = block_scan_256(f, lds, &ftot);
+    if (threadIdx.x == 0) __hip_atomic_store(&ready[blockIdx.x], (ftot << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t prev = 0;
+    if (threadIdx.x < blockIdx.x) {
+        uint32_t w;
+        while (((w = __hip_atomic_load(&ready[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 1u) == 0) __builtin_amdgcn_s_sleep(1);
+        prev = w >> 1;
+    }
+    uint32_t before;
+    block_scan_256(prev, lds, &before);
+    if (b < B) {
+        bucket_start[b] = start;
+        s1[b] = before + fex + (start + E - 1) / E;
+    }
+    if (blockIdx.x == (unsigned)NB - 1 && threadIdx.x == 0) {
+        bucket_start[B] = M;
+        s1[B] = before + ftot + (M + E - 1) / E;
+        st->M = M;
+        st->E = E;
+        st->ntasks = (M + E - 1) / E;
+        st->ovf_tasks = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // accumulation rounds
 // ---------------------------------------------------------------------------------------------
 // table30 entry: G1Affine30 = 2 x 13 limbs + pad = KZG_ROW_BYTES (112 B = 7 x 16 B by default); the 7 x 16 B that hold the
@@ -564,11 +823,20 @@ static int sort_blocks(size_t n) {
     return (int)g;
 }
 
+// level 1 of the two-level sort keeps 1024 cursors in LDS, so two blocks fit a CU
+static int sort2_blocks(size_t n) {
+    size_t g = (n + 2047) / 2048;
+    if (g < 1) g = 1;
+    if (g > 512) g = 512;
+    return (int)g;
+}
+
 size_t sum_points_scratch_count(size_t count) { return (count + SUM_L - 1) / SUM_L + 64; }
 
 struct MsmLayout {
-    int B, G;
+    int B, G, G2;
     size_t M_max, T1_max;
+    size_t off_bins, off_bin_base;
     size_t off_blk_hist, off_total, off_local, off_agg, off_bucket_start, off_s1, off_state, off_entries, off_bufA, off_bufB, off_tail,
         off_pass, bytes;
     TailLayout tail;
@@ -586,7 +854,14 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
         o = align_up(o + bytes, 256);
         return r;
     };
-    L.off_blk_hist = take((size_t)L.G * L.B * 4);
+    // c = 17: the region holds either the per-(block, bucket) counters of the single-pass sort or the level-1 records of the
+    // two-level sort (8 B per entry), whichever the context runs
+    L.G2 = sort2_blocks(n);
+    size_t sort_bytes = (size_t)L.G * L.B * 4;
+    if (srs->narrow17 && L.M_max * 8 > sort_bytes) sort_bytes = L.M_max * 8;
+    L.off_blk_hist = take(sort_bytes);
+    L.off_bins = take((size_t)L.G2 * NBINS * 4);
+    L.off_bin_base = take((2 * NBINS + 1) * 4);  // bin starts, then bin sizes
     L.off_total = take((size_t)L.B * 4);
     L.off_local = take((size_t)L.B * 4);
     L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
@@ -671,6 +946,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     if (!ctx->attr_msm_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
         ctx->attr_msm_set = true;
     }
     const int B_lo = L.B_lo, Btot = L.Btot, nhi = L.nhi, G = L.G, c = srs->c, W = srs->W;
@@ -759,6 +1035,7 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     if (!ctx->attr_msm_set) {  // per context (= per device): the LDS opt-in is a per-device function attribute
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
         ctx->attr_msm_set = true;
     }
     const int B = L.B, G = L.G, c = srs->c, W = srs->W;
@@ -782,12 +1059,29 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
     for (int p = 0; p < passes; p++) {
         const int w_lo = p * rows, w_hi = (p + 1) * rows < W ? (p + 1) * rows : W;
-        KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode, w_lo, w_hi);
-        // s1[0 .. B] = per-bucket start offsets of the round-1 output list
-        KZG_TRY(scan_run(ctx, st, blk_hist, G, B, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), bucket_start, s1,
-                         state, slots));
-        KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
-                   bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode, w_lo, w_hi);
+        if (srs->narrow17 && !ctx->opt_sort_single) {
+            const int G2 = L.G2;
+            const size_t per2 = (n + G2 - 1) / G2;
+            uint32_t *bins = (uint32_t *)(base + L.off_bins), *bin_base = (uint32_t *)(base + L.off_bin_base);
+            uint32_t *ready = (uint32_t *)(base + L.off_agg) + SCAN_SEG;
+            uint2 *rec = (uint2 *)blk_hist;
+            KZG_LAUNCH(ctx, st, "k_bin_hist", k_bin_hist, G2, 1024, 0, sc, n, sfmt, per2, bins, w_lo, w_hi);
+            uint32_t *bin_total = bin_base + NBINS + 1;
+            KZG_LAUNCH(ctx, st, "k_bin_scan", k_bin_scan, NBINS / 64, 1024, 0, bins, G2, bin_total, ready);
+            KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total, bin_base,
+                       (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
+            KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+            KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
+                       state, slots, ready);
+        } else {
+            KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode, w_lo,
+                       w_hi);
+            // s1[0 .. B] = per-bucket start offsets of the round-1 output list
+            KZG_TRY(scan_run(ctx, st, blk_hist, G, B, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), bucket_start,
+                             s1, state, slots));
+            KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
+                       bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode, w_lo, w_hi);
+        }
         hipStream_t as = st;
         if (accum_stream && accum_stream != st) {
             KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
