@@ -209,8 +209,11 @@ def test_wide_windows(engine, wb):
             "around_2^254": [((1 << 254) + d) % R for d in (-2, -1, 0, 1, 2, (1 << 237), -(1 << 237))] * (n // 7) + [R - 2] * (n % 7),
             "top_window_max": [((1 << 254) - 1) - (i % 3)  for i in range(n)],
         }
-        for name, sc in cases.items():
-            assert engine.msm(params.gs, sc) == want(sc), (wb, name)
+        for single_pass in ((0, 1) if wb == 17 else (0,)):   # 17: the two-level sort (default) and the single-pass one
+            engine.set_option("sort_single_pass", single_pass)
+            for name, sc in cases.items():
+                assert engine.msm(params.gs, sc) == want(sc), (wb, name, single_pass)
+        engine.set_option("sort_single_pass", 0)
         sub = cases["random"][:5000]
         assert engine.msm(params.gs, sub, offset=12345) == want(sub, 12345)
         assert engine.msm(params.gs, [], n=0) == bytes(96)
@@ -219,6 +222,7 @@ def test_wide_windows(engine, wb):
         assert got == [want(b) for b in batch]
         params.gs.free()
     finally:
+        engine.set_option("sort_single_pass", 0)
         engine.set_option("window_bits", 0)
 
 

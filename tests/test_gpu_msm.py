@@ -221,6 +221,33 @@ def test_msm_batch_pipeline_paths(engine):
     srs.free()
 
 
+@pytest.mark.parametrize("single_pass", [0, 1])
+def test_c17_sort_ragged_sizes(engine, single_pass):
+    """The production window width (c = 17, chosen by option at a small size) over ragged term counts around the chunk sizes of
+    the two-level sort (1024 scalars per level-1 chunk, 2048 records per level-2 chunk, one sort block per 2048 scalars), with
+    uniform, all-equal (every record of a window in one bin), zero and r - 1 scalars; both sort implementations."""
+    rng = random.Random(17 + single_pass)
+    n = 6200
+    engine.set_option("window_bits", 17)
+    engine.set_option("sort_single_pass", single_pass)
+    try:
+        params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+        assert params.gs.window_info() == (17, 15)
+        G = C.g1_generator()
+        for k in (1, 2, 63, 64, 1023, 1024, 1025, 2047, 2048, 2049, 4097, 6200):
+            for sc in (rand_scalars(rng, k), [rng.randrange(M.R)] * k, [M.R - 1] * k):
+                assert engine.msm(params.gs, sc) == C.g1_mul(G, C.poly_eval(sc, TAU)), (k, single_pass)
+        assert engine.msm(params.gs, [0] * 3000) == bytes(96)
+        sub = rand_scalars(rng, 2100)
+        off = 4000
+        want = C.g1_mul(G, C.poly_eval(sub, TAU) * pow(TAU, off, M.R) % M.R)
+        assert engine.msm(params.gs, sub, offset=off) == want
+        params.gs.free()
+    finally:
+        engine.set_option("sort_single_pass", 0)
+        engine.set_option("window_bits", 0)
+
+
 def test_sharded_srs_partials_sum_to_full_commit(engine):
     """Multi-GPU data path on one GPU: 4 contiguous SRS shards (kzg_srs_setup_g1_shard), one partial MSM
     each, kzg_g1_sum of the partials == commit against the full SRS == [p(tau)]G."""
