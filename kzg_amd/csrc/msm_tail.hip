@@ -372,7 +372,9 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     if (ctx->cur_tail_quads) {
         // one MSM alone on the GPU: the two depth-bound kernels run four lanes per point operation.  (Fold and row / column
         // sums are bound by their ~2 additions per bucket, not by depth: quads were measured slower there, 0.25 against 0.07 ms
-        // and 0.17 against 0.14 ms at c = 17.)
+        // and 0.17 against 0.14 ms at c = 17: a quad addition takes ~10 us against 16 for one lane, so a row sum by 32 or 64
+        // quads -- 8 or 4 sequential additions + 6 levels -- loses to one wave's 3 + 6.  Two one-lane waves per row sum, 1 + 6 + 1
+        // deep, measured 0.20 ms: the dispatcher does not put the 1024 waves on 1024 different SIMDs.)
         KZG_LAUNCH(ctx, st, "k_weighted_bits", k_weighted_bits_q, lr + lc + 1, 256, 0, rows, cols, lr, lc, Q);
         KZG_LAUNCH(ctx, st, "k_reduce_final", k_reduce_final_q, 1, 128, 0, Q, lr, lc, result);
     } else {
