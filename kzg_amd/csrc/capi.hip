@@ -137,11 +137,10 @@ static int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out,
         KZG_TRY(emit_point(ctx, lane, d_pt, out, ofmt));
         KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     } else {
-        void *d = lane_alloc(ctx, lane, 256);
-        if (!d) return fail(ctx, KZG_ERR_ALLOC, "output staging not reserved");
-        KZG_TRY(emit_point(ctx, lane, d_pt, d, ofmt));
+        // the kernel writes the <= 144 bytes straight into the lane's pinned host buffer (device-mapped, coherent): no copy
+        // command on the way out
         KZG_TRY(lane_pinned(ctx, lane, 4096));
-        KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned, d, psz, hipMemcpyDeviceToHost, st));
+        KZG_TRY(emit_point(ctx, lane, d_pt, ctx->lanes[lane].pinned, ofmt));
         KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
         memcpy(out, ctx->lanes[lane].pinned, psz);
     }

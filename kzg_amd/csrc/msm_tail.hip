@@ -125,6 +125,28 @@ __global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, 
     if (lane == 0) (wv < Rn ? rows[wv] : cols[wv - Rn]) = acc;
 }
 
+// Throughput form of k_rc_sums for the batched pipeline, where lane-time counts and depth does not: RC_LANES lanes per row /
+// column sum, each adding Cn / RC_LANES points in sequence before a log2(RC_LANES)-level butterfly -- 35 wave-additions per 8
+// sums instead of 72 (a butterfly level costs a full addition for half the useful work of the level before).
+constexpr int RC_LANES = 8;
+__global__ __launch_bounds__(256) void k_rc_sums_t(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int sum = gid / RC_LANES, l = gid % RC_LANES;
+    if (sum >= Rn + Cn) return;  // uniform over the lane group
+    MsmPoint acc = MsmPoint::infinity();
+    if (sum < Rn) {
+        const MsmPoint *row = dense + (size_t)sum * Cn;
+#pragma nounroll
+        for (int c = l; c < Cn; c += RC_LANES) acc = g1_add30(acc, row[c]);
+    } else {
+        const MsmPoint *col = dense + (sum - Rn);
+#pragma nounroll
+        for (int r = l; r < Rn; r += RC_LANES) acc = g1_add30(acc, col[(size_t)r * Cn]);
+    }
+    acc = butterfly_sum<RC_LANES>(acc);
+    if (l == 0) (sum < Rn ? rows[sum] : cols[sum - Rn]) = acc;
+}
+
 // Q[j] (j < lr): sum of rows whose index has bit j set; Q[lr + j] (j < lc): the same for the columns; Q[lr + lc]: all columns
 __global__ __launch_bounds__(256) void k_weighted_bits(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
     const int lane = threadIdx.x & 63;
@@ -354,9 +376,15 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     int Rn, Cn, lr, lc;
     tail_shape(B, &Rn, &Cn, &lr, &lc);
     // lane-group width: twice the expected partials per bucket still fit FOLD_SEQ sequential additions per lane 4 times over
+    // (batched pipeline: one lane per bucket as long as the expected run fits its FOLD_SEQ sequential additions twice over --
+    // a butterfly level is a full addition for every lane of the group, wasted lane-time when depth does not matter)
     size_t avg = expected_partials / (size_t)B + 1;
     int G = 1;
-    while (G < 64 && (size_t)G * 2 < avg) G *= 2;
+    if (ctx->cur_tail_quads) {
+        while (G < 64 && (size_t)G * 2 < avg) G *= 2;
+    } else {
+        while (G < 64 && (size_t)G * (FOLD_SEQ / 2) < avg) G *= 2;
+    }
     const int wpb = TAIL_THREADS / 64;
     const unsigned grid = (unsigned)(((size_t)B * G + TAIL_THREADS - 1) / TAIL_THREADS);
 #define KZG_FOLD(GG)                                                                                                      \
@@ -368,7 +396,11 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     }
 #undef KZG_FOLD
     KZG_LAUNCH(ctx, st, "k_fold_overflow", k_fold_overflow, 256, TAIL_THREADS, 0, part, scratch, s1, dense, state, tasks, arrive);
-    KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums, (Rn + Cn + wpb - 1) / wpb, TAIL_THREADS, 0, dense, Rn, Cn, rows, cols);
+    if (!ctx->cur_tail_quads && Rn >= RC_LANES && Cn >= RC_LANES) {
+        KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums_t, ((Rn + Cn) * RC_LANES + 255) / 256, 256, 0, dense, Rn, Cn, rows, cols);
+    } else {
+        KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums, (Rn + Cn + wpb - 1) / wpb, TAIL_THREADS, 0, dense, Rn, Cn, rows, cols);
+    }
     if (ctx->cur_tail_quads) {
         // one MSM alone on the GPU: the two depth-bound kernels run four lanes per point operation.  (Fold and row / column
         // sums are bound by their ~2 additions per bucket, not by depth: quads were measured slower there, 0.25 against 0.07 ms
