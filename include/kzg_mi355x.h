@@ -100,7 +100,9 @@ const char *kzg_last_error(kzg_ctx *ctx);
 int kzg_sync(kzg_ctx *ctx);
 /* tunables: "window_bits" (0 = auto, 4..20), "window_rows" (0 = one table row per window; applies to SRSs created afterwards),
  * "trusted_points" (0 / 1), "streams" (1..16: batch pipelining depth), "accum_streams" (0..4), "accum_blocks[_batch]",
- * "sort_threads[_batch]", "ntt_vec_log"; unknown keys -> KZG_ERR_SHAPE */
+ * "sort_threads[_batch]", "ntt_vec_log", "hw_queues" (0 = measure), "tail_quads" (0 / 1: latency-mode tail kernels of a
+ * lone MSM), "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only);
+ * unknown keys -> KZG_ERR_SHAPE */
 int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value);
 
 /* ---- SRS (KZGParams.gs, src/lib.rs:14-19; lagrange_basis_g, src/eval_form.rs:40-46) --------- */

@@ -40,8 +40,9 @@ def rand_scalar(kind):
 
 
 while time.time() < t_end:
-    wb = rng.choice([0, 0, 0, 4, 7, 9, 12, 13, 16, 17, 18, 19, 20])
+    wb = rng.choice([0, 0, 0, 4, 7, 9, 12, 13, 16, 17, 17, 17, 18, 19, 20])
     e.set_option("window_bits", wb)
+    e.set_option("sort_single_pass", rng.choice([0, 0, 1]))  # c = 17: two-level sort (default) / single-pass sort
     rows = rng.choice([0, 0, 0, 1, 2, 3, 5, 11])            # low-memory SRS: multi-pass MSM
     e.set_option("window_rows", rows)
     e.set_option("tail_quads", rng.randrange(2))             # latency-mode tail kernels on / off
@@ -178,6 +179,7 @@ while time.time() < t_end:
         fails += 1
         print("NTT MISMATCH", dict(log_n=log_n, seed=seed), flush=True)
 e.set_option("window_bits", 0)
+e.set_option("sort_single_pass", 0)
 group.close()
 print("fuzz done", cases, "failures:", fails, flush=True)
 sys.exit(1 if fails else 0)
