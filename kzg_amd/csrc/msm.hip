@@ -424,14 +424,36 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *blk_bins, int G, ui
     if (slice == 0) bin_total[bin] = tot;
 }
 
+// Level-1 record = (entry word, low 6 bucket bits).  Two encodings: 8 bytes (uint2) in general; 4 bytes when the table index
+// fits 25 bits (table rows x points <= 2^25, i.e. up to 2^21 points with 15 rows): index | sign << 25 | low bits << 26 --
+// half the record traffic of both levels.
+struct Rec8 {
+    typedef uint2 T;
+    static __device__ __forceinline__ T pack(uint32_t index, uint32_t neg, uint32_t lo) { return make_uint2(index | (neg << 31), lo); }
+    static __device__ __forceinline__ uint32_t entry(const T &r) { return r.x; }
+    static __device__ __forceinline__ uint32_t lo(const T &r) { return r.y; }
+    static __device__ __forceinline__ T invalid() { return make_uint2(0u, 0xffffffffu); }
+    static __device__ __forceinline__ bool valid(const T &r) { return r.y != 0xffffffffu; }
+};
+struct Rec4 {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T pack(uint32_t index, uint32_t neg, uint32_t lo) { return index | (neg << 25) | (lo << 26); }
+    static __device__ __forceinline__ uint32_t entry(const T &r) { return (r & 0x1ffffffu) | (((r >> 25) & 1u) << 31); }
+    static __device__ __forceinline__ uint32_t lo(const T &r) { return r >> 26; }
+    static __device__ __forceinline__ T invalid() { return 0xffffffffu; }  // index 2^25 - 1 with sign and lo = 63: never packed (index < 2^25 - 1)
+    static __device__ __forceinline__ bool valid(const T &r) { return r != 0xffffffffu; }
+};
+constexpr uint64_t REC4_MAX_INDEX = (1ull << 25) - 1;  // exclusive bound on table rows x padded points for Rec4
+
 // Level 1.  A block takes its scalars in chunks of 1024 (one per thread).  Per chunk the <= 15 K records are first sorted by bin
 // inside the LDS (count -> scan -> place, one packed word per record), then written out in that order: a wave's 64 stores
 // cover ~4 runs of ~15 consecutive records instead of 64 unrelated addresses, so the L2 sees ~7x fewer write requests.
 // packed word: bin (10) | low 6 bucket bits (6) | sign (1) | window - w_lo (4) | thread = scalar index in the chunk (10)
 constexpr int BIN_SCATTER_LDS = (3 * NBINS + 16 + 15 * 1024) * 4;
+template <class REC>
 __global__ __launch_bounds__(1024) void k_bin_scatter(const Fr *scalars, size_t n, int sfmt, size_t per_block, const uint32_t *blk_off,
                                                       const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
-                                                      uint32_t idx_base, uint2 *rec, int w_lo, int w_hi) {
+                                                      uint32_t idx_base, typename REC::T *rec, int w_lo, int w_hi) {
     uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS, *stage = wsum + 16;
     const uint32_t tid = threadIdx.x;
     {   // bin_base = exclusive scan of the bin sizes (every block computes it; block 0 publishes it for the later kernels)
@@ -472,8 +494,8 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const Fr *scalars, size_t 
         const uint32_t ebase = idx_base + (uint32_t)c0;
         for (uint32_t p = tid; p < tot; p += 1024) {
             const uint32_t v = stage[p], bin = v & (NBINS - 1);
-            const uint32_t entry = (((v >> 17) & 15u) * row_stride + ebase + (v >> 21)) | (((v >> 16) & 1u) << 31);
-            rec[cur[bin] + p - off[bin]] = make_uint2(entry, (v >> 10) & (BIN_BUCKETS - 1));
+            const uint32_t index = ((v >> 17) & 15u) * row_stride + ebase + (v >> 21);
+            rec[cur[bin] + p - off[bin]] = REC::pack(index, (v >> 16) & 1u, (v >> 10) & (BIN_BUCKETS - 1));
         }
         __syncthreads();
         cur[tid] += cnt[tid];
@@ -483,23 +505,25 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const Fr *scalars, size_t 
 // Level 2.  block = bin: bucket sizes -> total[], then the records -> entries[] in bucket order (order inside a bucket is
 // arbitrary, as before), again chunk-sorted in LDS first so that each bucket's share of a chunk is one run of stores.
 constexpr int BIN_SORT_THREADS = 256, BIN_SORT_UNROLL = 8, BIN_SORT_CHUNK = BIN_SORT_THREADS * BIN_SORT_UNROLL;
-__global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const uint2 *rec, const uint32_t *bin_base, uint32_t *entries,
+template <class REC>
+__global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const typename REC::T *rec, const uint32_t *bin_base, uint32_t *entries,
                                                                uint32_t *total) {
+    typedef typename REC::T RT;
     __shared__ uint32_t h[BIN_BUCKETS], cur[BIN_BUCKETS], off[BIN_BUCKETS];
-    __shared__ uint2 stage[BIN_SORT_CHUNK];
+    __shared__ RT stage[BIN_SORT_CHUNK];
     const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
     if (threadIdx.x < BIN_BUCKETS) h[threadIdx.x] = 0;
     __syncthreads();
     for (uint32_t base = r0 + threadIdx.x; base < r1; base += BIN_SORT_CHUNK) {
-        uint32_t lo[BIN_SORT_UNROLL];
+        RT e[BIN_SORT_UNROLL];
 #pragma unroll
         for (int k = 0; k < BIN_SORT_UNROLL; k++) {
             const uint32_t r = base + (uint32_t)k * BIN_SORT_THREADS;
-            lo[k] = r < r1 ? rec[r].y : 0xffffffffu;
+            e[k] = r < r1 ? rec[r] : REC::invalid();
         }
 #pragma unroll
         for (int k = 0; k < BIN_SORT_UNROLL; k++)
-            if (lo[k] != 0xffffffffu) atomicAdd(&h[lo[k]], 1u);
+            if (REC::valid(e[k])) atomicAdd(&h[REC::lo(e[k])], 1u);
     }
     __syncthreads();
     if (threadIdx.x < BIN_BUCKETS) {  // one wave
@@ -516,16 +540,16 @@ __global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const uint2 *rec,
     for (uint32_t c0 = r0; c0 < r1; c0 += BIN_SORT_CHUNK) {
         if (threadIdx.x < BIN_BUCKETS) h[threadIdx.x] = 0;
         __syncthreads();
-        uint2 e[BIN_SORT_UNROLL];
+        RT e[BIN_SORT_UNROLL];
         uint32_t rk[BIN_SORT_UNROLL];
 #pragma unroll
         for (int k = 0; k < BIN_SORT_UNROLL; k++) {
             const uint32_t r = c0 + threadIdx.x + (uint32_t)k * BIN_SORT_THREADS;
-            e[k] = r < r1 ? rec[r] : make_uint2(0u, 0xffffffffu);
+            e[k] = r < r1 ? rec[r] : REC::invalid();
         }
 #pragma unroll
         for (int k = 0; k < BIN_SORT_UNROLL; k++)
-            if (e[k].y != 0xffffffffu) rk[k] = atomicAdd(&h[e[k].y], 1u);
+            if (REC::valid(e[k])) rk[k] = atomicAdd(&h[REC::lo(e[k])], 1u);
         __syncthreads();
         if (threadIdx.x < BIN_BUCKETS) {
             const uint32_t v = h[threadIdx.x];
@@ -540,12 +564,13 @@ __global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const uint2 *rec,
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < BIN_SORT_UNROLL; k++)
-            if (e[k].y != 0xffffffffu) stage[off[e[k].y] + rk[k]] = e[k];
+            if (REC::valid(e[k])) stage[off[REC::lo(e[k])] + rk[k]] = e[k];
         __syncthreads();
         const uint32_t m = r1 - c0 < (uint32_t)BIN_SORT_CHUNK ? r1 - c0 : (uint32_t)BIN_SORT_CHUNK;
         for (uint32_t p = threadIdx.x; p < m; p += BIN_SORT_THREADS) {
-            const uint2 v = stage[p];
-            entries[cur[v.y] + p - off[v.y]] = v.x;
+            const RT v = stage[p];
+            const uint32_t b = REC::lo(v);
+            entries[cur[b] + p - off[b]] = REC::entry(v);
         }
         __syncthreads();
         if (threadIdx.x < BIN_BUCKETS) cur[threadIdx.x] += h[threadIdx.x];
@@ -946,7 +971,8 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     if (!ctx->attr_msm_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter<Rec4>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter<Rec8>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
         ctx->attr_msm_set = true;
     }
     const int B_lo = L.B_lo, Btot = L.Btot, nhi = L.nhi, G = L.G, c = srs->c, W = srs->W;
@@ -1035,7 +1061,8 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     if (!ctx->attr_msm_set) {  // per context (= per device): the LDS opt-in is a per-device function attribute
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter<Rec4>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter<Rec8>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
         ctx->attr_msm_set = true;
     }
     const int B = L.B, G = L.G, c = srs->c, W = srs->W;
@@ -1064,13 +1091,20 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
             const size_t per2 = (n + G2 - 1) / G2;
             uint32_t *bins = (uint32_t *)(base + L.off_bins), *bin_base = (uint32_t *)(base + L.off_bin_base);
             uint32_t *ready = (uint32_t *)(base + L.off_agg) + SCAN_SEG;
-            uint2 *rec = (uint2 *)blk_hist;
             KZG_LAUNCH(ctx, st, "k_bin_hist", k_bin_hist, G2, 1024, 0, sc, n, sfmt, per2, bins, w_lo, w_hi);
             uint32_t *bin_total = bin_base + NBINS + 1;
             KZG_LAUNCH(ctx, st, "k_bin_scan", k_bin_scan, NBINS / 64, 1024, 0, bins, G2, bin_total, ready);
-            KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total, bin_base,
-                       (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
-            KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+            if ((uint64_t)srs->rows * srs->npad < REC4_MAX_INDEX) {
+                uint32_t *rec = (uint32_t *)blk_hist;
+                KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter<Rec4>, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total,
+                           bin_base, (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
+                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec4>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+            } else {
+                uint2 *rec = (uint2 *)blk_hist;
+                KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter<Rec8>, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total,
+                           bin_base, (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
+                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec8>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+            }
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);
         } else {

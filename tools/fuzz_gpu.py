@@ -181,5 +181,12 @@ while time.time() < t_end:
 e.set_option("window_bits", 0)
 e.set_option("sort_single_pass", 0)
 group.close()
-print("fuzz done", cases, "failures:", fails, flush=True)
+summary = "seed %d, %.0f s: fuzz done %s failures: %d" % (seed, budget, cases, fails)
+print(summary, flush=True)
+try:  # RCCL prints its banner at exit, which pushes this line out of a `tail`: keep a copy where gpurun brings it back
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "fuzz.log"), "a") as f:
+        f.write(summary + "\n")
+except OSError:
+    pass
 sys.exit(1 if fails else 0)
