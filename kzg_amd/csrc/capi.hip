@@ -564,6 +564,8 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
     ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
     ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
     ctx->cur_tail_quads = nl > 1 ? 0 : ctx->opt_tail_quads;
+    // at least two MSMs per lane: the lanes never run dry, so the tail is organised for lane-time instead of depth
+    ctx->cur_tail_wide = nl > 1 && batch >= 2 * (size_t)nl;
     while (bp->nas && (int)ctx->sorted_events.size() < nl) {
         hipEvent_t e1 = nullptr, e2 = nullptr;
         KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
@@ -587,6 +589,7 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
     ctx->cur_accum_blocks = ctx->accum_blocks_single();
     ctx->cur_sort_threads = ctx->opt_sort_threads;
     ctx->cur_tail_quads = ctx->opt_tail_quads;
+    ctx->cur_tail_wide = false;
     if (rc == KZG_OK && !bp.out_dev) {
         hipError_t e = hipMemcpy(out, bp.d_out, out_bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));

@@ -67,6 +67,7 @@ struct kzg_ctx {
     int cur_accum_blocks = 256 * KZG_ACCUM_WAVES;  // value msm_run uses (set by the entry point)
     int opt_tail_quads = 1;            // single MSMs: four lanes per point operation in the tail kernels (latency mode, msm_tail.hip)
     int cur_tail_quads = 1;            // 0 inside a batched pipeline (lane-time counts there)
+    bool cur_tail_wide = false;        // a deep batched pipeline (>= 2 MSMs per lane): work-efficient fold width and row/column sums
     // kzg_msm_g1_batch: every k_accum_affine runs on one of this many dedicated streams, in submission order (0 = on its lane's
     // stream).  With the accumulation on the lanes' own streams the lanes fall into a convoy -- all sorting, then up to nine
     // accumulation kernels resident at once, then all in their tails -- and no accumulation kernel is resident 6 % of the time

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, 
     if (lane == 0) (wv < Rn ? rows[wv] : cols[wv - Rn]) = acc;
 }
 
-// Throughput form of k_rc_sums for the batched pipeline, where lane-time counts and depth does not: RC_LANES lanes per row /
+// Throughput form of k_rc_sums for a deep batched pipeline (two or more MSMs per lane), where lane-time counts and depth does not: RC_LANES lanes per row /
 // column sum, each adding Cn / RC_LANES points in sequence before a log2(RC_LANES)-level butterfly -- 35 wave-additions per 8
 // sums instead of 72 (a butterfly level costs a full addition for half the useful work of the level before).
 constexpr int RC_LANES = 8;
@@ -376,11 +376,11 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     int Rn, Cn, lr, lc;
     tail_shape(B, &Rn, &Cn, &lr, &lc);
     // lane-group width: twice the expected partials per bucket still fit FOLD_SEQ sequential additions per lane 4 times over
-    // (batched pipeline: one lane per bucket as long as the expected run fits its FOLD_SEQ sequential additions twice over --
+    // (deep batched pipeline: one lane per bucket as long as the expected run fits its FOLD_SEQ sequential additions twice over --
     // a butterfly level is a full addition for every lane of the group, wasted lane-time when depth does not matter)
     size_t avg = expected_partials / (size_t)B + 1;
     int G = 1;
-    if (ctx->cur_tail_quads) {
+    if (!ctx->cur_tail_wide) {
         while (G < 64 && (size_t)G * 2 < avg) G *= 2;
     } else {
         while (G < 64 && (size_t)G * (FOLD_SEQ / 2) < avg) G *= 2;
@@ -396,7 +396,7 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     }
 #undef KZG_FOLD
     KZG_LAUNCH(ctx, st, "k_fold_overflow", k_fold_overflow, 256, TAIL_THREADS, 0, part, scratch, s1, dense, state, tasks, arrive);
-    if (!ctx->cur_tail_quads && Rn >= RC_LANES && Cn >= RC_LANES) {
+    if (ctx->cur_tail_wide && Rn >= RC_LANES && Cn >= RC_LANES) {
         KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums_t, ((Rn + Cn) * RC_LANES + 255) / 256, 256, 0, dense, Rn, Cn, rows, cols);
     } else {
         KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums, (Rn + Cn + wpb - 1) / wpb, TAIL_THREADS, 0, dense, Rn, Cn, rows, cols);
