@@ -67,8 +67,8 @@ int srs_choose_window(int opt_window_bits, size_t n) {
         c = l >= 17 ? 17 : l >= 14 ? 13 : l >= 12 ? 10 : 8;
     }
     if (c < 4) c = 4;
-    // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17: same pipeline, 15 windows, the sort walks its scalars
-    // twice; 18..20 use the two-pass ("wide") sort of msm.hip and are only taken when asked for (option window_bits)
+    // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17: same pipeline, 15 windows, a two-level sort (msm.hip);
+    // 18..20 use the two-pass ("wide") sort of msm.hip and are only taken when asked for (option window_bits)
     if (c > 20) c = 20;
     return c;
 }
@@ -78,8 +78,7 @@ void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c_out, i
     int c = srs_choose_window(opt_window_bits, n);
     int W = (256 + c - 1) / c;
     // c = 17: 255 = 15 x 17, and a scalar k >= 2^254 is replaced by -(r - k) (all digit signs flipped), so the top window never
-    // carries out: 15 windows instead of 16.  2^16 buckets: the counting sort walks its scalars twice, half the buckets per walk
-    // (the u32 LDS counters of 2^15 buckets are what fits a CU).
+    // carries out: 15 windows instead of 16.  2^16 buckets: sorted in two levels (1024 bins of 64 buckets, msm.hip).
     bool narrow17 = c == 17;
     if (narrow17) W = 15;
     int rows = W;
