@@ -101,7 +101,9 @@ int kzg_sync(kzg_ctx *ctx);
 /* tunables: "window_bits" (0 = auto, 4..20), "window_rows" (0 = one table row per window; applies to SRSs created afterwards),
  * "trusted_points" (0 / 1), "streams" (1..16: batch pipelining depth), "accum_streams" (0..4), "accum_blocks[_batch]",
  * "sort_threads[_batch]", "ntt_vec_log", "hw_queues" (0 = measure), "tail_quads" (0 / 1: latency-mode tail kernels of a
- * lone MSM), "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only);
+ * lone MSM), "host_affine" (1 / 0: a lone result bound for host memory is converted to affine and serialised by the calling
+ * thread -- the same field code compiled for the host -- instead of one GPU lane; same bytes, ~90 us less latency),
+ * "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only);
  * unknown keys -> KZG_ERR_SHAPE */
 int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value);
 

@@ -3,6 +3,7 @@
 #include <algorithm>
 
 #include "common.h"
+#include "emit.h"
 
 namespace kzg {
 
@@ -129,7 +130,7 @@ static int stage_in(kzg_ctx *ctx, int lane, const void *src, size_t bytes, int f
 static size_t stage_bytes(size_t bytes, int flags) { return (flags & KZG_IN_DEVICE) ? 0 : align_up(bytes + 256, 256); }
 
 // result point: XYZZ on device -> ofmt at `out` (host or device)
-static int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
+int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
     size_t psz = point_format_bytes(ofmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     hipStream_t st = ctx->lanes[lane].stream;
@@ -137,12 +138,24 @@ static int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out,
         KZG_TRY(emit_point(ctx, lane, d_pt, out, ofmt));
         KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     } else {
-        // the kernel writes the <= 144 bytes straight into the lane's pinned host buffer (device-mapped, coherent): no copy
-        // command on the way out
         KZG_TRY(lane_pinned(ctx, lane, 4096));
-        KZG_TRY(emit_point(ctx, lane, d_pt, ctx->lanes[lane].pinned, ofmt));
-        KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        memcpy(out, ctx->lanes[lane].pinned, psz);
+        if (ctx->opt_host_affine) {
+            // A lone result for the host: copy the XYZZ point out and convert it on the calling thread with the same code
+            // (emit.h, compiled for the host): a CPU core does the Fq inversion of to_affine in a few microseconds, one GPU lane
+            // needs ~90 us for it, and this sits on the critical path of every blocking commit / create_witness.
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned, d_pt, sizeof(MsmPoint), hipMemcpyDeviceToHost, st));
+            KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            MsmPoint pt;
+            memcpy(&pt, ctx->lanes[lane].pinned, sizeof pt);
+            alignas(16) uint8_t buf[144];
+            emit_one(pt, buf, ofmt);
+            memcpy(out, buf, psz);
+        } else {
+            // the kernel writes the <= 144 bytes straight into the lane's pinned host buffer (device-mapped, coherent)
+            KZG_TRY(emit_point(ctx, lane, d_pt, ctx->lanes[lane].pinned, ofmt));
+            KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            memcpy(out, ctx->lanes[lane].pinned, psz);
+        }
     }
     if (ctx->prof) prof_collect(ctx);
     return KZG_OK;
@@ -303,6 +316,8 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_streams") {
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
+    } else if (k == "host_affine") {
+        ctx->opt_host_affine = value != 0;
     } else if (k == "sort_single_pass") {
         ctx->opt_sort_single = value != 0;
     } else if (k == "tail_quads") {

@@ -79,6 +79,7 @@ struct kzg_ctx {
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
     int opt_sort_threads_batch = 1024; // ... for batched MSMs
     int cur_sort_threads = 1024;
+    int opt_host_affine = 1;           // a lone result bound for host memory is converted to affine / serialised on the host (emit.h)
     int opt_sort_single = 0;           // 1: c = 17 sorts in one pass (2^16 cursors, two walks) instead of the two-level sort
     int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
     int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
@@ -174,6 +175,8 @@ typedef G1Xyzz30 MsmPoint;
 // ---- cross-TU entry points -------------------------------------------------------------------
 // msm.hip
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n);
+// one MSM result (device) -> `ofmt` at `out` (host, or device with KZG_OUT_DEVICE); synchronises the lane's stream (capi.hip)
+int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int ofmt, int flags);
 // d_scalars: device pointer to n scalars (sfmt); result: one device MsmPoint in the lane arena
 // accum_stream (optional): run k_accum_affine there instead of on the lane's stream, ordered by the two caller-owned events
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,

@@ -22,6 +22,7 @@
 //
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
 #include "msm_internal.h"
+#include "emit.h"
 
 namespace kzg {
 
@@ -715,58 +716,7 @@ __global__ __launch_bounds__(256) void k_sum_level(const MsmPoint *in, uint32_t 
     out[t] = acc;
 }
 
-// ---------------------------------------------------------------------------------------------
-// output formatting (Curve::to_affine + serialisation), one thread per point
-// ---------------------------------------------------------------------------------------------
-__device__ void write_be48(uint8_t *dst, const Fq &canon) {
-    for (int i = 0; i < 48; i++) dst[47 - i] = (uint8_t)(canon.v[i >> 2] >> (8 * (i & 3)));
-}
-
-__device__ bool fq_lexicographically_largest(const Fq &canon) {  // y > (q-1)/2
-    // (q-1)/2
-    constexpr uint32_t H[12] = {0xffffd555u, 0xdcff7fffu, 0x58a9ffffu, 0x0f55ffffu, 0x7b587b12u, 0xb3986950u,
-                                0x79c2895fu, 0xb23ba5c2u, 0x21a5d66bu, 0x258dd3dbu, 0x1cbff34du, 0x0d0088f5u};
-    for (int i = 11; i >= 0; i--) {
-        if (canon.v[i] > H[i]) return true;
-        if (canon.v[i] < H[i]) return false;
-    }
-    return false;
-}
-
-// one point -> `fmt` at `o` (one thread; includes the Fq inversion of to_affine)
-__device__ void emit_one(const MsmPoint &pt, uint8_t *o, int fmt) {
-    const G1Xyzz p = g1_xyzz_from30(pt);
-    if (fmt == KZG_G1_JACOBIAN_MONT_144) {
-        G1Jacobian j = g1_to_jacobian(p);
-        *reinterpret_cast<G1Jacobian *>(o) = j;
-        return;
-    }
-    G1Affine a = g1_to_affine(p);
-    if (fmt == KZG_G1_AFFINE_MONT_96) {
-        *reinterpret_cast<G1Affine *>(o) = a;
-        return;
-    }
-    Fq x = from_mont(a.x), y = from_mont(a.y);
-    if (fmt == KZG_G1_ZCASH_UNCOMPRESSED_96) {
-        if (a.is_inf()) {
-            for (int k = 0; k < 96; k++) o[k] = 0;
-            o[0] = 0x40;
-        } else {
-            write_be48(o, x);
-            write_be48(o + 48, y);
-        }
-    } else {  // compressed
-        if (a.is_inf()) {
-            for (int k = 0; k < 48; k++) o[k] = 0;
-            o[0] = 0xC0;
-        } else {
-            write_be48(o, x);
-            o[0] |= 0x80;
-            if (fq_lexicographically_largest(y)) o[0] |= 0x20;
-        }
-    }
-}
-
+// output formatting (Curve::to_affine + serialisation): emit.h
 __device__ __forceinline__ size_t format_bytes_dev(int fmt) {
     return fmt == KZG_G1_JACOBIAN_MONT_144 ? 144 : fmt == KZG_G1_ZCASH_COMPRESSED_48 ? 48 : 96;
 }

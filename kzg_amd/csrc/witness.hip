@@ -257,21 +257,7 @@ static int hscalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
 }
 
 static int finish_point_host(kzg_ctx *ctx, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
-    size_t psz = point_format_bytes(ofmt);
-    hipStream_t st = ctx->lanes[0].stream;
-    if (flags & KZG_OUT_DEVICE) {
-        KZG_TRY(emit_point(ctx, 0, d_pt, out, ofmt));
-        KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
-        return KZG_OK;
-    }
-    void *d = lane_alloc(ctx, 0, 256);
-    if (!d) return fail(ctx, KZG_ERR_ALLOC, "output staging not reserved");
-    KZG_TRY(emit_point(ctx, 0, d_pt, d, ofmt));
-    KZG_TRY(lane_pinned(ctx, 0, 4096));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[0].pinned, d, psz, hipMemcpyDeviceToHost, st));
-    KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
-    memcpy(out, ctx->lanes[0].pinned, psz);
-    return KZG_OK;
+    return finish_point(ctx, 0, d_pt, out, ofmt, flags);
 }
 
 // a[i] *= b[i]  (Montgomery product; with b in Montgomery form the result keeps a's form)

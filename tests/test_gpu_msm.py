@@ -71,6 +71,15 @@ def test_msm_offset_and_formats(engine, srs_small):
     assert engine.msm(srs, z) == bytes(96)
     assert engine.msm(srs, z, ofmt=L.G1_ZCASH_COMPRESSED) == M.g1_to_compressed(None)
     assert engine.msm(srs, z, ofmt=L.G1_ZCASH_UNCOMPRESSED) == M.g1_to_uncompressed(None)
+    # a lone host-bound result is converted on the host by default (emit.h compiled for the host); the GPU's k_emit_points
+    # (option host_affine = 0; also what batches and device outputs use) must give the same bytes in every format
+    for fmt in (L.G1_AFFINE_MONT, L.G1_ZCASH_COMPRESSED, L.G1_ZCASH_UNCOMPRESSED, L.G1_JACOBIAN_MONT):
+        on_host = [engine.msm(srs, v, offset=off, ofmt=fmt) for v in (sc, z, [M.R - 1] * n)]
+        engine.set_option("host_affine", 0)
+        try:
+            assert [engine.msm(srs, v, offset=off, ofmt=fmt) for v in (sc, z, [M.R - 1] * n)] == on_host, fmt
+        finally:
+            engine.set_option("host_affine", 1)
     # montgomery-form scalars, device resident
     buf = engine.alloc_scalars(n, sfmt=L.FR_MONT)
     buf.upload(b"".join(M.fr_to_mont_le(s) for s in sc))
