@@ -797,11 +797,21 @@ int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t 
     KZG_TRY(stage_in(ctx, 0, points, total * psz, flags, &d_raw));
     KZG_TRY(decode_points(ctx, st, d_raw, total, pfmt, dec, bad, level));
     KZG_TRY(points_to30(ctx, st, dec, pts, total));
-    KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, gstride, istride, tmp, d_out, ofmt));
+    // up to four host-bound sums (the combine step of a sharded commit has one): converted on the calling thread, as in finish_point
+    const bool on_host = !(flags & KZG_OUT_DEVICE) && ctx->opt_host_affine && groups <= 4;
+    KZG_TRY(sum_groups_emit(ctx, 0, pts, count, groups, gstride, istride, tmp, on_host ? nullptr : d_out, ofmt));
     int hbad = 0;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hbad, bad, sizeof(int), hipMemcpyDeviceToHost, st));
-    if (!(flags & KZG_OUT_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, groups * osz, hipMemcpyDeviceToHost, st));
+    MsmPoint hsum[4];
+    if (on_host) KZG_HIP_CHECK(ctx, hipMemcpyAsync(hsum, tmp, groups * sizeof(MsmPoint), hipMemcpyDeviceToHost, st));
+    else if (!(flags & KZG_OUT_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, d_out, groups * osz, hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+    if (on_host)
+        for (size_t gi = 0; gi < groups; gi++) {
+            alignas(16) uint8_t buf[144];
+            emit_one(hsum[gi], buf, ofmt);
+            memcpy((uint8_t *)out + gi * osz, buf, osz);
+        }
     if (ctx->prof) prof_collect(ctx);
     if (hbad) return fail(ctx, KZG_ERR_BAD_POINT, "a G1 point failed to decode or is not on the curve");
     return KZG_OK;

@@ -742,6 +742,7 @@ int sum_groups_emit(kzg_ctx *ctx, int lane, const MsmPoint *d_pts, size_t count,
     hipStream_t st = ctx->lanes[lane].stream;
     KZG_LAUNCH(ctx, st, "k_sum_groups", k_sum_groups, (unsigned)((groups + 63) / 64), 64, 0, d_pts, (uint32_t)count,
                (uint32_t)groups, gstride, istride, d_tmp);
+    if (!d_out) return KZG_OK;  // the caller converts d_tmp itself (a few host-bound results: emit.h on the calling thread)
     KZG_LAUNCH(ctx, st, "k_emit_points", k_emit_points, (unsigned)((groups + 63) / 64), 64, 0, d_tmp, groups, (size_t)1,
                (uint8_t *)d_out, ofmt);
     return KZG_OK;

@@ -73,13 +73,24 @@ def test_msm_offset_and_formats(engine, srs_small):
     assert engine.msm(srs, z, ofmt=L.G1_ZCASH_UNCOMPRESSED) == M.g1_to_uncompressed(None)
     # a lone host-bound result is converted on the host by default (emit.h compiled for the host); the GPU's k_emit_points
     # (option host_affine = 0; also what batches and device outputs use) must give the same bytes in every format
+    # (Jacobian coordinates are not canonical -- the order of additions inside a bucket differs from run to run -- so that
+    # format is compared as a point)
+    def jac_point(b):
+        X, Y, Z = (int.from_bytes(b[48 * i:48 * i + 48], "little") * rinv % M.Q for i in range(3))
+        if Z == 0:
+            return None
+        zi = pow(Z, -1, M.Q)
+        return (X * zi * zi % M.Q, Y * zi * zi * zi % M.Q)
+
     for fmt in (L.G1_AFFINE_MONT, L.G1_ZCASH_COMPRESSED, L.G1_ZCASH_UNCOMPRESSED, L.G1_JACOBIAN_MONT):
-        on_host = [engine.msm(srs, v, offset=off, ofmt=fmt) for v in (sc, z, [M.R - 1] * n)]
+        norm = jac_point if fmt == L.G1_JACOBIAN_MONT else (lambda b: b)
+        on_host = [norm(engine.msm(srs, v, offset=off, ofmt=fmt)) for v in (sc, z, [M.R - 1] * n)]
         engine.set_option("host_affine", 0)
         try:
-            assert [engine.msm(srs, v, offset=off, ofmt=fmt) for v in (sc, z, [M.R - 1] * n)] == on_host, fmt
+            assert [norm(engine.msm(srs, v, offset=off, ofmt=fmt)) for v in (sc, z, [M.R - 1] * n)] == on_host, fmt
         finally:
             engine.set_option("host_affine", 1)
+    assert jac_point(engine.msm(srs, sc, offset=off, ofmt=L.G1_JACOBIAN_MONT)) == P
     # montgomery-form scalars, device resident
     buf = engine.alloc_scalars(n, sfmt=L.FR_MONT)
     buf.upload(b"".join(M.fr_to_mont_le(s) for s in sc))
@@ -287,6 +298,14 @@ def test_g1_sum_batch(engine, srs_small):
         for i in range(3):
             acc = C.g1_add(acc, pts[3 * g + i])
         assert got[g] == acc
+    # 4 groups or fewer bound for the host are converted on the calling thread; 6 groups, and host_affine = 0, on the GPU
+    six = engine.g1_sum_batch(pts, 2, 6)
+    assert six == [C.g1_add(pts[2 * g], pts[2 * g + 1]) for g in range(6)]
+    engine.set_option("host_affine", 0)
+    try:
+        assert engine.g1_sum_batch(pts, 3, 4) == got
+    finally:
+        engine.set_option("host_affine", 1)
 
 
 def test_concurrent_callers(engine, srs_small):
