@@ -268,6 +268,8 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
     for (auto st : ctx->accum_streams)
         if (st) hipStreamDestroy(st);
     if (ctx->batch_out) hipFree(ctx->batch_out);
+    for (auto &ct : ctx->coset_tabs)
+        if (ct.second) hipFree(ct.second);
     ntt_plans_free(ctx);
     eval_tabs_free(ctx);
     fixed_base_free(ctx);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <array>
 #include <map>
 #include <mutex>
 #include <string>
@@ -94,6 +95,8 @@ struct kzg_ctx {
     std::map<uint32_t, kzg::NttPlan *> ntt_plans;          // key = log_n * 2 + inverse
     std::map<uint32_t, kzg::EvalDomainTables *> eval_tabs;  // key = log_d
     kzg::FixedBaseTable *fixed_base = nullptr;
+    // distribute_powers (coset NTTs): per coset generator g two device tables g^j and g^(1024 j), j < 1024 (witness.hip)
+    std::vector<std::pair<std::array<uint32_t, 8>, void *>> coset_tabs;
     void *batch_out = nullptr;  // device staging of kzg_msm_g1_batch results (grow-only)
     size_t batch_out_bytes = 0;
 };
