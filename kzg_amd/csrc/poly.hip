@@ -28,35 +28,38 @@ int fr_convert(kzg_ctx *ctx, hipStream_t stream, Fr *d_data, size_t n, int to_m)
 
 constexpr int BI_K = 16;
 
-// out[i] = 1/in[i] (Montgomery), zeros map to zero.  in != out.
-__global__ __launch_bounds__(256) void k_batch_inverse(const Fr *in, Fr *out, size_t n) {
+// out[i] = 1/in[i] (Montgomery), zeros map to zero.  in != out.  Thread t owns the BI_K elements t, t + T, t + 2T, ... (T threads:
+// every load and store of a wave is one contiguous 2 KiB run) and inverts their product once (Montgomery's trick).
+__global__ __launch_bounds__(256) void k_batch_inverse(const Fr *in, Fr *out, size_t n, size_t T) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    size_t i0 = t * BI_K;
-    if (i0 >= n) return;
-    size_t i1 = i0 + BI_K < n ? i0 + BI_K : n;
+    if (t >= T || t >= n) return;
     Fr prod = Fr::one();
-    for (size_t i = i0; i < i1; i++) {
+    size_t last = t;
+    for (size_t i = t; i < n; i += T) {
         out[i] = prod;
         Fr v = in[i];
         if (!v.is_zero()) prod = mul(prod, v);
+        last = i;
     }
     Fr iv = inv(prod);
-    for (size_t i = i1; i-- > i0;) {
+    for (size_t i = last;; i -= T) {
         Fr v = in[i];
         if (v.is_zero()) {
             out[i] = Fr::zero();
-            continue;
+        } else {
+            Fr r = mul(iv, out[i]);
+            iv = mul(iv, v);
+            out[i] = r;
         }
-        Fr r = mul(iv, out[i]);
-        iv = mul(iv, v);
-        out[i] = r;
+        if (i < T) break;  // i == t
     }
 }
 
 int batch_inverse(kzg_ctx *ctx, hipStream_t stream, const Fr *d_in, Fr *d_out, size_t n) {
     if (!n) return KZG_OK;
-    size_t threads = (n + BI_K - 1) / BI_K;
-    KZG_LAUNCH(ctx, stream, "k_batch_inverse", k_batch_inverse, (unsigned)((threads + 255) / 256), 256, 0, d_in, d_out, n);
+    size_t T = (n + BI_K - 1) / BI_K;
+    T = (T + 255) / 256 * 256;
+    KZG_LAUNCH(ctx, stream, "k_batch_inverse", k_batch_inverse, (unsigned)(T / 256), 256, 0, d_in, d_out, n, T);
     return KZG_OK;
 }
 
