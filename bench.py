@@ -331,6 +331,14 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     sharded = (world > 1 and not args.replicas) or args.sharded
 
+    # stdout carries exactly ONE line, the JSON record.  RCCL prints a banner (ROCm version / hostname / library path) through C
+    # stdio when a communicator is created, and that buffer is flushed at process exit -- after anything Python printed.  So
+    # file descriptor 1 is pointed at stderr for the whole run (this process, its native libraries, its children) and the
+    # record goes to the original stdout at the very end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     cpu = None
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
         try:
@@ -624,7 +632,8 @@ def main():
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
-        print(line, flush=True)
+        os.write(real_stdout, (line + "\n").encode())
+    os.close(real_stdout)
 
 
 if __name__ == "__main__":
