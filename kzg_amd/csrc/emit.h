@@ -2,8 +2,11 @@
 // Host and device: k_emit_points (msm.hip) runs it one thread per point on the GPU; for a lone result that goes to host memory
 // capi.hip copies the 224-byte point out and runs the same code on the calling thread (a CPU core inverts in a few
 // microseconds what one GPU lane needs ~90 us for, on the critical path of every blocking commit).
+// Depends only on the arithmetic headers and the public format constants, so the CPU test suite compiles it with g++
+// (tests/host_math.cpp) and checks the bytes against the oracle without a GPU.
 #pragma once
-#include "msm_internal.h"
+#include "../../include/kzg_mi355x.h"
+#include "curve30.h"
 
 namespace kzg {
 
@@ -23,7 +26,7 @@ KZG_HD bool fq_lexicographically_largest(const Fq &canon) {  // y > (q-1)/2
 }
 
 // one point -> `fmt` at `o` (one thread; includes the Fq inversion of to_affine)
-KZG_HD void emit_one(const MsmPoint &pt, uint8_t *o, int fmt) {
+KZG_HD void emit_one(const G1Xyzz30 &pt, uint8_t *o, int fmt) {
     const G1Xyzz p = g1_xyzz_from30(pt);
     if (fmt == KZG_G1_JACOBIAN_MONT_144) {
         G1Jacobian j = g1_to_jacobian(p);

@@ -88,3 +88,14 @@ void hm_fr29_butterflies(const uint32_t *u, const uint32_t *v, const uint32_t *w
     Fr zu = fr29_pack_canonical(mul29r(U, fr29_one())), zv = fr29_pack_canonical(mul29r(V, fr29_one()));
     memcpy(ou, zu.v, 32); memcpy(ov, zv.v, 32); }
 }
+#include "../kzg_amd/csrc/emit.h"
+extern "C" {
+// emit.h on the host (what capi.hip runs for a lone host-bound MSM result): k * P as a de-normalised XYZZ point in the signed
+// 30-bit form -> `fmt`; k == 0 gives the identity
+void hm_emit(const uint32_t *a, const uint32_t *k, int fmt, uint8_t *o) { G1Affine x; memcpy(&x, a, 96);
+    G1Xyzz p = g1_scalar_mul(x, k);
+    G1Xyzz30 q = g1_xyzz_to30(p);
+    alignas(16) uint8_t buf[144];
+    emit_one(q, buf, fmt);
+    memcpy(o, buf, fmt == KZG_G1_JACOBIAN_MONT_144 ? 144 : fmt == KZG_G1_ZCASH_COMPRESSED_48 ? 48 : 96); }
+}

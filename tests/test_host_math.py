@@ -94,6 +94,35 @@ def test_g1_ops(L):
     assert L.hm_g1_on_curve(P[:95] + bytes([P[95] ^ 1])) == 0
 
 
+def test_emit_host_path(L):
+    """emit.h compiled for the host -- what the library runs on the calling thread for a lone host-bound MSM result
+    (to_affine + serialisation of a de-normalised XYZZ point in the signed 30-bit form) -- against the oracle's encoders:
+    affine Montgomery, zcash compressed / uncompressed, Jacobian (compared as a point); identity included; both y signs."""
+    rng = random.Random(41)
+    G = C.g1_generator()
+    rinv = pow(M.FQ_MONT_R, -1, M.Q)
+    seen_sign = set()
+    for k in [0, 1, 2, 3, M.R - 1] + [rng.randrange(M.R) for _ in range(40)]:
+        want_blob = C.g1_mul(G, k)
+        want = C.blob_to_point(want_blob)
+        out = {}
+        for fmt, nbytes in ((0, 96), (1, 144), (2, 96), (3, 48)):
+            o = ctypes.create_string_buffer(nbytes)
+            L.hm_emit(G, b(k, 32), fmt, o)
+            out[fmt] = o.raw
+        assert out[0] == want_blob, k
+        assert out[2] == M.g1_to_uncompressed(want), k
+        assert out[3] == M.g1_to_compressed(want), k
+        X, Y, Z = (int.from_bytes(out[1][48 * i:48 * i + 48], "little") * rinv % M.Q for i in range(3))
+        if want is None:
+            assert Z == 0
+        else:
+            zi = pow(Z, -1, M.Q)
+            assert (X * zi * zi % M.Q, Y * zi * zi * zi % M.Q) == want, k
+            seen_sign.add(out[3][0] & 0x20)
+    assert seen_sign == {0, 0x20}
+
+
 def test_fq30_unsaturated_layer(L):
     """field30.h / curve30.h (the signed 13 x 30-bit representation used by k_accum_affine) vs the oracle."""
     rng = random.Random(30)
