@@ -419,6 +419,24 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(fr_convert(ctx, st, dx, k, 1));
         KZG_TRY(fr_convert(ctx, st, dy, k, 1));
     }
+    // pick a coset shift on which Z has no root: g = 7, then 7^2, ...  An opening point inside g*H (x = 7 is
+    // one) would make Z vanish there; the cosets 7^j*H are pairwise distinct, so at most k candidates fail.  This is the one
+    // host round trip of the call, so it comes first, while the stream holds nothing but the upload of the points.
+    Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = g1;
+    if (!small_poly) {
+        int *cflag = (int *)lane_alloc(ctx, 0, 256);
+        if (!cflag) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+        for (size_t attempt = 0;; attempt++) {
+            int on = 0;
+            KZG_HIP_CHECK(ctx, hipMemsetAsync(cflag, 0, sizeof(int), st));
+            KZG_LAUNCH(ctx, st, "k_any_on_coset", k_any_on_coset, gridfor(k), 256, 0, dx, k, inv(gsh), log_N, cflag);
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(&on, cflag, sizeof(int), hipMemcpyDeviceToHost, st));
+            KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
+            if (!on) break;
+            if (attempt > k) return fail(ctx, KZG_ERR_INTERNAL, "no usable coset shift");
+            gsh = mul(gsh, g1);
+        }
+    }
     // interpolant
     // Z = prod (X - x_i): its values on the M-th roots of unity (M = 2^m > k), one tree product per value, then one small iNTT;
     // Z'(x_i) the same way; the interpolant by chunked synthetic divisions.  Everything here is log- or sqrt-depth in k.
@@ -444,8 +462,12 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     }
     KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, rows, (uint32_t)k, I);
     // numerator and divisor on the coset g*H
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, pin, n, A, N, to_m);
+    const Fr *psrc = (const Fr *)coeffs;  // device-resident coefficients are read where they are
+    if (!(flags & KZG_IN_DEVICE)) {
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, hipMemcpyHostToDevice, st));
+        psrc = pin;
+    }
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, psrc, n, A, N, to_m);
     MsmPoint *res = nullptr;
     int hflag = 0;
     if (small_poly) {
@@ -455,21 +477,6 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(msm_run(ctx, 0, srs, 0, A, 0, KZG_FR_MONT_LE_32, &res));  // identity
     } else {
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
-        // pick a coset shift on which Z has no root: g = 7, then 7^2, ...  An opening point inside g*H (x = 7 is
-        // one) would make Z vanish there; the cosets 7^j*H are pairwise distinct, so at most k candidates fail.
-        Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = g1;
-        int *cflag = (int *)lane_alloc(ctx, 0, 256);
-        if (!cflag) return fail(ctx, KZG_ERR_ALLOC, "workspace");
-        for (size_t attempt = 0;; attempt++) {
-            int on = 0;
-            KZG_HIP_CHECK(ctx, hipMemsetAsync(cflag, 0, sizeof(int), st));
-            KZG_LAUNCH(ctx, st, "k_any_on_coset", k_any_on_coset, gridfor(k), 256, 0, dx, k, inv(gsh), log_N, cflag);
-            KZG_HIP_CHECK(ctx, hipMemcpyAsync(&on, cflag, sizeof(int), hipMemcpyDeviceToHost, st));
-            KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
-            if (!on) break;
-            if (attempt > k) return fail(ctx, KZG_ERR_INTERNAL, "no usable coset shift");
-            gsh = mul(gsh, g1);
-        }
         // (p - I) in coefficient form, then TWO forward coset NTTs (numerator, Z) and one inverse; Z and the numerator's
         // zero padding are not scaled
         KZG_LAUNCH(ctx, st, "k_sub_prefix", k_sub_prefix, gridfor(k), 256, 0, A, I, k);
