@@ -45,6 +45,47 @@ def test_config2_commit_2_20(engine, big):
         buf.free()
 
 
+def test_sort_variants_and_batch_tail_agree_2_20(engine, big):
+    """configs[1] at full size through every variant of the pipeline around the accumulation kernel: two-level sort (default)
+    and single-pass sort, latency-mode tail on and off, a lone MSM and a deep batch (work-efficient tail) -- the same bytes from
+    all of them, for full-width, u64-valued and all-equal coefficients (all-equal: every record of a window in ONE bin of the
+    two-level sort and one bucket: the overflow slices), each equal to [p(tau)]G."""
+    n, params, _ = big
+    G = C.g1_generator()
+    bufs = [engine.alloc_scalars(n).fill_random(31), engine.alloc_scalars(n).fill_random(32, u64_valued=True)]
+    eq = engine.alloc_scalars(n)
+    eq.upload(M.fr_to_le(0x1234567890ABCDEF1122334455667788990011223344556677889900AABBCCDD % R) * n)
+    bufs.append(eq)
+    want = [C.g1_mul(G, engine.poly_eval(b, TAU)) for b in bufs]
+    try:
+        for single_pass in (0, 1):
+            engine.set_option("sort_single_pass", single_pass)
+            for quads in (1, 0):
+                engine.set_option("tail_quads", quads)
+                assert [_msm_dev(engine, params.gs, b, n) for b in bufs] == want, (single_pass, quads)
+        engine.set_option("sort_single_pass", 0)
+        engine.set_option("tail_quads", 1)
+        # deep batch: 6 MSMs over 2 lanes (>= 2 per lane: the work-efficient tail), all against the first buffer's polynomial
+        engine.set_option("streams", 2)
+        rep = engine.alloc_scalars(6 * n)
+        for j in range(6):
+            hipcpy = bufs[j % 3].download()
+            v = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+            v.engine, v.n, v.sfmt, v.ptr = engine, n, rep.sfmt, ctypes.c_void_p(rep.ptr.value + 32 * n * j)
+            v.upload(hipcpy)
+        out = ctypes.create_string_buffer(96 * 6)
+        rc = engine.lib.kzg_msm_g1_batch(engine.ctx, params.gs.handle, 0, rep.ptr, n, 6, rep.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+        assert rc == 0, engine.last_error()
+        assert [out.raw[96 * j:96 * j + 96] for j in range(6)] == [want[j % 3] for j in range(6)]
+        rep.free()
+    finally:
+        engine.set_option("sort_single_pass", 0)
+        engine.set_option("tail_quads", 1)
+        engine.set_option("streams", 8)
+    for b in bufs:
+        b.free()
+
+
 def test_config3_eval_form_equals_coeff_form_2_20(engine, big):
     """configs[2]: NTT then Lagrange-SRS MSM gives the same commitment as the monomial MSM; iNTT round trip."""
     n, params, lag = big
