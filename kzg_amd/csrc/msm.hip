@@ -393,6 +393,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *wsum /
 // per bin: exclusive scan over the sort blocks' counts (in place) and the bin size.  Block q owns bins [64 q, 64 q + 64); its 16
 // waves each take a slice of the sort blocks (<= 32 counters per thread, loaded in one batch), the slices are chained through LDS.
 constexpr int BIN_SCAN_SLICES = 16, BIN_SCAN_MAXG = 32;
+constexpr int SORT2_MAX_BLOCKS = BIN_SCAN_SLICES * BIN_SCAN_MAXG;  // level-1 sort blocks k_bin_scan can chain (512)
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *blk_bins, int G, uint32_t *bin_total, uint32_t *ready) {
     __shared__ uint32_t part[BIN_SCAN_SLICES][64];
     if (blockIdx.x == 0 && threadIdx.x < SCAN_SEG) ready[threadIdx.x] = 0;  // k_scan_b's chained flag counts
@@ -803,7 +804,7 @@ static int sort_blocks(size_t n) {
 static int sort2_blocks(size_t n) {
     size_t g = (n + 2047) / 2048;
     if (g < 1) g = 1;
-    if (g > 512) g = 512;
+    if (g > SORT2_MAX_BLOCKS) g = SORT2_MAX_BLOCKS;
     return (int)g;
 }
 
