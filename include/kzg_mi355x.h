@@ -10,9 +10,15 @@
  *   - plain pointers and sizes only; no C++ exceptions or callbacks cross the ABI.
  *   - every call returns a kzg_status; 0 = ok, >0 = the reference's own error conditions,
  *     <0 = runtime failure (HIP).  kzg_last_error(ctx) gives a human-readable string.
- *   - a kzg_ctx is bound to one GPU and is thread-safe (calls on one ctx serialise on an internal
- *     mutex; use one ctx per host thread for concurrency).  There is NO CPU fallback: without a
- *     usable HIP device kzg_ctx_create fails with KZG_ERR_NO_DEVICE.
+ *   - a kzg_ctx is bound to one GPU and is thread-safe.  The reference's blocking prover calls -- kzg_commit_coeff,
+ *     kzg_commit_eval, kzg_msm_g1, kzg_witness_coeff, kzg_witness_eval (KZGProver / KZGProverEvalForm are Clone + &self,
+ *     src/coeff_form.rs:37-64) -- run CONCURRENTLY on one ctx: each call leases one of the context's lanes (option
+ *     "streams", default 8, up to 16), submits its kernels there and waits for its own result only, so N host threads
+ *     calling commit() against one resident SRS fill the GPU like kzg_msm_g1_batch does.  Every other call takes the
+ *     context exclusively (it waits for the leased lanes to drain).  A kzg_srs / kzg_srs_g2 is immutable after creation
+ *     and may be used from any number of threads and from every kzg_ctx on the same device.  kzg_last_error returns the
+ *     calling thread's own last failure.  There is NO CPU fallback: without a usable HIP device kzg_ctx_create fails
+ *     with KZG_ERR_NO_DEVICE.
  *   - points entering through kzg_srs_upload_g1/g2, the verifier entry points and kzg_pairing_check are validated the way
  *     blstrs' G1Affine / G2Affine deserialisation validates them upstream, in EVERY format: coordinates < q, on the curve,
  *     in the r-torsion subgroup ([r]P == O); failure -> KZG_ERR_BAD_POINT.  Option "trusted_points" = 1 skips the subgroup
@@ -92,6 +98,14 @@ enum { KZG_IN_DEVICE = 1, KZG_OUT_DEVICE = 2 };
 
 /* ---- context ------------------------------------------------------------------------------- */
 const char *kzg_version(void);
+/* Hardware queues: the pipelined paths (kzg_msm_g1_batch, concurrent blocking callers) want one HIP hardware queue per stream
+ * (lanes + 2); the HIP runtime sizes its pool from GPU_MAX_HW_QUEUES (default 4) at the FIRST HIP call of the process.  The
+ * library never changes the host's environment by itself.  A host that wants the full pipeline either exports
+ * GPU_MAX_HW_QUEUES (>= 18) itself or calls kzg_init_hw_queues(n) (n = 0: 24) BEFORE its first HIP call -- it sets the
+ * variable unless the host already did -- or starts with KZG_SET_HW_QUEUES=1 in the environment (the library's load-time
+ * constructor then makes that call).  Otherwise the engine measures the queues it has and narrows the pipeline to fit
+ * (4 queues: 3 lanes + 1 accumulation stream; loss: INTEGRATION.md section 6). */
+int kzg_init_hw_queues(int queues);
 int kzg_device_count(void);  /* usable HIP devices (0 if none) */
 /* device: HIP device ordinal.  Fails with KZG_ERR_NO_DEVICE if no gfx950-class device is usable. */
 int kzg_ctx_create(int device, kzg_ctx **out);
@@ -154,7 +168,9 @@ int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t grou
  *   - one process per GPU:  rank 0 calls kzg_mctx_unique_id, the host distributes the 128 bytes by any means (MPI, a TCP
  *     store, torch.distributed), every rank calls kzg_mctx_create_rank(device, rank, world, id)   (ncclCommInitRank).
  * RCCL (librccl.so.1) is loaded on first use; a group of one GPU needs no RCCL unless option "always_gather" is set.
- * Every entry point below is collective in the one-process-per-GPU mode: all ranks call it with the same arguments. */
+ * Every entry point below is collective in the one-process-per-GPU mode: all ranks call it with the same arguments.
+ * Failures stay collective too: a rank whose local phase fails still enters the exchange, its status travels with its
+ * partials, and EVERY rank returns that error (no rank is left waiting inside the all-gather). */
 typedef struct kzg_mctx kzg_mctx;
 typedef struct kzg_msrs kzg_msrs;   /* an SRS sharded contiguously over the group */
 enum { KZG_UNIQUE_ID_BYTES = 128 };
@@ -163,6 +179,10 @@ int kzg_mctx_unique_id(void *id_out);
 int kzg_mctx_create_rank(int device, int rank, int world, const void *unique_id, kzg_mctx **out);
 void kzg_mctx_destroy(kzg_mctx *m);
 const char *kzg_mctx_last_error(kzg_mctx *m);
+/* "rccl=<file> version=<n> hip=<runtime file> world=.. local=.. mode=..": which RCCL the group adopted (the copy the process
+ * already holds, else librccl.so.1 from the library path) and the HIP runtime it is bound to.  The library refuses an RCCL that
+ * is bound to a different HIP runtime than itself (streams and device pointers cross the boundary): KZG_ERR_INTERNAL. */
+int kzg_mctx_info(kzg_mctx *m, char *buf, size_t buflen);
 int kzg_mctx_world(const kzg_mctx *m);        /* ranks in the group */
 int kzg_mctx_local_count(const kzg_mctx *m);  /* GPUs this process drives (n, or 1 in the per-process mode) */
 int kzg_mctx_rank(const kzg_mctx *m, int local_index);          /* global rank of a local GPU */
@@ -190,10 +210,17 @@ int kzg_commit_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeff
 int kzg_commit_coeff_sharded_batch(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, size_t batch, int sfmt,
                                    int flags, void *out, int ofmt);
 /* KZGProver::create_witness over the group (src/coeff_form.rs:66-81): every rank computes the quotient (p - y)/(X - x) on its
- * GPU (a replicated O(n) scan) and reduces its own slice of it; host-resident coefficients only.
+ * GPU (a replicated O(n) scan) and reduces its own slice of it.  coeffs: the whole polynomial in host memory, or with
+ * KZG_IN_DEVICE an array of kzg_mctx_local_count() device pointers, entry i = the WHOLE polynomial resident on local GPU i.
  * KZG_ERR_POINT_NOT_ON_POLY iff p(x) != y. */
 int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *x, const void *y,
-                              int sfmt, void *out, int ofmt);
+                              int sfmt, int flags, void *out, int ofmt);
+/* KZGProver::create_witness_batched over the group (src/coeff_form.rs:83-111): interpolant and quotient (p - I)/Z replicated on
+ * every GPU (NTTs do not shard), the quotient MSM sharded like the commit.  Arguments and errors as kzg_witness_coeff_batched;
+ * coeffs as for kzg_witness_coeff_sharded.  out_w: one point (host), out_r: the interpolant, on every rank. */
+int kzg_witness_coeff_batched_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *xs,
+                                      const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt, void *out_r,
+                                      size_t *out_r_len);
 
 /* ---- NTT: EvaluationDomain::fft / ifft (src/ft.rs:111-140; best_fft :274-288) --------------- */
 /* EvaluationDomain::compute_omega (src/ft.rs:55-76): m = next pow2 >= d, exp = log2 m, omega.
@@ -329,13 +356,6 @@ int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen);
 /* number of window bits and windows the engine chose for this SRS (for G1-adds accounting) */
 int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows);
 int kzg_srs_table_rows(const kzg_srs *srs);   /* resident table rows (= windows unless option window_rows) */
-
-/* ---- unit-test hooks (device arithmetic exercised directly; used by tests/ only) -------------- */
-int kzg_test_fr_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery */
-int kzg_test_fq_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery, 48 B */
-int kzg_test_fr_inv(kzg_ctx *ctx, const void *a, size_t n, void *out);
-int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* affine mont 96 */
-int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k_canonical, size_t n, void *out);
 
 #ifdef __cplusplus
 }

@@ -305,7 +305,27 @@ class ShardedKZGProver {  // KZGProver (src/coeff_form.rs:37-81) with the SRS sp
     KZGWitness create_witness(const Polynomial &p, const Scalar &x, const Scalar &y) const {  // :66-81
         G1Affine out;
         g_.check(kzg_witness_coeff_sharded(g_.handle(), params_.gs, p.coeffs.data(), p.num_coeffs(), x.le.data(), y.le.data(),
-                                           KZG_FR_CANONICAL_LE_32, out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+                                           KZG_FR_CANONICAL_LE_32, 0, out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+    // :83-111; returns the witness, `r` receives the interpolant (as the reference's (KZGWitness, Polynomial) pair)
+    KZGWitness create_witness_batched(const Polynomial &p, const std::vector<Scalar> &xs, const std::vector<Scalar> &ys,
+                                      Polynomial *r) const {
+        G1Affine out;
+        const size_t k = xs.size();
+        std::vector<uint8_t> xb(32 * k), yb(32 * k), rb(32 * (k < 2 ? 2 : k));
+        for (size_t i = 0; i < k; i++) {
+            std::memcpy(&xb[32 * i], xs[i].le.data(), 32);
+            std::memcpy(&yb[32 * i], ys[i].le.data(), 32);
+        }
+        size_t rl = 0;
+        g_.check(kzg_witness_coeff_batched_sharded(g_.handle(), params_.gs, p.coeffs.data(), p.num_coeffs(), xb.data(), yb.data(), k,
+                                                   KZG_FR_CANONICAL_LE_32, 0, out.bytes.data(), KZG_G1_AFFINE_MONT_96, rb.data(), &rl));
+        if (r) {
+            std::vector<Scalar> c(rl);
+            std::memcpy(c.data(), rb.data(), 32 * rl);
+            *r = Polynomial::make(std::move(c));
+        }
         return out;
     }
 

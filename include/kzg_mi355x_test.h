@@ -1,0 +1,22 @@
+/*
+ * kzg_mi355x_test.h -- unit-test hooks: device arithmetic exercised directly.  NOT part of the product ABI: they exist only in
+ * the -DKZG_TEST_HOOKS build of the library (kzg_amd/libkzg_mi355x_hooks.so, built by `python -m kzg_amd.build` next to the
+ * product library and loaded by tests/ only).
+ */
+#ifndef KZG_MI355X_TEST_H
+#define KZG_MI355X_TEST_H
+#include "kzg_mi355x.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int kzg_test_fr_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery */
+int kzg_test_fq_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* Montgomery, 48 B */
+int kzg_test_fr_inv(kzg_ctx *ctx, const void *a, size_t n, void *out);
+int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* affine mont 96 */
+int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k_canonical, size_t n, void *out);
+/* the next sharded call of this group fails locally on local GPU 0 with `code` (status agreement across ranks, mgpu.hip) */
+int kzg_test_mctx_inject_failure(struct kzg_mctx *m, int code);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -47,6 +47,7 @@ def load(path=None):
     sz, i32, u32, u64, vp = ctypes.c_size_t, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p
     sig = {
         "kzg_version": (ctypes.c_char_p, []),
+        "kzg_init_hw_queues": (i32, [i32]),
         "kzg_device_count": (i32, []),
         "kzg_ctx_create": (i32, [i32, c_void_pp]),
         "kzg_ctx_destroy": (None, [vp]),
@@ -86,7 +87,9 @@ def load(path=None):
         "kzg_msrs_free": (None, [vp, vp]),
         "kzg_commit_coeff_sharded": (i32, [vp, vp, vp, sz, i32, i32, vp, i32]),
         "kzg_commit_coeff_sharded_batch": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
-        "kzg_witness_coeff_sharded": (i32, [vp, vp, vp, sz, vp, vp, i32, vp, i32]),
+        "kzg_witness_coeff_sharded": (i32, [vp, vp, vp, sz, vp, vp, i32, i32, vp, i32]),
+        "kzg_witness_coeff_batched_sharded": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, vp, ctypes.POINTER(sz)]),
+        "kzg_mctx_info": (i32, [vp, ctypes.c_char_p, sz]),
         "kzg_compute_omega": (i32, [sz, ctypes.POINTER(sz), ctypes.POINTER(u32), vp, i32]),
         "kzg_ntt_fr": (i32, [vp, vp, u32, i32, i32]),
         "kzg_coset_ntt_fr": (i32, [vp, vp, u32, i32, i32, i32]),
@@ -128,16 +131,16 @@ def load(path=None):
         "kzg_prof_reset": (i32, [vp]),
         "kzg_prof_get": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double)]),
         "kzg_prof_names": (i32, [vp, ctypes.c_char_p, sz]),
-        "kzg_test_fr_mul": (i32, [vp, vp, vp, sz, vp]),
-        "kzg_test_fq_mul": (i32, [vp, vp, vp, sz, vp]),
-        "kzg_test_fr_inv": (i32, [vp, vp, sz, vp]),
-        "kzg_test_g1_add": (i32, [vp, vp, vp, sz, vp]),
-        "kzg_test_g1_mul": (i32, [vp, vp, vp, sz, vp]),
     }
     for name, (res, args) in sig.items():
         f = getattr(L, name)  # raises AttributeError if the export is missing
         f.restype = res
         f.argtypes = args
     L._kzg_signatures = sig
+    # This module is the host: like a Rust host following INTEGRATION.md it asks for the hardware queues of the pipelined
+    # paths before the first HIP call of the process (the library itself never changes the environment).  KZG_HW_QUEUES=0
+    # leaves the runtime's default pool (the engine then narrows its pipeline to the queues it measures).
+    if os.environ.get("KZG_HW_QUEUES", "1") != "0":
+        L.kzg_init_hw_queues(0)
     _lib = L
     return L

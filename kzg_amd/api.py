@@ -15,6 +15,7 @@ import ctypes
 from . import _lib as L
 
 R_MODULUS = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+FR_MONT_R = (1 << 256) % R_MODULUS  # blst_fr / KZG_FR_MONT_LE_32: a * 2^256 mod r
 
 
 class KZGError(Exception):
@@ -580,14 +581,46 @@ class DeviceGroup:
         self._check(rc)
         return [out.raw[i * psz:(i + 1) * psz] for i in range(batch)]
 
-    def create_witness(self, srs, coeffs, point, ofmt=L.G1_AFFINE_MONT):
+    def _whole_poly_arg(self, coeffs):
+        """host blob / ints, or a list of DeviceBuffer (one per local GPU, each the WHOLE polynomial)"""
+        if isinstance(coeffs, (list, tuple)) and coeffs and isinstance(coeffs[0], DeviceBuffer):
+            ptrs = (ctypes.c_void_p * len(coeffs))(*[c.ptr.value for c in coeffs])
+            return ptrs, coeffs[0].n, coeffs[0].sfmt, L.IN_DEVICE
         blob = pack_scalars(coeffs)
+        return blob, len(blob) // 32, L.FR_CANONICAL, 0
+
+    def create_witness(self, srs, coeffs, point, ofmt=L.G1_AFFINE_MONT):
+        """KZGProver::create_witness over the group (replicated quotient, sharded MSM)."""
+        arg, n, sfmt, flags = self._whole_poly_arg(coeffs)
         x, y = point
+        conv = (lambda v: (v % R_MODULUS).to_bytes(32, "little")) if sfmt == L.FR_CANONICAL else (lambda v: (v * FR_MONT_R % R_MODULUS).to_bytes(32, "little"))
         out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
-        self._check(self.lib.kzg_witness_coeff_sharded(self.handle, srs.handle, blob, len(blob) // 32,
-                                                       (x % R_MODULUS).to_bytes(32, "little"), (y % R_MODULUS).to_bytes(32, "little"),
-                                                       L.FR_CANONICAL, out, ofmt))
+        self._check(self.lib.kzg_witness_coeff_sharded(self.handle, srs.handle, arg, n, conv(x), conv(y), sfmt, flags, out, ofmt))
         return out.raw
+
+    def create_witness_batched(self, srs, coeffs, points, ofmt=L.G1_AFFINE_MONT):
+        """KZGProver::create_witness_batched over the group: (witness bytes, interpolant coefficients)."""
+        arg, n, sfmt, flags = self._whole_poly_arg(coeffs)
+        k = len(points)
+        conv = (lambda v: (v % R_MODULUS).to_bytes(32, "little")) if sfmt == L.FR_CANONICAL else (lambda v: (v * FR_MONT_R % R_MODULUS).to_bytes(32, "little"))
+        xs = b"".join(conv(p[0]) for p in points)
+        ys = b"".join(conv(p[1]) for p in points)
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        rbuf = ctypes.create_string_buffer(32 * max(k, 2))
+        rlen = ctypes.c_size_t()
+        self._check(self.lib.kzg_witness_coeff_batched_sharded(self.handle, srs.handle, arg, n, xs, ys, k, sfmt, flags, out, ofmt,
+                                                               rbuf, ctypes.byref(rlen)))
+        r = unpack_scalars(rbuf.raw[:32 * rlen.value])
+        if sfmt != L.FR_CANONICAL:
+            rinv = pow(FR_MONT_R, -1, R_MODULUS)
+            r = [v * rinv % R_MODULUS for v in r]
+        return out.raw, r
+
+    def info(self):
+        """which RCCL / HIP runtime the group runs on (kzg_mctx_info)"""
+        buf = ctypes.create_string_buffer(1024)
+        self._check(self.lib.kzg_mctx_info(self.handle, buf, 1024))
+        return buf.value.decode()
 
     def close(self):
         if self.handle:

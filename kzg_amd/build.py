@@ -7,6 +7,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkzg_mi355x.so")
+# the same library with the unit-test hooks of include/kzg_mi355x_test.h compiled in (-DKZG_TEST_HOOKS): loaded by tests/ only
+OUT_HOOKS = os.path.join(HERE, "libkzg_mi355x_hooks.so")
+HOOK_SOURCES = ["capi.hip", "mgpu.hip"]  # the translation units that hold hooks
 SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip", "msm_wide.hip", "msm_tail.hip", "mgpu.hip", "gfft.hip"]
 # per-file extra flags (none at present; out-of-line multiplies for the tail kernels were measured: no gain)
 EXTRA_FLAGS = {}
@@ -26,6 +29,7 @@ def build(force=False, verbose=False):
     # every header / generated include: a stale object after a header-only edit would silently ship old kernels
     hdrs = [os.path.join(CSRC, h) for h in sorted(os.listdir(CSRC)) if h.endswith((".h", ".inc"))]
     hdrs.append(os.path.join(HERE, "..", "include", "kzg_mi355x.h"))
+    hdrs.append(os.path.join(HERE, "..", "include", "kzg_mi355x_test.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []
@@ -34,6 +38,10 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         if force or _stale(obj, [src] + hdrs):
             jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", src, "-o", obj])
+        if s in HOOK_SOURCES:
+            hobj = os.path.join(objdir, s.replace(".hip", "_hooks.o"))
+            if force or _stale(hobj, [src] + hdrs):
+                jobs.append([hipcc] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-DKZG_TEST_HOOKS", "-c", src, "-o", hobj])
 
     def run(cmd):
         if verbose:
@@ -50,6 +58,9 @@ def build(force=False, verbose=False):
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in srcs]
     if force or jobs or _stale(OUT, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl", "-lpthread"])
+    hobjs = [os.path.join(objdir, s.replace(".hip", "_hooks.o" if s in HOOK_SOURCES else ".o")) for s in srcs]
+    if force or jobs or _stale(OUT_HOOKS, hobjs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT_HOOKS] + hobjs + ["-ldl", "-lpthread"])
     return OUT
 
 

@@ -49,7 +49,7 @@ int lane_pinned(kzg_ctx *ctx, int lane, size_t bytes) {
 // ---------------------------------------------------------------------------------------------
 // profiling: HIP events recorded on the stream each kernel is launched on
 // ---------------------------------------------------------------------------------------------
-static hipEvent_t get_event(kzg_ctx *ctx) {
+static hipEvent_t get_event(kzg_ctx *ctx) {  // prof_mu held
     if (!ctx->event_pool.empty()) {
         hipEvent_t e = ctx->event_pool.back();
         ctx->event_pool.pop_back();
@@ -62,18 +62,23 @@ static hipEvent_t get_event(kzg_ctx *ctx) {
 
 ProfScope::ProfScope(kzg_ctx *c, hipStream_t s, const char *n) : ctx(c), stream(s), name(n) {
     if (!ctx->prof) return;
-    start = get_event(ctx);
-    stop = get_event(ctx);
+    {
+        std::lock_guard<std::mutex> lk(ctx->prof_mu);
+        start = get_event(ctx);
+        stop = get_event(ctx);
+    }
     hipEventRecord(start, stream);
 }
 
 ProfScope::~ProfScope() {
     if (!start) return;
     hipEventRecord(stop, stream);
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
     ctx->prof_pending.push_back(PendingEvent{name, start, stop});
 }
 
 void prof_collect(kzg_ctx *ctx) {
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
     for (auto &p : ctx->prof_pending) {
         float ms = 0.f;
         hipEventSynchronize(p.stop);
@@ -91,11 +96,6 @@ void prof_collect(kzg_ctx *ctx) {
 // ---------------------------------------------------------------------------------------------
 // helpers shared by the entry points
 // ---------------------------------------------------------------------------------------------
-struct Guard {
-    std::lock_guard<std::mutex> lk;
-    explicit Guard(kzg_ctx *c) : lk(c->mu) {}
-};
-
 static int host_scalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
     Fr v;
     memcpy(v.v, s, 32);
@@ -170,8 +170,9 @@ static bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 // element counts whose byte sizes cannot overflow the arena arithmetic (2^40 Fr elements = 32 TiB: far beyond any device)
 static bool count_ok(size_t n) { return n <= ((size_t)1 << 40); }
 
+#ifdef KZG_TEST_HOOKS
 // ---------------------------------------------------------------------------------------------
-// device unit-test kernels
+// device unit-test kernels (only in the -DKZG_TEST_HOOKS build: kzg_amd/libkzg_mi355x_hooks.so, include/kzg_mi355x_test.h)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_test_fr_mul(const Fr *a, const Fr *b, size_t n, Fr *o) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,6 +205,8 @@ __global__ __launch_bounds__(256) void k_test_g1_mul(const G1Affine *p, const Fr
     o[i] = g1_to_affine(g1_scalar_mul(p[i], kk.v));
 }
 
+#endif  // KZG_TEST_HOOKS
+
 }  // namespace kzg
 
 using namespace kzg;
@@ -213,12 +216,22 @@ using namespace kzg;
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *kzg_version(void) { return "kzg-mi355x 0.1.0 (gfx950)"; }
 
-// The batched pipeline wants one hardware queue per stream (16 lanes + 2 accumulation streams); the HIP runtime sizes its queue
-// pool from GPU_MAX_HW_QUEUES (default 4) when it initialises, i.e. at the first HIP call of the process.  A host that links or
-// loads this library before touching HIP therefore gets the right pool without exporting anything: the variable is set here, at
-// load time, unless the host has already chosen a value.  (A host that initialises HIP first keeps the runtime's 4 queues; the
-// pipeline then measures what it has -- probe_queues() -- and narrows itself, at ~4 % lower batched throughput.)
-__attribute__((constructor)) static void kzg_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+// The pipelined paths want one hardware queue per stream (16 lanes + 2 accumulation streams); the HIP runtime sizes its queue
+// pool from GPU_MAX_HW_QUEUES (default 4) when it initialises, i.e. at the first HIP call of the process.  The library does not
+// touch the host's environment on its own: the host either exports GPU_MAX_HW_QUEUES itself, or calls kzg_init_hw_queues()
+// before its first HIP call, or sets KZG_SET_HW_QUEUES=<n> to let the load-time constructor below do it.  Without any of these
+// the pipeline measures the queues it has (probe_queues) and narrows itself (4 queues: 3 lanes + 1 accumulation stream; loss
+// in INTEGRATION.md section 6, profiles/r03_hw_queues.txt).
+extern "C" int kzg_init_hw_queues(int queues) {
+    if (queues < 0 || queues > 64) return KZG_ERR_SHAPE;
+    char buf[16];
+    snprintf(buf, sizeof buf, "%d", queues ? queues : 24);
+    return setenv("GPU_MAX_HW_QUEUES", buf, 0) == 0 ? KZG_OK : KZG_ERR_INTERNAL;  // a value the host exported is kept
+}
+__attribute__((constructor)) static void kzg_optional_hw_queues() {
+    const char *e = getenv("KZG_SET_HW_QUEUES");
+    if (e && atoi(e) > 0) kzg_init_hw_queues(atoi(e) == 1 ? 0 : atoi(e));
+}
 
 extern "C" int kzg_device_count(void) {
     int count = 0;
@@ -235,6 +248,7 @@ extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+    ctx->lanes.reserve(KZG_MAX_LANES);  // never reallocated: leased lanes are indexed while an exclusive caller appends
     ctx->lanes.resize(1);
     if (hipStreamCreateWithFlags(&ctx->lanes[0].stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
@@ -244,7 +258,8 @@ extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
     return KZG_OK;
 }
 
-static int ensure_lanes(kzg_ctx *ctx, int want) {
+static int ensure_lanes(kzg_ctx *ctx, int want) {  // exclusive callers only
+    if (want > KZG_MAX_LANES) return fail(ctx, KZG_ERR_INTERNAL, "lane count");
     while ((int)ctx->lanes.size() < want) {
         Lane l;
         KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
@@ -279,10 +294,14 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
 extern "C" const char *kzg_last_error(kzg_ctx *ctx) {
     // copied under the context's lock into a per-thread buffer: another thread failing on the same context cannot
     // invalidate the returned pointer (it stays valid until this thread's next kzg_last_error call)
+    // the calling thread's own last failure on this context if it had one, else the context's last message
     if (!ctx) return "null context";
     static thread_local std::string tl_err;
-    {
-        Guard g(ctx);
+    ThreadErr &te = thread_err();
+    if (te.ctx == ctx) {
+        tl_err = te.msg;
+    } else {
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
         tl_err = ctx->err;
     }
     return tl_err.c_str();
@@ -306,6 +325,7 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "streams") {
         if (value < 1 || value > 16) return fail(ctx, KZG_ERR_SHAPE, "streams must be 1..16");
         ctx->opt_streams = (int)value;
+        ctx->pipe_planned = false;
     } else if (k == "accum_blocks" || k == "accum_blocks_batch") {
         if (value != 0 && (value < 64 || value > 256 * KZG_ACCUM_WAVES))
             return fail(ctx, KZG_ERR_SHAPE, "accum_blocks must be 0 (auto) or 64..256 x waves per SIMD");
@@ -318,16 +338,17 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "accum_streams") {
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
+        ctx->pipe_planned = false;
     } else if (k == "host_affine") {
         ctx->opt_host_affine = value != 0;
     } else if (k == "sort_single_pass") {
         ctx->opt_sort_single = value != 0;
     } else if (k == "tail_quads") {
         ctx->opt_tail_quads = value != 0;
-        ctx->cur_tail_quads = ctx->opt_tail_quads;
     } else if (k == "hw_queues") {
         if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "hw_queues must be 0 (GPU_MAX_HW_QUEUES or the ROCm default of 4) or 1..64");
         ctx->opt_hw_queues = (int)value;
+        ctx->pipe_planned = false;
     } else if (k == "window_rows") {
         if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "window_rows must be 0 (one table row per window) or 1..64");
         ctx->opt_window_rows = (int)value;
@@ -345,9 +366,11 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
 // ---------------------------------------------------------------------------------------------
 // device memory + profiling
 // ---------------------------------------------------------------------------------------------
+// kzg_dev_alloc / upload / download do not take the context exclusively (the HIP calls are thread-safe by themselves): a host
+// thread staging its next polynomial must not drain the other threads' commits.  Every entry point has synchronised its own
+// work before it returned, so a plain copy sees the results of all completed calls.
 extern "C" int kzg_dev_alloc(kzg_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return KZG_ERR_SHAPE;
-    Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     hipError_t e = hipMalloc(out, bytes ? bytes : 16);
     if (e != hipSuccess) return fail(ctx, KZG_ERR_ALLOC, hipGetErrorString(e));
@@ -363,16 +386,13 @@ extern "C" int kzg_dev_free(kzg_ctx *ctx, void *p) {
 }
 extern "C" int kzg_dev_upload(kzg_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes) {
     if (!ctx) return KZG_ERR_SHAPE;
-    Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (bytes) KZG_HIP_CHECK(ctx, hipMemcpy(dst_dev, src_host, bytes, hipMemcpyHostToDevice));
     return KZG_OK;
 }
 extern "C" int kzg_dev_download(kzg_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes) {
     if (!ctx) return KZG_ERR_SHAPE;
-    Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
     if (bytes) KZG_HIP_CHECK(ctx, hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
     return KZG_OK;
 }
@@ -415,25 +435,96 @@ extern "C" int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen) {
 // ---------------------------------------------------------------------------------------------
 // MSM
 // ---------------------------------------------------------------------------------------------
-static int msm_locked(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, int sfmt, int flags,
-                      void *out, int ofmt) {
-    KZG_TRY(check_sfmt(ctx, sfmt));
-    if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
-    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
-    KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
-    const void *d_sc = nullptr;
-    KZG_TRY(stage_in(ctx, 0, scalars, n * 32, flags, &d_sc));
-    MsmPoint *res = nullptr;
-    KZG_TRY(msm_run(ctx, 0, srs, offset, d_sc, n, sfmt, &res));
-    return finish_point(ctx, 0, res, out, ofmt, flags);
+static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out);
+static void set_lane_mode(kzg_ctx *ctx, int lane, bool pipelined, bool deep);
+
+// ---- leased lanes: the reference's blocking prover calls from many host threads (CtxGate, common.h) -------------------------
+struct Lease {
+    kzg_ctx *ctx = nullptr;
+    int lane = -1;
+    hipStream_t accum = nullptr;  // the FIFO accumulation stream of this call (nullptr: on the lane's own stream)
+    ~Lease() {
+        if (!ctx || lane < 0) return;
+        set_lane_mode(ctx, lane, false, false);  // exclusive callers (lane 0) find the lone-MSM shape
+        {
+            std::lock_guard<std::mutex> lk(ctx->mu.m);
+            ctx->mu.lane_busy &= ~(1u << lane);
+            ctx->mu.shared_active--;
+        }
+        ctx->mu.cv.notify_all();
+    }
+};
+
+// the pool concurrent callers lease from: `streams` lanes + the accumulation streams, planned like a batch of that depth
+static int plan_for_callers(kzg_ctx *ctx) {
+    int nl = 1, nas = 0;
+    KZG_TRY(plan_pipeline(ctx, ctx->opt_streams, &nl, &nas));
+    ctx->pipe_lanes = nl;
+    ctx->pipe_accum = nas;
+    ctx->pipe_planned = true;
+    return KZG_OK;
+}
+
+static int lease_lane(kzg_ctx *ctx, Lease *ls) {
+    CtxGate &g = ctx->mu;
+    std::unique_lock<std::mutex> lk(g.m);
+    for (;;) {
+        g.cv.wait(lk, [&] {
+            if (g.exclusive || g.excl_waiting) return false;
+            if (g.shared_active == 0 || !ctx->pipe_planned) return true;
+            return (g.lane_busy & ((1u << ctx->pipe_lanes) - 1u)) != ((1u << ctx->pipe_lanes) - 1u);
+        });
+        if (g.shared_active == 0 || ctx->pipe_planned) break;
+        // a second caller and no plan yet: take the context exclusively once (waits for the first caller), plan, try again
+        lk.unlock();
+        int rc;
+        {
+            Guard ex(ctx);
+            rc = hipSetDevice(ctx->device) == hipSuccess ? KZG_OK : fail(ctx, KZG_ERR_HIP, "hipSetDevice");
+            if (rc == KZG_OK && !ctx->pipe_planned) rc = plan_for_callers(ctx);
+        }
+        if (rc != KZG_OK) return rc;
+        lk.lock();
+    }
+    const int others = g.shared_active;
+    int lane = 0;
+    if (ctx->pipe_planned)
+        while (lane < ctx->pipe_lanes && (g.lane_busy >> lane & 1u)) lane++;
+    // (unplanned: only reached with no other caller active, lane 0)
+    g.lane_busy |= 1u << lane;
+    g.shared_active++;
+    ls->ctx = ctx;
+    ls->lane = lane;
+    // a lone caller gets the latency shape (full accumulation grid on its own stream, quad-lane tail kernels); with others in
+    // flight the call is one stage of a pipeline: batch-sized grid on a FIFO accumulation stream, lane-time tail
+    const bool pipelined = others > 0 && ctx->pipe_planned;
+    set_lane_mode(ctx, lane, pipelined, others >= 3);
+    if (pipelined && ctx->pipe_accum > 0) ls->accum = ctx->accum_streams[ctx->accum_rr.fetch_add(1) % (uint32_t)ctx->pipe_accum];
+    return KZG_OK;
+}
+
+static int lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res) {
+    if (ls.accum)
+        return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res, ls.accum, ctx->sorted_events[ls.lane], ctx->accum_events[ls.lane]);
+    return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res);
 }
 
 extern "C" int kzg_msm_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, int sfmt,
                           int flags, void *out, int ofmt) {
     if (!ctx || !srs || !out || (!scalars && n)) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
-    return msm_locked(ctx, srs, offset, scalars, n, sfmt, flags, out, ofmt);
+    KZG_TRY(check_sfmt(ctx, sfmt));
+    if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
+    KZG_TRY(lane_reserve(ctx, lane, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
+    const void *d_sc = nullptr;
+    KZG_TRY(stage_in(ctx, lane, scalars, n * 32, flags, &d_sc));
+    MsmPoint *res = nullptr;
+    KZG_TRY(lease_msm(ctx, ls, srs, offset, d_sc, n, sfmt, &res));
+    return finish_point(ctx, lane, res, out, ofmt, flags);
 }
 
 extern "C" int kzg_commit_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n, int sfmt, int flags,
@@ -444,10 +535,7 @@ extern "C" int kzg_commit_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *co
 extern "C" int kzg_commit_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const void *evals, size_t d, int sfmt, int flags,
                                void *out, int ofmt) {
     if (!ctx || !lagrange) return KZG_ERR_SHAPE;
-    if (d != lagrange->n) {
-        Guard g(ctx);
-        return fail(ctx, KZG_ERR_SHAPE, "assert!(self.d == evals.d) (src/eval_form.rs:115)");
-    }
+    if (d != lagrange->n) return fail(ctx, KZG_ERR_SHAPE, "assert!(self.d == evals.d) (src/eval_form.rs:115)");
     return kzg_msm_g1(ctx, lagrange, 0, evals, d, sfmt, flags, out, ofmt);
 }
 
@@ -515,11 +603,73 @@ struct BatchPipe {
     bool out_dev = false;
 };
 
+static void set_lane_mode(kzg_ctx *ctx, int lane, bool pipelined, bool deep) {
+    MsmMode &m = ctx->lanes[lane].mode;
+    m.accum_blocks = pipelined ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
+    m.sort_threads = pipelined ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
+    m.tail_quads = pipelined ? false : ctx->opt_tail_quads != 0;
+    m.tail_wide = pipelined && deep;
+}
+
+// Lanes and accumulation streams for a pipeline of up to `want` MSMs in flight (exclusive callers only: streams are created,
+// probed and re-ordered here).  Every stream must map to a hardware queue of its own (streams that share a queue serialise: a
+// lane's tail kernels would wait behind another lane's accumulation).  How many queues the process really has is MEASURED once
+// per context (probe_queues), so the plan does not depend on what the host exported before HIP initialised; with fewer queues
+// than lanes + accumulation streams the pipeline is narrowed to fit (measured on 4 queues: 3 lanes + 1 accumulation stream
+// 392/s, 2 + 2: 330/s, 4 + 0: 383/s, against 405/s with 18 queues; profiles/r02_hw_queues.txt).
+static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
+    int nl = want, nas = want > 1 ? ctx->opt_accum_streams : 0;
+    if (want > 1) {
+        KZG_TRY(ensure_lanes(ctx, want));
+        for (int i = 0; i < nas; i++)
+            if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking));
+        int queues = ctx->opt_hw_queues;
+        if (queues <= 0) {
+            if (ctx->probed_queues == 0 || ctx->probed_lanes < want || ctx->probed_accum < nas) {
+                KZG_TRY(probe_queues(ctx, want, nas));
+                ctx->probed_lanes = want;
+                ctx->probed_accum = nas;
+            }
+            queues = ctx->probed_queues;
+        }
+        if (nl + nas > queues) {
+            if (queues >= 4) {  // measured (profiles/r02_hw_queues.txt): Q = 4: 3 + 1 best; Q = 8: 6 + 2; Q = 12: 10 + 2; "many + 1" loses 10 %
+                nas = nas ? (queues >= 6 && nas >= 2 ? 2 : 1) : 0;
+                nl = queues - nas;
+            } else {
+                nas = 0;
+                nl = queues > 0 ? queues : 1;
+            }
+            if (nl > want) nl = want;
+        }
+        // hand the probed streams out so that the ones this plan uses are on different queues: lanes first, accumulation
+        // streams next; the others stay parked in the remaining probed slots
+        if (ctx->opt_hw_queues <= 0 && (int)ctx->probed_order.size() == ctx->probed_lanes + ctx->probed_accum &&
+            nl <= ctx->probed_lanes && nas <= ctx->probed_accum) {
+            for (auto &l : ctx->lanes) KZG_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
+            size_t r = 0;
+            for (int l = 0; l < nl; l++) ctx->lanes[l].stream = ctx->probed_order[r++];
+            for (int i = 0; i < nas; i++) ctx->accum_streams[i] = ctx->probed_order[r++];
+            for (int l = nl; l < ctx->probed_lanes; l++) ctx->lanes[l].stream = ctx->probed_order[r++];
+            for (int i = nas; i < ctx->probed_accum; i++) ctx->accum_streams[i] = ctx->probed_order[r++];
+            ctx->pipe_planned = false;  // the lease plan (below) re-derives itself from the new order
+        }
+    }
+    if (getenv("KZG_DEBUG")) fprintf(stderr, "kzg: pipeline plan: %d lanes + %d accumulation streams\n", nl, nas);
+    KZG_TRY(ensure_lanes(ctx, nl));
+    while (nas && (int)ctx->sorted_events.size() < nl) {
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
+        ctx->sorted_events.push_back(e1);
+        ctx->accum_events.push_back(e2);
+    }
+    *nl_out = nl;
+    *nas_out = nas;
+    return KZG_OK;
+}
+
 static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, int flags, BatchPipe *bp) {
-    bp->nl = (int)std::min<size_t>(batch, (size_t)ctx->opt_streams);
-    int nl = bp->nl;
-    ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
-    ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
     bp->out_dev = (flags & KZG_OUT_DEVICE) != 0;
     if (bp->out_dev) {
         bp->d_out = (uint8_t *)out;
@@ -534,62 +684,9 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
         }
         bp->d_out = (uint8_t *)ctx->batch_out;
     }
-    // Every stream must map to a hardware queue of its own (streams that share a queue serialise: a lane's tail kernels would
-    // wait behind another lane's accumulation).  How many queues the process really has is MEASURED once per context
-    // (probe_queues), so the plan does not depend on what the host exported before HIP initialised; with fewer queues than
-    // lanes + accumulation streams the pipeline is narrowed to fit (measured on 4 queues: 3 lanes + 1 accumulation stream
-    // 392/s, 2 + 2: 330/s, 4 + 0: 383/s, against 405/s with 18 queues; profiles/r02_hw_queues.txt).
-    bp->nas = nl > 1 ? ctx->opt_accum_streams : 0;
-    if (nl > 1) {
-        KZG_TRY(ensure_lanes(ctx, nl));
-        for (int i = 0; i < bp->nas; i++)
-            if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking));
-        int queues = ctx->opt_hw_queues;
-        if (queues <= 0) {
-            if (ctx->probed_queues == 0 || ctx->probed_lanes < nl || ctx->probed_accum < bp->nas) {
-                KZG_TRY(probe_queues(ctx, nl, bp->nas));
-                ctx->probed_lanes = nl;
-                ctx->probed_accum = bp->nas;
-            }
-            queues = ctx->probed_queues;
-        }
-        if (nl + bp->nas > queues) {
-            if (queues >= 4) {  // measured (profiles/r02_hw_queues.txt): Q = 4: 3 + 1 best; Q = 8: 6 + 2; Q = 12: 10 + 2; "many + 1" loses 10 %
-                bp->nas = bp->nas ? (queues >= 6 && bp->nas >= 2 ? 2 : 1) : 0;
-                bp->nl = queues - bp->nas;
-            } else {
-                bp->nas = 0;
-                bp->nl = queues > 0 ? queues : 1;
-            }
-            if (bp->nl > nl) bp->nl = nl;
-        }
-        // hand the probed streams out so that the ones this plan uses are on different queues: lanes first, accumulation
-        // streams next; the others stay parked in the remaining probed slots
-        if (ctx->opt_hw_queues <= 0 && (int)ctx->probed_order.size() == ctx->probed_lanes + ctx->probed_accum &&
-            bp->nl <= ctx->probed_lanes && bp->nas <= ctx->probed_accum) {
-            for (auto &l : ctx->lanes) KZG_HIP_CHECK(ctx, hipStreamSynchronize(l.stream));
-            size_t r = 0;
-            for (int l = 0; l < bp->nl; l++) ctx->lanes[l].stream = ctx->probed_order[r++];
-            for (int i = 0; i < bp->nas; i++) ctx->accum_streams[i] = ctx->probed_order[r++];
-            for (int l = bp->nl; l < ctx->probed_lanes; l++) ctx->lanes[l].stream = ctx->probed_order[r++];
-            for (int i = bp->nas; i < ctx->probed_accum; i++) ctx->accum_streams[i] = ctx->probed_order[r++];
-        }
-    }
-    nl = bp->nl;
-    if (getenv("KZG_DEBUG")) fprintf(stderr, "kzg: batch plan: %d lanes + %d accumulation streams\n", bp->nl, bp->nas);
-    KZG_TRY(ensure_lanes(ctx, nl));
-    ctx->cur_accum_blocks = nl > 1 ? ctx->accum_blocks_batch() : ctx->accum_blocks_single();
-    ctx->cur_sort_threads = nl > 1 ? ctx->opt_sort_threads_batch : ctx->opt_sort_threads;
-    ctx->cur_tail_quads = nl > 1 ? 0 : ctx->opt_tail_quads;
+    KZG_TRY(plan_pipeline(ctx, (int)std::min<size_t>(batch, (size_t)ctx->opt_streams), &bp->nl, &bp->nas));
     // at least two MSMs per lane: the lanes never run dry, so the tail is organised for lane-time instead of depth
-    ctx->cur_tail_wide = nl > 1 && batch >= 2 * (size_t)nl;
-    while (bp->nas && (int)ctx->sorted_events.size() < nl) {
-        hipEvent_t e1 = nullptr, e2 = nullptr;
-        KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
-        ctx->sorted_events.push_back(e1);
-        ctx->accum_events.push_back(e2);
-    }
+    for (int l = 0; l < bp->nl; l++) set_lane_mode(ctx, l, bp->nl > 1, batch >= 2 * (size_t)bp->nl);
     return KZG_OK;
 }
 
@@ -603,10 +700,7 @@ static int batch_msm(kzg_ctx *ctx, const BatchPipe &bp, size_t b, int lane, cons
 
 static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_t out_bytes) {
     for (int l = 0; l < bp.nl; l++) hipStreamSynchronize(ctx->lanes[l].stream);
-    ctx->cur_accum_blocks = ctx->accum_blocks_single();
-    ctx->cur_sort_threads = ctx->opt_sort_threads;
-    ctx->cur_tail_quads = ctx->opt_tail_quads;
-    ctx->cur_tail_wide = false;
+    for (int l = 0; l < bp.nl; l++) set_lane_mode(ctx, l, false, false);
     if (rc == KZG_OK && !bp.out_dev) {
         hipError_t e = hipMemcpy(out, bp.d_out, out_bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
@@ -941,26 +1035,28 @@ extern "C" int kzg_witness_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *c
                                  const void *y, int sfmt, int flags, void *out, int ofmt) {
     // KZGProver::create_witness (src/coeff_form.rs:66-81)
     if (!ctx || !srs || !coeffs || !x || !y || !out || n == 0) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     if (n - 1 > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
     Fr xm;
     KZG_TRY(host_scalar(ctx, x, sfmt, &xm));
     size_t need = msm_workspace_bytes(srs, n - 1) + stage_bytes(n * 32, flags) + n * 32 + (n / 2048 + 4) * 64 + 65536;
-    KZG_TRY(lane_reserve(ctx, 0, need));
-    hipStream_t st = ctx->lanes[0].stream;
+    KZG_TRY(lane_reserve(ctx, lane, need));
+    hipStream_t st = ctx->lanes[lane].stream;
     const void *d = nullptr;
-    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
-    Fr *dq = (Fr *)lane_alloc(ctx, 0, n * 32);
-    Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
+    KZG_TRY(stage_in(ctx, lane, coeffs, n * 32, flags, &d));
+    Fr *dq = (Fr *)lane_alloc(ctx, lane, n * 32);
+    Fr *dpx = (Fr *)lane_alloc(ctx, lane, 256);
     if (!dq || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
-    KZG_TRY(quotient_linear_run(ctx, 0, (const Fr *)d, n, xm, dq, dpx));
+    KZG_TRY(quotient_linear_run(ctx, lane, (const Fr *)d, n, xm, dq, dpx));
     Fr px;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
     MsmPoint *res = nullptr;
-    KZG_TRY(msm_run(ctx, 0, srs, 0, dq, n - 1, sfmt, &res));
-    KZG_TRY(finish_point(ctx, 0, res, out, ofmt, flags));  // synchronises the stream
+    KZG_TRY(lease_msm(ctx, ls, srs, 0, dq, n - 1, sfmt, &res));
+    KZG_TRY(finish_point(ctx, lane, res, out, ofmt, flags));  // synchronises the stream
     // remainder of (p - y)/(X - x) is p(x) - y: Some(_) => Err(PointNotOnPolynomial)
     if (memcmp(px.v, y, 32) != 0) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
     return KZG_OK;
@@ -970,7 +1066,9 @@ extern "C" int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const voi
                                 int flags, void *out, int ofmt) {
     // KZGProverEvalForm::create_witness (src/eval_form.rs:124-140)
     if (!ctx || !lagrange || !evals || !out) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
@@ -979,15 +1077,15 @@ extern "C" int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const voi
     uint32_t log_d = (uint32_t)ilog2_ceil(d);
     if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
     size_t need = msm_workspace_bytes(lagrange, d) + stage_bytes(d * 32, flags) + d * 32 + (d / 256 + 4) * 32 + 65536;
-    KZG_TRY(lane_reserve(ctx, 0, need));
+    KZG_TRY(lane_reserve(ctx, lane, need));
     const void *de = nullptr;
-    KZG_TRY(stage_in(ctx, 0, evals, d * 32, flags, &de));
-    Fr *dq = (Fr *)lane_alloc(ctx, 0, d * 32);
+    KZG_TRY(stage_in(ctx, lane, evals, d * 32, flags, &de));
+    Fr *dq = (Fr *)lane_alloc(ctx, lane, d * 32);
     if (!dq) return fail(ctx, KZG_ERR_ALLOC, "workspace");
-    KZG_TRY(quotient_eval_run(ctx, 0, (const Fr *)de, log_d, i, sfmt, dq));
+    KZG_TRY(quotient_eval_run(ctx, lane, (const Fr *)de, log_d, i, sfmt, dq));
     MsmPoint *res = nullptr;
-    KZG_TRY(msm_run(ctx, 0, lagrange, 0, dq, d, sfmt, &res));
-    return finish_point(ctx, 0, res, out, ofmt, flags);
+    KZG_TRY(lease_msm(ctx, ls, lagrange, 0, dq, d, sfmt, &res));
+    return finish_point(ctx, lane, res, out, ofmt, flags);
 }
 
 static int verify_against(kzg_ctx *ctx, const MsmPoint *res, const void *commitment, int pfmt, int *ok) {
@@ -1038,6 +1136,8 @@ extern "C" int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const
     return verify_against(ctx, res, commitment, pfmt, ok);
 }
 
+#ifdef KZG_TEST_HOOKS
+#include "../../include/kzg_mi355x_test.h"
 // ---------------------------------------------------------------------------------------------
 // test hooks
 // ---------------------------------------------------------------------------------------------
@@ -1097,3 +1197,4 @@ extern "C" int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k, size_
                            (G1Affine *)dout);
     }, n, 96, 2, p, k, 32, out, 96);
 }
+#endif  // KZG_TEST_HOOKS

@@ -6,6 +6,8 @@
 #include <stdio.h>
 
 #include <array>
+#include <atomic>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <string>
@@ -27,9 +29,23 @@ struct PendingEvent {
     hipEvent_t start, stop;
 };
 
+#ifndef KZG_ACCUM_WAVES
+#define KZG_ACCUM_WAVES 2  // waves per SIMD k_accum_affine is compiled for (VGPR budget 512 / waves)
+#endif
+
+// How one MSM is shaped for what else is on the GPU (set per lane by the entry point that submits it).
+struct MsmMode {
+    int accum_blocks = 256 * KZG_ACCUM_WAVES;  // k_accum_affine grid (a lone MSM: every SIMD holds its KZG_ACCUM_WAVES waves)
+    int sort_threads = 1024;                   // threads per k_hist / k_scatter block
+    bool tail_quads = true;   // four lanes per point operation in the depth-bound tail kernels (latency mode, msm_tail.hip)
+    bool tail_wide = false;   // a pipeline whose lanes never run dry: work-efficient fold width and row/column sums
+};
+
 // One independent execution lane: a HIP stream plus a bump-allocated scratch arena in HBM.
-// Single calls use lane 0; kzg_msm_g1_batch pipelines independent MSMs over several lanes.
+// Exclusive calls use lane 0; kzg_msm_g1_batch pipelines independent MSMs over several lanes; concurrent blocking callers
+// (commit / create_witness from many host threads) each lease one lane for the duration of their call.
 struct Lane {
+    MsmMode mode;
     hipStream_t stream = nullptr;
     char *arena = nullptr;
     size_t arena_bytes = 0;
@@ -42,15 +58,51 @@ struct NttPlan;
 struct FixedBaseTable;
 struct EvalDomainTables;
 
-}  // namespace kzg
+// Who may use the context when.  Two kinds of callers:
+//   exclusive  everything that works on lane 0 / the shared caches / all lanes at once (NTT, polynomial helpers, SRS setup,
+//              the batched entry points, options): one at a time, as before.  lock() / unlock() -- the type is a BasicLockable,
+//              so std::lock_guard<CtxGate> is the old "Guard".
+//   shared     the reference's blocking prover calls (KZGProver::commit / create_witness, both forms, src/coeff_form.rs:59-81,
+//              src/eval_form.rs:114-140: `&self` methods of a Clone type, callable from many threads).  Each leases a free lane
+//              under this short lock, submits its kernels there (accumulation kernels on the shared FIFO streams) and waits for
+//              its own stream only -- N host threads calling commit() keep the pipeline as full as kzg_msm_g1_batch does.
+// Exclusive callers wait for the leased lanes to drain and hold new leases off while they wait (no starvation).
+struct CtxGate {
+    std::mutex m;
+    std::condition_variable cv;
+    int shared_active = 0;
+    int excl_waiting = 0;
+    bool exclusive = false;
+    uint32_t lane_busy = 0;  // bit l: lane l is leased
+    void lock() {
+        std::unique_lock<std::mutex> lk(m);
+        excl_waiting++;
+        cv.wait(lk, [&] { return !exclusive && shared_active == 0; });
+        excl_waiting--;
+        exclusive = true;
+    }
+    void unlock() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            exclusive = false;
+        }
+        cv.notify_all();
+    }
+};
+constexpr int KZG_MAX_LANES = 24;  // lanes.reserve(): leased lanes are indexed while other threads append
 
-#ifndef KZG_ACCUM_WAVES
-#define KZG_ACCUM_WAVES 2  // waves per SIMD k_accum_affine is compiled for (VGPR budget 512 / waves)
-#endif
+}  // namespace kzg
 
 struct kzg_ctx {
     int device = 0;
-    std::mutex mu;
+    kzg::CtxGate mu;
+    std::mutex err_mu;   // err
+    std::mutex prof_mu;  // prof_map, prof_pending, event_pool
+    std::mutex cache_mu; // eval_tabs (the other caches are touched by exclusive callers only)
+    std::mutex accum_mu; // wait / launch / record on a shared accumulation stream is one unit
+    std::atomic<uint32_t> accum_rr{0};  // round robin over the accumulation streams (leased lanes)
+    bool pipe_planned = false;          // lanes + accumulation streams created, probed and ordered for concurrent callers
+    int pipe_lanes = 1, pipe_accum = 0;
     std::string err;
     std::vector<kzg::Lane> lanes;
     int opt_window_bits = 0;  // 0 = auto
@@ -65,10 +117,7 @@ struct kzg_ctx {
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
     int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)
-    int cur_accum_blocks = 256 * KZG_ACCUM_WAVES;  // value msm_run uses (set by the entry point)
     int opt_tail_quads = 1;            // single MSMs: four lanes per point operation in the tail kernels (latency mode, msm_tail.hip)
-    int cur_tail_quads = 1;            // 0 inside a batched pipeline (lane-time counts there)
-    bool cur_tail_wide = false;        // a deep batched pipeline (>= 2 MSMs per lane): work-efficient fold width and row/column sums
     // kzg_msm_g1_batch: every k_accum_affine runs on one of this many dedicated streams, in submission order (0 = on its lane's
     // stream).  With the accumulation on the lanes' own streams the lanes fall into a convoy -- all sorting, then up to nine
     // accumulation kernels resident at once, then all in their tails -- and no accumulation kernel is resident 6 % of the time
@@ -79,13 +128,12 @@ struct kzg_ctx {
     std::vector<hipEvent_t> sorted_events, accum_events;  // per lane
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
     int opt_sort_threads_batch = 1024; // ... for batched MSMs
-    int cur_sort_threads = 1024;
     int opt_host_affine = 1;           // a lone result bound for host memory is converted to affine / serialised on the host (emit.h)
     int opt_sort_single = 0;           // 1: c = 17 sorts in one pass (2^16 cursors, two walks) instead of the two-level sort
     int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
     int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
     int num_cus = 256;
-    bool attr_msm_set = false, attr_ntt_set = false, attr_wide_set = false;  // > 64 KiB dynamic-LDS opt-in done for this device
+    std::atomic<bool> attr_msm_set{false}, attr_ntt_set{false}, attr_wide_set{false};  // > 64 KiB dynamic-LDS opt-in done for this device
     // profiling
     bool prof = false;
     std::map<std::string, kzg::ProfEntry> prof_map;
@@ -115,6 +163,11 @@ struct kzg_srs {
 
 namespace kzg {
 
+struct Guard {  // exclusive use of the context for the scope
+    std::lock_guard<CtxGate> lk;
+    explicit Guard(kzg_ctx *c) : lk(c->mu) {}
+};
+
 // validation of decoded points (what blstrs' G1Affine / G2Affine deserialisation enforces upstream):
 //   POINTS_TRUSTED   nothing (the engine's own intermediate results)
 //   POINTS_ON_CURVE  limbs canonical (< q) and on the curve
@@ -124,10 +177,7 @@ enum { POINTS_TRUSTED = 0, POINTS_ON_CURVE = 1, POINTS_SUBGROUP = 2 };
 #define KZG_HIP_CHECK(ctx, expr)                                                                   \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
-        if (_e != hipSuccess) {                                                                    \
-            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
-            return KZG_ERR_HIP;                                                                    \
-        }                                                                                          \
+        if (_e != hipSuccess) return kzg::fail((ctx), KZG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
     } while (0)
 
 #define KZG_TRY(expr)                                                                              \
@@ -136,8 +186,24 @@ enum { POINTS_TRUSTED = 0, POINTS_ON_CURVE = 1, POINTS_SUBGROUP = 2 };
         if (_s != KZG_OK) return _s;                                                               \
     } while (0)
 
+// The message goes to the context (for callers that ask later from another thread) and to the calling thread's own slot:
+// with several threads inside one context kzg_last_error returns the failure of the caller's own last call.
+struct ThreadErr {
+    const kzg_ctx *ctx = nullptr;
+    std::string msg;
+};
+inline ThreadErr &thread_err() {
+    static thread_local ThreadErr te;
+    return te;
+}
 inline int fail(kzg_ctx *ctx, int code, const std::string &msg) {
-    ctx->err = msg;
+    {
+        std::lock_guard<std::mutex> lk(ctx->err_mu);
+        ctx->err = msg;
+    }
+    ThreadErr &te = thread_err();
+    te.ctx = ctx;
+    te.msg = msg;
     return code;
 }
 
@@ -220,6 +286,14 @@ int powers_run(kzg_ctx *ctx, hipStream_t st, const Fr &base_mont, size_t first, 
 int lagrange_scalars_run(kzg_ctx *ctx, hipStream_t st, const Fr &tau_mont, size_t d, Fr *d_out);      // L_i(tau)
 
 // witness.hip
+struct WitnessSink {
+    const kzg_srs *srs;    // the SRS (or SRS shard) the quotient MSM runs against
+    size_t first, len;     // it holds the points of the quotient coefficients [first, first + len)
+    size_t total;          // length of the whole SRS (the reference's slice bound)
+    void *d_partial;       // nullptr: witness to the caller; else the 144-byte Jacobian partial goes here (device)
+};
+int witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const void *coeffs, size_t n, const void *xs, const void *ys,
+                              size_t k, int sfmt, int flags, void *out_w, int ofmt, void *out_r, size_t *out_r_len);
 int vanishing_poly_run(kzg_ctx *ctx, hipStream_t st, const Fr *d_xs_mont, size_t k, Fr *d_z, Fr *d_tmp);  // k+1 coeffs each
 
 // cached per-context tables, released by kzg_ctx_destroy

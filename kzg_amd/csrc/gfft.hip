@@ -98,7 +98,7 @@ using namespace kzg;
 
 extern "C" int kzg_srs_lagrange_from_monomial_g1(kzg_ctx *ctx, const kzg_srs *mono, kzg_srs **out) {
     if (!ctx || !mono || !out) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const size_t d = mono->n;
     if (d == 0 || (d & (d - 1))) return fail(ctx, KZG_ERR_SHAPE, "assert!(d & (d - 1) == 0) (src/eval_form.rs:255-256)");

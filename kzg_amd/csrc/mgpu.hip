@@ -13,9 +13,13 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <functional>
 #include <thread>
 
 #include "common.h"
+#ifdef KZG_TEST_HOOKS
+#include "../../include/kzg_mi355x_test.h"
+#endif
 
 namespace kzg {
 
@@ -28,8 +32,19 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    std::string path;      // the file the adopted RCCL was loaded from
+    std::string hip_path;  // the HIP runtime it is bound to
+    int version = 0;
 };
+
+// the shared object that holds `addr`
+static std::string object_of(const void *addr) {
+    Dl_info di;
+    if (addr && dladdr(addr, &di) && di.dli_fname) return di.dli_fname;
+    return "?";
+}
 
 static std::mutex g_rccl_mu;
 static Rccl *g_rccl = nullptr;
@@ -40,8 +55,15 @@ static Rccl *rccl_load(std::string *err) {
     void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // a copy this process already holds (e.g. PyTorch's)
     const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+#ifdef KZG_TEST_HOOKS
+    if (getenv("KZG_TEST_NO_RCCL")) {  // tests: the load-failure path on a host that does have RCCL
+        if (h) dlclose(h);
+        h = dlopen("librccl-not-installed.so.1", RTLD_NOW | RTLD_LOCAL);
+    }
+#endif
     if (!h) {
-        *err = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+        const char *e = dlerror();  // read once: glibc clears the message on the first read
+        *err = std::string("cannot load RCCL (librccl.so.1): ") + (e ? e : "not found");
         return nullptr;
     }
     Rccl *r = new Rccl();
@@ -63,7 +85,20 @@ static Rccl *rccl_load(std::string *err) {
     r->GroupStart = (decltype(r->GroupStart))sym("ncclGroupStart");
     r->GroupEnd = (decltype(r->GroupEnd))sym("ncclGroupEnd");
     r->GetErrorString = (decltype(r->GetErrorString))sym("ncclGetErrorString");
+    r->GetVersion = (decltype(r->GetVersion))sym("ncclGetVersion");
     if (!ok) {
+        delete r;
+        return nullptr;
+    }
+    // Which RCCL was adopted, and is it bound to the same HIP runtime as this library?  A stream and device pointers are
+    // handed across, so two HIP runtimes in one process (PyTorch wheels ship their own next to /opt/rocm's) must not be mixed.
+    r->path = object_of((const void *)r->AllGather);
+    r->GetVersion(&r->version);
+    r->hip_path = object_of(dlsym(h, "hipStreamSynchronize"));  // resolved through RCCL's own dependency chain
+    const std::string mine = object_of((const void *)&hipStreamSynchronize);
+    if (r->hip_path != "?" && mine != "?" && r->hip_path != mine) {
+        *err = "RCCL " + r->path + " is bound to HIP runtime " + r->hip_path + " but this library runs on " + mine +
+               ": refusing to share streams across two runtimes (load the matching librccl.so.1 first, or fix the library path)";
         delete r;
         return nullptr;
     }
@@ -93,8 +128,59 @@ struct kzg_mctx {
     std::vector<size_t> cap_points;
     std::vector<void *> d_quot;      // create_witness: the quotient polynomial on each GPU
     std::vector<size_t> cap_quot;
+    std::vector<void *> h_status;    // pinned: the status words of all ranks after the exchange, per local GPU
+    int inject_fail = 0;             // KZG_TEST_HOOKS: the next local phase fails with this code on local GPU 0
     int nlocal() const { return (int)devices.size(); }
+    // one persistent host thread per local GPU (groups of several GPUs in one process): a sharded call hands each of them its
+    // GPU's share and waits -- no thread creation on the path of a 2 ms operation
+    struct Worker {
+        std::thread th;
+        std::mutex mu;
+        std::condition_variable cv;
+        std::function<int()> job;
+        bool has_job = false, done = false, quit = false;
+        int rc = 0;
+    };
+    std::vector<Worker *> workers;
 };
+
+static void worker_main(kzg_mctx::Worker *w) {
+    std::unique_lock<std::mutex> lk(w->mu);
+    for (;;) {
+        w->cv.wait(lk, [&] { return w->has_job || w->quit; });
+        if (w->quit) return;
+        std::function<int()> job = std::move(w->job);
+        w->has_job = false;
+        lk.unlock();
+        int rc = job();
+        lk.lock();
+        w->rc = rc;
+        w->done = true;
+        w->cv.notify_all();
+    }
+}
+
+static void workers_start(kzg_mctx *m) {
+    if (m->nlocal() < 2 || !m->workers.empty()) return;
+    for (int i = 0; i < m->nlocal(); i++) {
+        kzg_mctx::Worker *w = new kzg_mctx::Worker();
+        w->th = std::thread(worker_main, w);
+        m->workers.push_back(w);
+    }
+}
+
+static void workers_stop(kzg_mctx *m) {
+    for (kzg_mctx::Worker *w : m->workers) {
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        w->th.join();
+        delete w;
+    }
+    m->workers.clear();
+}
 
 struct kzg_msrs {
     size_t n = 0;
@@ -102,15 +188,16 @@ struct kzg_msrs {
     std::vector<size_t> first, len;
 };
 
+static std::mutex &merr_mu();
 static int mfail(kzg_mctx *m, int code, const std::string &msg) {
+    std::lock_guard<std::mutex> lk(merr_mu());
     m->err = msg;
     return code;
 }
 
 static int mfail_ctx(kzg_mctx *m, int i, int code) {
     const char *e = kzg_last_error(m->ctxs[i]);
-    m->err = "GPU " + std::to_string(m->devices[i]) + ": " + (e ? e : "");
-    return code;
+    return mfail(m, code, "GPU " + std::to_string(m->devices[i]) + ": " + (e ? e : ""));
 }
 
 #define KZG_NCCL(m, r, expr)                                                                                       \
@@ -129,17 +216,20 @@ extern "C" int kzg_shard_range(size_t n, int rank, int world, size_t *lo, size_t
 }
 
 static int mctx_make_ctxs(kzg_mctx *m) {
+    // sized first: kzg_mctx_destroy walks these per context when a later device fails (devices = [0, 99])
+    m->d_part.assign(m->nlocal(), nullptr);
+    m->d_gath.assign(m->nlocal(), nullptr);
+    m->cap_points.assign(m->nlocal(), 0);
+    m->d_quot.assign(m->nlocal(), nullptr);
+    m->cap_quot.assign(m->nlocal(), 0);
+    m->h_status.assign(m->nlocal(), nullptr);
     for (int i = 0; i < m->nlocal(); i++) {
         kzg_ctx *c = nullptr;
         int rc = kzg_ctx_create(m->devices[i], &c);
         if (rc != KZG_OK) return rc;
         m->ctxs.push_back(c);
     }
-    m->d_part.assign(m->nlocal(), nullptr);
-    m->d_gath.assign(m->nlocal(), nullptr);
-    m->cap_points.assign(m->nlocal(), 0);
-    m->d_quot.assign(m->nlocal(), nullptr);
-    m->cap_quot.assign(m->nlocal(), 0);
+    workers_start(m);
     return KZG_OK;
 }
 
@@ -228,6 +318,7 @@ extern "C" int kzg_mctx_create_rank(int device, int rank, int world, const void 
 
 extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
     if (!m) return;
+    workers_stop(m);
     for (int i = 0; i < (int)m->ctxs.size(); i++) {
         hipSetDevice(m->devices[i]);
         if (m->ctxs[i]) kzg_sync(m->ctxs[i]);
@@ -235,12 +326,38 @@ extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
         if (m->d_part[i]) hipFree(m->d_part[i]);
         if (m->d_gath[i]) hipFree(m->d_gath[i]);
         if (m->d_quot[i]) hipFree(m->d_quot[i]);
+        if (m->h_status[i]) hipHostFree(m->h_status[i]);
         if (m->ctxs[i]) kzg_ctx_destroy(m->ctxs[i]);
     }
     delete m;
 }
 
-extern "C" const char *kzg_mctx_last_error(kzg_mctx *m) { return m ? m->err.c_str() : "null group"; }
+static std::mutex g_merr_mu;  // m->err is written under it (mfail) and copied out under it
+static std::mutex &merr_mu() { return g_merr_mu; }
+
+extern "C" const char *kzg_mctx_last_error(kzg_mctx *m) {
+    // copied into a per-thread buffer, as kzg_last_error does: another thread failing on the group cannot invalidate the pointer
+    if (!m) return "null group";
+    static thread_local std::string tl;
+    std::lock_guard<std::mutex> lk(g_merr_mu);
+    tl = m->err;
+    return tl.c_str();
+}
+
+// which RCCL the group runs on: "rccl=<file> version=<n> hip=<runtime file>" (loads RCCL if that has not happened yet)
+extern "C" int kzg_mctx_info(kzg_mctx *m, char *buf, size_t buflen) {
+    if (!m || !buf || !buflen) return KZG_ERR_SHAPE;
+    std::string err;
+    Rccl *r = rccl_load(&err);
+    if (!r) {
+        std::lock_guard<std::mutex> lk(g_merr_mu);
+        m->err = err;
+        return KZG_ERR_INTERNAL;
+    }
+    snprintf(buf, buflen, "rccl=%s version=%d hip=%s world=%d local=%d mode=%s", r->path.c_str(), r->version, r->hip_path.c_str(),
+             m->world, m->nlocal(), m->per_process ? "process-per-gpu" : "one-process");
+    return KZG_OK;
+}
 extern "C" int kzg_mctx_world(const kzg_mctx *m) { return m ? m->world : 0; }
 extern "C" int kzg_mctx_local_count(const kzg_mctx *m) { return m ? m->nlocal() : 0; }
 extern "C" int kzg_mctx_rank(const kzg_mctx *m, int i) { return (m && i >= 0 && i < m->nlocal()) ? m->ranks[i] : -1; }
@@ -332,6 +449,13 @@ extern "C" void kzg_msrs_free(kzg_mctx *m, kzg_msrs *s) {
 // ---------------------------------------------------------------------------------------------
 // sharded commit
 // ---------------------------------------------------------------------------------------------
+// What a rank sends: `batch` 144-byte partials followed by one status slot of the same size (word 0 = the kzg_status of its
+// local phase; a whole point slot, so that the gathered records stay a whole number of points apart).  Every rank ALWAYS enters the exchange -- with its failure code when its local phase failed -- and every rank reads
+// every status afterwards, so a failing rank can neither leave the others waiting inside ncclAllGather nor be the only one to
+// report the failure: all ranks return the same error.
+constexpr size_t STATUS_BYTES = 16, STATUS_ALL_OFF = 256;  // pinned staging: own status at 0, every rank's from STATUS_ALL_OFF
+static size_t record_bytes(size_t batch) { return (batch + 1) * PARTIAL_BYTES; }
+
 static int mctx_buffers(kzg_mctx *m, size_t batch) {
     for (int i = 0; i < m->nlocal(); i++) {
         if (m->cap_points[i] >= batch) continue;
@@ -342,60 +466,109 @@ static int mctx_buffers(kzg_mctx *m, size_t batch) {
         m->d_part[i] = m->d_gath[i] = nullptr;
         m->cap_points[i] = 0;
         size_t cap = batch < 64 ? 64 : batch;
-        if (hipMalloc(&m->d_part[i], cap * PARTIAL_BYTES) != hipSuccess ||
-            hipMalloc(&m->d_gath[i], cap * PARTIAL_BYTES * (size_t)m->world) != hipSuccess)
+        if (hipMalloc(&m->d_part[i], record_bytes(cap)) != hipSuccess ||
+            hipMalloc(&m->d_gath[i], record_bytes(cap) * (size_t)m->world) != hipSuccess)
             return mfail(m, KZG_ERR_ALLOC, "hipMalloc(partial-point exchange buffers)");
+        if (!m->h_status[i] && hipHostMalloc(&m->h_status[i], STATUS_ALL_OFF + STATUS_BYTES * (size_t)m->world, hipHostMallocDefault) != hipSuccess)
+            return mfail(m, KZG_ERR_ALLOC, "hipHostMalloc(status words)");
         m->cap_points[i] = cap;
     }
     return KZG_OK;
 }
 
-// Stage 2 of every sharded operation: d_part[i] holds `batch` Jacobian partials on every local GPU.  One all-gather, then the
-// group's first local GPU adds the `world` partials of each polynomial and writes `batch` points in ofmt to `out` (host).
-static int mctx_combine(kzg_mctx *m, size_t batch, void *out, int ofmt) {
+// run f(i) for every local GPU (on the group's persistent worker threads when there are several); rcs[i] = its status
+template <class F>
+static void for_each_local(kzg_mctx *m, std::vector<int> &rcs, F f) {
+    const int L = m->nlocal();
+    rcs.assign(L, KZG_OK);
+    if (L == 1 || m->workers.empty()) {
+        for (int i = 0; i < L; i++) rcs[i] = f(i);
+    } else {
+        for (int i = 0; i < L; i++) {
+            kzg_mctx::Worker *w = m->workers[i];
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->job = [&f, i]() { return f(i); };
+            w->has_job = true;
+            w->done = false;
+            w->cv.notify_all();
+        }
+        for (int i = 0; i < L; i++) {
+            kzg_mctx::Worker *w = m->workers[i];
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->done; });
+            rcs[i] = w->rc;
+        }
+    }
+#ifdef KZG_TEST_HOOKS
+    if (m->inject_fail) {
+        rcs[0] = fail(m->ctxs[0], m->inject_fail, "injected local failure (test hook)");
+        m->inject_fail = 0;
+    }
+#endif
+}
+
+// Stage 2 of every sharded operation: d_part[i] holds `batch` Jacobian partials on every local GPU whose local phase succeeded
+// (local_rc[i] == KZG_OK).  One all-gather of partials + status, then the group's first local GPU adds the `world` partials of
+// each polynomial and writes `batch` points in ofmt to `out` (host).  Returns the first failing rank's status on every rank.
+static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local_rc, void *out, int ofmt) {
+    const bool exchange = m->world > 1 || m->always_gather;
+    int first_bad = -1;
+    for (int i = 0; i < m->nlocal(); i++)
+        if (local_rc[i] != KZG_OK && first_bad < 0) first_bad = i;
+    if (!exchange || !m->per_process) {
+        // every rank is in this process: a local failure is known to all of them already -- no collective to keep in step
+        if (first_bad >= 0) return mfail_ctx(m, first_bad, local_rc[first_bad]);
+    }
     const void *src = m->d_part[0];
-    size_t count = 1;
-    if (m->world > 1 || m->always_gather) {
+    size_t count = 1, gstride = 1, istride = batch;
+    if (exchange) {
         Rccl *r = nullptr;
         KZG_TRY(mctx_comm(m, &r));
+        const size_t rec = record_bytes(batch);
+        for (int i = 0; i < m->nlocal(); i++) {  // the status block rides behind the partials, in stream order
+            hipSetDevice(m->devices[i]);
+            int32_t *hs = (int32_t *)m->h_status[i];
+            hs[0] = local_rc[i];
+            hs[1] = m->ranks[i];
+            hs[2] = hs[3] = 0;
+            if (hipMemcpyAsync((uint8_t *)m->d_part[i] + batch * PARTIAL_BYTES, hs, STATUS_BYTES, hipMemcpyHostToDevice,
+                               m->ctxs[i]->lanes[0].stream) != hipSuccess)
+                return mfail(m, KZG_ERR_HIP, "status upload");
+        }
         KZG_NCCL(m, r, r->GroupStart());
         for (int i = 0; i < m->nlocal(); i++) {
-            ncclResult_t e = r->AllGather(m->d_part[i], m->d_gath[i], batch * PARTIAL_BYTES, ncclUint8, m->comms[i],
-                                          m->ctxs[i]->lanes[0].stream);
+            ncclResult_t e = r->AllGather(m->d_part[i], m->d_gath[i], rec, ncclUint8, m->comms[i], m->ctxs[i]->lanes[0].stream);
             if (e != ncclSuccess) {
                 r->GroupEnd();
                 return mfail(m, KZG_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(e));
             }
         }
         KZG_NCCL(m, r, r->GroupEnd());
-        // every local GPU's copy must be complete before its buffers are re-used by the next call
-        for (int i = 1; i < m->nlocal(); i++) {
+        // every local GPU's copy must be complete before its buffers are re-used by the next call; the statuses of all ranks
+        // come back with local GPU 0's
+        hipSetDevice(m->devices[0]);
+        int32_t *hall = (int32_t *)((uint8_t *)m->h_status[0] + STATUS_ALL_OFF);
+        if (hipMemcpy2DAsync(hall, STATUS_BYTES, (const uint8_t *)m->d_gath[0] + batch * PARTIAL_BYTES, rec, STATUS_BYTES,
+                             (size_t)m->world, hipMemcpyDeviceToHost, m->ctxs[0]->lanes[0].stream) != hipSuccess)
+            return mfail(m, KZG_ERR_HIP, "status download");
+        for (int i = 0; i < m->nlocal(); i++) {
             hipSetDevice(m->devices[i]);
             if (hipStreamSynchronize(m->ctxs[i]->lanes[0].stream) != hipSuccess) return mfail(m, KZG_ERR_HIP, "all-gather failed");
         }
-        src = m->d_gath[0];  // [world][batch] partials; the sum below runs on the same stream, after the collective
+        for (int rk = 0; rk < m->world; rk++)
+            if (hall[4 * rk] != KZG_OK) {
+                if (first_bad >= 0 && m->ranks[first_bad] == rk) return mfail_ctx(m, first_bad, local_rc[first_bad]);
+                return mfail(m, hall[4 * rk], "rank " + std::to_string(rk) + " failed in its local phase (status " +
+                                                  std::to_string(hall[4 * rk]) + "); every rank returns this error");
+            }
+        src = m->d_gath[0];  // [world] records of [batch partials, status slot]; the sum below runs on the same stream
         count = (size_t)m->world;
+        gstride = 1;
+        istride = batch + 1;
     }
-    int rc = g1_sum_batch_strided(m->ctxs[0], src, count, batch, 1, batch, KZG_G1_JACOBIAN_MONT_144, KZG_IN_DEVICE, out, ofmt,
+    int rc = g1_sum_batch_strided(m->ctxs[0], src, count, batch, gstride, istride, KZG_G1_JACOBIAN_MONT_144, KZG_IN_DEVICE, out, ofmt,
                                   POINTS_TRUSTED);  // the group's own partial sums
     if (rc != KZG_OK) return mfail_ctx(m, 0, rc);
-    return KZG_OK;
-}
-
-// run f(i) for every local GPU (one host thread each when there are several), return the first failure
-template <class F>
-static int for_each_local(kzg_mctx *m, F f) {
-    const int L = m->nlocal();
-    std::vector<int> rcs(L, KZG_OK);
-    if (L == 1) {
-        rcs[0] = f(0);
-    } else {
-        std::vector<std::thread> th;
-        for (int i = 0; i < L; i++) th.emplace_back([&, i]() { rcs[i] = f(i); });
-        for (auto &t : th) t.join();
-    }
-    for (int i = 0; i < L; i++)
-        if (rcs[i] != KZG_OK) return mfail_ctx(m, i, rcs[i]);
     return KZG_OK;
 }
 
@@ -415,7 +588,8 @@ extern "C" int kzg_commit_coeff_sharded_batch(kzg_mctx *m, const kzg_msrs *srs, 
     if (batch > (1u << 20)) return mfail(m, KZG_ERR_SHAPE, "batch <= 2^20");
     KZG_TRY(mctx_buffers(m, batch));
     const bool in_dev = (flags & KZG_IN_DEVICE) != 0;
-    KZG_TRY(for_each_local(m, [&](int i) {
+    std::vector<int> rcs;
+    for_each_local(m, rcs, [&](int i) {
         const size_t len = clip_len(srs->first[i], srs->len[i], n);  // this GPU's terms of an n-coefficient polynomial
         const void *sc;
         size_t stride;
@@ -428,8 +602,8 @@ extern "C" int kzg_commit_coeff_sharded_batch(kzg_mctx *m, const kzg_msrs *srs, 
         }
         return msm_batch_strided(m->ctxs[i], srs->shards[i], 0, sc, len, batch, stride, sfmt,
                                  (in_dev ? KZG_IN_DEVICE : 0) | KZG_OUT_DEVICE, m->d_part[i], KZG_G1_JACOBIAN_MONT_144);
-    }));
-    return mctx_combine(m, batch, out, ofmt);
+    });
+    return mctx_combine(m, batch, rcs, out, ofmt);
 }
 
 extern "C" int kzg_commit_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, int sfmt, int flags,
@@ -437,8 +611,13 @@ extern "C" int kzg_commit_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const 
     return kzg_commit_coeff_sharded_batch(m, srs, coeffs, n, 1, sfmt, flags, out, ofmt);
 }
 
+// the coefficient vector local GPU i reads: the host's (every GPU stages it) or, with KZG_IN_DEVICE, GPU i's resident copy
+static const void *whole_poly(const void *coeffs, int flags, int i) {
+    return (flags & KZG_IN_DEVICE) ? ((const void *const *)coeffs)[i] : coeffs;
+}
+
 extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *x,
-                                         const void *y, int sfmt, void *out, int ofmt) {
+                                         const void *y, int sfmt, int flags, void *out, int ofmt) {
     // KZGProver::create_witness (src/coeff_form.rs:66-81): q = (p - y)/(X - x) has n - 1 coefficients; rank r reduces
     // q[lo_r, hi_r) against its shard.  The O(n) quotient scan is replicated on every GPU.
     if (!m || !srs || !coeffs || !x || !y || !out || n == 0) return KZG_ERR_SHAPE;
@@ -446,6 +625,7 @@ extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const
     if ((int)srs->shards.size() != m->nlocal()) return mfail(m, KZG_ERR_SHAPE, "SRS belongs to another group");
     if (n - 1 > srs->n) return mfail(m, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
     if (!point_format_bytes(ofmt)) return mfail(m, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (flags & KZG_OUT_DEVICE) return mfail(m, KZG_ERR_SHAPE, "sharded create_witness writes its result to host memory");
     KZG_TRY(mctx_buffers(m, 1));
     for (int i = 0; i < m->nlocal(); i++) {
         if (m->cap_quot[i] >= n) continue;
@@ -457,11 +637,12 @@ extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const
         if (hipMalloc(&m->d_quot[i], n * 32) != hipSuccess) return mfail(m, KZG_ERR_ALLOC, "hipMalloc(quotient)");
         m->cap_quot[i] = n;
     }
-    std::vector<int> off_poly(m->nlocal(), 0);
-    int rc = for_each_local(m, [&](int i) {
-        int q = kzg_quotient_linear(m->ctxs[i], coeffs, n, x, y, sfmt, KZG_OUT_DEVICE, m->d_quot[i]);
+    const int in_dev = flags & KZG_IN_DEVICE;
+    std::vector<int> off_poly(m->nlocal(), 0), rcs;
+    for_each_local(m, rcs, [&](int i) {
+        int q = kzg_quotient_linear(m->ctxs[i], whole_poly(coeffs, flags, i), n, x, y, sfmt, in_dev | KZG_OUT_DEVICE, m->d_quot[i]);
         if (q == KZG_ERR_POINT_NOT_ON_POLY) {
-            off_poly[i] = 1;  // the reference fails after the division; the collective below must still be entered by all
+            off_poly[i] = 1;  // the reference fails after the division (every rank sees the same remainder)
             q = KZG_OK;
         }
         if (q != KZG_OK) return q;
@@ -469,9 +650,53 @@ extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const
         return msm_batch_strided(m->ctxs[i], srs->shards[i], 0, (const uint8_t *)m->d_quot[i] + srs->first[i] * 32, len, 1,
                                  len * 32, sfmt, KZG_IN_DEVICE | KZG_OUT_DEVICE, m->d_part[i], KZG_G1_JACOBIAN_MONT_144);
     });
-    if (rc != KZG_OK) return rc;
-    KZG_TRY(mctx_combine(m, 1, out, ofmt));
+    KZG_TRY(mctx_combine(m, 1, rcs, out, ofmt));
     for (int i = 0; i < m->nlocal(); i++)
         if (off_poly[i]) return mfail(m, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
     return KZG_OK;
 }
+
+extern "C" int kzg_witness_coeff_batched_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *xs,
+                                                 const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt,
+                                                 void *out_r, size_t *out_r_len) {
+    // KZGProver::create_witness_batched (src/coeff_form.rs:83-111) over the group: every rank computes the interpolant I and the
+    // quotient (p - I)/Z on its GPU (replicated: NTTs do not shard) and reduces its own slice of the quotient
+    // against its SRS shard; one exchange of 144-byte partials.  The reference's two failures (duplicate opening points -> the
+    // invert().unwrap() panic, a point off the polynomial) come out of the replicated part, identically on every rank.
+    if (!m || !srs || !coeffs || !xs || !ys || !out_w || !out_r || !out_r_len || n == 0) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if ((int)srs->shards.size() != m->nlocal()) return mfail(m, KZG_ERR_SHAPE, "SRS belongs to another group");
+    if (!point_format_bytes(ofmt)) return mfail(m, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (flags & KZG_OUT_DEVICE) return mfail(m, KZG_ERR_SHAPE, "sharded create_witness_batched writes its result to host memory");
+    if (k == 0 || k > 4096) return mfail(m, KZG_ERR_SHAPE, "1 <= opening points <= 4096");
+    KZG_TRY(mctx_buffers(m, 1));
+    const size_t rl = k == 1 ? 2 : k;
+    std::vector<std::vector<uint8_t>> rbuf(m->nlocal(), std::vector<uint8_t>(rl * 32));
+    std::vector<size_t> rlen(m->nlocal(), 0);
+    std::vector<int> soft(m->nlocal(), KZG_OK), rcs;  // the reference's own errors: identical on every rank, reported after the exchange
+    for_each_local(m, rcs, [&](int i) {
+        WitnessSink sink{srs->shards[i], srs->first[i], srs->len[i], srs->n, m->d_part[i]};
+        int rc = witness_coeff_batched_run(m->ctxs[i], sink, whole_poly(coeffs, flags, i), n, xs, ys, k, sfmt, flags & KZG_IN_DEVICE,
+                                           nullptr, ofmt, rbuf[i].data(), &rlen[i]);
+        if (rc == KZG_ERR_POINT_NOT_ON_POLY) {  // found after the partial was written, like the reference (division, then the test)
+            soft[i] = rc;
+            rc = KZG_OK;
+        }
+        return rc;
+    });
+    KZG_TRY(mctx_combine(m, 1, rcs, out_w, ofmt));
+    for (int i = 0; i < m->nlocal(); i++)
+        if (soft[i]) return mfail_ctx(m, i, soft[i]);
+    memcpy(out_r, rbuf[0].data(), rlen[0] * 32);
+    *out_r_len = rlen[0];
+    return KZG_OK;
+}
+
+#ifdef KZG_TEST_HOOKS
+extern "C" int kzg_test_mctx_inject_failure(kzg_mctx *m, int code) {
+    if (!m) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->inject_fail = code;
+    return KZG_OK;
+}
+#endif

@@ -913,6 +913,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     if ((uint64_t)srs->W * srs->npad >= (1ull << WIDE_HI_SHIFT))
         return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the wide-window entry encoding (window_bits 18..20: W * n < 2^27)");
     hipStream_t st = ctx->lanes[lane].stream;
+    const MsmMode mm = ctx->lanes[lane].mode;
     WideLayout L = wide_layout(srs, n ? n : 1);
     char *base = (char *)lane_alloc(ctx, lane, L.bytes);
     if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
@@ -942,11 +943,11 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     size_t lds_bytes = (size_t)B_lo * 4;
 
     // pass 1: LDS counting sort by the low 15 bucket bits (hi rides in the entry word)
-    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, 0, 0, W);
-    const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;
+    KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, mm.sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, 0, 0, W);
+    const uint32_t slots = (uint32_t)mm.accum_blocks * 256u;
     KZG_TRY(scan_run(ctx, st, blk_hist, G, B_lo, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), lo_start, s1_lo,
                      state, slots));  // M, E, ntasks
-    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
+    KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, mm.sort_threads, lds_bytes, sc, n, sfmt, c, W, B_lo, per_block, blk_hist, lo_start,
                (uint32_t)srs->npad, (uint32_t)offset, entries1, 1, 0, W);
     // pass 2: stable partition by hi; also yields the starts of all nhi * 2^15 buckets
     KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
@@ -956,7 +957,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, s1, Btot,
                (const uint4 *)srs->table30, bufA, state);
-    return msm_tail_run(ctx, st, bufA, bufB, s1, Btot, expected_partials(L.M_max, slots, Btot), state, base + L.off_tail, L.tail,
+    return msm_tail_run(ctx, st, mm, bufA, bufB, s1, Btot, expected_partials(L.M_max, slots, Btot), state, base + L.off_tail, L.tail,
                         d_result);
 }
 
@@ -1003,6 +1004,7 @@ __global__ __launch_bounds__(64) void k_combine_passes(const MsmPoint *S, int pa
 static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
                           MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
     hipStream_t st = ctx->lanes[lane].stream;
+    const MsmMode mm = ctx->lanes[lane].mode;
     MsmLayout L = msm_layout(srs, n ? n : 1);
     char *base = (char *)lane_alloc(ctx, lane, L.bytes);
     if (!base) return fail(ctx, KZG_ERR_ALLOC, "MSM workspace not reserved");
@@ -1035,7 +1037,7 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     // rows == W (the default): one pass, no doubling chain.
     const int rows = srs->rows, passes = (W + rows - 1) / rows;
     MsmPoint *pass_res = (MsmPoint *)(base + L.off_pass);
-    const uint32_t slots = (uint32_t)ctx->cur_accum_blocks * 256u;  // resident threads k_accum_affine is split over
+    const uint32_t slots = (uint32_t)mm.accum_blocks * 256u;  // resident threads k_accum_affine is split over
     for (int p = 0; p < passes; p++) {
         const int w_lo = p * rows, w_hi = (p + 1) * rows < W ? (p + 1) * rows : W;
         if (srs->narrow17 && !ctx->opt_sort_single) {
@@ -1060,31 +1062,33 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);
         } else {
-            KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode, w_lo,
+            KZG_LAUNCH(ctx, st, "k_hist", k_hist, G, mm.sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist, mode, w_lo,
                        w_hi);
             // s1[0 .. B] = per-bucket start offsets of the round-1 output list
             KZG_TRY(scan_run(ctx, st, blk_hist, G, B, total, (uint32_t *)(base + L.off_local), (uint32_t *)(base + L.off_agg), bucket_start,
                              s1, state, slots));
-            KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, ctx->cur_sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
+            KZG_LAUNCH(ctx, st, "k_scatter", k_scatter, G, mm.sort_threads, lds_bytes, sc, n, sfmt, c, W, B, per_block, blk_hist,
                        bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode, w_lo, w_hi);
-        }
-        hipStream_t as = st;
-        if (accum_stream && accum_stream != st) {
-            KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
-            KZG_HIP_CHECK(ctx, hipStreamWaitEvent(accum_stream, sorted_ev, 0));
-            as = accum_stream;
         }
         // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
         size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
         unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-        KZG_LAUNCH(ctx, as, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
-                   (const uint4 *)srs->table30, bufA, state);
-        if (as != st) {
-            KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, as));
+        if (accum_stream && accum_stream != st) {
+            // wait / launch / record on the shared FIFO stream is one unit: with concurrent callers the three must not
+            // interleave with another lane's (a kernel would pick up the other lane's dependency, a lane the other kernel's)
+            KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
+            std::lock_guard<std::mutex> alk(ctx->accum_mu);
+            KZG_HIP_CHECK(ctx, hipStreamWaitEvent(accum_stream, sorted_ev, 0));
+            KZG_LAUNCH(ctx, accum_stream, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
+                       (const uint4 *)srs->table30, bufA, state);
+            KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, accum_stream));
             KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
+        } else {
+            KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
+                       (const uint4 *)srs->table30, bufA, state);
         }
         MsmPoint *res = nullptr;
-        KZG_TRY(msm_tail_run(ctx, st, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, &res));
+        KZG_TRY(msm_tail_run(ctx, st, mm, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, &res));
         if (passes == 1) {
             *d_result = res;
             return KZG_OK;

@@ -45,7 +45,7 @@ struct TailLayout {
     size_t off_dense, off_rows, off_cols, off_Q, off_tasks, off_arrive, off_result, bytes;
 };
 TailLayout tail_layout(int B, size_t T1_max);
-int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
+int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmMode &mode, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
                  size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result);
 
 }  // namespace kzg

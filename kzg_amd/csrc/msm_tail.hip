@@ -367,7 +367,7 @@ TailLayout tail_layout(int B, size_t T1_max) {
 
 // part: the round-1 partial list (ordered by bucket, bucket b = [s1[b], s1[b+1])); scratch: a list of the same capacity;
 // expected_partials: how many partials round 1 is expected to emit (chooses the lane-group width of the fold)
-int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
+int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmMode &mode, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
                  size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result) {
     MsmPoint *dense = (MsmPoint *)(tail_base + L.off_dense), *rows = (MsmPoint *)(tail_base + L.off_rows);
     MsmPoint *cols = (MsmPoint *)(tail_base + L.off_cols), *Q = (MsmPoint *)(tail_base + L.off_Q);
@@ -380,7 +380,7 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     // a butterfly level is a full addition for every lane of the group, wasted lane-time when depth does not matter)
     size_t avg = expected_partials / (size_t)B + 1;
     int G = 1;
-    if (!ctx->cur_tail_wide) {
+    if (!mode.tail_wide) {
         while (G < 64 && (size_t)G * 2 < avg) G *= 2;
     } else {
         while (G < 64 && (size_t)G * (FOLD_SEQ / 2) < avg) G *= 2;
@@ -396,12 +396,12 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmPoint *part, MsmPoint *s
     }
 #undef KZG_FOLD
     KZG_LAUNCH(ctx, st, "k_fold_overflow", k_fold_overflow, 256, TAIL_THREADS, 0, part, scratch, s1, dense, state, tasks, arrive);
-    if (ctx->cur_tail_wide && Rn >= RC_LANES && Cn >= RC_LANES) {
+    if (mode.tail_wide && Rn >= RC_LANES && Cn >= RC_LANES) {
         KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums_t, ((Rn + Cn) * RC_LANES + 255) / 256, 256, 0, dense, Rn, Cn, rows, cols);
     } else {
         KZG_LAUNCH(ctx, st, "k_rc_sums", k_rc_sums, (Rn + Cn + wpb - 1) / wpb, TAIL_THREADS, 0, dense, Rn, Cn, rows, cols);
     }
-    if (ctx->cur_tail_quads) {
+    if (mode.tail_quads) {
         // one MSM alone on the GPU: the two depth-bound kernels run four lanes per point operation.  (Fold and row / column
         // sums are bound by their ~2 additions per bucket, not by depth: quads were measured slower there, 0.25 against 0.07 ms
         // and 0.17 against 0.14 ms at c = 17: a quad addition takes ~10 us against 16 for one lane, so a row sum by 32 or 64

@@ -330,10 +330,7 @@ __global__ __launch_bounds__(64) void k_verify_finish(const G1Xyzz *C, const G1A
 using namespace kzg;
 
 namespace {
-struct Lock {
-    std::lock_guard<std::mutex> lk;
-    explicit Lock(kzg_ctx *c) : lk(c->mu) {}
-};
+typedef kzg::Guard Lock;
 
 int load_scalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
     Fr v;

@@ -231,6 +231,9 @@ __global__ __launch_bounds__(256) void k_sub_one(const Fr *in, Fr *out, size_t n
 }
 
 static int eval_tables(kzg_ctx *ctx, hipStream_t st, uint32_t log_d, EvalDomainTables **out) {
+    // leased lanes (concurrent kzg_witness_eval callers) share the cache: one builder at a time, and a table is published
+    // only after the stream that built it has been synchronised
+    std::lock_guard<std::mutex> clk(ctx->cache_mu);
     auto it = ctx->eval_tabs.find(log_d);
     if (it != ctx->eval_tabs.end()) {
         *out = it->second;
@@ -358,7 +361,7 @@ using namespace kzg;
 
 extern "C" int kzg_fill_random_fr(kzg_ctx *ctx, void *dst_dev, size_t n, uint64_t seed, int u64_valued, int sfmt) {
     if (!ctx || (!dst_dev && n)) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (!n) return KZG_OK;
     hipStream_t st = ctx->lanes[0].stream;

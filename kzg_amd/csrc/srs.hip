@@ -403,7 +403,7 @@ static int load_host_scalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *out_mont)
 
 extern "C" int kzg_srs_upload_g1(kzg_ctx *ctx, const void *pts, size_t n, int pfmt, kzg_srs **out) {
     if (!ctx || !out || (!pts && n)) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     size_t psz = point_format_bytes(pfmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
@@ -491,7 +491,7 @@ extern "C" int kzg_srs_setup_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t 
 
 extern "C" int kzg_srs_setup_g1_shard(kzg_ctx *ctx, const void *sec, int sfmt, size_t first, size_t n, kzg_srs **out) {
     if (!ctx || !out || !sec) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     Fr tau;
     KZG_TRY(load_host_scalar(ctx, sec, sfmt, &tau));
@@ -519,7 +519,7 @@ extern "C" int kzg_srs_setup_g1_shard(kzg_ctx *ctx, const void *sec, int sfmt, s
 
 extern "C" int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *sec, int sfmt, size_t d, kzg_srs **out) {
     if (!ctx || !out || !sec) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (d == 0 || (d & (d - 1))) return fail(ctx, KZG_ERR_SHAPE, "Lagrange basis needs a power-of-two size (src/eval_form.rs:255-256)");
     uint32_t exp = (uint32_t)ilog2_ceil(d);
@@ -549,7 +549,7 @@ extern "C" int kzg_srs_setup_lagrange_g1(kzg_ctx *ctx, const void *sec, int sfmt
 
 extern "C" int kzg_srs_download_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, size_t n, void *out, int pfmt) {
     if (!ctx || !srs || (!out && n)) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "SRS download range out of bounds");
     if (n == 0) return KZG_OK;
@@ -584,7 +584,7 @@ extern "C" int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *wi
 extern "C" void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs) {
     if (!srs) return;
     if (ctx) {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        kzg::Guard g(ctx);
         hipSetDevice(ctx->device);
         for (auto &l : ctx->lanes) hipStreamSynchronize(l.stream);
     }

@@ -51,6 +51,8 @@ static int coset_tables(kzg_ctx *ctx, hipStream_t st, const Fr &g, const Fr **lo
     KZG_HIP_CHECK(ctx, hipMalloc((void **)&d, 2 * DP_TAB * sizeof(Fr)));
     int rc = pow_table(ctx, st, g, Fr::one(), DP_TAB, d);
     if (rc == KZG_OK) rc = pow_table(ctx, st, pow_u64(g, (uint64_t)DP_TAB), Fr::one(), DP_TAB, d + DP_TAB);
+    // published only once built: a later call may run on another stream and would read the tables unsynchronised
+    if (rc == KZG_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "coset tables");
     if (rc != KZG_OK) {
         hipFree(d);
         return rc;
@@ -289,10 +291,6 @@ static int hscalar(kzg_ctx *ctx, const void *s, int sfmt, Fr *mont) {
     return KZG_OK;
 }
 
-static int finish_point_host(kzg_ctx *ctx, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
-    return finish_point(ctx, 0, d_pt, out, ofmt, flags);
-}
-
 // a[i] *= b[i]  (Montgomery product; with b in Montgomery form the result keeps a's form)
 __global__ __launch_bounds__(256) void k_mul_assign(Fr *a, const Fr *b, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -302,7 +300,7 @@ __global__ __launch_bounds__(256) void k_mul_assign(Fr *a, const Fr *b, size_t n
 extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, int sfmt, int flags, void *out) {
     // Polynomial::fft_mul (src/polynomial.rs:167-183)
     if (!ctx || !a || !b || !out || na == 0 || nb == 0) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     uint32_t log_n = (uint32_t)ilog2_ceil(na + nb);   // from_coeffs(resize(n + k)) rounds up to 2^exp
@@ -331,7 +329,7 @@ extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *
 
 extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int sfmt, int flags) {
     if (!ctx || !data) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     (void)sfmt;  // linear map with Montgomery constants: the data's form is preserved
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
@@ -352,8 +350,30 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
                                          const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt,
                                          void *out_r, size_t *out_r_len) {
     if (!ctx || !srs || !coeffs || !xs || !ys || !out_w || !out_r || !out_r_len || n == 0) return KZG_ERR_SHAPE;
-    std::lock_guard<std::mutex> g(ctx->mu);
+    WitnessSink sink{srs, 0, srs->n, srs->n, nullptr};
+    return witness_coeff_batched_run(ctx, sink, coeffs, n, xs, ys, k, sfmt, flags, out_w, ofmt, out_r, out_r_len);
+}
+
+// KZGProver::create_witness_batched (src/coeff_form.rs:83-111).  `sink` says where the quotient MSM goes: the whole SRS of this
+// GPU and the witness to the caller (above), or one shard [first, first + len) of a group's SRS and the 144-byte partial into
+// the group's exchange buffer (mgpu.hip: the quotient is replicated on every GPU, the MSM is sharded -- SURVEY 8e).
+int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const void *coeffs, size_t n, const void *xs,
+                                   const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt, void *out_r,
+                                   size_t *out_r_len) {
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const kzg_srs *srs = sink.srs;
+    auto sink_len = [&](size_t cnt) { return cnt <= sink.first ? (size_t)0 : (cnt - sink.first < sink.len ? cnt - sink.first : sink.len); };
+    auto sink_msm = [&](Fr *q, size_t cnt, MsmPoint **res) {
+        const size_t len = sink_len(cnt);
+        return msm_run(ctx, 0, srs, 0, len ? q + sink.first : q, len, KZG_FR_MONT_LE_32, res);
+    };
+    auto sink_finish = [&](const MsmPoint *res) {
+        if (!sink.d_partial) return finish_point(ctx, 0, res, out_w, ofmt, flags);
+        KZG_TRY(emit_point(ctx, 0, res, sink.d_partial, KZG_G1_JACOBIAN_MONT_144));
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lanes[0].stream));
+        return (int)KZG_OK;
+    };
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no opening points (the reference recurses without bound on an empty slice)");
@@ -367,8 +387,8 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(hscalar(ctx, xs, sfmt, &xm));
         KZG_TRY(hscalar(ctx, ys, sfmt, &ym));
         size_t n2 = n < 2 ? 2 : n;
-        if (n2 - 1 > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
-        KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n2 - 1) + 4 * n2 * 32 + (n2 / 2048 + 8) * 64 + 65536));
+        if (n2 - 1 > sink.total) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
+        KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, sink_len(n2 - 1)) + 4 * n2 * 32 + (n2 / 2048 + 8) * 64 + 65536));
         Fr *p = (Fr *)lane_alloc(ctx, 0, n2 * 32), *pin = (Fr *)lane_alloc(ctx, 0, n2 * 32), *q = (Fr *)lane_alloc(ctx, 0, n2 * 32);
         Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
         if (!p || !pin || !q || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
@@ -379,8 +399,8 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         Fr px;
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
         MsmPoint *res = nullptr;
-        KZG_TRY(msm_run(ctx, 0, srs, 0, q, n2 - 1, KZG_FR_MONT_LE_32, &res));
-        KZG_TRY(finish_point_host(ctx, res, out_w, ofmt, flags));
+        KZG_TRY(sink_msm(q, n2 - 1, &res));
+        KZG_TRY(sink_finish(res));
         if (ctx->prof) prof_collect(ctx);
         if (!px.is_zero()) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
         Fr r0 = sub(ym, xm), r1 = Fr::one();
@@ -400,8 +420,8 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     if (log_N >= FR_TWO_ADICITY || log_N > 24) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     size_t N = (size_t)1 << log_N;
     size_t nq = small_poly ? 0 : n - k;
-    if (nq > srs->n) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
-    size_t need = msm_workspace_bytes(srs, nq ? nq : 1) + 12 * N * 32 + (size_t)k * k * 32 + 64 * (k + 2) * 32 + (2 << 20);
+    if (nq > sink.total) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
+    size_t need = msm_workspace_bytes(srs, sink_len(nq) ? sink_len(nq) : 1) + 12 * N * 32 + (size_t)k * k * 32 + 64 * (k + 2) * 32 + (2 << 20);
     KZG_TRY(lane_reserve(ctx, 0, need));
     Fr *dx = (Fr *)lane_alloc(ctx, 0, k * 32), *dy = (Fr *)lane_alloc(ctx, 0, k * 32);
     Fr *z0 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32);
@@ -456,7 +476,8 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     {
         uint32_t CH = 1;
         while ((uint64_t)CH * CH * 4 <= k) CH *= 2;             // CH = 2^floor(log2(k) / 2): 16 at k = 256, 64 at 4096
-        const uint32_t nch = (uint32_t)((k + 1 + CH - 1) / CH);  // <= 65
+        const uint32_t nch = (uint32_t)((k + 1 + CH - 1) / CH);  // <= 128 for k <= 4096 (k = 4095: CH = 32, nch = 128)
+        if (nch > 128) return fail(ctx, KZG_ERR_INTERNAL, "interpolation chunk count exceeds the kernel's LDS array (B[128])");
         KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, nch <= 64 ? 64 : 128, 0, dx, dy, deni, z0, (uint32_t)k, CH, nch,
                    rows);
     }
@@ -474,7 +495,7 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, I, k, Bv, N, 0);
         // deg I <= k-1 and deg p <= n-1 <= k-1: the quotient is zero and the division is exact iff p == I
         KZG_LAUNCH(ctx, st, "k_any_diff", k_any_diff, gridfor(N), 256, 0, A, Bv, N, flag);
-        KZG_TRY(msm_run(ctx, 0, srs, 0, A, 0, KZG_FR_MONT_LE_32, &res));  // identity
+        KZG_TRY(sink_msm(A, 0, &res));  // identity
     } else {
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
         // (p - I) in coefficient form, then TWO forward coset NTTs (numerator, Z) and one inverse; Z and the numerator's
@@ -488,12 +509,12 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
         KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 1, gsh));
         // exact division <=> deg q <= N-1-k <=> the top k coefficients vanish
         KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);
-        KZG_TRY(msm_run(ctx, 0, srs, 0, A, nq, KZG_FR_MONT_LE_32, &res));
+        KZG_TRY(sink_msm(A, nq, &res));
     }
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
     if (to_m) KZG_TRY(fr_convert(ctx, st, I, k, 0));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(out_r, I, k * 32, hipMemcpyDeviceToHost, st));
-    KZG_TRY(finish_point_host(ctx, res, out_w, ofmt, flags));
+    KZG_TRY(sink_finish(res));
     if (ctx->prof) prof_collect(ctx);
     if (hflag & 1) {
         // a zero denominator: duplicate opening points (the reference unwrap()s an invert() of zero)
@@ -543,7 +564,7 @@ extern "C" int kzg_domain_z(size_t d, const void *tau, int sfmt, void *out) {
 }
 
 static int vec_entry(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags, int op, const Fr *scale) {
-    std::lock_guard<std::mutex> g(ctx->mu);
+    kzg::Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     if (n > ((size_t)1 << 40)) return fail(ctx, KZG_ERR_SHAPE, "vector too long");
@@ -572,7 +593,7 @@ extern "C" int kzg_divide_by_z_on_coset(kzg_ctx *ctx, void *data, uint32_t log_n
     // A multiplication by a Montgomery-form constant preserves whichever form the data is in.
     if (!ctx || !data) return KZG_ERR_SHAPE;
     if (log_n >= FR_TWO_ADICITY) {
-        std::lock_guard<std::mutex> g(ctx->mu);
+        kzg::Guard g(ctx);
         return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     }
     const size_t d = (size_t)1 << log_n;

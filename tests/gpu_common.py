@@ -15,6 +15,47 @@ def engine():
     e.close()
 
 
+class HooksEngine:
+    """A context in the -DKZG_TEST_HOOKS build of the library (kzg_amd/libkzg_mi355x_hooks.so): the product library does not
+    export the unit-test hooks of include/kzg_mi355x_test.h."""
+
+    def __init__(self, device=0):
+        import ctypes
+        import os
+        import kzg_amd
+        kzg_amd.load()  # the product library first: it has asked for the hardware queues
+        so = os.path.join(os.path.dirname(kzg_amd.__file__), "libkzg_mi355x_hooks.so")
+        self.lib = ctypes.CDLL(so)
+        vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+        for name, args in {"kzg_test_fr_mul": [vp, vp, vp, sz, vp], "kzg_test_fq_mul": [vp, vp, vp, sz, vp],
+                           "kzg_test_fr_inv": [vp, vp, sz, vp], "kzg_test_g1_add": [vp, vp, vp, sz, vp],
+                           "kzg_test_g1_mul": [vp, vp, vp, sz, vp], "kzg_ctx_create": [i32, ctypes.POINTER(vp)],
+                           "kzg_ctx_destroy": [vp], "kzg_test_mctx_inject_failure": [vp, i32]}.items():
+            f = getattr(self.lib, name)
+            f.argtypes = args
+            f.restype = None if name == "kzg_ctx_destroy" else i32
+        self.lib.kzg_last_error.argtypes = [vp]
+        self.lib.kzg_last_error.restype = ctypes.c_char_p
+        self.ctx = vp()
+        rc = self.lib.kzg_ctx_create(device, ctypes.byref(self.ctx))
+        assert rc == 0, f"kzg_ctx_create in the hooks library failed: {rc}"
+
+    def last_error(self):
+        return (self.lib.kzg_last_error(self.ctx) or b"").decode()
+
+    def close(self):
+        if self.ctx:
+            self.lib.kzg_ctx_destroy(self.ctx)
+        self.ctx = None
+
+
+@pytest.fixture(scope="session")
+def hooks_engine():
+    e = HooksEngine(0)
+    yield e
+    e.close()
+
+
 def rand_scalars(rng, n, kind="full"):
     if kind == "full":
         return [rng.randrange(M.R) for _ in range(n)]

@@ -6,9 +6,14 @@ import pytest
 
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-from tests.gpu_common import engine  # noqa: F401
+from tests.gpu_common import hooks_engine  # noqa: F401
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine(hooks_engine):  # noqa: F811  the unit-test hooks live in the -DKZG_TEST_HOOKS build of the library, not in the product
+    return hooks_engine
 
 
 def _call(engine, fname, n, *bufs, out_elem):
