@@ -34,8 +34,9 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# No GPU_MAX_HW_QUEUES here: the library asks for its hardware queues itself when it is loaded and measures what it got
-# (capi.hip: kzg_default_hw_queues, probe_queues; profiles/r02_hw_queues.txt has the numbers for 4 / 8 / 18 queues).
+# Hardware queues: this process is the host.  Like a Rust host following INTEGRATION.md section 6 it asks for the queues of the
+# pipelined paths before its first HIP call -- kzg_amd.load() calls kzg_init_hw_queues(0) (KZG_HW_QUEUES=0 in the environment
+# skips that; the engine then measures the runtime's default pool and narrows its pipeline: profiles/r03_hw_queues.txt).
 
 LOG_N = 20
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -46,9 +47,10 @@ NTT_BYTES_PER_ELEM = 64        # one read + one write of a 32-byte 
 # (static count from the ISA).  tools/microbench.hip measured the chip's 64-bit multiply-add issue rate: 31.5 T lane-op/s at
 # 8 waves/SIMD, 23.7 T at the 2 waves/SIMD a 200-VGPR kernel holds (profiles/r01_microbench.txt).
 MADS_PER_ADD = 6 * 338 + 2 * 260 + 507
-MAD_PEAK_TLANE_S = 31.51
+MAD_PEAK_TLANE_S = 31.51       # reference value (round-1 microbench on another box); the line's `peak` is measured in this run
 MAD_PEAK_OCC2_TLANE_S = 23.70
 FR_MUL_PEAK_G_S = 111.0        # measured Fr (9 x 29-bit) multiplies per second of the NTT's multiply
+MADS_PER_FR29_MUL = 162        # 9 x 9 products + 9 x 9 reduction products of one Fr29 Montgomery multiply (fr29.h)
 TAU = 0x5EED5EED5EED5EED       # known secret for the synthetic SRS (setup(s, n), src/lib.rs:38)
 SEED = 1
 
@@ -176,7 +178,50 @@ def timeit(f, reps=3, warm=1):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0):
+def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=16, calls=12):
+    """The reference's call shape: `threads` host threads, each looping the BLOCKING kzg_commit_coeff (KZGProver::commit,
+    src/coeff_form.rs:59-64) on ONE context and one resident SRS, device-resident coefficients (thread t commits polynomial
+    t of the timed batch).  Returns commitments per second over all threads, and whether every result matched the batch's."""
+    import threading
+    lib, ctx = engine.lib, engine.ctx
+    want = {}
+    ref = ctypes.create_string_buffer(96)
+    for t in range(min(threads, n_polys)):
+        v = view(kzg_amd, scal, t * n, n)
+        assert lib.kzg_commit_coeff(ctx, srs.handle, v.ptr, n, v.sfmt, L.IN_DEVICE, ref, L.G1_AFFINE_MONT) == 0, engine.last_error()
+        want[t] = ref.raw
+    ok = [True] * threads
+    start = threading.Barrier(threads + 1)
+
+    def work(t):
+        v = view(kzg_amd, scal, (t % n_polys) * n, n)
+        out = ctypes.create_string_buffer(96)
+        start.wait()
+        for _ in range(calls):
+            rc = lib.kzg_commit_coeff(ctx, srs.handle, v.ptr, n, v.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            if rc != 0 or out.raw != want[t % n_polys]:
+                ok[t] = False
+
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    # one untimed round first (lanes, arenas and the queue plan come into being), then the timed one
+    start.wait()
+    for x in th:
+        x.join()
+    start = threading.Barrier(threads + 1)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for x in th:
+        x.start()
+    start.wait()
+    t0 = time.perf_counter()
+    for x in th:
+        x.join()
+    dt = time.perf_counter() - t0
+    return threads * calls / dt, all(ok)
+
+
+def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad_peak=MAD_PEAK_TLANE_S):
     """The other BASELINE configs at degree 2^log_n, inputs resident in HBM, each result checked by an identity that needs no
     oracle (eval-form == coeff-form, witness_eval == witness_coeff at omega^m); outside the timed region."""
     t_start = time.perf_counter()
@@ -220,6 +265,10 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0):
         "bound": "valu", "kernels": {k: round(v[1] / (reps + 1), 4) for k, v in sorted(prof.items()) if k.startswith("k_ntt")},
         "kernel_ms": round(kern_ms, 4), "achieved": round(fr_muls / (kern_ms / 1e3) / 1e9, 2), "peak": FR_MUL_PEAK_G_S,
         "unit": "G Fr-mul/s ((n/2) log n butterflies)", "frac": round(fr_muls / (kern_ms / 1e3) / 1e9 / FR_MUL_PEAK_G_S, 4),
+        # the same work in the unit the MSM is priced in: lane multiply-adds against the mad-issue peak measured in this run
+        "mad_achieved": round(fr_muls * MADS_PER_FR29_MUL / (kern_ms / 1e3) / 1e12, 3), "mad_peak": round(mad_peak, 2),
+        "mad_unit": "T lane-mad/s (%d per Fr29 multiply)" % MADS_PER_FR29_MUL,
+        "mad_frac": round(fr_muls * MADS_PER_FR29_MUL / (kern_ms / 1e3) / 1e12 / mad_peak, 4),
         "hbm": {"bound": "hbm", "achieved": round(nbytes / (kern_ms / 1e3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(nbytes / (kern_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5), "algorithmic_bytes": nbytes}}
     ev.upload(host_coeffs)
@@ -473,11 +522,12 @@ def main():
 
     check = None
     if args.check:
-        # known-tau identity for EVERY commitment of the last step: C_b == [p_b(tau)]G, p_b(tau) = sum_r tau^(lo_r) p_{b,r}(tau)
-        # from per-rank GPU Horner evaluations; the scalar multiplications of G are done by the oracle (checker only).
+        # known-tau identity for EVERY commitment of the last step: C_b == [p_b(tau)]G, p_b(tau) = sum_r tau^(lo_r) p_{b,r}(tau).
+        # Checker = the oracle throughout: each rank downloads its coefficient slices, the oracle's Horner loop evaluates them,
+        # the oracle multiplies G.  No HIP kernel on the right-hand side.
         from oracle import c_oracle as C
         R = kzg_amd.api.R_MODULUS
-        mine = [pow(TAU, lo, R) * engine.poly_eval(view(kzg_amd, scal, b * n_local, n_local), TAU) % R if n_local else 0
+        mine = [pow(TAU, lo, R) * C.poly_eval_bytes(view(kzg_amd, scal, b * n_local, n_local).download(), n_local, TAU) % R if n_local else 0
                 for b in range(args.batch)]
         if sharded and world > 1:
             allv = [None] * world
@@ -489,30 +539,48 @@ def main():
     # ---- roofline of the dominant kernel: HIP events recorded on the engine's streams over the timed region ----
     roofline = None
     latency_ms = None
+    mad_peak = MAD_PEAK_TLANE_S
     if rank == 0:
         prof = engine.prof_all()
         engine.prof_enable(False)
+        # the roofline peak, measured on THIS device in this run (~30 ms mad-issue loop, 8 waves per SIMD; and at the 2 waves
+        # per SIMD the accumulation kernel holds), right after the timed region
+        pk, pk2 = ctypes.c_double(), ctypes.c_double()
+        peak_measured = peak2_measured = None
+        if engine.lib.kzg_measure_mad_issue_rate(engine.ctx, 8, ctypes.byref(pk)) == 0 and pk.value > 0:
+            peak_measured = mad_peak = pk.value
+        if engine.lib.kzg_measure_mad_issue_rate(engine.ctx, 2, ctypes.byref(pk2)) == 0 and pk2.value > 0:
+            peak2_measured = pk2.value
         launches, total_ms = prof.get("k_accum_affine", (0, 0.0))
         if launches:
             avg_s = total_ms / launches / 1e3
             adds_per_launch = n_local * (4 if args.u64 else W)   # u64-valued scalars: 4 non-zero 16/17-bit windows
             mads_per_launch = float(adds_per_launch) * MADS_PER_ADD
+            # HBM traffic needs PMC counters (rocprofv3 --pmc passes, tools/collect_profiles.sh); nothing in this process can
+            # measure it, so the line carries null and names the profile that holds the collected figure
             traffic = None
+            traffic_profile = None
             tpath = os.path.join(ROOT, "profiles", "traffic.json")
             if os.path.exists(tpath) and n_local == (1 << 20) and not args.u64:
                 try:
-                    traffic = json.load(open(tpath)).get("k_accum_affine_bytes_per_launch")
+                    traffic_profile = {"bytes_per_launch": json.load(open(tpath)).get("k_accum_affine_bytes_per_launch"),
+                                       "source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, collected separately; "
+                                                 "not measured in this run)"}
                 except Exception:
-                    traffic = None
+                    traffic_profile = None
             t_mad = launches * mads_per_launch / dt / 1e12       # over the whole timed region (launches overlap on streams)
             hbm_achieved = BYTES_PER_TERM * n_local / avg_s / 1e9
             roofline = {
                 "bound": "valu", "kernel": "k_accum_affine", "resource": "v_mad_i64_i32 issue (integer VALU)",
-                "achieved": round(t_mad, 2), "peak": MAD_PEAK_TLANE_S, "unit": "T lane-mad/s", "frac": round(t_mad / MAD_PEAK_TLANE_S, 4),
-                "traffic": traffic,
+                "achieved": round(t_mad, 2), "peak": round(mad_peak, 2), "unit": "T lane-mad/s", "frac": round(t_mad / mad_peak, 4),
+                "peak_measured_this_run": None if peak_measured is None else round(peak_measured, 2),
+                "peak_reference": MAD_PEAK_TLANE_S, "frac_of_peak_reference": round(t_mad / MAD_PEAK_TLANE_S, 4),
+                "peak_at_2_waves_per_simd_measured_this_run": None if peak2_measured is None else round(peak2_measured, 2),
+                "traffic": traffic, "traffic_profiled": traffic_profile,
                 "derivation": "launches x terms x windows x %d mads per bucket addition (6 mul30 x 338 + 2 sqr30 x 260 + 1 fused "
-                              "muladd 507; 13 x 30-bit signed limbs) / wall time of the timed region; peak = measured "
-                              "v_mad_i64_i32 issue rate of the chip (tools/microbench.hip, profiles/r01_microbench.txt)" % MADS_PER_ADD,
+                              "muladd 507; 13 x 30-bit signed limbs) / wall time of the timed region; peak = the v_mad_i64_i32 issue "
+                              "rate of THIS device measured in this run (kzg_measure_mad_issue_rate: 8 chains per lane, 8 waves per "
+                              "SIMD, ~30 ms); peak_reference = round 1's figure from another box" % MADS_PER_ADD,
                 "peak_at_2_waves_per_simd": MAD_PEAK_OCC2_TLANE_S, "frac_of_occupancy_2_peak": round(t_mad / MAD_PEAK_OCC2_TLANE_S, 4),
                 "mads_per_bucket_add": MADS_PER_ADD, "launches": launches, "avg_kernel_ms": round(avg_s * 1e3, 4),
                 "hbm": {"bound": "hbm", "achieved": round(hbm_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -540,7 +608,7 @@ def main():
                 if l2:
                     k_s = ms2 / l2 / 1e3
                     roofline["alone"] = {"avg_kernel_ms": round(ms2 / l2, 4),
-                                         "valu_frac": round(mads_per_launch / k_s / 1e12 / MAD_PEAK_TLANE_S, 4),
+                                         "valu_frac": round(mads_per_launch / k_s / 1e12 / mad_peak, 4),
                                          "hbm_gbs": round(BYTES_PER_TERM * n_local / k_s / 1e9, 2),
                                          "hbm_frac": round(BYTES_PER_TERM * n_local / k_s / 1e9 / HBM_PEAK_GBS, 5),
                                          "kernel_ms_single_msm": {k: round(v[1] / l2, 4) for k, v in sorted(pa.items())}}
@@ -593,7 +661,11 @@ def main():
         t_extra = time.perf_counter()
         if mode == "single" and not args.no_paths:
             try:
-                res["paths"] = measure_paths(kzg_amd, L, engine, params, scal, n_poly, args.log_n)
+                res["paths"] = measure_paths(kzg_amd, L, engine, params, scal, n_poly, args.log_n, mad_peak=mad_peak)
+                per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch)
+                res["paths"]["blocking_callers_16_per_s"] = round(per_s, 2)
+                res["paths"]["blocking_callers_16_vs_value"] = round(per_s / value, 4)
+                res["paths"]["blocking_callers_16_match_batch_results"] = same
                 if args.log_n == 20 and not args.u64:
                     res["paths"].update(measure_spots(kzg_amd, L, engine, lambda: time.perf_counter() - t_extra < 45.0))
             except Exception as e:

@@ -353,6 +353,10 @@ int kzg_prof_reset(kzg_ctx *ctx);
 int kzg_prof_get(kzg_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);
 /* comma-separated list of kernel names seen so far */
 int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen);
+/* The v_mad_i64_i32 issue rate of THIS device, measured now (~30 ms at 8 waves per SIMD: 8 independent accumulator chains per
+ * lane), in 10^12 lane-multiply-adds per second: the roofline peak bench.py prices the bucket-accumulation kernel against
+ * (devices of one pool differ by several percent, and the sustained clock under this load is not the nominal one). */
+int kzg_measure_mad_issue_rate(kzg_ctx *ctx, int waves_per_simd, double *tera_lane_mads_per_s);
 /* number of window bits and windows the engine chose for this SRS (for G1-adds accounting) */
 int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows);
 int kzg_srs_table_rows(const kzg_srs *srs);   /* resident table rows (= windows unless option window_rows) */

@@ -127,6 +127,7 @@ def load(path=None):
         "kzg_dev_upload": (i32, [vp, vp, vp, sz]),
         "kzg_dev_download": (i32, [vp, vp, vp, sz]),
         "kzg_fill_random_fr": (i32, [vp, vp, sz, u64, i32, i32]),
+        "kzg_measure_mad_issue_rate": (i32, [vp, i32, ctypes.POINTER(ctypes.c_double)]),
         "kzg_prof_enable": (i32, [vp, i32]),
         "kzg_prof_reset": (i32, [vp]),
         "kzg_prof_get": (i32, [vp, ctypes.c_char_p, ctypes.POINTER(u64), ctypes.POINTER(ctypes.c_double)]),

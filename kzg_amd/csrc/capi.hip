@@ -432,6 +432,47 @@ extern "C" int kzg_prof_names(kzg_ctx *ctx, char *buf, size_t buflen) {
     return KZG_OK;
 }
 
+// The chip's v_mad_i64_i32 issue rate, measured on THIS device now (bench.py's roofline peak: boxes of one pool differ by
+// several percent and the clock a box sustains under this load is not its nominal one).  Eight independent accumulator chains per
+// lane, 8 waves per SIMD, ~30 ms: the same loop as tools/mad_issue.hip / tools/microbench.hip.
+__global__ __launch_bounds__(256) void k_mad_issue_rate(uint32_t *out, int iters, uint32_t seed) {
+    int32_t a = (int32_t)(seed + threadIdx.x), b = (int32_t)(seed * 3 + blockIdx.x);
+    uint64_t c0 = a, c1 = b, c2 = a ^ b, c3 = a + b, c4 = a * 3, c5 = b * 5, c6 = a * 7, c7 = b * 9;
+    for (int i = 0; i < iters; i++) {
+#define KZG_M(c) asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b) : "vcc");
+        KZG_M(c0) KZG_M(c1) KZG_M(c2) KZG_M(c3) KZG_M(c4) KZG_M(c5) KZG_M(c6) KZG_M(c7)
+#undef KZG_M
+    }
+    uint64_t s = c0 ^ c1 ^ c2 ^ c3 ^ c4 ^ c5 ^ c6 ^ c7;
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
+}
+
+extern "C" int kzg_measure_mad_issue_rate(kzg_ctx *ctx, int waves_per_simd, double *tera_lane_mads_per_s) {
+    if (!ctx || !tera_lane_mads_per_s || waves_per_simd < 1 || waves_per_simd > 8) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+    const int blocks = ctx->num_cus * waves_per_simd, iters = 25000 * waves_per_simd;
+    KZG_TRY(lane_reserve(ctx, 0, (size_t)blocks * 256 * 4 + 4096));
+    uint32_t *out = (uint32_t *)lane_alloc(ctx, 0, (size_t)blocks * 256 * 4);
+    if (!out) return fail(ctx, KZG_ERR_ALLOC, "workspace");
+    hipStream_t st = ctx->lanes[0].stream;
+    hipEvent_t e0, e1;
+    KZG_HIP_CHECK(ctx, hipEventCreate(&e0));
+    KZG_HIP_CHECK(ctx, hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_mad_issue_rate, dim3(blocks), dim3(256), 0, st, out, iters / 4, 7u);  // warm-up
+    hipEventRecord(e0, st);
+    hipLaunchKernelGGL(k_mad_issue_rate, dim3(blocks), dim3(256), 0, st, out, iters, 7u);
+    hipEventRecord(e1, st);
+    hipError_t e = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    if (e != hipSuccess || ms <= 0.f) return fail(ctx, KZG_ERR_HIP, "mad issue-rate measurement failed");
+    *tera_lane_mads_per_s = (double)blocks * 256.0 * (double)iters * 8.0 / ((double)ms * 1e-3) / 1e12;
+    return KZG_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // MSM
 // ---------------------------------------------------------------------------------------------

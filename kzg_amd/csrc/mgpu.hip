@@ -49,23 +49,8 @@ static std::string object_of(const void *addr) {
 static std::mutex g_rccl_mu;
 static Rccl *g_rccl = nullptr;
 
-static Rccl *rccl_load(std::string *err) {
-    std::lock_guard<std::mutex> lk(g_rccl_mu);
-    if (g_rccl) return g_rccl;
-    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);  // a copy this process already holds (e.g. PyTorch's)
-    const char *names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
-    for (int i = 0; !h && i < 3; i++) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-#ifdef KZG_TEST_HOOKS
-    if (getenv("KZG_TEST_NO_RCCL")) {  // tests: the load-failure path on a host that does have RCCL
-        if (h) dlclose(h);
-        h = dlopen("librccl-not-installed.so.1", RTLD_NOW | RTLD_LOCAL);
-    }
-#endif
-    if (!h) {
-        const char *e = dlerror();  // read once: glibc clears the message on the first read
-        *err = std::string("cannot load RCCL (librccl.so.1): ") + (e ? e : "not found");
-        return nullptr;
-    }
+// One candidate: resolve the entry points and find out which HIP runtime the copy is bound to.
+static Rccl *rccl_try(void *h, std::string *err) {
     Rccl *r = new Rccl();
     r->handle = h;
     bool ok = true;
@@ -90,20 +75,58 @@ static Rccl *rccl_load(std::string *err) {
         delete r;
         return nullptr;
     }
-    // Which RCCL was adopted, and is it bound to the same HIP runtime as this library?  A stream and device pointers are
-    // handed across, so two HIP runtimes in one process (PyTorch wheels ship their own next to /opt/rocm's) must not be mixed.
     r->path = object_of((const void *)r->AllGather);
     r->GetVersion(&r->version);
-    r->hip_path = object_of(dlsym(h, "hipStreamSynchronize"));  // resolved through RCCL's own dependency chain
-    const std::string mine = object_of((const void *)&hipStreamSynchronize);
-    if (r->hip_path != "?" && mine != "?" && r->hip_path != mine) {
-        *err = "RCCL " + r->path + " is bound to HIP runtime " + r->hip_path + " but this library runs on " + mine +
-               ": refusing to share streams across two runtimes (load the matching librccl.so.1 first, or fix the library path)";
-        delete r;
-        return nullptr;
-    }
-    g_rccl = r;
+    r->hip_path = object_of(dlsym(h, "hipStreamSynchronize"));  // resolved through this copy's own dependency chain
     return r;
+}
+
+// Which RCCL?  A stream and device pointers are handed across, so the copy must be bound to the SAME HIP runtime as this
+// library (PyTorch wheels ship their own librccl / libamdhip64 next to /opt/rocm's: two runtimes in one process must not be
+// mixed).  Candidates in order: the copy the process already holds (RTLD_NOLOAD: e.g. PyTorch's), librccl.so.1 from the library
+// path, /opt/rocm's.  The first one on this library's runtime is adopted (kzg_mctx_info reports it); if every loadable copy is
+// on another runtime the group refuses to form.
+static Rccl *rccl_load(std::string *err) {
+    std::lock_guard<std::mutex> lk(g_rccl_mu);
+    if (g_rccl) return g_rccl;
+    const std::string mine = object_of((const void *)&hipStreamSynchronize);
+    const char *names[] = {nullptr, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    std::string load_err = "not found", mismatches;
+    bool any = false;
+    for (int i = 0; i < 4; i++) {
+        void *h = i == 0 ? dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD) : dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+#ifdef KZG_TEST_HOOKS
+        if (getenv("KZG_TEST_NO_RCCL")) {  // tests: the load-failure path on a host that does have RCCL
+            if (h) dlclose(h);
+            h = dlopen("librccl-not-installed.so.1", RTLD_NOW | RTLD_LOCAL);
+        }
+#endif
+        if (!h) {
+            const char *e = dlerror();  // read once: glibc clears the message on the first read
+            if (e) load_err = e;
+            continue;
+        }
+        any = true;
+        std::string serr;
+        Rccl *r = rccl_try(h, &serr);
+        if (!r) {
+            load_err = serr;
+            continue;
+        }
+        if (r->hip_path != "?" && mine != "?" && r->hip_path != mine) {
+            mismatches += (mismatches.empty() ? "" : "; ") + r->path + " -> " + r->hip_path;
+            delete r;
+            continue;
+        }
+        g_rccl = r;
+        return r;
+    }
+    if (any && !mismatches.empty())
+        *err = "every loadable RCCL is bound to another HIP runtime than this library (" + mine + "): " + mismatches +
+               " -- refusing to share streams across two runtimes";
+    else
+        *err = std::string("cannot load RCCL (librccl.so.1): ") + load_err;
+    return nullptr;
 }
 
 constexpr size_t PARTIAL_BYTES = 144;  // KZG_G1_JACOBIAN_MONT_144: no field inversion per partial

@@ -8,10 +8,7 @@ locally (EC addition is not an RCCL reduction op, so "all-reduce" = all-gather +
   * shard_range            -- the library's partition rule (host-only C helper, usable without a GPU);
   * group_from_torch       -- one process per GPU under torch.distributed: rank 0 draws the RCCL unique id, the process
                               group carries the 128 bytes to the other ranks, every rank joins with kzg_mctx_create_rank;
-  * ProtocolModel          -- the same exchange (partials -> all_gather laid out [world][batch] -> per-polynomial sums) over
-                              any torch.distributed backend with the local operations injected.  It exists so that the
-                              N > 1 protocol can be exercised on CPU with gloo (tests/test_distributed_gloo.py injects the
-                              oracle); it is not a product path.
+(The CPU model of the exchange used by the world-size-2 gloo test lives with the tests: tests/protocol_model.py.)
 """
 import ctypes
 
@@ -40,22 +37,3 @@ def group_from_torch(dist, device, rank, world):
     from .api import DeviceGroup
     uid = broadcast_unique_id(dist, rank, DeviceGroup.unique_id) if world > 1 else DeviceGroup.unique_id()
     return DeviceGroup.for_rank(device, rank, world, uid)
-
-
-class ProtocolModel:
-    """The exchange of mgpu.hip with injected local operations (CPU tests only).
-
-    local_msm(scalar_shards, batch) -> torch.uint8[batch * point_bytes]: this rank's partial points;
-    local_sum(gathered, world, batch) -> list of `batch` results, where gathered is torch.uint8 laid out
-    [world][batch][point_bytes] exactly as ncclAllGather leaves it (partial of rank w for polynomial b at (w*batch+b))."""
-
-    def __init__(self, dist, rank, world, local_msm, local_sum, point_bytes=96):
-        self.dist, self.rank, self.world = dist, rank, world
-        self.local_msm, self.local_sum, self.pb = local_msm, local_sum, point_bytes
-
-    def commit_batch(self, scalar_shards, batch):
-        import torch
-        mine = self.local_msm(scalar_shards, batch)
-        gathered = torch.empty(self.world * batch * self.pb, dtype=torch.uint8)
-        self.dist.all_gather_into_tensor(gathered, mine)
-        return self.local_sum(gathered, self.world, batch)

@@ -760,6 +760,34 @@ def lagrange_basis_g1_known_tau(tau, d):
 # --------------------------------------------------------------------------------------
 # selfcheck: validates the constants above (run by tests/test_oracle_model.py)
 # --------------------------------------------------------------------------------------
+# ---- the synthetic-input stream of the engine's ABI (not a reference function) -------------------------------------------
+# kzg_fill_random_fr (include/kzg_mi355x.h) fills device buffers with SplitMix64(seed + 4 i + k) limbs, reduced mod r; the
+# reference benches draw u64-valued coefficients (benches/commit_coeff_form.rs:16-21), which is the `u64_valued` flavour.
+# Restated here so that production-size golden commitments (tests/golden/prod.json) are computed by this model alone.
+def splitmix64(z):
+    m = (1 << 64) - 1
+    z = (z + 0x9E3779B97F4A7C15) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return z ^ (z >> 31)
+
+
+def splitmix_scalar(seed, i, u64_valued=False):
+    m = (1 << 64) - 1
+    v = 0
+    for k in range(1 if u64_valued else 4):
+        v |= splitmix64((seed + 4 * i + k) & m) << (64 * k)
+    return v % R
+
+
+def splitmix_poly_eval(seed, n, x, u64_valued=False):
+    """p(x) for p = sum_i splitmix_scalar(seed, i) X^i, i < n (Horner from the top, Polynomial::eval src/polynomial.rs:156-165)"""
+    acc = 0
+    for i in range(n - 1, -1, -1):
+        acc = (acc * x + splitmix_scalar(seed, i, u64_valued)) % R
+    return acc
+
+
 def selfcheck():
     z = BLS_Z
     assert R == z ** 4 - z ** 2 + 1

@@ -85,7 +85,29 @@ def main():
                    "evals": [sc(c) for c in ev.coeffs], "commit": pt(evp.commit(ev)), "index": 3,
                    "witness": pt(evp.create_witness(ev, 3, fast=False))}
     json.dump(kzg, open(os.path.join(HERE, "kzg.json"), "w"), indent=0)
+    if "--prod" in sys.argv or not os.path.exists(os.path.join(HERE, "prod.json")):
+        prod_vectors()
     print("golden vectors written to", HERE)
+
+
+def prod_vectors():
+    """Production-path goldens (prod.json): 48 bytes each.  (tau, seed, n, distribution) -> compressed commit(p) = [p(tau)]G for
+    p = the SplitMix64 coefficient stream of kzg_fill_random_fr, at the sizes where the engine runs its production MSM path
+    (17-bit windows, two-level sort, 15 table rows: 2^17, 2^20, 2^21), plus one create_witness at 2^20.  Computed by the python
+    model alone -- coefficient stream, Horner evaluation, one scalar multiplication of the generator -- in about a minute."""
+    tau = 0x5EED5EED5EED5EED
+    cases = []
+    for log_n, seed, u64 in ((17, 1701, False), (20, 2001, False), (20, 2002, True), (21, 2101, False)):
+        n = 1 << log_n
+        ptau = M.splitmix_poly_eval(seed, n, tau, u64)
+        cases.append({"log_n": log_n, "seed": seed, "u64_valued": u64, "p_tau": sc(ptau), "commit": pt(M.g1_mul(M.G1, ptau))})
+    n, seed = 1 << 20, 2001
+    x = M.splitmix_scalar(77, 0)
+    y = M.splitmix_poly_eval(seed, n, x)
+    ptau = M.splitmix_poly_eval(seed, n, tau)
+    w = (ptau - y) * M.fr_inv((tau - x) % M.R) % M.R
+    wit = {"log_n": 20, "seed": seed, "x": sc(x), "y": sc(y), "witness": pt(M.g1_mul(M.G1, w))}
+    json.dump({"tau": sc(tau), "commits": cases, "witness": wit}, open(os.path.join(HERE, "prod.json"), "w"), indent=0)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,45 @@
+"""TEST SCAFFOLD (not a product path): the exchange of kzg_amd/csrc/mgpu.hip restated over any torch.distributed backend with
+the per-rank GPU operations injected, so that the N > 1 protocol -- partition rule, record layout, status agreement -- can be
+exercised on CPU with gloo (tests/test_distributed_gloo.py injects the oracle).
+
+Record a rank contributes (mgpu.hip, record_bytes): `batch` partial points followed by ONE status slot of the same size whose
+first 4 bytes are the rank's local kzg_status (little-endian int32).  Every rank always enters the all-gather, with its failure
+code if its local phase failed; afterwards every rank reads every status and all return the first failing rank's code.  The
+gathered buffer is [world][batch + 1][point_bytes]; polynomial b's partial of rank w sits at slot w * (batch + 1) + b."""
+import struct
+
+
+class RankFailed(Exception):
+    def __init__(self, rank, status):
+        super().__init__(f"rank {rank} failed in its local phase (status {status})")
+        self.rank, self.status = rank, status
+
+
+class ProtocolModel:
+    """local_msm(scalar_shards, batch) -> bytes[batch * point_bytes] (this rank's partial points; may raise);
+    local_sum(slots, world, batch, stride) -> list of `batch` results, slots = the gathered bytes, partial of rank w for
+    polynomial b at slot w * stride + b."""
+
+    def __init__(self, dist, rank, world, local_msm, local_sum, point_bytes=96):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.local_msm, self.local_sum, self.pb = local_msm, local_sum, point_bytes
+
+    def commit_batch(self, scalar_shards, batch):
+        import torch
+        status = 0
+        try:
+            mine = bytes(self.local_msm(scalar_shards, batch))
+            assert len(mine) == batch * self.pb
+        except Exception as e:  # noqa: BLE001  the rank still enters the exchange, with its failure code
+            status = getattr(e, "status", -4)
+            mine = bytes(batch * self.pb)
+        rec = mine + struct.pack("<ii", status, self.rank) + bytes(self.pb - 8)
+        gathered = torch.empty(self.world * len(rec), dtype=torch.uint8)
+        self.dist.all_gather_into_tensor(gathered, torch.frombuffer(bytearray(rec), dtype=torch.uint8))
+        raw = gathered.numpy().tobytes()
+        stride = batch + 1
+        for w in range(self.world):
+            st = struct.unpack_from("<i", raw, (w * stride + batch) * self.pb)[0]
+            if st != 0:
+                raise RankFailed(w, st)
+        return self.local_sum(raw, self.world, batch, stride)

@@ -1,8 +1,8 @@
 """N>1 protocol on CPU: world_size-2 torch.distributed (gloo), contiguous SRS shards (kzg_shard_range), one partial point
-per rank and polynomial, all_gather laid out [world][batch], per-polynomial sums -- kzg_amd.distributed.ProtocolModel with the
-oracle standing in for the per-rank GPU operations (tests may use the oracle; the product never does).  The product's own
-exchange (kzg_amd/csrc/mgpu.hip, RCCL) is exercised on the GPU by tests/test_gpu_mgpu.py; this test pins the partition rule,
-the gathered layout and the unique-id hand-off it relies on."""
+per rank and polynomial plus the status slot, all_gather laid out [world][batch + 1], status agreement, per-polynomial sums --
+tests/protocol_model.py with the oracle standing in for the per-rank GPU operations (tests may use the oracle; the product never
+does).  The product's own exchange (kzg_amd/csrc/mgpu.hip, RCCL) is exercised on the GPU by tests/test_gpu_mgpu.py; this test
+pins the partition rule, the gathered layout, the unique-id hand-off and "a failing rank fails every rank, nobody hangs"."""
 import os
 import random
 import socket
@@ -11,7 +11,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from kzg_amd.distributed import ProtocolModel, broadcast_unique_id, shard_range
+from kzg_amd.distributed import broadcast_unique_id, shard_range
+from tests.protocol_model import ProtocolModel, RankFailed
 from oracle import c_oracle as C
 from oracle import kzg_model as M
 
@@ -35,15 +36,14 @@ def _worker(rank, world, port, n, tau, seed, q):
     shard = full[96 * lo: 96 * hi]
 
     def local_msm(polys, batch):
-        return torch.frombuffer(bytearray(b"".join(C.msm_g1(shard, sc) for sc in polys)), dtype=torch.uint8)
+        return b"".join(C.msm_g1(shard, sc) for sc in polys)
 
-    def local_sum(gathered, nranks, batch):
-        raw = bytes(gathered.numpy().tobytes())      # [world][batch][96], as ncclAllGather leaves it
+    def local_sum(raw, nranks, batch, stride):        # [world][batch + 1][96], as ncclAllGather leaves it
         res = []
         for b in range(batch):
             acc = bytes(96)
-            for w in range(nranks):                   # = k_sum_groups with gstride 1, istride batch
-                acc = C.g1_add(acc, raw[96 * (w * batch + b): 96 * (w * batch + b + 1)])
+            for w in range(nranks):                   # = k_sum_groups with gstride 1, istride batch + 1
+                acc = C.g1_add(acc, raw[96 * (w * stride + b): 96 * (w * stride + b + 1)])
             res.append(acc)
         return res
 
@@ -53,7 +53,23 @@ def _worker(rank, world, port, n, tau, seed, q):
     committer = ProtocolModel(dist, rank, world, local_msm, local_sum)
     # a batch of two polynomials: p and 3*p (distinguishes the [world][batch] layout from its transpose)
     got = committer.commit_batch([coeffs[lo:hi], [3 * c % M.R for c in coeffs[lo:hi]]], 2)
-    q.put((rank, got))
+    # status agreement: rank 1's local phase fails (allocation failure, code -3); BOTH ranks leave the exchange with that error
+    class Boom(Exception):
+        status = -3
+
+    def failing_msm(polys, batch):
+        if rank == 1:
+            raise Boom()
+        return local_msm(polys, batch)
+
+    try:
+        ProtocolModel(dist, rank, world, failing_msm, local_sum).commit_batch([coeffs[lo:hi]], 1)
+        agreed = None
+    except RankFailed as e:
+        agreed = (e.rank, e.status)
+    # and the group is still usable afterwards
+    again = committer.commit_batch([coeffs[lo:hi]], 1)
+    q.put((rank, (got, agreed, again)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -83,4 +99,6 @@ def test_sharded_commit_world2_gloo():
     coeffs = [rng.randrange(M.R) for _ in range(n)]
     ptau = C.poly_eval(coeffs, tau)
     want = [C.g1_mul(C.g1_generator(), ptau), C.g1_mul(C.g1_generator(), 3 * ptau % M.R)]   # [p(tau)]G, [3p(tau)]G
-    assert results[0] == results[1] == want
+    assert results[0][0] == results[1][0] == want
+    assert results[0][1] == results[1][1] == (1, -3)
+    assert results[0][2] == results[1][2] == want[:1]

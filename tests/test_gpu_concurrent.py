@@ -1,0 +1,149 @@
+"""The reference's call shape: KZGProver is Clone + &self (src/coeff_form.rs:37-64), so many host threads call commit() /
+create_witness() at once.  On one kzg_ctx each blocking call leases a lane (capi.hip, CtxGate in common.h); these tests drive
+one context from 16 threads with mixed calls and check every result against the oracle, and share one resident SRS between
+contexts."""
+import ctypes
+import threading
+
+import pytest
+
+import kzg_amd
+from kzg_amd import _lib as L
+from oracle import c_oracle as C
+from oracle import kzg_model as M
+from tests.gpu_common import engine  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+R = M.R
+TAU = 0x5EED5EED5EED5EED
+b32 = lambda v: (v % R).to_bytes(32, "little")  # noqa: E731
+
+
+def _run_threads(n_threads, fn):
+    errs = []
+
+    def wrap(t):
+        try:
+            fn(t)
+        except BaseException as e:  # noqa: BLE001
+            errs.append((t, repr(e)))
+
+    th = [threading.Thread(target=wrap, args=(t,)) for t in range(n_threads)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+
+
+@pytest.mark.parametrize("n,threads,rounds", [(1 << 12, 16, 6), (1 << 17, 16, 3)])
+def test_concurrent_mixed_calls_small(engine, n, threads, rounds):
+    """commit (coeff + eval form), create_witness (both forms), a wrong-y witness and an exclusive call (NTT) interleaved from
+    16 threads on ONE context: every result equals the oracle's."""
+    engine.set_option("streams", 16)
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    lag = kzg_amd.setup_lagrange(engine, TAU, n)
+    log_n = n.bit_length() - 1
+    _, _, omega = kzg_amd.compute_omega(n)
+    G = C.g1_generator()
+    polys = []
+    for t in range(threads):
+        buf = engine.alloc_scalars(n).fill_random(9000 + t)
+        raw = buf.download()
+        ev = engine.alloc_scalars(n)
+        ev.upload(C.fft_bytes(raw, log_n))
+        ptau = C.poly_eval_bytes(raw, n, TAU)
+        x = kzg_amd.splitmix_scalar(31, t)
+        y = C.poly_eval_bytes(raw, n, x)
+        m = (977 * t + 5) % n
+        xm = pow(omega, m, R)
+        ym = C.poly_eval_bytes(raw, n, xm)
+        polys.append(dict(buf=buf, ev=ev, commit=C.g1_mul(G, ptau), x=x, y=y, m=m,
+                          wit=C.g1_mul(G, (ptau - y) * pow(TAU - x, -1, R) % R),
+                          wit_m=C.g1_mul(G, (ptau - ym) * pow(TAU - xm, -1, R) % R)))
+
+    def work(t):
+        p = polys[t]
+        lib, ctx = engine.lib, engine.ctx
+        out = ctypes.create_string_buffer(96)
+        for r in range(rounds):
+            rc = lib.kzg_commit_coeff(ctx, params.gs.handle, p["buf"].ptr, n, p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == 0 and out.raw == p["commit"], ("commit", t, r, rc)
+            rc = lib.kzg_witness_coeff(ctx, params.gs.handle, p["buf"].ptr, n, b32(p["x"]), b32(p["y"]), p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == 0 and out.raw == p["wit"], ("witness", t, r, rc)
+            rc = lib.kzg_commit_eval(ctx, lag.handle, p["ev"].ptr, n, p["ev"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == 0 and out.raw == p["commit"], ("commit_eval", t, r, rc)
+            rc = lib.kzg_witness_eval(ctx, lag.handle, p["ev"].ptr, n, p["m"], p["ev"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == 0 and out.raw == p["wit_m"], ("witness_eval", t, r, rc)
+            rc = lib.kzg_witness_coeff(ctx, params.gs.handle, p["buf"].ptr, n, b32(p["x"]), b32(p["y"] + 1), p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == L.KZG_ERR_POINT_NOT_ON_POLY, ("wrong y", t, r, rc)
+            assert b"point not on polynomial" in lib.kzg_last_error(ctx)   # the calling thread's own failure
+            if t % 5 == 0:   # an exclusive call in the middle of the others' leases (host-resident data: nothing shared)
+                xs = [t, r, 3, 4]
+                assert engine.ntt(xs, 2) == C.fft(xs)
+            # host-resident coefficients (staged on the leased lane)
+            if r == 0 and n <= 1 << 12:
+                rc = lib.kzg_commit_coeff(ctx, params.gs.handle, p["buf"].download(), n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT)
+                assert rc == 0 and out.raw == p["commit"]
+
+    try:
+        _run_threads(threads, work)
+    finally:
+        engine.set_option("streams", 8)
+        for p in polys:
+            p["buf"].free()
+            p["ev"].free()
+        params.gs.free()
+        lag.free()
+
+
+def test_concurrent_2_20_sixteen_threads(engine):
+    """16 host threads, degree 2^20 (BASELINE configs[1]'s size), mixed commit / create_witness on one context and one resident
+    SRS; expected values from the oracle (downloaded coefficients, Horner, one scalar multiplication each)."""
+    n, threads = 1 << 20, 16
+    engine.set_option("streams", 16)
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    G = C.g1_generator()
+    polys = []
+    for t in range(threads):
+        buf = engine.alloc_scalars(n).fill_random(7000 + t, u64_valued=(t % 4 == 3))
+        raw = buf.download()
+        ptau = C.poly_eval_bytes(raw, n, TAU)
+        x = kzg_amd.splitmix_scalar(47, t)
+        y = C.poly_eval_bytes(raw, n, x)
+        polys.append(dict(buf=buf, commit=C.g1_mul(G, ptau), x=x, y=y, wit=C.g1_mul(G, (ptau - y) * pow(TAU - x, -1, R) % R)))
+        del raw
+
+    def work(t):
+        p = polys[t]
+        lib, ctx = engine.lib, engine.ctx
+        out = ctypes.create_string_buffer(96)
+        for r in range(4):
+            if (t + r) % 2 == 0:
+                rc = lib.kzg_commit_coeff(ctx, params.gs.handle, p["buf"].ptr, n, p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+                assert rc == 0 and out.raw == p["commit"], ("commit", t, r, rc)
+            else:
+                rc = lib.kzg_witness_coeff(ctx, params.gs.handle, p["buf"].ptr, n, b32(p["x"]), b32(p["y"]), p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+                assert rc == 0 and out.raw == p["wit"], ("witness", t, r, rc)
+
+    try:
+        _run_threads(threads, work)
+        # and the same SRS from a second context on the same device (an SRS is not bound to the context that built it),
+        # both contexts busy at once
+        e2 = kzg_amd.Engine(0)
+
+        def work2(t):
+            eng = engine if t % 2 == 0 else e2
+            out = ctypes.create_string_buffer(96)
+            p = polys[t]
+            for _ in range(2):
+                rc = eng.lib.kzg_commit_coeff(eng.ctx, params.gs.handle, p["buf"].ptr, n, p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+                assert rc == 0 and out.raw == p["commit"], ("two contexts", t, rc)
+
+        _run_threads(8, work2)
+        e2.close()
+    finally:
+        engine.set_option("streams", 8)
+        for p in polys:
+            p["buf"].free()
+        params.gs.free()

@@ -1,7 +1,10 @@
 """Parity at BASELINE.json's full sizes through size-independent properties (known-tau identities, eval-form ==
 coeff-form, linearity, round trips), plus adversarial scalar distributions that force the deep paths of the MSM
-(multi-level bucket folding, single-bucket inputs, every window size).  The oracle only supplies one scalar
-multiplication per check."""
+(multi-level bucket folding, single-bucket inputs, every window size).
+
+Every expected value comes from the ORACLE: the coefficient bytes are downloaded and p(tau), p(x), I(tau) are computed by
+oracle/kzg_oracle.c's Horner loop (`oeval`, ~0.1 s per 2^20 evaluation), then one oracle scalar multiplication.  No right-hand
+side below touches a HIP kernel; the engine's own kzg_poly_eval is checked as a value under test (test_poly_eval_2_20)."""
 import ctypes
 import random
 
@@ -28,6 +31,26 @@ def big(engine):
     lag.free()
 
 
+_dl_cache = {}
+
+
+def oeval(p, x):
+    """p(x) by the oracle.  p: a DeviceBuffer (downloaded once, cached by address) or a list of ints."""
+    if isinstance(p, kzg_amd.DeviceBuffer):
+        key = (p.ptr.value, p.n)
+        if key not in _dl_cache:
+            if len(_dl_cache) > 4:
+                _dl_cache.clear()
+            _dl_cache[key] = p.download()
+        return C.poly_eval_bytes(_dl_cache[key], p.n, x)
+    return C.poly_eval(p, x)
+
+
+def _fresh(buf):
+    """forget a cached download (the buffer was rewritten or freed)"""
+    _dl_cache.pop((buf.ptr.value, buf.n), None)
+
+
 def _msm_dev(engine, srs, buf, n, offset=0):
     out = ctypes.create_string_buffer(96)
     rc = engine.lib.kzg_msm_g1(engine.ctx, srs.handle, offset, buf.ptr, n, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
@@ -41,8 +64,18 @@ def test_config2_commit_2_20(engine, big):
     for seed, u64 in ((11, False), (12, True)):
         buf = engine.alloc_scalars(n).fill_random(seed, u64_valued=u64)
         got = _msm_dev(engine, params.gs, buf, n)
-        assert got == C.g1_mul(C.g1_generator(), engine.poly_eval(buf, TAU))
-        buf.free()
+        assert got == C.g1_mul(C.g1_generator(), oeval(buf, TAU))
+        _fresh(buf); buf.free()
+
+
+def test_poly_eval_2_20(engine, big):
+    """kzg_poly_eval (the Horner-scan kernels) as a value under test: equal to the oracle's evaluation at 2^20."""
+    n, _, _ = big
+    buf = engine.alloc_scalars(n).fill_random(15)
+    for x in (TAU, 0, 1, R - 1, kzg_amd.splitmix_scalar(3, 3)):
+        assert engine.poly_eval(buf, x) == oeval(buf, x)
+    _fresh(buf)
+    _fresh(buf); buf.free()
 
 
 def test_sort_variants_and_batch_tail_agree_2_20(engine, big):
@@ -56,7 +89,7 @@ def test_sort_variants_and_batch_tail_agree_2_20(engine, big):
     eq = engine.alloc_scalars(n)
     eq.upload(M.fr_to_le(0x1234567890ABCDEF1122334455667788990011223344556677889900AABBCCDD % R) * n)
     bufs.append(eq)
-    want = [C.g1_mul(G, engine.poly_eval(b, TAU)) for b in bufs]
+    want = [C.g1_mul(G, oeval(b, TAU)) for b in bufs]
     try:
         for single_pass in (0, 1):
             engine.set_option("sort_single_pass", single_pass)
@@ -83,7 +116,7 @@ def test_sort_variants_and_batch_tail_agree_2_20(engine, big):
         engine.set_option("tail_quads", 1)
         engine.set_option("streams", 8)
     for b in bufs:
-        b.free()
+        _fresh(b); b.free()
 
 
 def test_config3_eval_form_equals_coeff_form_2_20(engine, big):
@@ -93,6 +126,7 @@ def test_config3_eval_form_equals_coeff_form_2_20(engine, big):
     orig = buf.download()
     c1 = _msm_dev(engine, params.gs, buf, n)
     engine.ntt(buf, 20)
+    _fresh(buf)
     c2 = _msm_dev(engine, lag, buf, n)
     assert c1 == c2
     ok = ctypes.c_int()
@@ -100,16 +134,16 @@ def test_config3_eval_form_equals_coeff_form_2_20(engine, big):
     assert rc == 0 and ok.value == 1
     engine.ntt(buf, 20, inverse=True)
     assert buf.download() == orig
-    buf.free()
+    _fresh(buf); buf.free()
 
 
 def test_config4_witnesses_2_20(engine, big):
     """configs[3]: create_witness (single opening) and create_witness_batched (k = 256) at degree 2^20."""
     n, params, lag = big
     buf = engine.alloc_scalars(n).fill_random(14)
-    ptau = engine.poly_eval(buf, TAU)
+    ptau = oeval(buf, TAU)
     x = kzg_amd.splitmix_scalar(99, 0)
-    y = engine.poly_eval(buf, x)
+    y = oeval(buf, x)
     out = ctypes.create_string_buffer(96)
     b32 = lambda v: (v % R).to_bytes(32, "little")  # noqa: E731
     rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(x), b32(y), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
@@ -118,27 +152,28 @@ def test_config4_witnesses_2_20(engine, big):
     assert rc == L.KZG_ERR_POINT_NOT_ON_POLY
     k = 256
     xs = [kzg_amd.splitmix_scalar(7, i) for i in range(k)]
-    ys = [engine.poly_eval(buf, v) for v in xs]
+    ys = [oeval(buf, v) for v in xs]
     rbuf, rlen = ctypes.create_string_buffer(32 * k), ctypes.c_size_t()
     rc = engine.lib.kzg_witness_coeff_batched(engine.ctx, params.gs.handle, buf.ptr, n, kzg_amd.pack_scalars(xs), kzg_amd.pack_scalars(ys),
                                               k, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
     assert rc == 0 and rlen.value == k
     I = kzg_amd.unpack_scalars(rbuf.raw)
-    assert all(engine.poly_eval(I, xs[i]) == ys[i] for i in (0, 17, 255))
+    assert all(oeval(I, xs[i]) == ys[i] for i in (0, 17, 255))
     Z = 1
     for v in xs:
         Z = Z * (TAU - v) % R
-    assert out.raw == C.g1_mul(C.g1_generator(), (ptau - engine.poly_eval(I, TAU)) * pow(Z, -1, R) % R)
+    assert out.raw == C.g1_mul(C.g1_generator(), (ptau - oeval(I, TAU)) * pow(Z, -1, R) % R)
     # eval-form witness at index m == coeff-form witness at w^m
     m = 54321
     xm = pow(kzg_amd.compute_omega(n)[2], m, R)
-    ym = engine.poly_eval(buf, xm)
+    ym = oeval(buf, xm)
     rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(xm), b32(ym), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
     w_coeff = out.raw
     engine.ntt(buf, 20)
+    _fresh(buf)
     rc2 = engine.lib.kzg_witness_eval(engine.ctx, lag.handle, buf.ptr, n, m, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
     assert rc == 0 and rc2 == 0 and out.raw == w_coeff
-    buf.free()
+    _fresh(buf); buf.free()
 
 
 def test_msm_linearity_and_offsets_2_20(engine, big):
@@ -148,7 +183,7 @@ def test_msm_linearity_and_offsets_2_20(engine, big):
     b = engine.alloc_scalars(n).fill_random(22)
     ca, cb = _msm_dev(engine, params.gs, a, n), _msm_dev(engine, params.gs, b, n)
     # a + b evaluated through the known-tau identity: p_a(tau) + p_b(tau)
-    s = (engine.poly_eval(a, TAU) + engine.poly_eval(b, TAU)) % R
+    s = (oeval(a, TAU) + oeval(b, TAU)) % R
     assert engine.g1_sum([ca, cb]) == C.g1_mul(C.g1_generator(), s)
     h = 333_333
     lo = _msm_dev(engine, params.gs, a, h)
@@ -156,7 +191,7 @@ def test_msm_linearity_and_offsets_2_20(engine, big):
     hi_buf.engine, hi_buf.n, hi_buf.sfmt, hi_buf.ptr = engine, n - h, a.sfmt, ctypes.c_void_p(a.ptr.value + 32 * h)
     hi = _msm_dev(engine, params.gs, hi_buf, n - h, offset=h)
     assert engine.g1_sum([lo, hi]) == ca
-    a.free(); b.free()
+    _fresh(a); _fresh(b); a.free(); b.free()
 
 
 @pytest.mark.parametrize("case", ["all_equal", "two_values", "zeros_and_ones", "single_window", "max_digits"])
@@ -295,7 +330,7 @@ def test_config5_2_24_sharded_8_ways_and_whole(engine):
         rc = engine.lib.kzg_msm_g1(engine.ctx, shard.handle, 0, view.ptr, hi - lo, buf.sfmt, L.IN_DEVICE, out, L.G1_JACOBIAN_MONT)
         assert rc == 0, engine.last_error()
         parts.append(out.raw)
-        ptau = (ptau + pow(TAU, lo, R) * engine.poly_eval(view, TAU)) % R
+        ptau = (ptau + pow(TAU, lo, R) * oeval(view, TAU)) % R
         shard.free()
     want = C.g1_mul(C.g1_generator(), ptau)
     out = ctypes.create_string_buffer(96)
@@ -306,7 +341,7 @@ def test_config5_2_24_sharded_8_ways_and_whole(engine):
     assert params.gs.window_info() == (17, 15)
     assert _msm_dev(engine, params.gs, buf, n) == want
     params.gs.free()
-    buf.free()
+    _fresh(buf); buf.free()
 
 
 def test_compute_lagrange_basis_2_20_without_tau(engine, big):
@@ -322,7 +357,7 @@ def test_compute_lagrange_basis_2_20_without_tau(engine, big):
     c1 = _msm_dev(engine, params.gs, buf, n)
     engine.ntt(buf, 20)
     assert _msm_dev(engine, got, buf, n) == c1
-    buf.free()
+    _fresh(buf); buf.free()
     got.free()
 
 
@@ -332,9 +367,9 @@ def test_config4_secondary_witness_many_2_20_k256(engine, big):
     n, params, _ = big
     k = 256
     buf = engine.alloc_scalars(n).fill_random(41)
-    ptau = engine.poly_eval(buf, TAU)
+    ptau = oeval(buf, TAU)
     xs = [kzg_amd.splitmix_scalar(4242, i) for i in range(k)]
-    ys = [engine.poly_eval(buf, x) for x in xs]
+    ys = [oeval(buf, x) for x in xs]
     ys[100] = (ys[100] + 1) % R
     prover = kzg_amd.KZGProver(params)
     ws, ok = prover.create_witness_many(None, list(zip(xs, ys)), coeffs_device=buf)
@@ -343,4 +378,4 @@ def test_config4_secondary_witness_many_2_20_k256(engine, big):
     for j in range(k):
         yj = ys[j] if j != 100 else (ys[j] - 1) % R
         assert ws[j] == C.g1_mul(G, (ptau - yj) * pow(TAU - xs[j], -1, R) % R), j
-    buf.free()
+    _fresh(buf); buf.free()

@@ -102,3 +102,47 @@ def test_golden_verify(engine):
     assert verifier.verify_eval_batched([GU.sc(h) for h in b["xs_bad"]], c, wit, pfmt=L.G1_ZCASH_COMPRESSED) == b["ok_bad"]
     for h in (params.gs, params.hs, up, lag_h):
         h.free()
+
+
+@pytest.mark.parametrize("case", GU.load("prod.json")["commits"], ids=lambda c: f"2^{c['log_n']}_seed{c['seed']}")
+def test_golden_production_path_commit(engine, case):
+    """tests/golden/prod.json: commitments at the sizes where the production MSM path runs (17-bit windows, two-level sort, 15
+    table rows), computed by oracle/kzg_model.py alone (coefficient stream, Horner, one scalar multiplication).  Nothing on the
+    right-hand side comes from this process: 48 committed bytes per case."""
+    tau = GU.sc(GU.load("prod.json")["tau"])
+    n = 1 << case["log_n"]
+    params = kzg_amd.setup(engine, tau, n, g2_len=0)
+    assert params.gs.window_info() == (17, 15)
+    buf = engine.alloc_scalars(n).fill_random(case["seed"], u64_valued=case["u64_valued"])
+    import ctypes
+    out = ctypes.create_string_buffer(48)
+    rc = engine.lib.kzg_commit_coeff(engine.ctx, params.gs.handle, buf.ptr, n, buf.sfmt, L.IN_DEVICE, out, L.G1_ZCASH_COMPRESSED)
+    assert rc == 0, engine.last_error()
+    assert out.raw.hex() == case["commit"]
+    # the batched pipeline (the path bench.py times) on the same polynomial, three copies
+    out3 = ctypes.create_string_buffer(48 * 3)
+    rep = engine.alloc_scalars(3 * n)
+    blob = buf.download()
+    rep.upload(blob * 3)
+    rc = engine.lib.kzg_msm_g1_batch(engine.ctx, params.gs.handle, 0, rep.ptr, n, 3, rep.sfmt, L.IN_DEVICE, out3, L.G1_ZCASH_COMPRESSED)
+    assert rc == 0, engine.last_error()
+    assert [out3.raw[48 * j:48 * j + 48].hex() for j in range(3)] == [case["commit"]] * 3
+    rep.free()
+    buf.free()
+    params.gs.free()
+
+
+def test_golden_production_path_witness(engine):
+    g = GU.load("prod.json")
+    tau, w = GU.sc(g["tau"]), g["witness"]
+    n = 1 << w["log_n"]
+    params = kzg_amd.setup(engine, tau, n, g2_len=0)
+    buf = engine.alloc_scalars(n).fill_random(w["seed"])
+    import ctypes
+    out = ctypes.create_string_buffer(48)
+    rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, bytes.fromhex(w["x"]), bytes.fromhex(w["y"]), buf.sfmt,
+                                      L.IN_DEVICE, out, L.G1_ZCASH_COMPRESSED)
+    assert rc == 0, engine.last_error()
+    assert out.raw.hex() == w["witness"]
+    buf.free()
+    params.gs.free()

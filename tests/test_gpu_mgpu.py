@@ -12,7 +12,7 @@ from kzg_amd import _lib as L
 from kzg_amd.distributed import shard_range
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-from tests.gpu_common import engine, rand_scalars  # noqa: F401
+from tests.gpu_common import engine, hooks_engine, rand_scalars  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 
@@ -127,3 +127,150 @@ def test_group_rejects_bad_arguments():
     assert lib.kzg_mctx_create_rank(0, 3, 2, None, ctypes.byref(h)) == L.KZG_ERR_SHAPE
     arr = (ctypes.c_int * 1)(99)
     assert lib.kzg_mctx_create(arr, 1, ctypes.byref(h)) == L.KZG_ERR_NO_DEVICE
+    # a later device fails after an earlier context exists: the half-built group is torn down cleanly
+    arr = (ctypes.c_int * 2)(0, 99)
+    assert lib.kzg_mctx_create(arr, 2, ctypes.byref(h)) == L.KZG_ERR_NO_DEVICE
+
+
+def test_group_info_names_the_adopted_rccl(group):
+    info = group.info()
+    assert "rccl=" in info and "librccl" in info and "hip=" in info and "version=" in info
+    assert f"world={group.world}" in info
+
+
+def test_group_device_resident_witness_and_batched(engine, group):
+    """kzg_witness_coeff_sharded with the polynomial resident on every local GPU, and create_witness_batched over the group
+    (replicated interpolant + quotient, sharded MSM): equal to the single-GPU calls and to the known-tau identities."""
+    group.set_option("always_gather", 1)
+    rng = random.Random(15)
+    n = 5000
+    srs = group.setup(TAU, n)
+    coeffs = rand_scalars(rng, n)
+    ptau = C.poly_eval(coeffs, TAU)
+    G = C.g1_generator()
+    x = rng.randrange(M.R)
+    y = C.poly_eval(coeffs, x)
+    want_w = C.g1_mul(G, (ptau - y) * M.fr_inv(TAU - x) % M.R)
+    bufs = []
+    for i in range(group.local_count):
+        b = group.engine(i).alloc_scalars(n)
+        b.upload(kzg_amd.pack_scalars(coeffs))
+        bufs.append(b)
+    assert group.create_witness(srs, bufs, (x, y)) == want_w
+    assert group.create_witness(srs, coeffs, (x, y)) == want_w
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        group.create_witness(srs, bufs, (x, (y + 1) % M.R))
+    for k in (1, 2, 7, 64):
+        xs = [rng.randrange(M.R) for _ in range(k)]
+        ys = [C.poly_eval(coeffs, v) for v in xs]
+        single = kzg_amd.KZGProver(kzg_amd.setup(engine, TAU, n, g2_len=0))
+        w1 = single.create_witness_batched(kzg_amd.Polynomial(coeffs), xs, ys)
+        for arg in (coeffs, bufs):
+            w, r = group.create_witness_batched(srs, arg, list(zip(xs, ys)))
+            assert w == w1.elem() and r == w1.polynomial().coeffs, k
+        if k >= 2:
+            Z = 1
+            for v in xs:
+                Z = Z * (TAU - v) % M.R
+            assert w == C.g1_mul(G, (ptau - C.poly_eval(r, TAU)) * M.fr_inv(Z) % M.R), k
+        single.parameters.gs.free()
+    ys_bad = list(ys)
+    ys_bad[3] = (ys_bad[3] + 1) % M.R
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        group.create_witness_batched(srs, bufs, list(zip(xs, ys_bad)))
+    with pytest.raises(kzg_amd.ReferencePanic):           # duplicate opening points: invert().unwrap()
+        group.create_witness_batched(srs, coeffs, [(xs[0], ys[0]), (xs[0], ys[0]), (xs[1], ys[1])])
+    for b in bufs:
+        b.free()
+    srs.free()
+    group.set_option("always_gather", 0)
+
+
+def _hooks_group(hooks, per_process):
+    """a device group inside the -DKZG_TEST_HOOKS build of the library"""
+    lib = hooks.lib
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.kzg_mctx_create.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    lib.kzg_mctx_create_rank.argtypes = [i32, i32, i32, vp, ctypes.POINTER(vp)]
+    lib.kzg_mctx_unique_id.argtypes = [vp]
+    lib.kzg_mctx_destroy.argtypes = [vp]
+    lib.kzg_mctx_destroy.restype = None
+    lib.kzg_mctx_set_option.argtypes = [vp, ctypes.c_char_p, ctypes.c_int64]
+    lib.kzg_mctx_last_error.argtypes = [vp]
+    lib.kzg_mctx_last_error.restype = ctypes.c_char_p
+    lib.kzg_srs_setup_g1_sharded.argtypes = [vp, vp, i32, sz, ctypes.POINTER(vp)]
+    lib.kzg_msrs_free.argtypes = [vp, vp]
+    lib.kzg_msrs_free.restype = None
+    lib.kzg_commit_coeff_sharded.argtypes = [vp, vp, vp, sz, i32, i32, vp, i32]
+    h = vp()
+    if per_process:
+        uid = ctypes.create_string_buffer(128)
+        assert lib.kzg_mctx_unique_id(uid) == 0
+        assert lib.kzg_mctx_create_rank(0, 0, 1, uid, ctypes.byref(h)) == 0
+    else:
+        arr = (i32 * 1)(0)
+        assert lib.kzg_mctx_create(arr, 1, ctypes.byref(h)) == 0
+    return h
+
+
+@pytest.mark.parametrize("per_process", [False, True])
+def test_local_failure_is_agreed_on_not_hung(hooks_engine, per_process):
+    """A rank whose local phase fails still enters the exchange (per-process mode) and every rank returns its error; the group
+    stays usable.  World of one with the all-gather forced on: the failure travels through ncclAllGather in the status slot."""
+    lib = hooks_engine.lib
+    h = _hooks_group(hooks_engine, per_process)
+    assert lib.kzg_mctx_set_option(h, b"always_gather", 1) == 0
+    n = 500
+    srs = ctypes.c_void_p()
+    assert lib.kzg_srs_setup_g1_sharded(h, (TAU % M.R).to_bytes(32, "little"), L.FR_CANONICAL, n, ctypes.byref(srs)) == 0
+    rng = random.Random(16)
+    coeffs = rand_scalars(rng, n)
+    blob = kzg_amd.pack_scalars(coeffs)
+    out = ctypes.create_string_buffer(96)
+    want = C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU))
+    assert lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw == want
+    assert lib.kzg_test_mctx_inject_failure(h, L.KZG_ERR_ALLOC) == 0
+    rc = lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT)
+    assert rc == L.KZG_ERR_ALLOC
+    assert b"injected local failure" in lib.kzg_mctx_last_error(h)
+    # the next call is unaffected
+    assert lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw == want
+    lib.kzg_msrs_free(h, srs)
+    lib.kzg_mctx_destroy(h)
+
+
+def test_rccl_load_failure_is_an_error_not_a_crash():
+    """ADVICE r2: dlerror() read twice -> std::string(nullptr).  With RCCL unloadable (forced in a child process, hooks build)
+    kzg_mctx_unique_id and a forced all-gather return the 'cannot load RCCL' error."""
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import ctypes, os, sys
+sys.path.insert(0, %r)
+import kzg_amd
+kzg_amd.load()
+lib = ctypes.CDLL(os.path.join(os.path.dirname(kzg_amd.__file__), "libkzg_mi355x_hooks.so"))
+buf = ctypes.create_string_buffer(128)
+rc = lib.kzg_mctx_unique_id(buf)
+assert rc == -4, rc
+h = ctypes.c_void_p()
+arr = (ctypes.c_int * 1)(0)
+assert lib.kzg_mctx_create(arr, 1, ctypes.byref(h)) == 0
+lib.kzg_mctx_set_option.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int64]
+assert lib.kzg_mctx_set_option(h, b"always_gather", 1) == 0
+srs = ctypes.c_void_p()
+lib.kzg_srs_setup_g1_sharded.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+assert lib.kzg_srs_setup_g1_sharded(h, (5).to_bytes(32, "little"), 1, 8, ctypes.byref(srs)) == 0
+out = ctypes.create_string_buffer(96)
+lib.kzg_commit_coeff_sharded.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+rc = lib.kzg_commit_coeff_sharded(h, srs, (1).to_bytes(32, "little") * 8, 8, 1, 0, out, 0)
+lib.kzg_mctx_last_error.restype = ctypes.c_char_p
+lib.kzg_mctx_last_error.argtypes = [ctypes.c_void_p]
+msg = lib.kzg_mctx_last_error(h)
+assert rc == -4 and b"cannot load RCCL" in msg, (rc, msg)
+print("ok")
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, KZG_TEST_NO_RCCL="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr

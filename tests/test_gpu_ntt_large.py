@@ -1,0 +1,119 @@
+"""NTT parity above 2^14 (src/ft.rs:111-178): bit-exact against the C oracle's serial_fft restatement at EVERY size 2^15..2^22
+and at 2^24 -- forward, inverse, and the coset transforms -- so that the four-step kernels' inter-pass twiddle table (n <= 2^21)
+and the two-level twiddle branch taken for log_n > 21 (ntt.hip) are both compared element for element, plus direct evaluations
+p(w^i) by the oracle's Horner loop as a check that does not go through any FFT."""
+import ctypes
+
+import pytest
+
+import kzg_amd
+from kzg_amd import _lib as L
+from oracle import c_oracle as C
+from oracle import kzg_model as M
+from tests.gpu_common import engine  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+R = M.R
+
+
+def _coset_scale(blob, n, g):
+    """distribute_powers (src/ft.rs:142-160 as used by coset_fft): element i times g^i, on canonical LE bytes"""
+    out, pw = bytearray(len(blob)), 1
+    for i in range(n):
+        out[32 * i:32 * i + 32] = (int.from_bytes(blob[32 * i:32 * i + 32], "little") * pw % R).to_bytes(32, "little")
+        pw = pw * g % R
+    return bytes(out)
+
+
+@pytest.mark.parametrize("log_n", [15, 16, 17, 18, 19, 20, 21, 22])
+def test_ntt_bit_exact_vs_oracle(engine, log_n):
+    n = 1 << log_n
+    buf = engine.alloc_scalars(n).fill_random(500 + log_n)
+    a0 = buf.download()
+    want = C.fft_bytes(a0, log_n)
+    engine.ntt(buf, log_n)
+    assert buf.download() == want                      # EvaluationDomain::fft
+    engine.ntt(buf, log_n, inverse=True)
+    assert buf.download() == a0                        # fft_composition (src/ft.rs:447-479)
+    engine.ntt(buf, log_n, inverse=True)
+    assert buf.download() == C.fft_bytes(a0, log_n, inverse=True)   # EvaluationDomain::ifft on its own
+    # two direct evaluations by the oracle's Horner loop: element i of the transform is p(w^i)
+    _, _, omega = kzg_amd.compute_omega(n)
+    for i in (1, n - 3):
+        assert int.from_bytes(want[32 * i:32 * i + 32], "little") == C.poly_eval_bytes(a0, n, pow(omega, i, R))
+    buf.free()
+
+
+@pytest.mark.parametrize("log_n", [15, 18, 20, 22])
+def test_coset_ntt_bit_exact_vs_oracle(engine, log_n):
+    """coset_fft = distribute_powers(7) then fft; icoset_fft = ifft then distribute_powers(7^-1) (src/ft.rs:142-178)."""
+    n = 1 << log_n
+    buf = engine.alloc_scalars(n).fill_random(600 + log_n)
+    a0 = buf.download()
+    rc = engine.lib.kzg_coset_ntt_fr(engine.ctx, buf.ptr, log_n, 0, buf.sfmt, L.IN_DEVICE)
+    assert rc == 0, engine.last_error()
+    assert buf.download() == C.fft_bytes(_coset_scale(a0, n, 7), log_n)
+    rc = engine.lib.kzg_coset_ntt_fr(engine.ctx, buf.ptr, log_n, 1, buf.sfmt, L.IN_DEVICE)
+    assert rc == 0 and buf.download() == a0
+    buf.upload(a0)
+    rc = engine.lib.kzg_coset_ntt_fr(engine.ctx, buf.ptr, log_n, 1, buf.sfmt, L.IN_DEVICE)
+    assert rc == 0 and buf.download() == _coset_scale(C.fft_bytes(a0, log_n, inverse=True), n, pow(7, -1, R))
+    buf.free()
+
+
+def test_ntt_2_24_bit_exact_and_sampled(engine):
+    """The largest size the ABI advertises: bit-exact against the oracle's FFT over all 2^24 outputs (about half a minute of CPU),
+    a dozen outputs also against direct Horner evaluation (no FFT involved), round trip, Montgomery-form input."""
+    log_n = 24
+    n = 1 << log_n
+    buf = engine.alloc_scalars(n).fill_random(2424)
+    a0 = buf.download()
+    engine.ntt(buf, log_n)
+    got = buf.download()
+    want = C.fft_bytes(a0, log_n)
+    assert got == want
+    _, _, omega = kzg_amd.compute_omega(n)
+    idx = [0, 1, 2, 4095, 4096, 4097, (1 << 12) * 4095 + 1, n // 2, n // 2 + 1, n - 1] + [kzg_amd.splitmix_scalar(9, j) % n for j in range(2)]
+    for i in idx:
+        assert int.from_bytes(got[32 * i:32 * i + 32], "little") == C.poly_eval_bytes(a0, n, pow(omega, i, R)), i
+    engine.ntt(buf, log_n, inverse=True)
+    assert buf.download() == a0
+    del got
+    # Montgomery-form data through the same kernels (linear map with Montgomery-form twiddles)
+    rc = engine.lib.kzg_fill_random_fr(engine.ctx, buf.ptr, n, 2424, 0, L.FR_MONT)
+    assert rc == 0
+    mbuf = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    mbuf.engine, mbuf.n, mbuf.sfmt, mbuf.ptr = engine, n, L.FR_MONT, buf.ptr
+    engine.ntt(mbuf, log_n)
+    head = mbuf.download(4)
+    rinv = pow(M.FR_MONT_R, -1, R)
+    for i in range(4):
+        assert int.from_bytes(head[32 * i:32 * i + 32], "little") * rinv % R == int.from_bytes(want[32 * i:32 * i + 32], "little")
+    buf.free()
+
+
+def test_verify_poly_eval_2_22(engine):
+    """KZGVerifierEvalForm::verify_poly (src/eval_form.rs:162-171) above 2^21: ifft of the evaluations (two-level twiddles) then
+    the monomial MSM equals the coefficient-form commitment; a perturbed evaluation is rejected."""
+    log_n = 22
+    n = 1 << log_n
+    tau = 0x5EED5EED5EED5EED
+    params = kzg_amd.setup(engine, tau, n, g2_len=0)
+    buf = engine.alloc_scalars(n).fill_random(2222)
+    a0 = buf.download()
+    out = ctypes.create_string_buffer(96)
+    rc = engine.lib.kzg_commit_coeff(engine.ctx, params.gs.handle, buf.ptr, n, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and out.raw == C.g1_mul(C.g1_generator(), C.poly_eval_bytes(a0, n, tau))
+    engine.ntt(buf, log_n)
+    ok = ctypes.c_int()
+    rc = engine.lib.kzg_verify_poly_eval(engine.ctx, params.gs.handle, out.raw, L.G1_AFFINE_MONT, buf.ptr, n, buf.sfmt, L.IN_DEVICE, ctypes.byref(ok))
+    assert rc == 0 and ok.value == 1
+    ev = bytearray(buf.download(1, offset=12345))
+    ev[0] ^= 1
+    v = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    v.engine, v.n, v.sfmt, v.ptr = engine, 1, buf.sfmt, ctypes.c_void_p(buf.ptr.value + 32 * 12345)
+    v.upload(bytes(ev))
+    rc = engine.lib.kzg_verify_poly_eval(engine.ctx, params.gs.handle, out.raw, L.G1_AFFINE_MONT, buf.ptr, n, buf.sfmt, L.IN_DEVICE, ctypes.byref(ok))
+    assert rc == 0 and ok.value == 0
+    buf.free()
+    params.gs.free()
