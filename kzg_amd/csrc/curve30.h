@@ -153,23 +153,23 @@ KZG_HD G1Xyzz30 g1_add30(const G1Xyzz30 &p, const G1Xyzz30 &q) {
 
 // acc += (negate ? -a : a), split in two so the caller can re-use the registers of `a` for the next
 // gather as soon as the two products that read it are done:
-//   phase 1: U2 = x2 * ZZ1, S2 = (+-y2) * ZZZ1              (the only uses of the affine point)
+//   phase 1: P = x2 * ZZ1 - X1, R = (+-y2) * ZZZ1 - Y1     (the only uses of the affine point; the subtractions are merged
+//            into the products' output columns, field30.h mul30_sub: both come out normalised)
 //   phase 2: everything else; `reload` re-fetches the affine point in the rare doubling case.
 struct Madd30Mid {
-    Fq30 U2, S2;
+    Fq30 P, R;
 };
 
 KZG_HD Madd30Mid g1_madd30_phase1(const G1Xyzz30 &p, const G1Affine30 &a, bool negate) {
     Madd30Mid m;
-    m.U2 = mul30(a.x, p.zz);
-    m.S2 = mul30(cneg30(a.y, negate), p.zzz);
+    m.P = mul30_sub(a.x, p.zz, p.x);
+    m.R = mul30_sub(cneg30(a.y, negate), p.zzz, p.y);
     return m;
 }
 
 template <class Reload>
 KZG_HD G1Xyzz30 g1_madd30_phase2(const G1Xyzz30 &p, const Madd30Mid &m, bool negate, Reload reload) {
-    Fq30 Pp = sub30(m.U2, p.x);
-    Fq30 R = sub30(m.S2, p.y);
+    const Fq30 &Pp = m.P, &R = m.R;
     Fq30 PP = sqr30(Pp);
     if (is_zero30(PP)) {
         // same x: either the same point (double it) or its inverse (infinity)
@@ -183,7 +183,7 @@ KZG_HD G1Xyzz30 g1_madd30_phase2(const G1Xyzz30 &p, const Madd30Mid &m, bool neg
     r.pad[0] = r.pad[1] = r.pad[2] = 0;
     r.zz = mul30(p.zz, PP);
     r.zzz = mul30(p.zzz, PPP);
-    r.x = sub30(sqr30(R), add2x30(PPP, Q));
+    r.x = sqr30_sub2(R, PPP, Q);  // X3 = R^2 - PPP - 2Q, one digit extraction
     // Y3 = R (Q - X3) + (-Y1) PPP: one double-width accumulation, one reduction
     r.y = muladd30(R, sub30(Q, r.x), neg30(p.y), PPP);
     return r;

@@ -84,6 +84,40 @@ KZG_HD Fq30 mul30_inline(const Fq30 &a, const Fq30 &b) {
     return r;
 }
 
+// a*b/R30 - c with the subtraction MERGED into the product: c's limb j enters output column 13 + j of the scan (one
+// multiply-add by the constant -1), so the difference comes out of the digit extraction already normalised -- no limb-wise
+// subtraction, no separate carry pass (13 multiply-adds instead of ~61 instructions).  |result| <= |a*b|/R30 + q/2 + |c|.
+// c: any limbs below 2^31 in magnitude.
+KZG_HD Fq30 mul30_sub_inline(const Fq30 &a, const Fq30 &b, const Fq30 &c) {
+    int32_t m[F30_N];
+    Fq30 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < F30_N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc = mac30(acc, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = mac30(acc, m[i], Fq30Consts::mod(k - i));
+        m[k] = sext30((uint32_t)acc * Fq30Consts::INV);
+        acc = mac30(acc, m[k], Fq30Consts::mod(0));
+        acc = sar30(acc);
+    }
+#pragma unroll
+    for (int k = F30_N; k < 2 * F30_N - 1; k++) {
+#pragma unroll
+        for (int i = k - F30_N + 1; i < F30_N; i++) {
+            acc = mac30(acc, a.v[i], b.v[k - i]);
+            acc = mac30(acc, m[i], Fq30Consts::mod(k - i));
+        }
+        acc = mac30(acc, c.v[k - F30_N], -1);
+        r.v[k - F30_N] = sext30((uint32_t)acc);
+        acc = sar30(acc + (uint64_t)F30_HALF);
+    }
+    acc = mac30(acc, c.v[F30_N - 1], -1);
+    r.v[F30_N - 1] = (int32_t)acc;
+    return r;
+}
+
 // (a*b + c*d)/R30 with ONE reduction.  A column of the fused scan holds up to 39 products of magnitude 2^58, which
 // would overflow the signed accumulator; in the five columns with more than 30 products the multiple of 2^30
 // accumulated so far is set aside before the c*d products go in and rejoins the carry afterwards.
@@ -165,6 +199,42 @@ KZG_HD Fq30 sqr30_inline(const Fq30 &a) {
     return r;
 }
 
+// a^2/R30 - c - 2e, both subtrahends merged into the square's output columns (X3 = R^2 - PPP - 2Q of the mixed addition).
+KZG_HD Fq30 sqr30_sub2_inline(const Fq30 &a, const Fq30 &c, const Fq30 &e) {
+    int32_t m[F30_N], d[F30_N];
+    Fq30 r;
+#pragma unroll
+    for (int i = 0; i < F30_N; i++) d[i] = a.v[i] * 2;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < F30_N; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc = mac30(acc, a.v[i], d[k - i]);
+        if ((k & 1) == 0) acc = mac30(acc, a.v[k / 2], a.v[k / 2]);
+#pragma unroll
+        for (int i = 0; i < k; i++) acc = mac30(acc, m[i], Fq30Consts::mod(k - i));
+        m[k] = sext30((uint32_t)acc * Fq30Consts::INV);
+        acc = mac30(acc, m[k], Fq30Consts::mod(0));
+        acc = sar30(acc);
+    }
+#pragma unroll
+    for (int k = F30_N; k < 2 * F30_N - 1; k++) {
+#pragma unroll
+        for (int i = k - F30_N + 1; 2 * i < k; i++) acc = mac30(acc, a.v[i], d[k - i]);
+        if ((k & 1) == 0) acc = mac30(acc, a.v[k / 2], a.v[k / 2]);
+#pragma unroll
+        for (int i = k - F30_N + 1; i < F30_N; i++) acc = mac30(acc, m[i], Fq30Consts::mod(k - i));
+        acc = mac30(acc, c.v[k - F30_N], -1);
+        acc = mac30(acc, e.v[k - F30_N], -2);
+        r.v[k - F30_N] = sext30((uint32_t)acc);
+        acc = sar30(acc + (uint64_t)F30_HALF);
+    }
+    acc = mac30(acc, c.v[F30_N - 1], -1);
+    acc = mac30(acc, e.v[F30_N - 1], -2);
+    r.v[F30_N - 1] = (int32_t)acc;
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__) && defined(KZG_OOL_MUL30)
 // Optional (-DKZG_OOL_MUL30): ONE out-of-line body per operation (operands travel in VGPR tuples; struct arguments
 // would go through scratch): a mixed addition is ~25 KB of code instead of ~80 KB.  Measured slower than inlining
@@ -230,6 +300,29 @@ KZG_HD Fq30 sqr30(const Fq30 &a) { return sqr30_asm(a); }
 KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) { return mul30_inline(a, b); }
 KZG_HD Fq30 sqr30(const Fq30 &a) { return sqr30_inline(a); }
 #endif
+
+// merged-subtraction forms: generated single-chain versions on the device (default build), the portable ones elsewhere.
+// -DKZG_NO_MERGED_SUB selects product + sub30 (the previous formulation; A/B builds).
+KZG_HD Fq30 sub30(const Fq30 &a, const Fq30 &b);
+KZG_HD Fq30 add2x30(const Fq30 &a, const Fq30 &b);
+KZG_HD Fq30 mul30_sub(const Fq30 &a, const Fq30 &b, const Fq30 &c) {
+#if defined(KZG_NO_MERGED_SUB)
+    return sub30(mul30(a, b), c);
+#elif defined(KZG_HAVE_MULADD30_ASM)
+    return mul30_sub_asm(a, b, c);
+#else
+    return mul30_sub_inline(a, b, c);
+#endif
+}
+KZG_HD Fq30 sqr30_sub2(const Fq30 &a, const Fq30 &c, const Fq30 &e) {
+#if defined(KZG_NO_MERGED_SUB)
+    return sub30(sqr30(a), add2x30(c, e));
+#elif defined(KZG_HAVE_MULADD30_ASM)
+    return sqr30_sub2_asm(a, c, e);
+#else
+    return sqr30_sub2_inline(a, c, e);
+#endif
+}
 
 KZG_HD Fq30 muladd30(const Fq30 &a, const Fq30 &b, const Fq30 &c, const Fq30 &d) {
 #if defined(KZG_HAVE_MULADD30_ASM)

@@ -48,6 +48,10 @@ void hm_sqr30_raw(const int32_t *a, int32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq
 void hm_muladd30_raw(const int32_t *a, const int32_t *b, const int32_t *c, const int32_t *d, int32_t *o) {
     Fq30 x, y, u, w; memcpy(x.v, a, 52); memcpy(y.v, b, 52); memcpy(u.v, c, 52); memcpy(w.v, d, 52);
     Fq30 z = muladd30_inline(x, y, u, w); memcpy(o, z.v, 52); }
+void hm_mul30_sub_raw(const int32_t *a, const int32_t *b, const int32_t *c, int32_t *o) { Fq30 x, y, u; memcpy(x.v, a, 52); memcpy(y.v, b, 52);
+    memcpy(u.v, c, 52); Fq30 z = mul30_sub(x, y, u); memcpy(o, z.v, 52); }
+void hm_sqr30_sub2_raw(const int32_t *a, const int32_t *c, const int32_t *e, int32_t *o) { Fq30 x, u, w; memcpy(x.v, a, 52); memcpy(u.v, c, 52);
+    memcpy(w.v, e, 52); Fq30 z = sqr30_sub2(x, u, w); memcpy(o, z.v, 52); }
 void hm_normalize30_raw(const int32_t *a, int32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq30 z = normalize30(x); memcpy(o, z.v, 52); }
 void hm_from30_raw(const int32_t *a, uint32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq z = from30(x); memcpy(o, z.v, 48); }
 // chain of n mixed additions in the 30-bit representation: acc = first; acc += pts[i] (sign bit i of `signs`)

@@ -229,6 +229,20 @@ def test_fq30_raw_limb_bounds(L):
         if ka != "neg_of_min":                 # sqr30 doubles its operand: needs the normalised range
             a = limbs(ka)
             check(out(L.hm_sqr30_raw, a), val(a) ** 2, 0.5001 + val(a) ** 2 / M.Q / M.Q * qr)
+    # merged subtractions (mul30_sub, sqr30_sub2): exact a*b/R - c and a^2/R - c - 2e as integers mod q, normalised output
+    for ka in kinds:
+        for kb in kinds:
+            a, c, u = limbs(ka), limbs(kb), limbs(kb if ka == "rnd" else ka)
+            r = out(L.hm_mul30_sub_raw, a, c, u)
+            assert all(-H <= v < H for v in r[:12]), r
+            assert ((val(r) + val(u)) * R30 - val(a) * val(c)) % M.Q == 0
+            assert abs(val(r)) <= abs(val(a) * val(c)) // R30 + M.Q // 2 + abs(val(u)) + 2
+            if ka != "neg_of_min":
+                e = limbs(kb)
+                r = out(L.hm_sqr30_sub2_raw, a, u, e)
+                assert all(-H <= v < H for v in r[:12]), r
+                assert ((val(r) + val(u) + 2 * val(e)) * R30 - val(a) ** 2) % M.Q == 0
+                assert abs(val(r)) <= val(a) ** 2 // R30 + M.Q // 2 + abs(val(u)) + 2 * abs(val(e)) + 2
     # same-sign worst case for every column at once
     a = [H] * 12 + [1 << 20]
     check(out(L.hm_muladd30_raw, a, a, a, a), 2 * val(a) ** 2, 0.5001 + 2 * val(a) ** 2 / M.Q / M.Q * qr)

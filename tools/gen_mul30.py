@@ -23,7 +23,9 @@ def block(products, mnem="v_mad_i64_i32"):
         ops.append((cons, expr))
         return len(ops)
     for (x, xc, y, yc) in products:
-        lines.append(f"{mnem} %0, vcc, %{ref(xc, x)}, %{ref(yc, y)}, %0")
+        xtxt = f"%{ref(xc, x)}"
+        ytxt = y if yc == "i" else f"%{ref(yc, y)}"       # "i": an inline constant written into the instruction
+        lines.append(f"{mnem} %0, vcc, {xtxt}, {ytxt}, %0")
     assert len(ops) + 1 <= MAX_OPS, len(ops)
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({e})' for c, e in ops)
@@ -34,7 +36,7 @@ def emit_products(products, mnem="v_mad_i64_i32"):
     """split a column's product list into blocks that respect the operand limit"""
     out, cur, names = "", [], set()
     for p in products:
-        new = {(p[1], p[0]), (p[3], p[2])}
+        new = {(p[1], p[0])} | ({(p[3], p[2])} if p[3] != "i" else set())
         if len(names | new) + 1 > MAX_OPS:
             out += block(cur, mnem)
             cur, names = [], set()
@@ -49,8 +51,12 @@ def q(j):
     return f"Fq30Consts::mod({j})"
 
 
-def gen_mul():
-    s = "__device__ __forceinline__ Fq30 mul30_asm(const Fq30 &a, const Fq30 &b) {\n    int32_t m[F30_N];\n    Fq30 r;\n    uint64_t acc = 0;\n"
+def gen_mul(name="mul30_asm", subs=()):
+    """subs: ((operand, constant), ...): the result is a*b/R + sum constant * operand, the extra terms entering the output
+    columns as one v_mad_i64_i32 by an inline constant each (a subtraction merged into the product: no separate limb-wise
+    subtraction and carry pass, and the result comes out normalised)."""
+    args = "".join(f", const Fq30 &{o}" for o, _ in subs)
+    s = f"__device__ __forceinline__ Fq30 {name}(const Fq30 &a, const Fq30 &b{args}) {{\n    int32_t m[F30_N];\n    Fq30 r;\n    uint64_t acc = 0;\n"
     for k in range(N):
         prods = [(f"a.v[{i}]", "v", f"b.v[{k - i}]", "v") for i in range(k + 1)]
         prods += [(f"m[{i}]", "v", q(k - i), "s") for i in range(k)]
@@ -61,14 +67,18 @@ def gen_mul():
         for i in range(k - N + 1, N):
             prods.append((f"a.v[{i}]", "v", f"b.v[{k - i}]", "v"))
             prods.append((f"m[{i}]", "v", q(k - i), "s"))
+        prods += [(f"{o}.v[{k - N}]", "v", str(c), "i") for o, c in subs]
         s += emit_products(prods)
         s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+    if subs:
+        s += emit_products([(f"{o}.v[{N - 1}]", "v", str(c), "i") for o, c in subs])
     s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
     return s
 
 
-def gen_sqr():
-    s = ("__device__ __forceinline__ Fq30 sqr30_asm(const Fq30 &a) {\n    int32_t m[F30_N], d[F30_N];\n    Fq30 r;\n"
+def gen_sqr(name="sqr30_asm", subs=()):
+    args = "".join(f", const Fq30 &{o}" for o, _ in subs)
+    s = (f"__device__ __forceinline__ Fq30 {name}(const Fq30 &a{args}) {{\n    int32_t m[F30_N], d[F30_N];\n    Fq30 r;\n"
          "#pragma unroll\n    for (int i = 0; i < F30_N; i++) d[i] = a.v[i] * 2;\n    uint64_t acc = 0;\n")
 
     def cross(k, lo):
@@ -82,8 +92,11 @@ def gen_sqr():
         s += f"    m[{k}] = sext30((uint32_t)acc * Fq30Consts::INV);\n    acc = sar30(mac30(acc, m[{k}], {q(0)}));\n"
     for k in range(N, 2 * N - 1):
         prods = cross(k, k - N + 1) + [(f"m[{i}]", "v", q(k - i), "s") for i in range(k - N + 1, N)]
+        prods += [(f"{o}.v[{k - N}]", "v", str(c), "i") for o, c in subs]
         s += emit_products(prods)
         s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+    if subs:
+        s += emit_products([(f"{o}.v[{N - 1}]", "v", str(c), "i") for o, c in subs])
     s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
     return s
 
@@ -147,7 +160,8 @@ def gen_fr29():
 
 
 def main(dst):
-    out = "// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_mul() + gen_sqr() + gen_muladd()
+    out = ("// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_mul() + gen_sqr() + gen_muladd() +
+           gen_mul("mul30_sub_asm", (("c", -1),)) + gen_sqr("sqr30_sub2_asm", (("c", -1), ("e", -2))))
     open(dst, "w").write(out)
     print("wrote", dst)
     if len(sys.argv) > 2:

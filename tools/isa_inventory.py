@@ -34,11 +34,18 @@ def cls(op):
 
 
 def main():
-    tmp = tempfile.mkdtemp()
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c",
-                           os.path.join(ROOT, "kzg_amd", "csrc", "msm.hip"), "-o", os.path.join(tmp, "msm.o"), "--save-temps"],
-                          cwd=tmp, stderr=subprocess.DEVNULL)
-    L = open(os.path.join(tmp, "msm-hip-amdgcn-amd-amdhsa-gfx950.s")).read().split("\n")
+    """python tools/isa_inventory.py [path/to/msm_dev_pp.s]: default = the assembly the build actually assembled
+    (kzg_amd/build/msm_dev_pp.s, after strip_asm_nops); `--compile` recompiles msm.hip the plain way instead."""
+    if "--compile" in sys.argv:
+        tmp = tempfile.mkdtemp()
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c",
+                               os.path.join(ROOT, "kzg_amd", "csrc", "msm.hip"), "-o", os.path.join(tmp, "msm.o"), "--save-temps"],
+                              cwd=tmp, stderr=subprocess.DEVNULL)
+        path = os.path.join(tmp, "msm-hip-amdgcn-amd-amdhsa-gfx950.s")
+    else:
+        args = [a for a in sys.argv[1:] if not a.startswith("-")]
+        path = args[0] if args else os.path.join(ROOT, "kzg_amd", "build", "msm_dev_pp.s")
+    L = open(path).read().split("\n")
     start = [i for i, l in enumerate(L) if l.startswith("_ZN3kzg14k_accum_affine")][0]
     end = [i for i, l in enumerate(L) if l.startswith(".Lfunc_end") and i > start][0]
     blocks, cur = [], ("entry", [])
@@ -56,15 +63,19 @@ def main():
         if t:
             cur[1].append(t)
     blocks.append(cur)
-    # the mixed addition = the block with 676 mads (phase 1: two multiplies) + the block with 2379 (phase 2)
-    hot = [b for b in blocks if sum(i.startswith("v_mad_i64_i32") for i in b[1]) in (676, 2379)]
+    # the mixed addition = the two blocks of the loop body with the most multiply-adds (phase 1: two products, phase 2: the rest)
+    mads = lambda b: sum(i.startswith("v_mad_i64_i32") for i in b[1])  # noqa: E731
+    # phase 1 = two products (676 multiply-adds, 702 with the merged subtractions), phase 2 = the rest (2379 / 2405); the other
+    # large block of the loop is the doubling branch (never taken on the hot path)
+    hot = [b for b in blocks if mads(b) in (676, 702, 2379, 2405)]
     c = collections.Counter()
     for _, ins in hot:
         for i in ins:
             c[cls(i.split()[0])] += 1
     n = sum(c.values())
     valu = sum(v for k, v in c.items() if "not VALU" not in k)
-    print("k_accum_affine, one XYZZ mixed addition (blocks %s): %d instructions, %d of them VALU" % (", ".join(b[0] for b in hot), n, valu))
+    print("%s\nk_accum_affine, one XYZZ mixed addition (blocks %s with %s multiply-adds): %d instructions, %d of them VALU" %
+          (os.path.relpath(path, ROOT), ", ".join(b[0] for b in hot), " + ".join(str(mads(b)) for b in hot), n, valu))
     for k, v in c.most_common():
         print("%6d  %5.1f %%  %s" % (v, 100.0 * v / n, k))
 

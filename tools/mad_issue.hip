@@ -1,6 +1,8 @@
 // mad_issue.hip -- what limits v_mad_i64_i32 issue at LOW occupancy (k_accum_affine holds 2 waves per SIMD)?
-//   variants: number of independent accumulator chains per wave (1, 2, 4, 8), carry-out destination (always vcc, or rotating
-//   over 8 SGPR pairs), and a mix with the non-mad instructions of mul30.  Waves per SIMD 1, 2, 3, 4, 8.
+//   variants: number of independent accumulator chains per wave (1, 2, 3, 4, 8), carry-out destination (always vcc, or rotating
+//   over SGPR pairs), and column-shaped streams with the non-mad instructions of mul30: one multiply alone (a single dependent
+//   chain, as mul30_gfx950.inc emits it) against two and three independent multiplies interleaved instruction by instruction.
+//   Loop bodies hold 96..192 mads so that the loop branch does not pace a lone wave.  Waves per SIMD 1, 2, 3, 4, 8.
 // Build: hipcc --offload-arch=gfx950 -O3 -o tools/bin/mad_issue tools/mad_issue.hip
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -16,12 +18,15 @@ __global__ __launch_bounds__(256) void k_mad(uint32_t *out, int iters, uint32_t 
     uint64_t c[8];
     for (int k = 0; k < 8; k++) c[k] = a * (k + 1);
     for (int i = 0; i < iters; i++) {
-        if (!ROT) {
-            MAD_VCC(c[0 % CHAINS]); MAD_VCC(c[1 % CHAINS]); MAD_VCC(c[2 % CHAINS]); MAD_VCC(c[3 % CHAINS]);
-            MAD_VCC(c[4 % CHAINS]); MAD_VCC(c[5 % CHAINS]); MAD_VCC(c[6 % CHAINS]); MAD_VCC(c[7 % CHAINS]);
-        } else {
-            MAD_S(c[0 % CHAINS], 20, 21); MAD_S(c[1 % CHAINS], 22, 23); MAD_S(c[2 % CHAINS], 24, 25); MAD_S(c[3 % CHAINS], 26, 27);
-            MAD_S(c[4 % CHAINS], 28, 29); MAD_S(c[5 % CHAINS], 30, 31); MAD_S(c[6 % CHAINS], 32, 33); MAD_S(c[7 % CHAINS], 34, 35);
+#pragma unroll
+        for (int u = 0; u < 12; u++) {
+            if (!ROT) {
+                MAD_VCC(c[0 % CHAINS]); MAD_VCC(c[1 % CHAINS]); MAD_VCC(c[2 % CHAINS]); MAD_VCC(c[3 % CHAINS]);
+                MAD_VCC(c[4 % CHAINS]); MAD_VCC(c[5 % CHAINS]); MAD_VCC(c[6 % CHAINS]); MAD_VCC(c[7 % CHAINS]);
+            } else {
+                MAD_S(c[0 % CHAINS], 20, 21); MAD_S(c[1 % CHAINS], 22, 23); MAD_S(c[2 % CHAINS], 24, 25); MAD_S(c[3 % CHAINS], 26, 27);
+                MAD_S(c[4 % CHAINS], 28, 29); MAD_S(c[5 % CHAINS], 30, 31); MAD_S(c[6 % CHAINS], 36, 37); MAD_S(c[7 % CHAINS], 38, 39);
+            }
         }
     }
     uint64_t s = 0;
@@ -29,20 +34,39 @@ __global__ __launch_bounds__(256) void k_mad(uint32_t *out, int iters, uint32_t 
     out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
 }
 
-// the shape of one column of mul30: a dependent chain of NM mads, then quotient digit (mul_lo, bfe), one more mad, 64-bit shift
-template <int NM>
-__global__ __launch_bounds__(256) void k_column(uint32_t *out, int iters, uint32_t seed) {
+// NMUL independent multiplies in flight, each the stream of mul30's low-half column: a chain of 13 mads, quotient digit
+// (v_mul_lo_u32, sign extension), one more mad, 64-bit shift.  The chains are interleaved mad by mad.
+template <int NMUL, int ROT>
+__global__ __launch_bounds__(256) void k_columns(uint32_t *out, int iters, uint32_t seed) {
     int32_t a = (int32_t)(seed + threadIdx.x), b = (int32_t)(seed * 3 + blockIdx.x);
-    uint64_t acc = a;
+    uint64_t acc[3];
+    for (int k = 0; k < 3; k++) acc[k] = a * (k + 1);
     for (int i = 0; i < iters; i++) {
 #pragma unroll
-        for (int k = 0; k < NM; k++) MAD_VCC(acc);
-        uint32_t m = (uint32_t)acc * 0x12345679u;
-        int32_t ms = (int32_t)(m << 2) >> 2;
-        asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(ms), "v"(b) : "vcc");
-        acc = (uint64_t)((int64_t)acc >> 30);
+        for (int col = 0; col < 4; col++) {
+#pragma unroll
+            for (int k = 0; k < 13; k++) {
+                if (!ROT) {
+                    MAD_VCC(acc[0]);
+                    if (NMUL > 1) MAD_VCC(acc[1]);
+                    if (NMUL > 2) MAD_VCC(acc[2]);
+                } else {
+                    MAD_S(acc[0], 20, 21);
+                    if (NMUL > 1) MAD_S(acc[1], 22, 23);
+                    if (NMUL > 2) MAD_S(acc[2], 24, 25);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < NMUL; j++) {
+                uint32_t m = (uint32_t)acc[j] * 0x12345679u;
+                int32_t ms = (int32_t)(m << 2) >> 2;
+                asm volatile("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc[j]) : "v"(ms), "v"(b) : "vcc");
+                acc[j] = (uint64_t)((int64_t)acc[j] >> 30);
+            }
+        }
     }
-    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)acc ^ (uint32_t)(acc >> 32);
+    uint64_t s = acc[0] ^ acc[1] ^ acc[2];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)s ^ (uint32_t)(s >> 32);
 }
 
 template <class K>
@@ -62,7 +86,7 @@ int main() {
     hipDeviceProp_t p; CHECK(hipGetDeviceProperties(&p, 0));
     int cus = p.multiProcessorCount;
     uint32_t *out; CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
-    const int iters = 40000;  // 320k mads per lane: ~3 ms at 2 waves/SIMD, long enough for the clock to settle
+    const int iters = 3500;  // x 96 mads per lane: ~3 ms at 2 waves/SIMD, long enough for the clock to settle
     const int wl[] = {1, 2, 3, 4, 8};
     printf("v_mad_i64_i32, %d CUs; T lane-mad/s and nominal cycles per wave-instruction per SIMD at 2.4 GHz\n", cus);
     for (int wi = 0; wi < 5; wi++) {
@@ -72,20 +96,30 @@ int main() {
             {"8 chains, vcc", time_kernel(k_mad<8, 0>, grid, block, 3, out, iters)},
             {"8 chains, rotating sdst", time_kernel(k_mad<8, 1>, grid, block, 3, out, iters)},
             {"4 chains, vcc", time_kernel(k_mad<4, 0>, grid, block, 3, out, iters)},
+            {"4 chains, rotating sdst", time_kernel(k_mad<4, 1>, grid, block, 3, out, iters)},
+            {"3 chains, vcc", time_kernel(k_mad<3, 0>, grid, block, 3, out, iters)},
             {"2 chains, vcc", time_kernel(k_mad<2, 0>, grid, block, 3, out, iters)},
             {"2 chains, rotating sdst", time_kernel(k_mad<2, 1>, grid, block, 3, out, iters)},
             {"1 chain, vcc", time_kernel(k_mad<1, 0>, grid, block, 3, out, iters)},
             {"1 chain, rotating sdst", time_kernel(k_mad<1, 1>, grid, block, 3, out, iters)},
         };
         for (auto &x : r) {
-            double ops = (double)cus * w * 256 * iters * 8;
+            double ops = (double)cus * w * 256 * iters * 96;
             printf("waves/SIMD %d  %-26s %8.3f ms  %7.2f T lane-mad/s  %6.2f cyc\n", w, x.name, x.ms, ops / x.ms / 1e9,
-                   x.ms * 1e-3 * 2.4e9 / ((double)iters * 8 * w));
+                   x.ms * 1e-3 * 2.4e9 / ((double)iters * 96 * w));
         }
-        const int it2 = 6000;
-        double t13 = time_kernel(k_column<13>, grid, block, 3, out, it2), t25 = time_kernel(k_column<25>, grid, block, 3, out, it2);
-        printf("waves/SIMD %d  column of 13+1 mads + 4 ops   %8.3f ms  %7.2f T lane-mad/s\n", w, t13, (double)cus * w * 256 * it2 * 14 / t13 / 1e9);
-        printf("waves/SIMD %d  column of 25+1 mads + 4 ops   %8.3f ms  %7.2f T lane-mad/s\n", w, t25, (double)cus * w * 256 * it2 * 26 / t25 / 1e9);
+        const int it2 = 3000;
+        struct { const char *name; int nm; double ms; } c[] = {
+            {"columns: 1 multiply alone, vcc", 1, time_kernel(k_columns<1, 0>, grid, block, 3, out, it2)},
+            {"columns: 2 multiplies interleaved, vcc", 2, time_kernel(k_columns<2, 0>, grid, block, 3, out, it2 / 2)},
+            {"columns: 2 interleaved, rotating sdst", 2, time_kernel(k_columns<2, 1>, grid, block, 3, out, it2 / 2)},
+            {"columns: 3 multiplies interleaved, vcc", 3, time_kernel(k_columns<3, 0>, grid, block, 3, out, it2 / 3)},
+            {"columns: 3 interleaved, rotating sdst", 3, time_kernel(k_columns<3, 1>, grid, block, 3, out, it2 / 3)},
+        };
+        for (auto &x : c) {
+            double mads = (double)cus * w * 256 * (it2 / x.nm) * 4 * 14 * x.nm;
+            printf("waves/SIMD %d  %-40s %8.3f ms  %7.2f T lane-mad/s\n", w, x.name, x.ms, mads / x.ms / 1e9);
+        }
     }
     return 0;
 }
