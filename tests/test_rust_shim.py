@@ -1,0 +1,124 @@
+"""The Rust shim as files (integration/mi355x_sys.rs, integration/mi355x.rs) against the C header: no Rust toolchain in this image,
+so the check is structural -- both sides are parsed independently and every function must agree in name, arity, and the KIND of
+every parameter and of the return value (integer width / usize / f64 / pointer depth, constness and pointee)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+C_SCALARS = {"int": "i32", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "double": "f64"}
+C_POINTEES = {"void": "void", "char": "char", "int": "i32", "size_t": "usize", "uint32_t": "u32", "uint64_t": "u64", "double": "f64"}
+R_SCALARS = {"c_int": "i32", "i32": "i32", "usize": "usize", "u32": "u32", "u64": "u64", "i64": "i64", "f64": "f64"}
+R_POINTEES = {"c_void": "void", "c_char": "char", "c_int": "i32", "usize": "usize", "u32": "u32", "u64": "u64", "f64": "f64"}
+
+
+def kind_c(t):
+    t = t.replace("struct ", "").strip()
+    const = t.startswith("const ")
+    if const:
+        t = t[6:]
+    depth = t.count("*")
+    base = t.replace("*", "").replace("const", "").strip()
+    if depth == 0:
+        return "void" if base == "void" else C_SCALARS[base]
+    return ("const " if const else "mut ") + "*" * depth + C_POINTEES.get(base, base)
+
+
+def kind_rust(t):
+    t = t.strip()
+    depth, const = 0, None
+    while t.startswith("*"):
+        m = re.match(r"\*(const|mut)\s+(.*)", t)
+        if const is None or depth >= 0:
+            inner_const = m.group(1) == "const"
+        const = inner_const        # the innermost qualifier is the pointee's constness
+        depth += 1
+        t = m.group(2)
+    if depth == 0:
+        return R_SCALARS[t]
+    return ("const " if const else "mut ") + "*" * depth + R_POINTEES.get(t, t)
+
+
+def header_sigs():
+    src = open(os.path.join(ROOT, "include", "kzg_mi355x.h")).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"#[^\n]*", " ", src)
+    src = re.sub(r"\s+", " ", src)
+    sigs = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(kzg_[a-z0-9_]+)\s*\(([^()]*)\)\s*;", src):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3).strip()
+        if not ret or ret.startswith(("typedef", "struct", "enum")):
+            continue
+        params = []
+        if args and args != "void":
+            for a in args.split(","):
+                mm = re.match(r"^(.*?)([A-Za-z_][A-Za-z0-9_]*)$", a.strip())
+                params.append(kind_c(mm.group(1)))
+        sigs[name] = (kind_c(ret), params)
+    return sigs
+
+
+def rust_sigs(text):
+    sigs = {}
+    body = text[text.index('extern "C" {'):]
+    body = body[:body.index("\n}")]
+    for m in re.finditer(r"pub fn (kzg_[a-z0-9_]+)\(([^)]*)\)\s*(?:->\s*([^;]+))?;", body):
+        name, args, ret = m.group(1), m.group(2).strip(), (m.group(3) or "").strip()
+        params = [kind_rust(a.split(":", 1)[1]) for a in args.split(",")] if args else []
+        sigs[name] = (kind_rust(ret) if ret else "void", params)
+    return sigs
+
+
+def test_sys_binding_matches_header():
+    hs = header_sigs()
+    rs = rust_sigs(open(os.path.join(ROOT, "integration", "mi355x_sys.rs")).read())
+    assert len(hs) >= 80
+    assert set(hs) == set(rs), (sorted(set(hs) - set(rs)), sorted(set(rs) - set(hs)))
+    for name in hs:
+        assert hs[name] == rs[name], (name, hs[name], rs[name])
+    # an out-parameter of an opaque handle is a pointer to a mutable pointer on both sides
+    assert hs["kzg_ctx_create"][1][1] == "mut **kzg_ctx" and hs["kzg_commit_coeff"][1][1] == "const *kzg_srs"
+
+
+def test_sys_binding_is_what_the_generator_writes():
+    import subprocess
+    import sys
+    before = open(os.path.join(ROOT, "integration", "mi355x_sys.rs")).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_rust_sys.py")], stdout=subprocess.DEVNULL)
+    assert open(os.path.join(ROOT, "integration", "mi355x_sys.rs")).read() == before, "integration/mi355x_sys.rs is stale: run tools/gen_rust_sys.py"
+
+
+def test_splices_call_the_abi_with_the_right_arity():
+    """integration/mi355x.rs: every sys::kzg_* call passes as many arguments as the header declares, and the five splices exist."""
+    hs = header_sigs()
+    src = open(os.path.join(ROOT, "integration", "mi355x.rs")).read()
+    src = re.sub(r"//[^\n]*", "", src)
+    calls = 0
+    for m in re.finditer(r"sys::(kzg_[a-z0-9_]+)\s*\(", src):
+        name = m.group(1)
+        assert name in hs, name
+        depth, i, args, cur = 1, m.end(), [], ""
+        while depth:
+            ch = src[i]
+            if ch in "([{":
+                depth += 1
+            elif ch in ")]}":
+                depth -= 1
+                if depth == 0:
+                    break
+            if ch == "," and depth == 1:
+                args.append(cur)
+                cur = ""
+            else:
+                cur += ch
+            i += 1
+        if cur.strip():
+            args.append(cur)
+        assert len(args) == len(hs[name][1]), (name, len(args), len(hs[name][1]))
+        calls += 1
+    assert calls >= 15
+    for fn in ("pub fn commit(", "pub fn create_witness(", "pub fn create_witness_batched(", "pub fn commit_eval(", "pub fn create_witness_eval(",
+               "pub fn fft_in_place("):
+        assert fn in src, fn
+    for cite in ("src/coeff_form.rs:59-64", "src/coeff_form.rs:66-81", "src/coeff_form.rs:83-111", "src/eval_form.rs:114-140", "src/ft.rs:111-140"):
+        assert cite in open(os.path.join(ROOT, "integration", "mi355x.rs")).read(), cite
