@@ -365,6 +365,7 @@ def main():
     ap.add_argument("--u64", action="store_true", help="u64-valued coefficients (the reference benches' distribution)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the `paths` measurements after the timed region")
+    ap.add_argument("--callers", action="store_true", help="with --no-paths: still measure paths.blocking_callers_16_per_s")
     ap.add_argument("--strong", action="store_true", help="N>1 (default there): one degree-2^log_n commitment sharded N ways")
     ap.add_argument("--config5", action="store_true", help="N>1: BASELINE configs[4], 2^21 terms per rank (degree 2^24 at N = 8)")
     ap.add_argument("--weak", action="store_true", help="N>1: 2^log_n terms per rank (degree N * 2^log_n)")
@@ -670,6 +671,10 @@ def main():
                     res["paths"].update(measure_spots(kzg_amd, L, engine, lambda: time.perf_counter() - t_extra < 45.0))
             except Exception as e:
                 res["paths"] = {"error": str(e)}
+        elif mode == "single" and args.callers:
+            per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch)
+            res["paths"] = {"blocking_callers_16_per_s": round(per_s, 2), "blocking_callers_16_vs_value": round(per_s / value, 4),
+                            "blocking_callers_16_match_batch_results": same}
         if mode == "single" and not args.no_cpu_baseline:
             if cpu is not None:
                 try:

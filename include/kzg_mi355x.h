@@ -13,7 +13,7 @@
  *   - a kzg_ctx is bound to one GPU and is thread-safe.  The reference's blocking prover calls -- kzg_commit_coeff,
  *     kzg_commit_eval, kzg_msm_g1, kzg_witness_coeff, kzg_witness_eval (KZGProver / KZGProverEvalForm are Clone + &self,
  *     src/coeff_form.rs:37-64) -- run CONCURRENTLY on one ctx: each call leases one of the context's lanes (option
- *     "streams", default 8, up to 16), submits its kernels there and waits for its own result only, so N host threads
+ *     "streams", default and maximum 16), submits its kernels there and waits for its own result only, so N host threads
  *     calling commit() against one resident SRS fill the GPU like kzg_msm_g1_batch does.  Every other call takes the
  *     context exclusively (it waits for the leased lanes to drain).  A kzg_srs / kzg_srs_g2 is immutable after creation
  *     and may be used from any number of threads and from every kzg_ctx on the same device.  kzg_last_error returns the

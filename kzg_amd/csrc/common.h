@@ -106,7 +106,7 @@ struct kzg_ctx {
     std::string err;
     std::vector<kzg::Lane> lanes;
     int opt_window_bits = 0;  // 0 = auto
-    int opt_streams = 8;
+    int opt_streams = 16;  // lanes: depth of the batched pipeline and of the pool concurrent blocking callers lease from
     int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
     int opt_hw_queues = 0;             // hardware queues to plan the batched pipeline for (0 = measure: probe_queues in capi.hip)
     int probed_queues = 0;             // hardware queues the probed streams were found on (0 = not measured yet)
