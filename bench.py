@@ -56,8 +56,28 @@ SEED = 1
 
 
 def g1_adds_per_msm(n, c, W):
-    """algorithmic G1 additions, n*W bucket accumulations + bucket reduction."""
-    return n * W + 2 * (1 << (c - 1))
+    """algorithmic G1 additions, n*W bucket accumulations + bucket reduction (W: digits per scalar; positional
+    tables, c = 18: the measured average number of NAF digits, 2^16 buckets)."""
+    return n * W + 2 * (1 << ((17 if c == 18 else c) - 1))
+
+
+def naf18_avg_digits(blob):
+    """Average number of width-18 NAF digits (kzg_amd/csrc/naf.h) of the canonical 32-byte scalars in `blob`: what one scalar
+    contributes to the sorted entry list when the SRS uses positional tables."""
+    R = 0x73eda753299d7d483339d80809a1d80553bda402fffe5bfeffffffff00000001
+    tot, cnt = 0, 0
+    for o in range(0, len(blob), 32):
+        k = int.from_bytes(blob[o:o + 32], "little") % R
+        if k >> 254:
+            k = R - k
+        while k:
+            if k & 1:
+                d = k & 0x3ffff
+                k -= d - (1 << 18) if d >= (1 << 17) else d
+                tot += 1
+            k >>= 1
+        cnt += 1
+    return tot / max(cnt, 1)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -486,6 +506,11 @@ def main():
         params = kzg_amd.setup(engine, TAU, n_poly, g2_len=0)    # gs[i] = [tau^i]G
         srs = params.gs
     c, W = srs.window_info()
+    digits = float(W)              # sorted entries per scalar
+    if c == 18:                    # positional tables: the NAF digit count depends on the scalars -- measured on a sample of the input
+        digits = naf18_avg_digits(view(kzg_amd, scal, 0, min(n_local, 4096)).download())
+    elif args.u64:
+        digits = 4.0               # u64-valued scalars: 4 non-zero 16/17-bit windows
     out = ctypes.create_string_buffer(96 * max(args.batch, 1))
 
     if not sharded:
@@ -555,7 +580,7 @@ def main():
         launches, total_ms = prof.get("k_accum_affine", (0, 0.0))
         if launches:
             avg_s = total_ms / launches / 1e3
-            adds_per_launch = n_local * (4 if args.u64 else W)   # u64-valued scalars: 4 non-zero 16/17-bit windows
+            adds_per_launch = n_local * digits
             mads_per_launch = float(adds_per_launch) * MADS_PER_ADD
             # HBM traffic needs PMC counters (rocprofv3 --pmc passes, tools/collect_profiles.sh); nothing in this process can
             # measure it, so the line carries null and names the profile that holds the collected figure
@@ -578,7 +603,8 @@ def main():
                 "peak_reference": MAD_PEAK_TLANE_S, "frac_of_peak_reference": round(t_mad / MAD_PEAK_TLANE_S, 4),
                 "peak_at_2_waves_per_simd_measured_this_run": None if peak2_measured is None else round(peak2_measured, 2),
                 "traffic": traffic, "traffic_profiled": traffic_profile,
-                "derivation": "launches x terms x windows x %d mads per bucket addition (6 mul30 x 338 + 2 sqr30 x 260 + 1 fused "
+                "digits_per_scalar": round(digits, 3),
+                "derivation": "launches x terms x digits per scalar x %d mads per bucket addition (6 mul30 x 338 + 2 sqr30 x 260 + 1 fused "
                               "muladd 507; 13 x 30-bit signed limbs) / wall time of the timed region; peak = the v_mad_i64_i32 issue "
                               "rate of THIS device measured in this run (kzg_measure_mad_issue_rate: 8 chains per lane, 8 waves per "
                               "SIMD, ~30 ms); peak_reference = round 1's figure from another box" % MADS_PER_ADD,
@@ -646,10 +672,12 @@ def main():
                 "workload": workloads[mode], "mode": mode, "polynomial_coefficients": n_poly,
                 "scalars": "u64-valued Fr" if args.u64 else "uniform full-width Fr (SplitMix64 counter stream)",
                 "terms_per_rank": n_local, "window_bits": c, "windows": W, "srs": "setup(tau, n) generated on the GPU",
+                "table": ("positional: 255 rows 2^j P per point, width-18 NAF digits (%.2f per scalar)" % digits) if c == 18 else
+                         "%d window rows 2^(%d w) P per point" % (srs.table_rows() if hasattr(srs, "table_rows") else W, c),
                 "inputs_resident_in_hbm": True,
             },
             **({"note": group_note} if group_note else {}),
-            "g1_adds_per_sec": round(value * (world if mode != "replicas" else 1) * g1_adds_per_msm(n_local, c, W), 1),
+            "g1_adds_per_sec": round(value * (world if mode != "replicas" else 1) * g1_adds_per_msm(n_local, c, digits), 1),
             "msm_terms_per_sec": round(value * n_poly, 1),
             "parity_pin": "fr-literal+known-tau",   # G1 layer: no literal vector in the reference
             "single_commit_latency_ms": None if latency_ms is None else round(latency_ms, 4),

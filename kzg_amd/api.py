@@ -307,6 +307,9 @@ class Srs:
     def __len__(self):
         return self.engine.lib.kzg_srs_len(self.handle)
 
+    def table_rows(self):
+        return self.engine.lib.kzg_srs_table_rows(self.handle)
+
     def window_info(self):
         c, w = ctypes.c_int(), ctypes.c_int()
         self.engine.lib.kzg_srs_window_info(self.handle, ctypes.byref(c), ctypes.byref(w))

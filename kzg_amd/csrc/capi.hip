@@ -352,6 +352,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "window_rows") {
         if (value < 0 || value > 64) return fail(ctx, KZG_ERR_SHAPE, "window_rows must be 0 (one table row per window) or 1..64");
         ctx->opt_window_rows = (int)value;
+    } else if (k == "naf_window") {
+        if (value != 0 && value != 18) return fail(ctx, KZG_ERR_SHAPE, "naf_window must be 0 (window tables) or 18 (positional tables, width-18 NAF digits)");
+        ctx->opt_naf_window = (int)value;
     } else if (k == "trusted_points") {
         ctx->opt_trusted_points = value != 0;
     } else if (k == "ntt_vec_log") {

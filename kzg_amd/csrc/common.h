@@ -113,6 +113,8 @@ struct kzg_ctx {
     int probed_lanes = 0, probed_accum = 0;  // which streams that measurement covered: lanes [0, probed_lanes), accumulation streams
     std::vector<hipStream_t> probed_order;  // the probed streams, one per queue first
     int opt_window_rows = 0;           // 0 = every window has its table row; r > 0: keep r rows (low-memory SRS, multi-pass MSM)
+    int opt_naf_window = 0;            // SRSs created afterwards: 18 = positional tables + width-18 NAF digits (17x the table; measured
+                                       // +3.7 % batched throughput at 2^20, nothing below 2^19, +1.3 ms on a lone commit: off by default)
     int opt_trusted_points = 0;        // 1: caller vouches for its points (skip the subgroup check of uploads / verifier inputs)
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
     int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort
@@ -156,6 +158,14 @@ struct kzg_srs {
     int W = 0;           // windows = ceil(256 / c) (15 in the c = 17 single-pass mode); table row w holds 2^(c*w) * P_i
     int rows = 0;        // table rows resident (= W unless option window_rows asked for fewer: then an MSM takes ceil(W / rows) passes)
     bool narrow17 = false;  // c = 17: single-pass sort walking the scalars twice (half the buckets per walk), balanced scalars
+    // Positional tables (naf = 18): the table holds 2^j P_i for EVERY bit position j (255 rows) instead of every c-th, and a
+    // scalar is recoded in width-18 non-adjacent form: odd digits |d| < 2^17 at arbitrary positions, at least 18 apart -- 13.9
+    // non-zero digits per 255-bit scalar on average instead of the 15 of fixed 17-bit windows (-7.4 % bucket additions) into
+    // the same 2^16 buckets (bucket (|d| - 1) / 2, weight 2 b + 1).  c = 17 / W = 15 then describe the bucket count and the
+    // maximum digits per scalar; rows = 255.  Costs 17x the table (32.6 KiB per point: 34 GB at 2^20), and the random gathers
+    // over 34 GB cost 10 % more per entry than over 2 GB (profiles/r03_naf_tables.txt): opt-in (option naf_window = 18).
+    int naf = 0;
+    int row_shift = 0;   // row w holds 2^(row_shift w) P: c for window tables, 1 for positional tables
     kzg::G1Affine *table = nullptr;  // [W][npad], affine Montgomery
     void *table30 = nullptr;         // [W][npad] G1Affine30 (2 x 13 x 30-bit limbs + pad, KZG_ROW_BYTES = 128 B): what k_accum_affine gathers
     int device = 0;
@@ -273,7 +283,9 @@ int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t 
 
 // srs.hip
 int srs_choose_window(int opt_window_bits, size_t n);
-void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c, int *W, int *rows, bool *narrow17);
+void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c, int *W, int *rows, bool *narrow17, int opt_naf = 0, int *naf = nullptr);
+// scalars' digits one MSM pass turns into sorted entries, at most
+inline size_t srs_entries_per_scalar(const kzg_srs *s) { return s->naf ? (size_t)s->W : (size_t)s->rows; }
 int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out);
 int srs_finish_from_xyzz(kzg_ctx *ctx, kzg_srs *srs, G1Xyzz *d_row0_xyzz);  // batch-affine row 0 then precompute rows
 int srs_precompute(kzg_ctx *ctx, kzg_srs *srs);                              // rows 1..W-1 from row 0

@@ -23,6 +23,7 @@
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
 #include "msm_internal.h"
 #include "emit.h"
+#include "naf.h"
 
 namespace kzg {
 
@@ -504,6 +505,106 @@ __global__ __launch_bounds__(1024) void k_bin_scatter(const Fr *scalars, size_t 
     }
 }
 
+// ---- positional tables: width-18 NAF digits (kzg_srs::naf) ----------------------------------------------------------------
+// A digit record: bits 0..16 bucket index (|d| - 1) / 2, bit 17 sign, bits 18..25 bit position (= table row), bit 31 valid.
+// k_naf_recode turns every scalar into <= 15 records (stored digit-ordinal-major, recs[k * n + i]: coalesced) and counts the
+// level-1 bins of its sort block on the way (the k_bin_hist of this path); k_bin_scatter_naf is k_bin_scatter reading records.
+// Recoding walks the scalar from bit 0 with a carry: without a carry the next digit starts at the next 1 bit, with a carry
+// (the previous digit was negative: 2^18 was borrowed) at the next 0 bit, which the carry turns into a 1; the digit is the 18
+// bits from there, taken as a negative number when its top bit is set.  Digits are odd and at least 18 positions apart.
+__global__ __launch_bounds__(1024) void k_naf_recode(const Fr *scalars, size_t n, int sfmt, size_t per_block, uint32_t *recs, uint32_t *blk_bins) {
+    __shared__ uint32_t h[NBINS];
+    __shared__ uint32_t limbs[1024 * 12];  // 8 limbs of the balanced scalar + zero padding, per thread (dynamic bit addressing)
+    for (int b = threadIdx.x; b < NBINS; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    uint32_t *L = limbs + threadIdx.x * 12;
+    size_t i0 = (size_t)blockIdx.x * per_block;
+    size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint32_t s[8];
+        load_scalar(scalars, i, sfmt, s);
+        uint32_t flip = 0;
+        if (s[7] & 0x40000000u) {  // k >= 2^254: use r - k < 2^254 with every digit sign flipped
+            uint64_t bw = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint64_t d = (uint64_t)FrParams::mod(k) - s[k] - bw;
+                s[k] = (uint32_t)d;
+                bw = (d >> 63) & 1u;
+            }
+            flip = 1;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) L[k] = s[k];
+        L[8] = L[9] = L[10] = L[11] = 0;
+        uint32_t d[NAF_MAX_DIGITS];
+        const int cnt = naf18_digits(L, flip, d);
+#pragma unroll
+        for (int k = 0; k < NAF_MAX_DIGITS; k++) {
+            const uint32_t r = k < cnt ? d[k] : 0u;
+            recs[(size_t)k * n + i] = r;
+            if (r) atomicAdd(&h[(r & 0x1ffffu) >> BIN_SHIFT], 1u);
+        }
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NBINS; b += blockDim.x) blk_bins[(size_t)blockIdx.x * NBINS + b] = h[b];
+}
+
+// k_bin_scatter for digit records: the packed LDS word carries the digit's ORDINAL (4 bits) where the window index was; the bit
+// position (table row) is read back from the record when the entry is written out (the block read it a moment ago: L2).
+template <class REC>
+__global__ __launch_bounds__(1024) void k_bin_scatter_naf(const uint32_t *recs, size_t n, size_t per_block, const uint32_t *blk_off,
+                                                          const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
+                                                          uint32_t idx_base, typename REC::T *rec) {
+    uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS, *stage = wsum + 16;
+    const uint32_t tid = threadIdx.x;
+    {
+        uint32_t tot;
+        const uint32_t ex = block_scan_1024(bin_total[tid], wsum, &tot);
+        cur[tid] = ex + blk_off[(size_t)blockIdx.x * NBINS + tid];
+        if (blockIdx.x == 0) {
+            bin_base[tid] = ex;
+            if (tid == 0) bin_base[NBINS] = tot;
+        }
+    }
+    const size_t i0 = (size_t)blockIdx.x * per_block;
+    const size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t c0 = i0; c0 < i1; c0 += 1024) {
+        cnt[tid] = 0;
+        __syncthreads();
+        uint32_t pk[NAF_MAX_DIGITS], rk[NAF_MAX_DIGITS];
+#pragma unroll
+        for (int k = 0; k < NAF_MAX_DIGITS; k++) {
+            pk[k] = 0xffffffffu;
+            if (c0 + tid < i1) {
+                const uint32_t r = recs[(size_t)k * n + c0 + tid];
+                if (r & NAF_REC_VALID) {
+                    const uint32_t idx = r & 0x1ffffu, bin = idx >> BIN_SHIFT;
+                    rk[k] = atomicAdd(&cnt[bin], 1u);
+                    pk[k] = bin | ((idx & (BIN_BUCKETS - 1)) << 10) | (((r >> 17) & 1u) << 16) | ((uint32_t)k << 17) | (tid << 21);
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t tot;
+        off[tid] = block_scan_1024(cnt[tid], wsum, &tot);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NAF_MAX_DIGITS; k++)
+            if (pk[k] != 0xffffffffu) stage[off[pk[k] & (NBINS - 1)] + rk[k]] = pk[k];
+        __syncthreads();
+        const uint32_t ebase = idx_base + (uint32_t)c0;
+        for (uint32_t p = tid; p < tot; p += 1024) {
+            const uint32_t v = stage[p], bin = v & (NBINS - 1), t = v >> 21, k = (v >> 17) & 15u;
+            const uint32_t row = (recs[(size_t)k * n + c0 + t] >> 18) & 0xffu;
+            const uint32_t index = row * row_stride + ebase + t;
+            rec[cur[bin] + p - off[bin]] = REC::pack(index, (v >> 16) & 1u, (v >> 10) & (BIN_BUCKETS - 1));
+        }
+        __syncthreads();
+        cur[tid] += cnt[tid];
+    }
+}
+
 // Level 2.  block = bin: bucket sizes -> total[], then the records -> entries[] in bucket order (order inside a bucket is
 // arbitrary, as before), again chunk-sorted in LDS first so that each bucket's share of a chunk is one run of stores.
 constexpr int BIN_SORT_THREADS = 256, BIN_SORT_UNROLL = 8, BIN_SORT_CHUNK = BIN_SORT_THREADS * BIN_SORT_UNROLL;
@@ -813,7 +914,7 @@ size_t sum_points_scratch_count(size_t count) { return (count + SUM_L - 1) / SUM
 struct MsmLayout {
     int B, G, G2;
     size_t M_max, T1_max;
-    size_t off_bins, off_bin_base;
+    size_t off_bins, off_bin_base, off_recs;
     size_t off_blk_hist, off_total, off_local, off_agg, off_bucket_start, off_s1, off_state, off_entries, off_bufA, off_bufB, off_tail,
         off_pass, bytes;
     TailLayout tail;
@@ -823,7 +924,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     MsmLayout L;
     L.B = 1 << (srs->c - 1);
     L.G = sort_blocks(n);
-    L.M_max = n * (size_t)srs->rows;  // entries of one pass
+    L.M_max = n * srs_entries_per_scalar(srs);  // entries of one pass
     L.T1_max = (size_t)ACC_SLOTS + L.B + 1;  // round-1 partials: one per thread slot + one per bucket boundary
     size_t o = 0;
     auto take = [&](size_t bytes) {
@@ -839,6 +940,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.off_blk_hist = take(sort_bytes);
     L.off_bins = take((size_t)L.G2 * NBINS * 4);
     L.off_bin_base = take((2 * NBINS + 1) * 4);  // bin starts, then bin sizes
+    L.off_recs = take(srs->naf ? (size_t)NAF_MAX_DIGITS * n * 4 : 0);  // positional tables: the digit records of the scalars
     L.off_total = take((size_t)L.B * 4);
     L.off_local = take((size_t)L.B * 4);
     L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
@@ -1017,6 +1119,8 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter<Rec4>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter<Rec8>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter_naf<Rec4>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter_naf<Rec8>, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER_LDS));
         ctx->attr_msm_set = true;
     }
     const int B = L.B, G = L.G, c = srs->c, W = srs->W;
@@ -1035,12 +1139,35 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     // One pass per `rows` windows: the table holds rows 0 .. rows-1 (2^(c w') P), so pass p reduces the digits of windows
     // [p rows, (p+1) rows) to S_p = sum_i (sum_{w'} d_{i, p rows + w'} 2^(c w')) P_i and the result is sum_p 2^(c rows p) S_p.
     // rows == W (the default): one pass, no doubling chain.
-    const int rows = srs->rows, passes = (W + rows - 1) / rows;
+    const int rows = srs->naf ? W : srs->rows, passes = (W + rows - 1) / rows;  // positional tables: one pass, always
     MsmPoint *pass_res = (MsmPoint *)(base + L.off_pass);
     const uint32_t slots = (uint32_t)mm.accum_blocks * 256u;  // resident threads k_accum_affine is split over
     for (int p = 0; p < passes; p++) {
         const int w_lo = p * rows, w_hi = (p + 1) * rows < W ? (p + 1) * rows : W;
-        if (srs->narrow17 && !ctx->opt_sort_single) {
+        if (srs->naf) {
+            // positional tables: recode (+ level-1 histogram), then the two-level sort on the digit records
+            const int G2 = L.G2;
+            const size_t per2 = (n + G2 - 1) / G2;
+            uint32_t *bins = (uint32_t *)(base + L.off_bins), *bin_base = (uint32_t *)(base + L.off_bin_base);
+            uint32_t *ready = (uint32_t *)(base + L.off_agg) + SCAN_SEG;
+            uint32_t *recs = (uint32_t *)(base + L.off_recs);
+            KZG_LAUNCH(ctx, st, "k_naf_recode", k_naf_recode, G2, 1024, 0, sc, n, sfmt, per2, recs, bins);
+            uint32_t *bin_total = bin_base + NBINS + 1;
+            KZG_LAUNCH(ctx, st, "k_bin_scan", k_bin_scan, NBINS / 64, 1024, 0, bins, G2, bin_total, ready);
+            if ((uint64_t)srs->rows * srs->npad < REC4_MAX_INDEX) {
+                uint32_t *rec = (uint32_t *)blk_hist;
+                KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter_naf<Rec4>, G2, 1024, BIN_SCATTER_LDS, recs, n, per2, bins, bin_total, bin_base,
+                           (uint32_t)srs->npad, (uint32_t)offset, rec);
+                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec4>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+            } else {
+                uint2 *rec = (uint2 *)blk_hist;
+                KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter_naf<Rec8>, G2, 1024, BIN_SCATTER_LDS, recs, n, per2, bins, bin_total, bin_base,
+                           (uint32_t)srs->npad, (uint32_t)offset, rec);
+                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec8>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+            }
+            KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
+                       state, slots, ready);
+        } else if (srs->narrow17 && !ctx->opt_sort_single) {
             const int G2 = L.G2;
             const size_t per2 = (n + G2 - 1) / G2;
             uint32_t *bins = (uint32_t *)(base + L.off_bins), *bin_base = (uint32_t *)(base + L.off_bin_base);
@@ -1088,7 +1215,8 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
                        (const uint4 *)srs->table30, bufA, state);
         }
         MsmPoint *res = nullptr;
-        KZG_TRY(msm_tail_run(ctx, st, mm, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, &res));
+        KZG_TRY(msm_tail_run(ctx, st, mm, bufA, bufB, s1, B, expected_partials(L.M_max, slots, B), state, base + L.off_tail, L.tail, &res,
+                             srs->naf != 0));
         if (passes == 1) {
             *d_result = res;
             return KZG_OK;
@@ -1106,6 +1234,7 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
     if (srs->c > 16 && !srs->narrow17) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
     if ((uint64_t)srs->rows * srs->npad >= (1ull << 31))
         return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (table rows * points < 2^31)");
+    if (srs->naf && offset + n > srs->npad) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
     return msm_run_narrow(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result, accum_stream, sorted_ev, accum_ev);
 }
 

@@ -46,6 +46,7 @@ struct TailLayout {
 };
 TailLayout tail_layout(int B, size_t T1_max);
 int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmMode &mode, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
-                 size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result);
+                 size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result,
+                 bool odd_weights = false);
 
 }  // namespace kzg

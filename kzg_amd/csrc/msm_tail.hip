@@ -169,12 +169,15 @@ __global__ __launch_bounds__(256) void k_weighted_bits(const MsmPoint *rows, con
 }
 
 // result = sum_{j < lr} 2^(j + lc) Q[j] + sum_{j < lc} 2^j Q[lr + j] + Q[lr + lc]        (lr + lc + 1 <= 32 lanes)
-__global__ __launch_bounds__(64) void k_reduce_final(const MsmPoint *Q, int lr, int lc, MsmPoint *result) {
+//        = sum_b b B_b + sum_b B_b = sum_b (b + 1) B_b.
+// odd (positional tables: bucket b holds the digits of magnitude 2 b + 1): 2 sum_b b B_b + sum_b B_b -- every bit slice one
+// doubling more, the plain total as it is.
+__global__ __launch_bounds__(64) void k_reduce_final(const MsmPoint *Q, int lr, int lc, MsmPoint *result, int odd) {
     const int lane = threadIdx.x;
     const int cnt = lr + lc + 1;
     MsmPoint p = lane < cnt ? Q[lane] : MsmPoint::infinity();
-    const int shift = lane < lr ? lane + lc : (lane < lr + lc ? lane - lr : 0);
-    const int maxshift = lr > 0 ? lr + lc - 1 : (lc > 0 ? lc - 1 : 0);
+    const int shift = lane < lr ? lane + lc + odd : (lane < lr + lc ? lane - lr + odd : 0);
+    const int maxshift = (lr > 0 ? lr + lc - 1 : (lc > 0 ? lc - 1 : 0)) + odd;
     for (int k = 0; k < maxshift; k++)
         if (k < shift && lane < cnt) p = g1_dbl30(p);
     p = butterfly_sum<32>(p);
@@ -318,13 +321,13 @@ __global__ __launch_bounds__(256) void k_weighted_bits_q(const MsmPoint *rows, c
 }
 
 // 32 quads (two waves): quad i doubles Q[i] shift_i times, then the block sum
-__global__ __launch_bounds__(128) void k_reduce_final_q(const MsmPoint *Q, int lr, int lc, MsmPoint *result) {
+__global__ __launch_bounds__(128) void k_reduce_final_q(const MsmPoint *Q, int lr, int lc, MsmPoint *result, int odd) {
     __shared__ MsmPoint lds[2];
     const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
     const int cnt = lr + lc + 1;
     MsmPoint p = qd < cnt ? Q[qd] : MsmPoint::infinity();
-    const int shift = qd < lr ? qd + lc : (qd < lr + lc ? qd - lr : 0);
-    const int maxshift = lr > 0 ? lr + lc - 1 : (lc > 0 ? lc - 1 : 0);
+    const int shift = qd < lr ? qd + lc + odd : (qd < lr + lc ? qd - lr + odd : 0);
+    const int maxshift = (lr > 0 ? lr + lc - 1 : (lc > 0 ? lc - 1 : 0)) + odd;
 #pragma nounroll
     for (int k = 0; k < maxshift; k++)
         if (k < shift && qd < cnt) p = qdbl(p, role);
@@ -368,7 +371,7 @@ TailLayout tail_layout(int B, size_t T1_max) {
 // part: the round-1 partial list (ordered by bucket, bucket b = [s1[b], s1[b+1])); scratch: a list of the same capacity;
 // expected_partials: how many partials round 1 is expected to emit (chooses the lane-group width of the fold)
 int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmMode &mode, const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, int B,
-                 size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result) {
+                 size_t expected_partials, MsmState *state, char *tail_base, const TailLayout &L, MsmPoint **d_result, bool odd_weights) {
     MsmPoint *dense = (MsmPoint *)(tail_base + L.off_dense), *rows = (MsmPoint *)(tail_base + L.off_rows);
     MsmPoint *cols = (MsmPoint *)(tail_base + L.off_cols), *Q = (MsmPoint *)(tail_base + L.off_Q);
     uint32_t *tasks = (uint32_t *)(tail_base + L.off_tasks), *arrive = (uint32_t *)(tail_base + L.off_arrive);
@@ -408,10 +411,10 @@ int msm_tail_run(kzg_ctx *ctx, hipStream_t st, const MsmMode &mode, const MsmPoi
         // quads -- 8 or 4 sequential additions + 6 levels -- loses to one wave's 3 + 6.  Two one-lane waves per row sum, 1 + 6 + 1
         // deep, measured 0.20 ms: the dispatcher does not put the 1024 waves on 1024 different SIMDs.)
         KZG_LAUNCH(ctx, st, "k_weighted_bits", k_weighted_bits_q, lr + lc + 1, 256, 0, rows, cols, lr, lc, Q);
-        KZG_LAUNCH(ctx, st, "k_reduce_final", k_reduce_final_q, 1, 128, 0, Q, lr, lc, result);
+        KZG_LAUNCH(ctx, st, "k_reduce_final", k_reduce_final_q, 1, 128, 0, Q, lr, lc, result, odd_weights ? 1 : 0);
     } else {
         KZG_LAUNCH(ctx, st, "k_weighted_bits", k_weighted_bits, (lr + lc + 1 + wpb - 1) / wpb, TAIL_THREADS, 0, rows, cols, lr, lc, Q);
-        KZG_LAUNCH(ctx, st, "k_reduce_final", k_reduce_final, 1, 64, 0, Q, lr, lc, result);
+        KZG_LAUNCH(ctx, st, "k_reduce_final", k_reduce_final, 1, 64, 0, Q, lr, lc, result, odd_weights ? 1 : 0);
     }
     *d_result = result;
     return KZG_OK;

@@ -74,7 +74,20 @@ int srs_choose_window(int opt_window_bits, size_t n) {
 }
 
 // window bits, windows, resident table rows for an SRS of n points under the given options
-void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c_out, int *W_out, int *rows_out, bool *narrow17_out) {
+constexpr int NAF_ROWS = 255;  // positional tables: bit positions 0..254 of a balanced scalar (k or r - k, below 2^254)
+
+void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c_out, int *W_out, int *rows_out, bool *narrow17_out, int opt_naf,
+               int *naf_out) {
+    if (naf_out) *naf_out = 0;
+    // positional tables only on request (option naf_window = 18): see kzg_srs::naf for the trade
+    if (naf_out && opt_naf == 18) {
+        *naf_out = 18;
+        *c_out = 17;       // 2^16 buckets
+        *W_out = 15;       // digits are >= 18 positions apart: at most 15 of them below bit 255
+        *rows_out = NAF_ROWS;
+        *narrow17_out = true;
+        return;
+    }
     int c = srs_choose_window(opt_window_bits, n);
     int W = (256 + c - 1) / c;
     // c = 17: 255 = 15 x 17, and a scalar k >= 2^254 is replaced by -(r - k) (all digit signs flipped), so the top window never
@@ -93,7 +106,8 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     kzg_srs *s = new kzg_srs();
     s->n = n;
     s->npad = n ? n : 1;
-    srs_shape(ctx->opt_window_bits, ctx->opt_window_rows, n, &s->c, &s->W, &s->rows, &s->narrow17);
+    srs_shape(ctx->opt_window_bits, ctx->opt_window_rows, n, &s->c, &s->W, &s->rows, &s->narrow17, ctx->opt_naf_window, &s->naf);
+    s->row_shift = s->naf ? 1 : s->c;
     s->device = ctx->device;
     // `table` keeps row 0 only (the points themselves, canonical saturated form: download, re-upload);
     // the window rows live in the 30-bit table built by srs_precompute.
@@ -121,7 +135,8 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
     hipStream_t st = ctx->lanes[0].stream;
     const size_t n = srs->n;
     size_t npts = (size_t)srs->rows * srs->npad;
-    KZG_HIP_CHECK(ctx, hipMalloc(&srs->table30, npts * sizeof(G1Affine30)));
+    hipError_t e30 = hipMalloc(&srs->table30, npts * sizeof(G1Affine30));
+    if (e30 != hipSuccess) return fail(ctx, KZG_ERR_ALLOC, std::string("hipMalloc(SRS window table): ") + hipGetErrorString(e30));
     G1Affine30 *t30 = (G1Affine30 *)srs->table30;
     const size_t CHUNK = (size_t)1 << 20;
     size_t chunk = n < CHUNK ? n : CHUNK;
@@ -137,7 +152,7 @@ int srs_precompute(kzg_ctx *ctx, kzg_srs *srs) {
         G1Affine *cur = rows[w & 1];
         for (size_t o = 0; o < n; o += chunk) {
             size_t m = n - o < chunk ? n - o : chunk;
-            KZG_LAUNCH(ctx, st, "k_dbl_c", k_dbl_c, (unsigned)((m + 255) / 256), 256, 0, prev + o, tmp, m, srs->c);
+            KZG_LAUNCH(ctx, st, "k_dbl_c", k_dbl_c, (unsigned)((m + 255) / 256), 256, 0, prev + o, tmp, m, srs->row_shift);
             KZG_TRY(batch_to_affine(ctx, st, tmp, cur + o, m));
         }
         KZG_LAUNCH(ctx, st, "k_table_to30", k_table_to30, gn, 256, 0, cur, t30 + (size_t)w * srs->npad, n);
@@ -566,7 +581,8 @@ extern "C" int kzg_srs_footprint(size_t n, int window_bits, int window_rows, siz
     if (!bytes || (window_bits != 0 && (window_bits < 4 || window_bits > 20)) || window_rows < 0) return KZG_ERR_SHAPE;
     int c, W, rows;
     bool n17;
-    srs_shape(window_bits, window_rows, n, &c, &W, &rows, &n17);
+    int naf = 0;
+    srs_shape(window_bits, window_rows, n, &c, &W, &rows, &n17, 0, &naf);  // the default policy: window tables
     const size_t npad = n ? n : 1;
     *bytes = npad * (sizeof(G1Affine) + (size_t)rows * sizeof(G1Affine30));
     return KZG_OK;
@@ -576,7 +592,7 @@ extern "C" int kzg_srs_table_rows(const kzg_srs *srs) { return srs ? srs->rows :
 
 extern "C" int kzg_srs_window_info(const kzg_srs *srs, int *window_bits, int *windows) {
     if (!srs) return KZG_ERR_SHAPE;
-    if (window_bits) *window_bits = srs->c;
+    if (window_bits) *window_bits = srs->naf ? srs->naf : srs->c;  // positional tables: the NAF width (18)
     if (windows) *windows = srs->W;
     return KZG_OK;
 }

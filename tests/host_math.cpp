@@ -34,6 +34,7 @@ void hm_fq_inv_fermat(const uint32_t *a, uint32_t *o) { Fq x; memcpy(x.v, a, 48)
 void hm_fr_inv_fermat(const uint32_t *a, uint32_t *o) { Fr x; memcpy(x.v, a, 32); Fr z = inv_fermat(x); memcpy(o, z.v, 32); }
 }
 #include "../kzg_amd/csrc/curve30.h"
+#include "../kzg_amd/csrc/naf.h"
 extern "C" {
 // Fq30: x*R384 (48 B) -> to30 -> mul30 -> from30 -> 48 B, must equal the saturated Montgomery product
 void hm_mul30(const uint32_t *a, const uint32_t *b, uint32_t *o) { Fq x, y; memcpy(x.v, a, 48); memcpy(y.v, b, 48);
@@ -52,6 +53,9 @@ void hm_mul30_sub_raw(const int32_t *a, const int32_t *b, const int32_t *c, int3
     memcpy(u.v, c, 52); Fq30 z = mul30_sub(x, y, u); memcpy(o, z.v, 52); }
 void hm_sqr30_sub2_raw(const int32_t *a, const int32_t *c, const int32_t *e, int32_t *o) { Fq30 x, u, w; memcpy(x.v, a, 52); memcpy(u.v, c, 52);
     memcpy(w.v, e, 52); Fq30 z = sqr30_sub2(x, u, w); memcpy(o, z.v, 52); }
+// width-18 NAF recoding (naf.h): k as 8 limbs (below 2^254) -> up to 15 digit records
+int hm_naf18(const uint32_t *k, uint32_t flip, uint32_t *out) { uint32_t L[12]; for (int i = 0; i < 8; i++) L[i] = k[i]; L[8] = L[9] = L[10] = L[11] = 0;
+    return naf18_digits(L, flip, out); }
 void hm_normalize30_raw(const int32_t *a, int32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq30 z = normalize30(x); memcpy(o, z.v, 52); }
 void hm_from30_raw(const int32_t *a, uint32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq z = from30(x); memcpy(o, z.v, 48); }
 // chain of n mixed additions in the 30-bit representation: acc = first; acc += pts[i] (sign bit i of `signs`)

@@ -104,15 +104,20 @@ def test_golden_verify(engine):
         h.free()
 
 
+@pytest.mark.parametrize("naf", [0, 18], ids=["windows_c17", "positional_naf18"])
 @pytest.mark.parametrize("case", GU.load("prod.json")["commits"], ids=lambda c: f"2^{c['log_n']}_seed{c['seed']}")
-def test_golden_production_path_commit(engine, case):
+def test_golden_production_path_commit(engine, case, naf):
     """tests/golden/prod.json: commitments at the sizes where the production MSM path runs (17-bit windows, two-level sort, 15
     table rows), computed by oracle/kzg_model.py alone (coefficient stream, Horner, one scalar multiplication).  Nothing on the
     right-hand side comes from this process: 48 committed bytes per case."""
     tau = GU.sc(GU.load("prod.json")["tau"])
     n = 1 << case["log_n"]
-    params = kzg_amd.setup(engine, tau, n, g2_len=0)
-    assert params.gs.window_info() == (17, 15)
+    engine.set_option("naf_window", naf)          # both production table layouts against the same 48 committed bytes
+    try:
+        params = kzg_amd.setup(engine, tau, n, g2_len=0)
+    finally:
+        engine.set_option("naf_window", 0)
+    assert params.gs.window_info() == ((18, 15) if naf else (17, 15))
     buf = engine.alloc_scalars(n).fill_random(case["seed"], u64_valued=case["u64_valued"])
     import ctypes
     out = ctypes.create_string_buffer(48)

@@ -291,3 +291,39 @@ def test_fr29_ntt_arithmetic(L):
                 t = V * w % R
                 U, V = (U + t) % R, (U - t) % R
             assert int.from_bytes(ou.raw, "little") == U and int.from_bytes(ov.raw, "little") == V
+
+
+def test_naf18_recoding(L):
+    """naf.h: the width-18 NAF digits of the positional tables.  k = sum d 2^p exactly, digits odd with |d| < 2^17, positions at
+    least 18 apart and below 255, at most 15 of them, sign combined with the flip of a balanced scalar; edge patterns: 0, 1, runs
+    of ones (a carry through the whole run), alternating bits, the largest balanced value, digits at the very top."""
+    import struct
+    rng = random.Random(1818)
+
+    def recode(k, flip=0):
+        out = (ctypes.c_uint32 * 15)()
+        cnt = L.hm_naf18(k.to_bytes(32, "little"), flip, out)
+        return [out[i] for i in range(cnt)]
+
+    cases = [0, 1, 2, 3, (1 << 17) - 1, 1 << 17, (1 << 17) + 1, (1 << 18) - 1, 1 << 18, (1 << 254) - 1, (1 << 253) + 1, (1 << 254) - (1 << 200),
+             int("aaaaaaaa" * 8, 16) >> 2, int("55555555" * 8, 16) >> 2, (1 << 64) - 1, (1 << 128) - 1, ((1 << 254) - 1) ^ ((1 << 100) - 1),
+             (M.R - 1) // 2, M.R - (M.R >> 1), (1 << 236) * ((1 << 17) + 1), (1 << 237) * ((1 << 17) - 1)]
+    cases += [rng.randrange(1 << 254) for _ in range(3000)] + [rng.getrandbits(64) for _ in range(300)]
+    cases += [rng.getrandbits(rng.randrange(1, 254)) for _ in range(1000)]
+    total = 0
+    for k in cases:
+        assert k < (1 << 254)
+        for flip in (0, 1):
+            recs = recode(k, flip)
+            assert len(recs) <= 15
+            val, last = 0, -18
+            for r in recs:
+                assert r >> 31 == 1
+                idx, sign, p = r & 0x1ffff, (r >> 17) & 1, (r >> 18) & 0xff
+                mag = 2 * idx + 1
+                assert mag < (1 << 17) and p - last >= 18 and p <= 254
+                last = p
+                val += (-mag if sign ^ flip else mag) << p
+            assert val == k, hex(k)
+        total += len(recs)
+    assert total / len(cases) < 14.2
