@@ -27,6 +27,9 @@ struct alignas(16) G1Affine30 {  // table entry: x, y normalised; identity = all
     Fq30 x, y;
     uint32_t pad[(KZG_ROW_BYTES - 104) / 4];
     KZG_HD bool is_inf() const { return x.limbs_all_zero() && y.limbs_all_zero(); }
+    // the same test for a VALIDATED table entry, on y alone: the curve has odd order (no point of order two, so y != 0 on every
+    // finite point), and a table coordinate is below q in magnitude, so y = 0 mod q means all limbs zero
+    KZG_HD bool is_inf_table() const { return y.limbs_all_zero(); }
 };
 
 struct alignas(16) G1Xyzz30 {  // 224 B: what the MSM partial-sum buffers hold
@@ -176,24 +179,35 @@ KZG_HD G1Xyzz30 g1_madd30_phase2(const G1Xyzz30 &p, const Madd30Mid &m, bool neg
         if (!is_zero30(sqr30(R))) return G1Xyzz30::infinity();
         return g1_dbl30(g1_from_affine30(reload(), negate));
     }
+    // X3, ZZ3, ZZZ3 and Q come out with UNSIGNED digits (field30.h mul30u: no rounding add per digit).  Each of them only ever
+    // meets a balanced partner again -- x2, y2, PP, PPP -- or a subtraction; P, R, PP, PPP, Y3 stay balanced.  A point that
+    // leaves the accumulation loop is normalised first (g1_normalize30).
     Fq30 PPP = mul30(Pp, PP);
-    Fq30 Q = mul30(p.x, PP);
+    Fq30 Q = mul30u(p.x, PP);
     G1Xyzz30 r;
     r.inf = 0;
     r.pad[0] = r.pad[1] = r.pad[2] = 0;
-    r.zz = mul30(p.zz, PP);
-    r.zzz = mul30(p.zzz, PPP);
-    r.x = sqr30_sub2(R, PPP, Q);  // X3 = R^2 - PPP - 2Q, one digit extraction
+    r.zz = mul30u(p.zz, PP);
+    r.zzz = mul30u(p.zzz, PPP);
+    r.x = sqr30_sub2u(R, PPP, Q);  // X3 = R^2 - PPP - 2Q, one digit extraction
     // Y3 = R (Q - X3) + (-Y1) PPP: one double-width accumulation, one reduction
     r.y = muladd30(R, sub30(Q, r.x), neg30(p.y), PPP);
     return r;
+}
+
+// the accumulator of a madd chain back in the form every other operation expects (balanced digits)
+KZG_HD G1Xyzz30 g1_normalize30(G1Xyzz30 p) {
+    p.x = normalize30(p.x);
+    p.zz = normalize30(p.zz);
+    p.zzz = normalize30(p.zzz);
+    return p;
 }
 
 KZG_HD G1Xyzz30 g1_madd30(const G1Xyzz30 &p, const G1Affine30 &a, bool negate) {
     if (a.is_inf()) return p;
     if (p.inf) return g1_from_affine30(a, negate);
     Madd30Mid m = g1_madd30_phase1(p, a, negate);
-    return g1_madd30_phase2(p, m, negate, [&]() { return a; });
+    return g1_normalize30(g1_madd30_phase2(p, m, negate, [&]() { return a; }));
 }
 
 }  // namespace kzg

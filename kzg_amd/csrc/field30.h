@@ -56,6 +56,11 @@ KZG_HD uint64_t sar30(uint64_t acc) { return (uint64_t)((int64_t)acc >> F30_B); 
 
 // Montgomery product a*b/R30 mod q, balanced: |result| <= |a*b|/R30 + q/2.  Operand limbs |.| <= 2^29.
 // Result normalised.
+// UNSIGNED_OUT: the output digits 0..11 come out in [0, 2^30) (floor carries) instead of balanced -- one instruction less per
+// digit (no rounding add).  Such a value may be ONE operand of a later product whose other operand is balanced: a column then
+// holds at most 12 products below 2^59 plus the m*q part, 2^29 * sum |q_j| = 2^60.6 for this q: 2^62.93 in all (host-checked at
+// the extremes, tests/test_host_math.py); two unsigned operands would overflow.  Subtraction operands may be either.
+template <bool UNSIGNED_OUT = false>
 KZG_HD Fq30 mul30_inline(const Fq30 &a, const Fq30 &b) {
     int32_t m[F30_N];
     Fq30 r;
@@ -77,8 +82,13 @@ KZG_HD Fq30 mul30_inline(const Fq30 &a, const Fq30 &b) {
             acc = mac30(acc, a.v[i], b.v[k - i]);
             acc = mac30(acc, m[i], Fq30Consts::mod(k - i));
         }
-        r.v[k - F30_N] = sext30((uint32_t)acc);
-        acc = sar30(acc + (uint64_t)F30_HALF);
+        if (UNSIGNED_OUT) {
+            r.v[k - F30_N] = (int32_t)((uint32_t)acc & F30_MASK);
+            acc = sar30(acc);
+        } else {
+            r.v[k - F30_N] = sext30((uint32_t)acc);
+            acc = sar30(acc + (uint64_t)F30_HALF);
+        }
     }
     r.v[F30_N - 1] = (int32_t)acc;
     return r;
@@ -200,6 +210,7 @@ KZG_HD Fq30 sqr30_inline(const Fq30 &a) {
 }
 
 // a^2/R30 - c - 2e, both subtrahends merged into the square's output columns (X3 = R^2 - PPP - 2Q of the mixed addition).
+template <bool UNSIGNED_OUT = false>
 KZG_HD Fq30 sqr30_sub2_inline(const Fq30 &a, const Fq30 &c, const Fq30 &e) {
     int32_t m[F30_N], d[F30_N];
     Fq30 r;
@@ -226,8 +237,13 @@ KZG_HD Fq30 sqr30_sub2_inline(const Fq30 &a, const Fq30 &c, const Fq30 &e) {
         for (int i = k - F30_N + 1; i < F30_N; i++) acc = mac30(acc, m[i], Fq30Consts::mod(k - i));
         acc = mac30(acc, c.v[k - F30_N], -1);
         acc = mac30(acc, e.v[k - F30_N], -2);
-        r.v[k - F30_N] = sext30((uint32_t)acc);
-        acc = sar30(acc + (uint64_t)F30_HALF);
+        if (UNSIGNED_OUT) {
+            r.v[k - F30_N] = (int32_t)((uint32_t)acc & F30_MASK);
+            acc = sar30(acc);
+        } else {
+            r.v[k - F30_N] = sext30((uint32_t)acc);
+            acc = sar30(acc + (uint64_t)F30_HALF);
+        }
     }
     acc = mac30(acc, c.v[F30_N - 1], -1);
     acc = mac30(acc, e.v[F30_N - 1], -2);
@@ -268,7 +284,7 @@ __device__ __noinline__ i32x13 mul30_ool(i32x13 a, i32x13 b) {
         x.v[i] = a[i];
         y.v[i] = b[i];
     }
-    Fq30 z = mul30_inline(x, y);
+    Fq30 z = mul30_inline<false>(x, y);
     i32x13 r;
 #pragma unroll
     for (int i = 0; i < F30_N; i++) r[i] = z.v[i];
@@ -297,7 +313,7 @@ KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) { return mul30_asm(a, b); }
 KZG_HD Fq30 sqr30(const Fq30 &a) { return sqr30_asm(a); }
 #define KZG_HAVE_MULADD30_ASM 1
 #else
-KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) { return mul30_inline(a, b); }
+KZG_HD Fq30 mul30(const Fq30 &a, const Fq30 &b) { return mul30_inline<false>(a, b); }
 KZG_HD Fq30 sqr30(const Fq30 &a) { return sqr30_inline(a); }
 #endif
 
@@ -320,7 +336,28 @@ KZG_HD Fq30 sqr30_sub2(const Fq30 &a, const Fq30 &c, const Fq30 &e) {
 #elif defined(KZG_HAVE_MULADD30_ASM)
     return sqr30_sub2_asm(a, c, e);
 #else
-    return sqr30_sub2_inline(a, c, e);
+    return sqr30_sub2_inline<false>(a, c, e);
+#endif
+}
+
+// unsigned-digit outputs (see mul30_inline): for products whose result meets only balanced partners afterwards.
+// -DKZG_NO_UNSIGNED_DIGITS: the balanced versions (A/B builds).
+KZG_HD Fq30 mul30u(const Fq30 &a, const Fq30 &b) {
+#if defined(KZG_NO_UNSIGNED_DIGITS)
+    return mul30(a, b);
+#elif defined(KZG_HAVE_MULADD30_ASM)
+    return mul30u_asm(a, b);
+#else
+    return mul30_inline<true>(a, b);
+#endif
+}
+KZG_HD Fq30 sqr30_sub2u(const Fq30 &a, const Fq30 &c, const Fq30 &e) {
+#if defined(KZG_NO_UNSIGNED_DIGITS) || defined(KZG_NO_MERGED_SUB)
+    return sqr30_sub2(a, c, e);
+#elif defined(KZG_HAVE_MULADD30_ASM)
+    return sqr30_sub2u_asm(a, c, e);
+#else
+    return sqr30_sub2_inline<true>(a, c, e);
 #endif
 }
 

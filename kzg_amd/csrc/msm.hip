@@ -779,13 +779,13 @@ __global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uin
         int mode = 0;
         Madd30Mid mid;
         if (k == bend) {  // bucket boundary: flush and restart
-            out[pos++] = acc;
+            out[pos++] = g1_normalize30(acc);
             do {
                 b++;
                 bend = bucket_start[b + 1];
             } while (bend <= k);
             mode = 1;
-        } else if (cur.is_inf()) {
+        } else if (cur.is_inf_table()) {
             mode = 2;
         } else if (acc.inf) {
             mode = 1;
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256, KZG_ACCUM_WAVES) void k_accum_affine(const uin
         }
         if (mode == 0) acc = g1_madd30_phase2(acc, mid, neg_k, [&]() { return load_entry_point30(table30, ent_k); });
     }
-    out[pos] = acc;
+    out[pos] = g1_normalize30(acc);
 }
 
 __global__ __launch_bounds__(256) void k_sum_level(const MsmPoint *in, uint32_t count, int L, MsmPoint *out) {

@@ -56,6 +56,10 @@ void hm_sqr30_sub2_raw(const int32_t *a, const int32_t *c, const int32_t *e, int
 // width-18 NAF recoding (naf.h): k as 8 limbs (below 2^254) -> up to 15 digit records
 int hm_naf18(const uint32_t *k, uint32_t flip, uint32_t *out) { uint32_t L[12]; for (int i = 0; i < 8; i++) L[i] = k[i]; L[8] = L[9] = L[10] = L[11] = 0;
     return naf18_digits(L, flip, out); }
+void hm_mul30u_raw(const int32_t *a, const int32_t *b, int32_t *o) { Fq30 x, y; memcpy(x.v, a, 52); memcpy(y.v, b, 52);
+    Fq30 z = mul30u(x, y); memcpy(o, z.v, 52); }
+void hm_sqr30_sub2u_raw(const int32_t *a, const int32_t *c, const int32_t *e, int32_t *o) { Fq30 x, u, w; memcpy(x.v, a, 52); memcpy(u.v, c, 52);
+    memcpy(w.v, e, 52); Fq30 z = sqr30_sub2u(x, u, w); memcpy(o, z.v, 52); }
 void hm_normalize30_raw(const int32_t *a, int32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq30 z = normalize30(x); memcpy(o, z.v, 52); }
 void hm_from30_raw(const int32_t *a, uint32_t *o) { Fq30 x; memcpy(x.v, a, 52); Fq z = from30(x); memcpy(o, z.v, 48); }
 // chain of n mixed additions in the 30-bit representation: acc = first; acc += pts[i] (sign bit i of `signs`)
@@ -66,6 +70,21 @@ void hm_madd30_chain(const uint32_t *pts, int n, uint64_t signs, uint32_t *o) {
     G1Affine r = g1_to_affine(g1_xyzz_from30(acc)); memcpy(o, &r, 96); }
 }
 extern "C" {
+// the same chain the way k_accum_affine runs it: phase 1 / phase 2 with the accumulator left in its lazy form (unsigned digits
+// in X, ZZ, ZZZ) across iterations, identity / restart handled as in the kernel, normalised once at the end
+void hm_madd30_chain_kernel_form(const uint32_t *pts, int n, uint64_t signs, uint32_t *o) {
+    const G1Affine *p = (const G1Affine *)pts;
+    G1Affine30 first = g1_affine_to30(p[0]);
+    G1Xyzz30 acc = g1_from_affine30(first, signs & 1);
+    for (int i = 1; i < n; i++) {
+        const G1Affine30 cur = g1_affine_to30(p[i]);
+        const bool neg = (signs >> i) & 1;
+        if (cur.is_inf()) continue;
+        if (acc.inf) { acc = g1_from_affine30(cur, neg); continue; }
+        Madd30Mid mid = g1_madd30_phase1(acc, cur, neg);
+        acc = g1_madd30_phase2(acc, mid, neg, [&]() { return cur; });
+    }
+    G1Affine r = g1_to_affine(g1_xyzz_from30(g1_normalize30(acc))); memcpy(o, &r, 96); }
 // general 30-bit addition / doubling on de-normalised operands built from madd30 / dbl30 chains
 void hm_add30(const uint32_t *a, const uint32_t *b, uint32_t *o) { G1Affine x, y; memcpy(&x, a, 96); memcpy(&y, b, 96);
     G1Affine30 x30 = g1_affine_to30(x), y30 = g1_affine_to30(y);

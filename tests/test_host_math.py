@@ -139,8 +139,10 @@ def test_fq30_unsaturated_layer(L):
     G, INF = C.g1_generator(), bytes(96)
 
     def chain(ps, signs):
-        o = ctypes.create_string_buffer(96)
+        o, o2 = ctypes.create_string_buffer(96), ctypes.create_string_buffer(96)
         L.hm_madd30_chain(b"".join(ps), len(ps), ctypes.c_uint64(signs), o)
+        L.hm_madd30_chain_kernel_form(b"".join(ps), len(ps), ctypes.c_uint64(signs), o2)   # lazy accumulator, as k_accum_affine
+        assert o.raw == o2.raw
         return o.raw
 
     def ref(ps, signs):
@@ -156,8 +158,8 @@ def test_fq30_unsaturated_layer(L):
              ([INF, INF, P, P], 0b1000), ([P, P, P], 0b010), ([P] + [pts[1]] * 5, 0), ([P, P, pts[2], P, P], 0b11000)]
     for ps, s in cases:            # doubling, inverse, identity points, infinity mid-chain
         assert chain(ps, s) == ref(ps, s), (len(ps), s)
-    for trial in range(6):         # random chains (the lazy-reduction bounds are exercised repeatedly)
-        k = rng.randrange(2, 40)
+    for trial in range(8):         # random chains (the lazy-reduction bounds are exercised repeatedly)
+        k = rng.randrange(2, 40) if trial < 6 else 64
         ps = [rng.choice(pts) if rng.random() < 0.3 else C.g1_mul(G, rng.randrange(1, M.R)) for _ in range(k)]
         s = rng.getrandbits(k)
         assert chain(ps, s) == ref(ps, s)
@@ -243,6 +245,37 @@ def test_fq30_raw_limb_bounds(L):
                 assert all(-H <= v < H for v in r[:12]), r
                 assert ((val(r) + val(u) + 2 * val(e)) * R30 - val(a) ** 2) % M.Q == 0
                 assert abs(val(r)) <= val(a) ** 2 // R30 + M.Q // 2 + abs(val(u)) + 2 * abs(val(e)) + 2
+    # unsigned-digit outputs (mul30u, sqr30_sub2u) and their use as ONE operand of the next product: balanced x unsigned at the
+    # extremes (every unsigned digit 2^30 - 1 against every balanced digit +-2^29: the column bound 2^62.93 of field30.h)
+    U = (1 << B) - 1
+
+    def ulimbs(kind):
+        if kind == "umax":
+            l = [U] * 12
+        elif kind == "uzero":
+            l = [0] * 12
+        else:
+            l = [rng.randrange(0, 1 << B) for _ in range(12)]
+        return l + [rng.randrange(-(1 << 23), 1 << 23)]
+
+    for ka in kinds:
+        for ku in ("umax", "umax", "urnd", "urnd", "uzero"):
+            a, u = limbs(ka), ulimbs(ku)
+            for fn in (L.hm_mul30u_raw, L.hm_mul30_raw):            # unsigned operand into both output flavours
+                r = out(fn, a, u)
+                assert ((val(r)) * R30 - val(a) * val(u)) % M.Q == 0, (ka, ku)
+                assert abs(val(r)) <= abs(val(a) * val(u)) // R30 + M.Q // 2 + 2
+                if fn is L.hm_mul30u_raw:
+                    assert all(0 <= v < (1 << B) for v in r[:12]), r
+                else:
+                    assert all(-H <= v < H for v in r[:12]), r
+            r = out(L.hm_mul30_sub_raw, a, u, ulimbs("umax"))       # unsigned operand and unsigned subtrahend
+            assert all(-H <= v < H for v in r[:12])
+            if ka != "neg_of_min":
+                c, e = limbs(ka), ulimbs(ku)
+                r = out(L.hm_sqr30_sub2u_raw, a, c, e)
+                assert all(0 <= v < (1 << B) for v in r[:12]), r
+                assert ((val(r) + val(c) + 2 * val(e)) * R30 - val(a) ** 2) % M.Q == 0
     # same-sign worst case for every column at once
     a = [H] * 12 + [1 << 20]
     check(out(L.hm_muladd30_raw, a, a, a, a), 2 * val(a) ** 2, 0.5001 + 2 * val(a) ** 2 / M.Q / M.Q * qr)

@@ -51,7 +51,14 @@ def q(j):
     return f"Fq30Consts::mod({j})"
 
 
-def gen_mul(name="mul30_asm", subs=()):
+def digit_out(k, unsigned_out):
+    """the output digit of column k and the carry into the next one: balanced (round to nearest) or unsigned (floor: no rounding add)"""
+    if unsigned_out:
+        return f"    r.v[{k - N}] = (int32_t)((uint32_t)acc & F30_MASK);\n    acc = sar30(acc);\n"
+    return f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+
+
+def gen_mul(name="mul30_asm", subs=(), unsigned_out=False):
     """subs: ((operand, constant), ...): the result is a*b/R + sum constant * operand, the extra terms entering the output
     columns as one v_mad_i64_i32 by an inline constant each (a subtraction merged into the product: no separate limb-wise
     subtraction and carry pass, and the result comes out normalised)."""
@@ -69,14 +76,14 @@ def gen_mul(name="mul30_asm", subs=()):
             prods.append((f"m[{i}]", "v", q(k - i), "s"))
         prods += [(f"{o}.v[{k - N}]", "v", str(c), "i") for o, c in subs]
         s += emit_products(prods)
-        s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+        s += digit_out(k, unsigned_out)
     if subs:
         s += emit_products([(f"{o}.v[{N - 1}]", "v", str(c), "i") for o, c in subs])
     s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
     return s
 
 
-def gen_sqr(name="sqr30_asm", subs=()):
+def gen_sqr(name="sqr30_asm", subs=(), unsigned_out=False):
     args = "".join(f", const Fq30 &{o}" for o, _ in subs)
     s = (f"__device__ __forceinline__ Fq30 {name}(const Fq30 &a{args}) {{\n    int32_t m[F30_N], d[F30_N];\n    Fq30 r;\n"
          "#pragma unroll\n    for (int i = 0; i < F30_N; i++) d[i] = a.v[i] * 2;\n    uint64_t acc = 0;\n")
@@ -94,7 +101,7 @@ def gen_sqr(name="sqr30_asm", subs=()):
         prods = cross(k, k - N + 1) + [(f"m[{i}]", "v", q(k - i), "s") for i in range(k - N + 1, N)]
         prods += [(f"{o}.v[{k - N}]", "v", str(c), "i") for o, c in subs]
         s += emit_products(prods)
-        s += f"    r.v[{k - N}] = sext30((uint32_t)acc);\n    acc = sar30(acc + (uint64_t)F30_HALF);\n"
+        s += digit_out(k, unsigned_out)
     if subs:
         s += emit_products([(f"{o}.v[{N - 1}]", "v", str(c), "i") for o, c in subs])
     s += f"    r.v[{N - 1}] = (int32_t)acc;\n    return r;\n}}\n"
@@ -161,7 +168,8 @@ def gen_fr29():
 
 def main(dst):
     out = ("// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_mul() + gen_sqr() + gen_muladd() +
-           gen_mul("mul30_sub_asm", (("c", -1),)) + gen_sqr("sqr30_sub2_asm", (("c", -1), ("e", -2))))
+           gen_mul("mul30_sub_asm", (("c", -1),)) + gen_sqr("sqr30_sub2_asm", (("c", -1), ("e", -2))) +
+           gen_mul("mul30u_asm", unsigned_out=True) + gen_sqr("sqr30_sub2u_asm", (("c", -1), ("e", -2)), unsigned_out=True))
     open(dst, "w").write(out)
     print("wrote", dst)
     if len(sys.argv) > 2:
