@@ -351,6 +351,7 @@ constexpr int BIN_SHIFT = 6, BIN_BUCKETS = 1 << BIN_SHIFT, NBINS = 1024;
 
 __global__ __launch_bounds__(1024) void k_bin_hist(const Fr *scalars, size_t n, int sfmt, size_t per_block, uint32_t *blk_bins,
                                                    int w_lo, int w_hi) {
+    KZG_SIDE_PRIO_STMT;
     __shared__ uint32_t h[NBINS];
     for (int b = threadIdx.x; b < NBINS; b += blockDim.x) h[b] = 0;
     __syncthreads();
@@ -396,6 +397,7 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *wsum /
 constexpr int BIN_SCAN_SLICES = 16, BIN_SCAN_MAXG = 32;
 constexpr int SORT2_MAX_BLOCKS = BIN_SCAN_SLICES * BIN_SCAN_MAXG;  // level-1 sort blocks k_bin_scan can chain (512)
 __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *blk_bins, int G, uint32_t *bin_total, uint32_t *ready) {
+    KZG_SIDE_PRIO_STMT;
     __shared__ uint32_t part[BIN_SCAN_SLICES][64];
     if (blockIdx.x == 0 && threadIdx.x < SCAN_SEG) ready[threadIdx.x] = 0;  // k_scan_b's chained flag counts
     const int binl = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -457,6 +459,7 @@ template <class REC>
 __global__ __launch_bounds__(1024) void k_bin_scatter(const Fr *scalars, size_t n, int sfmt, size_t per_block, const uint32_t *blk_off,
                                                       const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
                                                       uint32_t idx_base, typename REC::T *rec, int w_lo, int w_hi) {
+    KZG_SIDE_PRIO_STMT;
     uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS, *stage = wsum + 16;
     const uint32_t tid = threadIdx.x;
     {   // bin_base = exclusive scan of the bin sizes (every block computes it; block 0 publishes it for the later kernels)
@@ -611,6 +614,7 @@ constexpr int BIN_SORT_THREADS = 256, BIN_SORT_UNROLL = 8, BIN_SORT_CHUNK = BIN_
 template <class REC>
 __global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const typename REC::T *rec, const uint32_t *bin_base, uint32_t *entries,
                                                                uint32_t *total) {
+    KZG_SIDE_PRIO_STMT;
     typedef typename REC::T RT;
     __shared__ uint32_t h[BIN_BUCKETS], cur[BIN_BUCKETS], off[BIN_BUCKETS];
     __shared__ RT stage[BIN_SORT_CHUNK];
@@ -684,6 +688,7 @@ __global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const typename RE
 __global__ __launch_bounds__(SCAN_SEG) void k_scan_b_bins(const uint32_t *total, const uint32_t *bin_base, int B, int NB,
                                                           uint32_t *bucket_start, uint32_t *s1, MsmState *st, uint32_t slots,
                                                           uint32_t *ready) {
+    KZG_SIDE_PRIO_STMT;
     __shared__ uint32_t lds[4];
     const uint32_t M = bin_base[NBINS];
     const uint32_t my_prefix = bin_base[blockIdx.x * (SCAN_SEG / BIN_BUCKETS)];
@@ -824,6 +829,7 @@ __device__ __forceinline__ size_t format_bytes_dev(int fmt) {
 }
 
 __global__ __launch_bounds__(64) void k_emit_points(const MsmPoint *pts, size_t count, size_t stride_pts, uint8_t *out, int fmt) {
+    KZG_SIDE_PRIO_STMT;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     emit_one(pts[i * stride_pts], out + i * format_bytes_dev(fmt), fmt);

@@ -5,6 +5,17 @@
 #pragma once
 #include "common.h"
 
+// Wave priority of the sort and tail kernels (s_setprio, 0..3): they are the short, latency-bound kernels of the pipeline and run
+// next to the long accumulation kernels, whose waves are older and therefore win the VALU arbitration (priority, then age).
+#ifndef KZG_SIDE_PRIO
+#define KZG_SIDE_PRIO 0
+#endif
+#if KZG_SIDE_PRIO > 0
+#define KZG_SIDE_PRIO_STMT __builtin_amdgcn_s_setprio(KZG_SIDE_PRIO)
+#else
+#define KZG_SIDE_PRIO_STMT ((void)0)
+#endif
+
 namespace kzg {
 
 constexpr uint32_t ACC_SLOTS = 256 * 4 * KZG_ACCUM_WAVES * 64;  // resident threads of k_accum_affine: 256 CUs x 4 SIMDs x waves/SIMD x 64

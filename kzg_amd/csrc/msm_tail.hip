@@ -61,6 +61,7 @@ __device__ __forceinline__ MsmPoint wave_sum(const MsmPoint *p, uint32_t lo, uin
 template <int G>
 __global__ __launch_bounds__(256) void k_fold_dense(const MsmPoint *part, const uint32_t *s1, int B, MsmPoint *dense, MsmState *st,
                                                     uint32_t *tasks, uint32_t *arrive) {
+    KZG_SIDE_PRIO_STMT;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid / G, g = gid % G;
     if (b >= (uint32_t)B) return;
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(const MsmPoint *part, const 
 
 __global__ __launch_bounds__(256) void k_fold_overflow(const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, MsmPoint *dense,
                                                        const MsmState *st, const uint32_t *tasks, uint32_t *arrive) {
+    KZG_SIDE_PRIO_STMT;
     const uint32_t T = st->ovf_tasks;
     if (T == 0) return;
     const int lane = threadIdx.x & 63;
@@ -110,6 +112,7 @@ __global__ __launch_bounds__(256) void k_fold_overflow(const MsmPoint *part, Msm
 }
 
 __global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
+    KZG_SIDE_PRIO_STMT;
     const int lane = threadIdx.x & 63;
     const int wv = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wv >= Rn + Cn) return;
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, 
 // sums instead of 72 (a butterfly level costs a full addition for half the useful work of the level before).
 constexpr int RC_LANES = 8;
 __global__ __launch_bounds__(256) void k_rc_sums_t(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
+    KZG_SIDE_PRIO_STMT;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int sum = gid / RC_LANES, l = gid % RC_LANES;
     if (sum >= Rn + Cn) return;  // uniform over the lane group
@@ -149,6 +153,7 @@ __global__ __launch_bounds__(256) void k_rc_sums_t(const MsmPoint *dense, int Rn
 
 // Q[j] (j < lr): sum of rows whose index has bit j set; Q[lr + j] (j < lc): the same for the columns; Q[lr + lc]: all columns
 __global__ __launch_bounds__(256) void k_weighted_bits(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
+    KZG_SIDE_PRIO_STMT;
     const int lane = threadIdx.x & 63;
     const int wv = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     if (wv > lr + lc) return;
@@ -173,6 +178,7 @@ __global__ __launch_bounds__(256) void k_weighted_bits(const MsmPoint *rows, con
 // odd (positional tables: bucket b holds the digits of magnitude 2 b + 1): 2 sum_b b B_b + sum_b B_b -- every bit slice one
 // doubling more, the plain total as it is.
 __global__ __launch_bounds__(64) void k_reduce_final(const MsmPoint *Q, int lr, int lc, MsmPoint *result, int odd) {
+    KZG_SIDE_PRIO_STMT;
     const int lane = threadIdx.x;
     const int cnt = lr + lc + 1;
     MsmPoint p = lane < cnt ? Q[lane] : MsmPoint::infinity();
@@ -301,6 +307,7 @@ __device__ __forceinline__ MsmPoint block_quad_sum(MsmPoint acc, MsmPoint *lds, 
 }
 
 __global__ __launch_bounds__(256) void k_weighted_bits_q(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
+    KZG_SIDE_PRIO_STMT;
     __shared__ MsmPoint lds[4];
     const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
     const int wv = blockIdx.x;  // <= lr + lc
@@ -322,6 +329,7 @@ __global__ __launch_bounds__(256) void k_weighted_bits_q(const MsmPoint *rows, c
 
 // 32 quads (two waves): quad i doubles Q[i] shift_i times, then the block sum
 __global__ __launch_bounds__(128) void k_reduce_final_q(const MsmPoint *Q, int lr, int lc, MsmPoint *result, int odd) {
+    KZG_SIDE_PRIO_STMT;
     __shared__ MsmPoint lds[2];
     const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
     const int cnt = lr + lc + 1;
