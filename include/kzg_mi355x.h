@@ -52,7 +52,9 @@ extern "C" {
 #endif
 
 /* Limits (each returns KZG_ERR_SHAPE with a message in kzg_last_error; tests/test_gpu_validation.py):
- *   NTT / coset NTT / verify_poly_eval      log_n <= 24                      (two LDS passes of <= 2^12 points)
+ *   kzg_ntt_fr                              log_n <= 28                      (2^24: two LDS passes of <= 2^12 points; above: one
+ *                                                                             more four-step level of <= 16 around them)
+ *   coset NTT / verify_poly_eval / poly_mul / create_witness_batched         log_n <= 24
  *   kzg_witness_coeff_batched,
  *   kzg_verify_eval_batched                 k <= 4096 opening points          (single-workgroup interpolation kernels)
  *   kzg_srs_lagrange_from_monomial_g1       d <= 2^24;  _g2: d <= 1024

@@ -990,9 +990,10 @@ extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse,
     Guard g(ctx);
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
-    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^24 are not supported (two LDS passes of <= 2^12 points each)");
+    if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^28 are not supported (2^24-point two-pass transforms under one 16-point outer level)");
     size_t n = (size_t)1 << log_n;
-    KZG_TRY(lane_reserve(ctx, 0, n * 32 + stage_bytes(n * 32, flags) + 8192));
+    // above 2^24: the transposed copy of the whole vector + the inner transform's 2^24-element scratch + the outer twiddle tables
+    KZG_TRY(lane_reserve(ctx, 0, (log_n > 24 ? n * 32 + ((size_t)1 << 24) * 32 + (1 << 20) : n * 32) + stage_bytes(n * 32, flags) + 8192));
     hipStream_t st = ctx->lanes[0].stream;
     const void *d = nullptr;
     KZG_TRY(stage_in(ctx, 0, data, n * 32, flags, &d));

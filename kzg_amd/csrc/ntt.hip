@@ -290,9 +290,109 @@ void ntt_plans_free(kzg_ctx *ctx) {
     ctx->ntt_plans.clear();
 }
 
+// ---- sizes above 2^24: one more four-step level around the two-pass transform -------------------------------------------
+// n = A * B with B = 2^24 and A = 2^(log_n - 24) <= 16:  X[k1 + A k2] = sum_j2 w_B^(j2 k2) w_n^(j2 k1) (sum_j1 x[j1 B + j2] w_A^(j1 k1)).
+//   k_ntt_outer: thread j2 takes its A elements (stride B), an A-point transform in registers (w_A = w_n^B), times w_n^(j2 k1)
+//                (and 1/A for the inverse), back in place at [k1 B + j2];
+//   A two-pass transforms of the contiguous rows [k1 B, (k1 + 1) B)  (ntt_run, which scales by 1/B for the inverse);
+//   k_ntt_outer_transpose: [k1 B + k2] -> [k1 + A k2]  (out of place, copied back).
+// Plain saturated Fr arithmetic: this level does A + log A multiplications per element against the ~10 of the inner transform.
+template <int LOGA>
+__global__ __launch_bounds__(256) void k_ntt_outer(Fr *data, size_t B, const Fr *pw_lo, const Fr *pw_hi, uint32_t lo_bits, Fr wA, Fr scale) {
+    constexpr int A = 1 << LOGA;
+    const size_t j2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j2 >= B) return;
+    Fr x[A];
+#pragma unroll
+    for (int j1 = 0; j1 < A; j1++) x[j1] = data[(size_t)j1 * B + j2];
+    // bit-reversal + DIT stages, twiddles w_A^(j << (LOGA - 1 - s)) by repeated multiplication
+    Fr y[A];
+#pragma unroll
+    for (int i = 0; i < A; i++) {
+        int r = 0;
+#pragma unroll
+        for (int b = 0; b < LOGA; b++) r |= ((i >> b) & 1) << (LOGA - 1 - b);
+        y[r] = x[i];
+    }
+    Fr wp[A / 2 > 0 ? A / 2 : 1];  // w_A^i
+    wp[0] = Fr::one();
+#pragma unroll
+    for (int i = 1; i < A / 2; i++) wp[i] = mul(wp[i - 1], wA);
+#pragma unroll
+    for (int st = 0; st < LOGA; st++) {
+        const int m = 1 << st;
+#pragma unroll
+        for (int k = 0; k < A; k += 2 * m)
+#pragma unroll
+            for (int j = 0; j < m; j++) {
+                Fr t = j == 0 ? y[k + j + m] : mul(y[k + j + m], wp[j << (LOGA - 1 - st)]);
+                Fr u = y[k + j];
+                y[k + j] = add(u, t);
+                y[k + j + m] = sub(u, t);
+            }
+    }
+    // inter-level twiddle w_n^(j2 k1), scale folded in
+    const Fr w1 = mul(pw_hi[j2 >> lo_bits], pw_lo[j2 & (((size_t)1 << lo_bits) - 1)]);
+    Fr w = scale;
+#pragma unroll
+    for (int k1 = 0; k1 < A; k1++) {
+        data[(size_t)k1 * B + j2] = mul(y[k1], w);
+        w = mul(w, w1);
+    }
+}
+
+template <int LOGA>
+__global__ __launch_bounds__(256) void k_ntt_outer_transpose(const Fr *in, Fr *out, size_t B) {
+    constexpr int A = 1 << LOGA;
+    const size_t k2 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k2 >= B) return;
+#pragma unroll
+    for (int k1 = 0; k1 < A; k1++) out[(size_t)A * k2 + k1] = in[(size_t)k1 * B + k2];
+}
+
+int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse);
+
+static int ntt_run_large(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
+    const uint32_t la = log_n - 24;
+    const size_t B = (size_t)1 << 24, n = (size_t)1 << log_n, A = (size_t)1 << la;
+    hipStream_t st = ctx->lanes[lane].stream;
+    Fr w = host_omega(log_n);
+    if (inverse) w = inv(w);
+    const uint32_t lo_bits = 12;
+    Fr *scratch = (Fr *)lane_alloc(ctx, lane, n * sizeof(Fr));
+    Fr *pw_lo = (Fr *)lane_alloc(ctx, lane, ((size_t)1 << lo_bits) * sizeof(Fr));
+    Fr *pw_hi = (Fr *)lane_alloc(ctx, lane, (B >> lo_bits) * sizeof(Fr));
+    if (!scratch || !pw_lo || !pw_hi) return fail(ctx, KZG_ERR_ALLOC, "NTT workspace not reserved");
+    KZG_TRY(pow_table(ctx, st, w, Fr::one(), (size_t)1 << lo_bits, pw_lo));
+    KZG_TRY(pow_table(ctx, st, pow_u64(w, 1ull << lo_bits), Fr::one(), B >> lo_bits, pw_hi));
+    const Fr wA = pow_u64(w, (uint64_t)B);
+    const Fr scale = inverse ? inv(from_u64<FrParams>((uint64_t)A)) : Fr::one();
+    const unsigned grid = (unsigned)(B / 256);
+    switch (la) {
+        case 1: KZG_LAUNCH(ctx, st, "k_ntt_outer", k_ntt_outer<1>, grid, 256, 0, d_data, B, pw_lo, pw_hi, lo_bits, wA, scale); break;
+        case 2: KZG_LAUNCH(ctx, st, "k_ntt_outer", k_ntt_outer<2>, grid, 256, 0, d_data, B, pw_lo, pw_hi, lo_bits, wA, scale); break;
+        case 3: KZG_LAUNCH(ctx, st, "k_ntt_outer", k_ntt_outer<3>, grid, 256, 0, d_data, B, pw_lo, pw_hi, lo_bits, wA, scale); break;
+        default: KZG_LAUNCH(ctx, st, "k_ntt_outer", k_ntt_outer<4>, grid, 256, 0, d_data, B, pw_lo, pw_hi, lo_bits, wA, scale); break;
+    }
+    for (size_t k1 = 0; k1 < A; k1++) {
+        const size_t mark = ctx->lanes[lane].arena_used;  // the inner transform's scratch is released after each row
+        KZG_TRY(ntt_run(ctx, lane, d_data + k1 * B, 24, inverse));
+        ctx->lanes[lane].arena_used = mark;
+    }
+    switch (la) {
+        case 1: KZG_LAUNCH(ctx, st, "k_ntt_outer_transpose", k_ntt_outer_transpose<1>, grid, 256, 0, d_data, scratch, B); break;
+        case 2: KZG_LAUNCH(ctx, st, "k_ntt_outer_transpose", k_ntt_outer_transpose<2>, grid, 256, 0, d_data, scratch, B); break;
+        case 3: KZG_LAUNCH(ctx, st, "k_ntt_outer_transpose", k_ntt_outer_transpose<3>, grid, 256, 0, d_data, scratch, B); break;
+        default: KZG_LAUNCH(ctx, st, "k_ntt_outer_transpose", k_ntt_outer_transpose<4>, grid, 256, 0, d_data, scratch, B); break;
+    }
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_data, scratch, n * sizeof(Fr), hipMemcpyDeviceToDevice, st));
+    return KZG_OK;
+}
+
 int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
-    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^24 are not supported (two LDS passes of <= 2^12 points each)");
+    if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^28 are not supported (2^24-point two-pass transforms under one 16-point outer level)");
+    if (log_n > 24) return ntt_run_large(ctx, lane, d_data, log_n, inverse);
     hipStream_t st = ctx->lanes[lane].stream;
     NttPlan *p = nullptr;
     KZG_TRY(ntt_plan(ctx, st, log_n, inverse, &p));

@@ -333,6 +333,7 @@ extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int in
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     (void)sfmt;  // linear map with Montgomery constants: the data's form is preserved
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "coset NTT sizes above 2^24 are not supported");
     size_t n = (size_t)1 << log_n;
     KZG_TRY(lane_reserve(ctx, 0, 2 * n * 32 + 65536));
     hipStream_t st = ctx->lanes[0].stream;

@@ -117,3 +117,30 @@ def test_verify_poly_eval_2_22(engine):
     assert rc == 0 and ok.value == 0
     buf.free()
     params.gs.free()
+
+
+
+@pytest.mark.parametrize("log_n,full", [(25, True), (26, False), (28, False)])
+def test_ntt_above_2_24(engine, log_n, full):
+    """EvaluationDomain::fft beyond the two-pass range (the reference goes to 2^31, src/ft.rs:55-76): one more four-step level
+    (A = 2, 4, 16 columns of 2^24) around the two-pass transform.  2^25 bit-exact against the oracle's FFT; every size: outputs
+    against direct Horner evaluation (indices with k mod A != 0 and k / A large: both index components), round trip, and the
+    inverse on its own at a sampled index through the forward identity ifft(x)[i] = fft(x)[(n - i) mod n] / n."""
+    n = 1 << log_n
+    buf = engine.alloc_scalars(n).fill_random(700 + log_n)
+    a0 = buf.download()
+    engine.ntt(buf, log_n)
+    _, _, omega = kzg_amd.compute_omega(n)
+    idx = [1, (n >> 1) + 3, n - 2] if log_n < 28 else [n - 5]
+    got = {i: int.from_bytes(buf.download(1, offset=i), "little") for i in idx}
+    if full:
+        assert buf.download() == C.fft_bytes(a0, log_n)
+    for i in idx:
+        assert got[i] == C.poly_eval_bytes(a0, n, pow(omega, i, R)), i
+    engine.ntt(buf, log_n, inverse=True)
+    assert buf.download() == a0                       # fft_composition
+    engine.ntt(buf, log_n, inverse=True)              # ifft(x)[i] = fft(x)[(n - i) mod n] / n
+    i = idx[0]
+    inv_n = pow(n, -1, R)
+    assert int.from_bytes(buf.download(1, offset=(n - i) % n), "little") == got[i] * inv_n % R
+    buf.free()
