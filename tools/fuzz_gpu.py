@@ -45,6 +45,8 @@ while time.time() < t_end:
     e.set_option("sort_single_pass", rng.choice([0, 0, 1]))  # c = 17: two-level sort (default) / single-pass sort
     rows = rng.choice([0, 0, 0, 1, 2, 3, 5, 11])            # low-memory SRS: multi-pass MSM
     e.set_option("window_rows", rows)
+    naf = 18 if (wb == 0 and rows == 0 and rng.random() < 0.3) else 0   # positional tables + width-18 NAF digits (opt-in layout)
+    e.set_option("naf_window", naf)
     e.set_option("tail_quads", rng.randrange(2))             # latency-mode tail kernels on / off
     e.set_option("hw_queues", rng.choice([0, 0, 1, 3, 4, 6]))  # pipeline plans
     e.set_option("streams", rng.choice([1, 2, 4, 8]))
@@ -67,7 +69,7 @@ while time.time() < t_end:
         cases["msm"] += 1
         if got != want:
             fails += 1
-            print("MSM MISMATCH", dict(window_bits=wb, rows=rows, nmax=nmax, n=n, off=off, kind=kind, seed=seed), flush=True)
+            print("MSM MISMATCH", dict(window_bits=wb, rows=rows, naf=naf, nmax=nmax, n=n, off=off, kind=kind, seed=seed), flush=True)
     if nmax >= 33:
         n = rng.randrange(1, min(nmax, 3000) + 1)
         batch = rng.randrange(1, 12)
@@ -129,6 +131,41 @@ while time.time() < t_end:
                 pass
     params.gs.free()
     e.set_option("window_rows", 0)
+    e.set_option("naf_window", 0)
+    # concurrent blocking callers: 6 host threads, each its own polynomial, commit + witness on ONE context and one SRS
+    if rng.random() < 0.25:
+        import threading
+        nn = rng.choice([300, 5000, 40000])
+        e.set_option("window_bits", 0)
+        pc = kzg_amd.setup(e, TAU, nn, g2_len=0)
+        prover = kzg_amd.KZGProver(pc)
+        jobs = []
+        for t in range(6):
+            co = [rand_scalar(rng.randrange(2)) for _ in range(nn)]
+            x = rand_scalar(0)
+            y = C.poly_eval(co, x)
+            ptau = C.poly_eval(co, TAU)
+            jobs.append((kzg_amd.Polynomial(co), x, y, C.g1_mul(C.g1_generator(), ptau),
+                         C.g1_mul(C.g1_generator(), (ptau - y) * pow(TAU - x, -1, R) % R) if (TAU - x) % R else None))
+        bad = []
+
+        def work(t):
+            poly, x, y, wc, ww = jobs[t]
+            for _ in range(3):
+                if prover.commit(poly) != wc:
+                    bad.append(("commit", t))
+                if ww is not None and prover.create_witness(poly, (x, y)) != ww:
+                    bad.append(("witness", t))
+        th = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+        for x_ in th:
+            x_.start()
+        for x_ in th:
+            x_.join()
+        cases["concurrent"] = cases.get("concurrent", 0) + 1
+        if bad:
+            fails += 1
+            print("CONCURRENT CALLERS MISMATCH", dict(n=nn, bad=bad[:4], seed=seed), flush=True)
+        pc.gs.free()
     # device group (one GPU, RCCL all-gather forced on): commit and witness over the group
     n = rng.choice([1, 7, 300, 5000])
     gsrs = group.setup(TAU, n)
