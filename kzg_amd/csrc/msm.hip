@@ -734,8 +734,17 @@ __device__ __forceinline__ G1Affine30 load_entry_point30(const uint4 *table30, u
     const uint4 *src = table30 + (size_t)(ent & 0x7fffffffu) * (KZG_ROW_BYTES / 16);
     G1Affine30 p;
     uint4 *dst = reinterpret_cast<uint4 *>(&p);
+#if defined(KZG_GATHER_NT)
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+    for (int k = 0; k < 7; k++) {   // A/B: every table line is read once per MSM
+        const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src) + k);
+        dst[k] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < 7; k++) dst[k] = src[k];
+#endif
     return p;
 }
 
