@@ -125,6 +125,7 @@ def test_config3_eval_form_equals_coeff_form_2_20(engine, big):
     buf = engine.alloc_scalars(n).fill_random(13)
     orig = buf.download()
     c1 = _msm_dev(engine, params.gs, buf, n)
+    assert c1 == C.g1_mul(C.g1_generator(), C.poly_eval_bytes(orig, n, TAU))      # the oracle pins what the two forms agree on
     engine.ntt(buf, 20)
     _fresh(buf)
     c2 = _msm_dev(engine, lag, buf, n)
@@ -350,6 +351,13 @@ def test_compute_lagrange_basis_2_20_without_tau(engine, big):
     n, params, lag = big
     got = kzg_amd.compute_lagrange_basis(params)
     assert len(got) == n
+    # the closed form it is compared with below, pinned by the oracle at a few indices: L_i(tau) G with
+    # L_i(tau) = (tau^n - 1) w^i / (n (tau - w^i))
+    _, _, omega = kzg_amd.compute_omega(n)
+    for i in (0, 1, 54321, n - 1):
+        wi = pow(omega, i, R)
+        li = (pow(TAU, n, R) - 1) * wi % R * pow(n * (TAU - wi) % R, -1, R) % R
+        assert lag.download(i, 1) == C.g1_mul(C.g1_generator(), li), i
     step = 1 << 14                                   # 64 windows of 2^14 points: 96 MiB compared piecewise
     for off in range(0, n, step):
         assert got.download(off, step) == lag.download(off, step), off
