@@ -731,7 +731,17 @@ __global__ __launch_bounds__(SCAN_SEG) void k_scan_b_bins(const uint32_t *total,
 // table30 entry: G1Affine30 = 2 x 13 limbs + pad = KZG_ROW_BYTES (112 B = 7 x 16 B by default); the 7 x 16 B that hold the
 // coordinates are what gets loaded
 __device__ __forceinline__ G1Affine30 load_entry_point30(const uint4 *table30, uint32_t ent) {
+#if defined(KZG_TIMING_GATHER)
+    // timing experiments only (wrong results): where the cost of the gathers comes from.  1: every gather inside the same 128 KiB (no
+    // HBM, no TLB misses); 2: 512 lines, each in a 2 MiB page of its own (no HBM, TLB misses); 3: inside 64 MiB (Infinity Cache);
+    // 4: inside 512 MiB (HBM, a quarter of the pages)
+    const uint32_t e_ = ent & 0x7fffffffu;
+    const size_t row_ = KZG_TIMING_GATHER == 1 ? (e_ & 0x3ffu) : KZG_TIMING_GATHER == 2 ? ((size_t)(e_ & 0x1ffu) << 14)
+                        : KZG_TIMING_GATHER == 3 ? (e_ & 0x7ffffu) : (e_ & 0x3fffffu);
+    const uint4 *src = table30 + row_ * (KZG_ROW_BYTES / 16);
+#else
     const uint4 *src = table30 + (size_t)(ent & 0x7fffffffu) * (KZG_ROW_BYTES / 16);
+#endif
     G1Affine30 p;
     uint4 *dst = reinterpret_cast<uint4 *>(&p);
 #if defined(KZG_GATHER_NT)
