@@ -135,7 +135,7 @@ struct kzg_ctx {
     int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
     int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
     int num_cus = 256;
-    std::atomic<bool> attr_msm_set{false}, attr_ntt_set{false}, attr_wide_set{false};  // > 64 KiB dynamic-LDS opt-in done for this device
+    std::atomic<bool> attr_msm_set{false}, attr_ntt_set{false}, attr_wide_set{false}, attr_sort20_set{false};  // > 64 KiB dynamic-LDS opt-in done for this device
     // profiling
     bool prof = false;
     std::map<std::string, kzg::ProfEntry> prof_map;
@@ -157,7 +157,8 @@ struct kzg_srs {
     int c = 0;           // window bits (signed digits, 2^(c-1) buckets)
     int W = 0;           // windows = ceil(256 / c) (15 in the c = 17 single-pass mode); table row w holds 2^(c*w) * P_i
     int rows = 0;        // table rows resident (= W unless option window_rows asked for fewer: then an MSM takes ceil(W / rows) passes)
-    bool narrow17 = false;  // c = 17: single-pass sort walking the scalars twice (half the buckets per walk), balanced scalars
+    bool narrow17 = false;  // c = 17: 15 windows, balanced scalars; two-level sort (or, option sort_single_pass, one pass walking the scalars twice)
+    bool sort20 = false;    // c = 20: 13 windows, 2^19 buckets, two-level sort (msm_wide.hip); option sort_single_pass: the older two-pass path
     // Positional tables (naf = 18): the table holds 2^j P_i for EVERY bit position j (255 rows) instead of every c-th, and a
     // scalar is recoded in width-18 non-adjacent form: odd digits |d| < 2^17 at arbitrary positions, at least 18 apart -- 13.9
     // non-zero digits per 255-bit scalar on average instead of the 15 of fixed 17-bit windows (-7.4 % bucket additions) into

@@ -22,126 +22,11 @@
 //
 // Everything is enqueued on one stream with device-side counts; the host never syncs inside an MSM.
 #include "msm_internal.h"
+#include "msm_sort.h"
 #include "emit.h"
 #include "naf.h"
 
 namespace kzg {
-
-// ---------------------------------------------------------------------------------------------
-// scalar -> signed digits
-// ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sel8(const uint32_t s[8], int idx) {
-    uint32_t r = s[0];
-    r = idx == 1 ? s[1] : r;
-    r = idx == 2 ? s[2] : r;
-    r = idx == 3 ? s[3] : r;
-    r = idx == 4 ? s[4] : r;
-    r = idx == 5 ? s[5] : r;
-    r = idx == 6 ? s[6] : r;
-    r = idx == 7 ? s[7] : r;
-    return r;
-}
-
-// The digit extraction needs the canonical value.  Montgomery input: from_mont() returns it.  Canonical input is taken mod r
-// (a 256-bit value is < 2.3 r: at most two subtractions), so that a caller's non-canonical scalar gives the same group element
-// at every window width -- the balanced c = 17 recoding (r - k) and the 15 x 17-bit window split both assume k < r.
-__device__ __forceinline__ void load_scalar(const Fr *scalars, size_t i, int sfmt, uint32_t s[8]) {
-    Fr v = scalars[i];
-    if (sfmt == KZG_FR_MONT_LE_32) {
-        v = from_mont(v);
-    } else {
-#pragma unroll
-        for (int rep = 0; rep < 2; rep++) {
-            uint32_t d[8];
-            uint64_t bw = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                uint64_t t = (uint64_t)v.v[k] - FrParams::mod(k) - bw;
-                d[k] = (uint32_t)t;
-                bw = (t >> 63) & 1u;
-            }
-            if (!bw) {
-#pragma unroll
-                for (int k = 0; k < 8; k++) v.v[k] = d[k];
-            }
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = v.v[k];
-}
-
-// calls f(w, magnitude in [1, 2^(c-1)], negative) for every non-zero signed digit.
-// balanced (the c = 17 single-pass mode, W * c = 255): a scalar with bit 254 set is replaced by r - k < 2^254 with every digit
-// sign flipped (k = -(r - k) mod r), so the top window's raw digit stays <= 2^(c-1) and nothing carries out of window W - 1.
-template <class F>
-__device__ __forceinline__ void for_each_digit(const uint32_t s_in[8], int c, int W, bool balanced, F f) {
-    uint32_t s[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = s_in[k];
-    uint32_t flip = 0;
-    if (balanced && (s[7] & 0x40000000u)) {
-        uint64_t bw = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint64_t d = (uint64_t)FrParams::mod(k) - s[k] - bw;
-            s[k] = (uint32_t)d;
-            bw = (d >> 63) & 1u;
-        }
-        flip = 1;
-    }
-    uint32_t carry = 0;
-    const uint32_t mask = (1u << c) - 1u;
-    const uint32_t half = 1u << (c - 1);
-    for (int w = 0; w < W; w++) {
-        int o = w * c;
-        int limb = o >> 5, sh = o & 31;
-        uint32_t lo = sel8(s, limb);
-        uint32_t hi = (limb < 7) ? sel8(s, limb + 1) : 0u;
-        uint64_t both = ((uint64_t)hi << 32) | lo;
-        uint32_t raw = ((uint32_t)(both >> sh) & mask) + carry;
-        uint32_t neg = raw > half ? 1u : 0u;
-        uint32_t mag = neg ? ((1u << c) - raw) : raw;
-        carry = neg;
-        if (mag) f(w, mag, neg ^ flip);
-    }
-}
-
-// The same for a window width fixed at compile time: every limb index and shift is a constant, so the digits come straight out
-// of registers (the generic version selects limbs with a chain of compares).  Used for the production width c = 17, W = 15.
-template <int C, int WN, class F>
-__device__ __forceinline__ void for_each_digit_fixed(const uint32_t s_in[8], bool balanced, F f) {
-    uint32_t s[9];
-#pragma unroll
-    for (int k = 0; k < 8; k++) s[k] = s_in[k];
-    s[8] = 0;
-    uint32_t flip = 0;
-    if (balanced && (s[7] & 0x40000000u)) {
-        uint64_t bw = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            uint64_t d = (uint64_t)FrParams::mod(k) - s[k] - bw;
-            s[k] = (uint32_t)d;
-            bw = (d >> 63) & 1u;
-        }
-        flip = 1;
-    }
-    uint32_t carry = 0;
-    constexpr uint32_t mask = (1u << C) - 1u;
-    constexpr uint32_t half = 1u << (C - 1);
-#pragma unroll
-    for (int w = 0; w < WN; w++) {
-        constexpr int dummy = 0;
-        (void)dummy;
-        const int o = w * C, limb = o >> 5, sh = o & 31;
-        const uint32_t lo = s[limb], hi = s[limb + 1 > 8 ? 8 : limb + 1];
-        const uint64_t both = ((uint64_t)hi << 32) | lo;
-        const uint32_t raw = ((uint32_t)(both >> sh) & mask) + carry;
-        const uint32_t neg = raw > half ? 1u : 0u;
-        const uint32_t mag = neg ? ((1u << C) - raw) : raw;
-        carry = neg;
-        if (mag) f(w, mag, neg ^ flip);
-    }
-}
 
 // dispatch: the fixed-width version for c = 17 (W = 15, balanced), the generic one otherwise
 template <class F>
@@ -189,29 +74,6 @@ __global__ __launch_bounds__(1024) void k_hist(const Fr *scalars, size_t n, int 
 // k_scan_a: block j owns the 256 buckets [256 j, 256 j + 256).  Per bucket: exclusive scan over the sort blocks' counts (in
 // place), total[b] = bucket size; then the block-local exclusive scan local[b] of the totals and the block aggregate agg[j].
 constexpr int SCAN_SEG = 256;
-__device__ __forceinline__ uint32_t block_scan_256(uint32_t v, uint32_t *lds, uint32_t *total_out) {
-    // exclusive scan of one value per thread over a 256-thread block (4 waves): wave shuffles + one LDS pass
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) lds[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; w++) {
-        uint32_t t = lds[w];
-        if (w < wave) woff += t;
-        tot += t;
-    }
-    __syncthreads();
-    *total_out = tot;
-    return incl - v + woff;
-}
-
 __global__ __launch_bounds__(SCAN_SEG) void k_scan_a(uint32_t *blk_hist, int G, int B, uint32_t *total, uint32_t *local, uint32_t *agg,
                                                      uint32_t *ready) {
     __shared__ uint32_t lds[4];
@@ -347,7 +209,7 @@ __global__ __launch_bounds__(1024) void k_scatter(const Fr *scalars, size_t n, i
 //            land in the bin's own <= few-hundred-KB range.
 // The bucket sizes come out of level 2 (total[]), bin_base[] is the exclusive scan of the bin sizes = the bucket starts of every
 // 64th bucket, so k_scan_b needs no cross-block pass for the starts.
-constexpr int BIN_SHIFT = 6, BIN_BUCKETS = 1 << BIN_SHIFT, NBINS = 1024;
+constexpr int BIN_SHIFT = 6, BIN_BUCKETS = 1 << BIN_SHIFT;  // NBINS = 1024 bins (msm_internal.h)
 
 __global__ __launch_bounds__(1024) void k_bin_hist(const Fr *scalars, size_t n, int sfmt, size_t per_block, uint32_t *blk_bins,
                                                    int w_lo, int w_hi) {
@@ -367,29 +229,6 @@ __global__ __launch_bounds__(1024) void k_bin_hist(const Fr *scalars, size_t n, 
     }
     __syncthreads();
     for (int b = threadIdx.x; b < NBINS; b += blockDim.x) blk_bins[(size_t)blockIdx.x * NBINS + b] = h[b];
-}
-
-// exclusive scan of one value per thread over a 1024-thread block; *total_out = the block sum
-__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *wsum /* 16 words of LDS */, uint32_t *total_out) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        uint32_t u = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += u;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) {
-        uint32_t u = wsum[w];
-        if (w < wave) woff += u;
-        tot += u;
-    }
-    __syncthreads();
-    *total_out = tot;
-    return incl - v + woff;
 }
 
 // per bin: exclusive scan over the sort blocks' counts (in place) and the bin size.  Block q owns bins [64 q, 64 q + 64); its 16
@@ -939,7 +778,7 @@ size_t sum_points_scratch_count(size_t count) { return (count + SUM_L - 1) / SUM
 struct MsmLayout {
     int B, G, G2;
     size_t M_max, T1_max;
-    size_t off_bins, off_bin_base, off_recs;
+    size_t off_bins, off_bin_base, off_recs, off_seg;
     size_t off_blk_hist, off_total, off_local, off_agg, off_bucket_start, off_s1, off_state, off_entries, off_bufA, off_bufB, off_tail,
         off_pass, bytes;
     TailLayout tail;
@@ -962,10 +801,12 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.G2 = sort2_blocks(n);
     size_t sort_bytes = (size_t)L.G * L.B * 4;
     if (srs->narrow17 && L.M_max * 8 > sort_bytes) sort_bytes = L.M_max * 8;
+    if (srs->sort20) sort_bytes = L.M_max * 8;  // c = 20 has no single-pass mode here: the records only
     L.off_blk_hist = take(sort_bytes);
     L.off_bins = take((size_t)L.G2 * NBINS * 4);
     L.off_bin_base = take((2 * NBINS + 1) * 4);  // bin starts, then bin sizes
     L.off_recs = take(srs->naf ? (size_t)NAF_MAX_DIGITS * n * 4 : 0);  // positional tables: the digit records of the scalars
+    L.off_seg = take(srs->sort20 ? 3 * 256 * 4 : 0);  // segment sums / maxima / total of the round-1 layout scan (wide_s1_layout)
     L.off_total = take((size_t)L.B * 4);
     L.off_local = take((size_t)L.B * 4);
     L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
@@ -1089,6 +930,11 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
 }
 
 size_t msm_workspace_bytes(const kzg_srs *srs, size_t n) {
+    if (srs->sort20) {  // either path, by option sort_single_pass at call time (the older one only below its size limit)
+        const size_t a = msm_layout(srs, n ? n : 1).bytes;
+        const size_t b = (uint64_t)srs->W * srs->npad < (1ull << WIDE_HI_SHIFT) ? wide_layout(srs, n ? n : 1).bytes : 0;
+        return a > b ? a : b;
+    }
     return (srs->c > 16 && !srs->narrow17) ? wide_layout(srs, n ? n : 1).bytes : msm_layout(srs, n ? n : 1).bytes;
 }
 
@@ -1192,6 +1038,15 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
             }
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);
+        } else if (srs->sort20) {
+            const int G2 = L.G2;
+            uint32_t *bins = (uint32_t *)(base + L.off_bins), *bin_base = (uint32_t *)(base + L.off_bin_base);
+            uint32_t *ready = (uint32_t *)(base + L.off_agg) + SCAN_SEG, *bin_total = bin_base + NBINS + 1;
+            uint32_t *seg = (uint32_t *)(base + L.off_seg);
+            KZG_TRY(sort20_hist(ctx, st, sc, n, sfmt, G2, bins));
+            KZG_LAUNCH(ctx, st, "k_bin_scan", k_bin_scan, NBINS / 64, 1024, 0, bins, G2, bin_total, ready);
+            KZG_TRY(sort20_place(ctx, st, sc, n, sfmt, G2, bins, bin_total, bin_base, (uint32_t)srs->npad, (uint32_t)offset, blk_hist, entries,
+                                 bucket_start, s1, state, slots, seg, seg + 256, seg + 512));
         } else if (srs->narrow17 && !ctx->opt_sort_single) {
             const int G2 = L.G2;
             const size_t per2 = (n + G2 - 1) / G2;
@@ -1256,7 +1111,8 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
-    if (srs->c > 16 && !srs->narrow17) return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
+    if (srs->c > 16 && !srs->narrow17 && !(srs->sort20 && !ctx->opt_sort_single))
+        return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
     if ((uint64_t)srs->rows * srs->npad >= (1ull << 31))
         return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (table rows * points < 2^31)");
     if (srs->naf && offset + n > srs->npad) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");

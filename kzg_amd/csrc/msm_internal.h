@@ -51,6 +51,17 @@ int wide_sort_pass2(kzg_ctx *ctx, hipStream_t st, const uint32_t *entries1, cons
                     uint32_t *binbase, const uint32_t *lo_start, int B_lo, uint32_t *entries2, uint32_t *bucket_start);
 int wide_s1_layout(kzg_ctx *ctx, hipStream_t st, const uint32_t *bucket_start, int Btot, MsmState *state, uint32_t *segsums,
                    uint32_t *segmaxs, uint32_t *segtotal, uint32_t *s1_out);
+// Two-level sort of the widest window (c = 20: 13 windows, 2^19 buckets = 1024 bins of 512), msm_wide.hip.  Same structure as the
+// c = 17 sort of msm.hip (level 1 by bin with the chunk sorted in LDS first, level 2 one block per bin), 8-byte records.
+constexpr int NBINS = 1024;         // level-1 bins of both two-level sorts
+constexpr int SORT20_C = 20, SORT20_W = 13, SORT20_SHIFT = 9, SORT20_BUCKETS = 1 << SORT20_SHIFT;
+int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, uint32_t *bins);
+// after k_bin_scan (msm.hip): records by bin, then entries by bucket; bucket_start[0 .. B], state (M, E, ntasks), s1[0 .. B]
+int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
+                 const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
+                 uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
+                 uint32_t *segtotal);
+
 // msm_tail.hip: everything after the bucket accumulation (fold to one point per bucket, sum (b+1) B_b)
 struct TailLayout {
     size_t off_dense, off_rows, off_cols, off_Q, off_tasks, off_arrive, off_result, bytes;

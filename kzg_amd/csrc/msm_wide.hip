@@ -2,6 +2,7 @@
 // scans over the 2^(c-1) buckets (the tail is shared with the narrow path: msm_tail.hip).  Orchestrated from msm.hip (msm_run_wide); see
 // msm_internal.h for why they live in their own translation unit.  DESIGN.md section 8 has the measurements.
 #include "msm_internal.h"
+#include "msm_sort.h"
 
 namespace kzg {
 
@@ -249,6 +250,164 @@ __global__ __launch_bounds__(256) void k_s1_finish(const uint32_t *start, int B,
 }
 
 // ---------------------------------------------------------------------------------------------
+// c = 20: two-level sort (13 windows of 20 bits cover 260 >= 255 bits, so the plain signed recoding never carries out of the top
+// window: no balanced scalars).  Record = (entry word, low 9 bucket bits | bin << 16): the bin rides along so that level 1 can
+// stage finished records in LDS.
+// ---------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) uint32_t lds_u32[];
+
+__global__ __launch_bounds__(1024) void k_bin_hist20(const Fr *scalars, size_t n, int sfmt, size_t per_block, uint32_t *blk_bins) {
+    __shared__ uint32_t h[NBINS];
+    for (int b = threadIdx.x; b < NBINS; b += blockDim.x) h[b] = 0;
+    __syncthreads();
+    size_t i0 = (size_t)blockIdx.x * per_block;
+    size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += blockDim.x) {
+        uint32_t s[8];
+        load_scalar(scalars, i, sfmt, s);
+        for_each_digit_fixed<SORT20_C, SORT20_W>(s, false, [&](int, uint32_t mag, uint32_t) { atomicAdd(&h[(mag - 1) >> SORT20_SHIFT], 1u); });
+    }
+    __syncthreads();
+    for (int b = threadIdx.x; b < NBINS; b += blockDim.x) blk_bins[(size_t)blockIdx.x * NBINS + b] = h[b];
+}
+
+// Level 1: as k_bin_scatter of msm.hip (chunks of 1024 scalars, the chunk's <= 13 K records sorted by bin in LDS, then written
+// out as runs), with the finished 8-byte records in the stage.
+constexpr int BIN_SCATTER20_LDS = (3 * NBINS + 16) * 4 + SORT20_W * 1024 * 8;
+__global__ __launch_bounds__(1024) void k_bin_scatter20(const Fr *scalars, size_t n, int sfmt, size_t per_block, const uint32_t *blk_off,
+                                                        const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
+                                                        uint32_t idx_base, uint2 *rec) {
+    uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS;
+    uint2 *stage = reinterpret_cast<uint2 *>(wsum + 16);
+    const uint32_t tid = threadIdx.x;
+    {   // bin_base = exclusive scan of the bin sizes (every block computes it; block 0 publishes it for the later kernels)
+        uint32_t tot;
+        const uint32_t ex = block_scan_1024(bin_total[tid], wsum, &tot);
+        cur[tid] = ex + blk_off[(size_t)blockIdx.x * NBINS + tid];
+        if (blockIdx.x == 0) {
+            bin_base[tid] = ex;
+            if (tid == 0) bin_base[NBINS] = tot;
+        }
+    }
+    const size_t i0 = (size_t)blockIdx.x * per_block;
+    const size_t i1 = i0 + per_block < n ? i0 + per_block : n;
+    for (size_t c0 = i0; c0 < i1; c0 += 1024) {
+        cnt[tid] = 0;
+        __syncthreads();
+        uint2 pk[SORT20_W];
+        uint32_t rk[SORT20_W], have = 0;
+        if (c0 + tid < i1) {
+            uint32_t s[8];
+            load_scalar(scalars, c0 + tid, sfmt, s);
+            const uint32_t e0 = idx_base + (uint32_t)c0 + tid;
+            for_each_digit_fixed<SORT20_C, SORT20_W>(s, false, [&](int w, uint32_t mag, uint32_t neg) {
+                const uint32_t idx = mag - 1, bin = idx >> SORT20_SHIFT;
+                rk[w] = atomicAdd(&cnt[bin], 1u);
+                pk[w] = make_uint2(((uint32_t)w * row_stride + e0) | (neg << 31), (idx & (SORT20_BUCKETS - 1)) | (bin << 16));
+                have |= 1u << w;
+            });
+        }
+        __syncthreads();
+        uint32_t tot;
+        off[tid] = block_scan_1024(cnt[tid], wsum, &tot);
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < SORT20_W; w++)
+            if ((have >> w) & 1u) stage[off[pk[w].y >> 16] + rk[w]] = pk[w];
+        __syncthreads();
+        for (uint32_t p = tid; p < tot; p += 1024) {
+            const uint2 v = stage[p];
+            const uint32_t bin = v.y >> 16;
+            rec[cur[bin] + p - off[bin]] = v;
+        }
+        __syncthreads();
+        cur[tid] += cnt[tid];
+    }
+}
+
+// Level 2: one block per bin.  Counts the bin's 512 buckets (their starts = bucket_start[], two per thread), then places the
+// records chunk by chunk, each chunk sorted by bucket in LDS first.  Block 0 also sets the equal-split state.
+constexpr int SORT20_THREADS = 256, SORT20_UNROLL = 8, SORT20_CHUNK = SORT20_THREADS * SORT20_UNROLL;
+__global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec, const uint32_t *bin_base, uint32_t *entries,
+                                                               uint32_t *bucket_start, MsmState *st, uint32_t slots) {
+    __shared__ uint32_t h[SORT20_BUCKETS], cur[SORT20_BUCKETS], off[SORT20_BUCKETS], sc[4];
+    __shared__ uint2 stage[SORT20_CHUNK];
+    const uint32_t tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
+    const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
+    if (blockIdx.x == 0 && tid == 0) {
+        const uint32_t M = bin_base[NBINS];
+        uint32_t E = (M + slots - 1) / slots;
+        if (E < 8) E = 8;
+        st->M = M;
+        st->E = E;
+        st->ntasks = (M + E - 1) / E;
+        st->ovf_tasks = 0;
+        bucket_start[(size_t)NBINS * SORT20_BUCKETS] = M;
+    }
+    h[b0] = 0;
+    h[b1] = 0;
+    __syncthreads();
+    for (uint32_t base = r0 + tid; base < r1; base += SORT20_CHUNK) {
+        uint2 e[SORT20_UNROLL];
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++) {
+            const uint32_t r = base + (uint32_t)k * SORT20_THREADS;
+            e[k] = r < r1 ? rec[r] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++)
+            if (e[k].y != 0xffffffffu) atomicAdd(&h[e[k].y & 0xffffu], 1u);
+    }
+    __syncthreads();
+    {
+        const uint32_t v0 = h[b0], v1 = h[b1];
+        uint32_t tot;
+        const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
+        cur[b0] = r0 + ex;
+        cur[b1] = r0 + ex + v0;
+        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b0] = r0 + ex;
+        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b1] = r0 + ex + v0;
+    }
+    for (uint32_t c0 = r0; c0 < r1; c0 += SORT20_CHUNK) {
+        h[b0] = 0;
+        h[b1] = 0;
+        __syncthreads();
+        uint2 e[SORT20_UNROLL];
+        uint32_t rk[SORT20_UNROLL];
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++) {
+            const uint32_t r = c0 + tid + (uint32_t)k * SORT20_THREADS;
+            e[k] = r < r1 ? rec[r] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++)
+            if (e[k].y != 0xffffffffu) rk[k] = atomicAdd(&h[e[k].y & 0xffffu], 1u);
+        __syncthreads();
+        {
+            const uint32_t v0 = h[b0], v1 = h[b1];
+            uint32_t tot;
+            const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
+            off[b0] = ex;
+            off[b1] = ex + v0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++)
+            if (e[k].y != 0xffffffffu) stage[off[e[k].y & 0xffffu] + rk[k]] = e[k];
+        __syncthreads();
+        const uint32_t m = r1 - c0 < (uint32_t)SORT20_CHUNK ? r1 - c0 : (uint32_t)SORT20_CHUNK;
+        for (uint32_t p = tid; p < m; p += SORT20_THREADS) {
+            const uint2 v = stage[p];
+            const uint32_t b = v.y & 0xffffu;
+            entries[cur[b] + p - off[b]] = v.x;
+        }
+        __syncthreads();
+        cur[b0] += h[b0];
+        cur[b1] += h[b1];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // launchers used by msm.hip's wide orchestration
 // ---------------------------------------------------------------------------------------------
 int wide_sort_pass2(kzg_ctx *ctx, hipStream_t st, const uint32_t *entries1, const MsmState *state, int nhi, uint32_t *blockcnt,
@@ -263,6 +422,28 @@ int wide_sort_pass2(kzg_ctx *ctx, hipStream_t st, const uint32_t *entries1, cons
     KZG_LAUNCH(ctx, st, "k_hi_scatter", k_hi_scatter, HI_BLOCKS, HI_THREADS, 16 * HI_THREADS * 4, entries1, state, nhi, binbase,
                lo_start, B_lo, entries2, bucket_start);
     return KZG_OK;
+}
+
+int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, uint32_t *bins) {
+    const size_t per2 = (n + G2 - 1) / G2;
+    KZG_LAUNCH(ctx, st, "k_bin_hist", k_bin_hist20, G2, 1024, 0, (const Fr *)d_scalars, n, sfmt, per2, bins);
+    return KZG_OK;
+}
+
+int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
+                 const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
+                 uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
+                 uint32_t *segtotal) {
+    if (!ctx->attr_sort20_set) {
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter20, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER20_LDS));
+        ctx->attr_sort20_set = true;
+    }
+    const size_t per2 = (n + G2 - 1) / G2;
+    KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter20, G2, 1024, BIN_SCATTER20_LDS, (const Fr *)d_scalars, n, sfmt, per2, bins, bin_total,
+               bin_base, row_stride, idx_base, (uint2 *)rec);
+    KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort20, NBINS, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, entries, bucket_start, state,
+               slots);
+    return wide_s1_layout(ctx, st, bucket_start, NBINS * SORT20_BUCKETS, state, segsums, segmaxs, segtotal, s1);
 }
 
 int wide_s1_layout(kzg_ctx *ctx, hipStream_t st, const uint32_t *bucket_start, int Btot, MsmState *state, uint32_t *segsums,

@@ -64,16 +64,21 @@ int srs_choose_window(int opt_window_bits, size_t n) {
         // 14, 15) are avoided: every scalar then lands in the same handful of buckets of that window, which the fold handles
         // through its overflow path (correct, but a 0.2 ms serial stage).  c = 8, 10, 13, 16, 17 have 7, 5, 8, 15, 17 bits there.
         const int l = ilog2_ceil(n ? n : 1);
-        c = l >= 17 ? 17 : l >= 14 ? 13 : l >= 12 ? 10 : 8;
+        // From 2^22 points on 20 bits (13 windows, 2^19 buckets, its own two-level sort): the accumulation's 13 % fewer additions
+        // outgrow the 8x bucket reduction -- same box, batched: 2^20 397 against 432/s, 2^21 224 against 221, 2^22 118.7
+        // against 109.7 (profiles/r03_window20.txt).
+        c = l >= 22 ? 20 : l >= 17 ? 17 : l >= 14 ? 13 : l >= 12 ? 10 : 8;
     }
     if (c < 4) c = 4;
     // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17: same pipeline, 15 windows, a two-level sort (msm.hip);
-    // 18..20 use the two-pass ("wide") sort of msm.hip and are only taken when asked for (option window_bits)
+    // 18, 19 use the two-pass ("wide") sort of msm.hip and are only taken when asked for (option window_bits); 20: two-level sort
+    // of msm_wide.hip, the default from 2^22 points on
     if (c > 20) c = 20;
     return c;
 }
 
 // window bits, windows, resident table rows for an SRS of n points under the given options
+constexpr int SORT20_C_BITS = 20;  // = SORT20_C of msm_internal.h
 constexpr int NAF_ROWS = 255;  // positional tables: bit positions 0..254 of a balanced scalar (k or r - k, below 2^254)
 
 void srs_shape(int opt_window_bits, int opt_window_rows, size_t n, int *c_out, int *W_out, int *rows_out, bool *narrow17_out, int opt_naf,
@@ -108,6 +113,7 @@ int srs_alloc(kzg_ctx *ctx, size_t n, kzg_srs **out) {
     s->npad = n ? n : 1;
     srs_shape(ctx->opt_window_bits, ctx->opt_window_rows, n, &s->c, &s->W, &s->rows, &s->narrow17, ctx->opt_naf_window, &s->naf);
     s->row_shift = s->naf ? 1 : s->c;
+    s->sort20 = !s->naf && s->c == SORT20_C_BITS;
     s->device = ctx->device;
     // `table` keeps row 0 only (the points themselves, canonical saturated form: download, re-upload);
     // the window rows live in the 30-bit table built by srs_precompute.

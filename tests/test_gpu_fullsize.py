@@ -258,7 +258,7 @@ def test_default_window_choice(engine, n):
 
 @pytest.mark.parametrize("wb", [16, 17, 18, 19, 20])
 def test_wide_windows(engine, wb):
-    """Window widths chosen by option (window_bits): 16 (the default below 2^19 points tops out at 15) and the widths above it.  18..20: two-pass sort, 2^(wb-1) buckets, row/column bucket reduction.
+    """Window widths chosen by option (window_bits): 16 (the default below 2^19 points tops out at 15) and the widths above it.  18..20: two-pass sort, 2^(wb-1) buckets, row/column bucket reduction; 20 by default through its own two-level sort (1024 bins of 512 buckets, 13 windows).
     17: single-pass sort that walks the scalars twice (half the 2^16 buckets per walk), 15 windows, scalars >= 2^254 replaced by -(r - k).
     Random, adversarial (one bucket, extreme digits, values around 2^254 and r) and u64-valued scalars at 2^16 terms,
     sub-ranges with an offset, and the batched entry point, each against the known-tau identity."""
@@ -286,7 +286,7 @@ def test_wide_windows(engine, wb):
             "around_2^254": [((1 << 254) + d) % R for d in (-2, -1, 0, 1, 2, (1 << 237), -(1 << 237))] * (n // 7) + [R - 2] * (n % 7),
             "top_window_max": [((1 << 254) - 1) - (i % 3)  for i in range(n)],
         }
-        for single_pass in ((0, 1) if wb == 17 else (0,)):   # 17: the two-level sort (default) and the single-pass one
+        for single_pass in ((0, 1) if wb in (17, 20) else (0,)):   # 17, 20: the two-level sort (default) and the older one
             engine.set_option("sort_single_pass", single_pass)
             for name, sc in cases.items():
                 assert engine.msm(params.gs, sc) == want(sc), (wb, name, single_pass)
@@ -339,9 +339,17 @@ def test_config5_2_24_sharded_8_ways_and_whole(engine):
     assert rc == 0 and out.raw == want
     # the whole SRS on one GPU
     params = kzg_amd.setup(engine, TAU, n, g2_len=0)
-    assert params.gs.window_info() == (17, 15)
+    assert params.gs.window_info() == (20, 13)     # from 2^22 points on: 13 windows of 20 bits
     assert _msm_dev(engine, params.gs, buf, n) == want
     params.gs.free()
+    engine.set_option("window_bits", 17)           # and the 15-window layout at the same size
+    try:
+        params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+        assert params.gs.window_info() == (17, 15)
+        assert _msm_dev(engine, params.gs, buf, n) == want
+        params.gs.free()
+    finally:
+        engine.set_option("window_bits", 0)
     _fresh(buf); buf.free()
 
 
