@@ -8,8 +8,13 @@ here the chain starts from the carry.  Everything that is not a multiply-add (qu
 stays in C between the blocks."""
 import sys
 
+import os
+
 N = 13
 MAX_OPS = 30
+# experiment: carry-out destination of the multiply-adds rotating over ROT scratch SGPR pairs instead of always vcc (a lone wave
+# then issues dependent-free multiply-adds faster: tools/mad_issue.hip); 0 = vcc
+ROT = int(os.environ.get("KZG_GEN_ROT", "0"))
 
 
 def block(products, mnem="v_mad_i64_i32"):
@@ -22,13 +27,17 @@ def block(products, mnem="v_mad_i64_i32"):
                 return i + 1
         ops.append((cons, expr))
         return len(ops)
-    for (x, xc, y, yc) in products:
-        xtxt = f"%{ref(xc, x)}"
-        ytxt = y if yc == "i" else f"%{ref(yc, y)}"       # "i": an inline constant written into the instruction
-        lines.append(f"{mnem} %0, vcc, {xtxt}, {ytxt}, %0")
-    assert len(ops) + 1 <= MAX_OPS, len(ops)
+    for n_, (x, xc, y, yc) in enumerate(products):
+        xtxt = f"%{ref(xc, x) + ROT}"
+        ytxt = y if yc == "i" else f"%{ref(yc, y) + ROT}"       # "i": an inline constant written into the instruction
+        sdst = f"%{1 + n_ % ROT}" if ROT else "vcc"
+        lines.append(f"{mnem} %0, {sdst}, {xtxt}, {ytxt}, %0")
+    assert len(ops) + 1 + ROT <= MAX_OPS, len(ops)
     body = "\\n\\t".join(lines)
     ins = ", ".join(f'"{c}"({e})' for c, e in ops)
+    if ROT:
+        outs = "".join(f', "=&s"(rot_sink[{k}])' for k in range(ROT))
+        return f'    {{ uint64_t rot_sink[{ROT}]; asm("{body}" : "+v"(acc){outs} : {ins}); }}\n'
     return f'    asm("{body}" : "+v"(acc) : {ins} : "vcc");\n'
 
 
@@ -37,7 +46,7 @@ def emit_products(products, mnem="v_mad_i64_i32"):
     out, cur, names = "", [], set()
     for p in products:
         new = {(p[1], p[0])} | ({(p[3], p[2])} if p[3] != "i" else set())
-        if len(names | new) + 1 > MAX_OPS:
+        if len(names | new) + 1 + ROT > MAX_OPS:
             out += block(cur, mnem)
             cur, names = [], set()
         cur.append(p)
