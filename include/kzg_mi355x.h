@@ -59,11 +59,12 @@ extern "C" {
  *   kzg_verify_eval_batched                 k <= 4096 opening points          (single-workgroup interpolation kernels)
  *   kzg_srs_lagrange_from_monomial_g1       d <= 2^24;  _g2: d <= 1024
  *   MSM                                     table rows x points < 2^31       (the sorted entry is a 31-bit table index + sign);
- *                                           window_bits 18..20 (option): windows x points < 2^27
+ *                                           window_bits 18, 19 (option), and 20 with option sort_single_pass: windows x points < 2^27
  *   kzg_g1_sum_batch                        count <= 2^20, groups <= 2^24
  *   kzg_commit_coeff_sharded_batch          batch <= 2^20
  * SRS footprint in HBM: points x (96 + rows x 128) bytes, rows = windows = ceil(256 / c) with c chosen from the size
- * (c = 17, 15 windows from 2^17 points on; 13 / 10 / 8 bits below: 1.97 GiB at 2^20, 31.5 GiB at 2^24; kzg_srs_footprint computes it).  A host that
+ * (c = 20, 13 windows from 2^22 points on; c = 17, 15 windows from 2^17 on; 13 / 10 / 8 bits below: 1.97 GiB at 2^20, 27.5 GiB at 2^24;
+ * kzg_srs_footprint computes it).  A host that
  * keeps many SRSs resident can trade speed for memory with option "window_rows" = r < windows: only r table rows are kept and
  * every MSM takes ceil(windows / r) passes over its scalars plus a doubling chain of c x r x (passes - 1) doublings. */
 typedef struct kzg_ctx kzg_ctx;
