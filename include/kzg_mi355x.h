@@ -63,7 +63,7 @@ extern "C" {
  *   kzg_g1_sum_batch                        count <= 2^20, groups <= 2^24
  *   kzg_commit_coeff_sharded_batch          batch <= 2^20
  * SRS footprint in HBM: points x (96 + rows x 128) bytes, rows = windows = ceil(256 / c) with c chosen from the size
- * (c = 20, 13 windows from 2^22 points on; c = 17, 15 windows from 2^17 on; 13 / 10 / 8 bits below: 1.97 GiB at 2^20, 27.5 GiB at 2^24;
+ * (c = 20, 13 windows from 2^23 points on; c = 17, 15 windows from 2^17 on; 13 / 10 / 8 bits below: 1.97 GiB at 2^20, 27.5 GiB at 2^24;
  * kzg_srs_footprint computes it).  A host that
  * keeps many SRSs resident can trade speed for memory with option "window_rows" = r < windows: only r table rows are kept and
  * every MSM takes ceil(windows / r) passes over its scalars plus a doubling chain of c x r x (passes - 1) doublings. */

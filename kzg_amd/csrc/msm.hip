@@ -778,7 +778,7 @@ size_t sum_points_scratch_count(size_t count) { return (count + SUM_L - 1) / SUM
 struct MsmLayout {
     int B, G, G2;
     size_t M_max, T1_max;
-    size_t off_bins, off_bin_base, off_recs, off_seg;
+    size_t off_bins, off_bin_base, off_recs, off_seg, off_hv;
     size_t off_blk_hist, off_total, off_local, off_agg, off_bucket_start, off_s1, off_state, off_entries, off_bufA, off_bufB, off_tail,
         off_pass, bytes;
     TailLayout tail;
@@ -807,6 +807,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.off_bin_base = take((2 * NBINS + 1) * 4);  // bin starts, then bin sizes
     L.off_recs = take(srs->naf ? (size_t)NAF_MAX_DIGITS * n * 4 : 0);  // positional tables: the digit records of the scalars
     L.off_seg = take(srs->sort20 ? 3 * 256 * 4 : 0);  // segment sums / maxima / total of the round-1 layout scan (wide_s1_layout)
+    L.off_hv = take(srs->sort20 ? SORT20_HV_BYTES : 0);   // bins sorted in slices (msm_wide.hip)
     L.off_total = take((size_t)L.B * 4);
     L.off_local = take((size_t)L.B * 4);
     L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
@@ -1046,7 +1047,7 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
             KZG_TRY(sort20_hist(ctx, st, sc, n, sfmt, G2, bins));
             KZG_LAUNCH(ctx, st, "k_bin_scan", k_bin_scan, NBINS / 64, 1024, 0, bins, G2, bin_total, ready);
             KZG_TRY(sort20_place(ctx, st, sc, n, sfmt, G2, bins, bin_total, bin_base, (uint32_t)srs->npad, (uint32_t)offset, blk_hist, entries,
-                                 bucket_start, s1, state, slots, seg, seg + 256, seg + 512));
+                                 bucket_start, s1, state, slots, seg, seg + 256, seg + 512, (uint32_t *)(base + L.off_hv)));
         } else if (srs->narrow17 && !ctx->opt_sort_single) {
             const int G2 = L.G2;
             const size_t per2 = (n + G2 - 1) / G2;

@@ -60,7 +60,9 @@ int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, i
 int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
                  const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
                  uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
-                 uint32_t *segtotal);
+                 uint32_t *segtotal, uint32_t *hv);
+// hv: descriptor of the bins sorted in slices (2 + 2 NBINS words, 256-byte padded) followed by the per-slice bucket counts
+constexpr size_t SORT20_HV_WORDS = 2112, SORT20_HV_BYTES = (SORT20_HV_WORDS + (size_t)2560 * SORT20_BUCKETS) * 4;
 
 // msm_tail.hip: everything after the bucket accumulation (fold to one point per bucket, sum (b+1) B_b)
 struct TailLayout {

@@ -276,17 +276,30 @@ __global__ __launch_bounds__(1024) void k_bin_hist20(const Fr *scalars, size_t n
 constexpr int BIN_SCATTER20_LDS = (3 * NBINS + 16) * 4 + SORT20_W * 1024 * 8;
 __global__ __launch_bounds__(1024) void k_bin_scatter20(const Fr *scalars, size_t n, int sfmt, size_t per_block, const uint32_t *blk_off,
                                                         const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
-                                                        uint32_t idx_base, uint2 *rec) {
+                                                        uint32_t idx_base, uint2 *rec, uint32_t *hv) {
     uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS;
     uint2 *stage = reinterpret_cast<uint2 *>(wsum + 16);
     const uint32_t tid = threadIdx.x;
     {   // bin_base = exclusive scan of the bin sizes (every block computes it; block 0 publishes it for the later kernels)
         uint32_t tot;
-        const uint32_t ex = block_scan_1024(bin_total[tid], wsum, &tot);
+        const uint32_t size = bin_total[tid];
+        const uint32_t ex = block_scan_1024(size, wsum, &tot);
         cur[tid] = ex + blk_off[(size_t)blockIdx.x * NBINS + tid];
-        if (blockIdx.x == 0) {
+        if (blockIdx.x == 0) {  // (uniform branch: the scan inside is executed by the whole block)
             bin_base[tid] = ex;
             if (tid == 0) bin_base[NBINS] = tot;
+            // heavy bins -> slices (see k_bin_sort20)
+            uint32_t SL = (tot + 2047) / 2048;
+            if (SL < 32768u) SL = 32768u;
+            const uint32_t ns = size > 4 * SL ? (size + SL - 1) / SL : 0u;
+            uint32_t nsl;
+            const uint32_t s0 = block_scan_1024(ns, wsum, &nsl);
+            hv[2 + tid] = s0;
+            hv[2 + NBINS + tid] = ns;
+            if (tid == 0) {
+                hv[0] = nsl;
+                hv[1] = SL;
+            }
         }
     }
     const size_t i0 = (size_t)blockIdx.x * per_block;
@@ -327,48 +340,21 @@ __global__ __launch_bounds__(1024) void k_bin_scatter20(const Fr *scalars, size_
 
 // Level 2: one block per bin.  Counts the bin's 512 buckets (their starts = bucket_start[], two per thread), then places the
 // records chunk by chunk, each chunk sorted by bucket in LDS first.  Block 0 also sets the equal-split state.
+//
+// HEAVY bins.  One block per bin assumes bins of similar size.  They are not when many digits are small: u64-valued scalars put the
+// whole top window (4 bits + carry at c = 20) into the first 17 buckets = bin 0, all-equal scalars put everything into 13
+// buckets.  A bin of more than 4 SL records (SL = max(32768, M / 2048)) is therefore cut into slices of SL records that are
+// sorted by separate blocks: k_heavy_count20 (per-slice bucket counts), k_heavy_scan20 (per bucket the exclusive scan over the
+// bin's slices, then the bucket starts), k_heavy_place20.  The descriptor hv[] is written by block 0 of k_bin_scatter20:
+// hv[0] = slices in total (0: the three kernels return at once), hv[1] = SL, hv[2 + bin] = first slice of the bin,
+// hv[2 + NBINS + bin] = its slice count (0 = not heavy: k_bin_sort20 takes it).  At most M / SL + M / (4 SL) <= 2560 slices.
 constexpr int SORT20_THREADS = 256, SORT20_UNROLL = 8, SORT20_CHUNK = SORT20_THREADS * SORT20_UNROLL;
-__global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec, const uint32_t *bin_base, uint32_t *entries,
-                                                               uint32_t *bucket_start, MsmState *st, uint32_t slots) {
-    __shared__ uint32_t h[SORT20_BUCKETS], cur[SORT20_BUCKETS], off[SORT20_BUCKETS], sc[4];
-    __shared__ uint2 stage[SORT20_CHUNK];
+
+// records [c_begin, c_end) -> entries[], by bucket; cur[] = next free position per bucket (set and synchronised by the caller)
+__device__ __forceinline__ void sort20_place_range(const uint2 *rec, uint32_t c_begin, uint32_t c_end, uint32_t *entries, uint32_t *h,
+                                                   uint32_t *cur, uint32_t *off, uint32_t *sc, uint2 *stage) {
     const uint32_t tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
-    const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
-    if (blockIdx.x == 0 && tid == 0) {
-        const uint32_t M = bin_base[NBINS];
-        uint32_t E = (M + slots - 1) / slots;
-        if (E < 8) E = 8;
-        st->M = M;
-        st->E = E;
-        st->ntasks = (M + E - 1) / E;
-        st->ovf_tasks = 0;
-        bucket_start[(size_t)NBINS * SORT20_BUCKETS] = M;
-    }
-    h[b0] = 0;
-    h[b1] = 0;
-    __syncthreads();
-    for (uint32_t base = r0 + tid; base < r1; base += SORT20_CHUNK) {
-        uint2 e[SORT20_UNROLL];
-#pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++) {
-            const uint32_t r = base + (uint32_t)k * SORT20_THREADS;
-            e[k] = r < r1 ? rec[r] : make_uint2(0u, 0xffffffffu);
-        }
-#pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++)
-            if (e[k].y != 0xffffffffu) atomicAdd(&h[e[k].y & 0xffffu], 1u);
-    }
-    __syncthreads();
-    {
-        const uint32_t v0 = h[b0], v1 = h[b1];
-        uint32_t tot;
-        const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
-        cur[b0] = r0 + ex;
-        cur[b1] = r0 + ex + v0;
-        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b0] = r0 + ex;
-        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b1] = r0 + ex + v0;
-    }
-    for (uint32_t c0 = r0; c0 < r1; c0 += SORT20_CHUNK) {
+    for (uint32_t c0 = c_begin; c0 < c_end; c0 += SORT20_CHUNK) {
         h[b0] = 0;
         h[b1] = 0;
         __syncthreads();
@@ -377,7 +363,7 @@ __global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec,
 #pragma unroll
         for (int k = 0; k < SORT20_UNROLL; k++) {
             const uint32_t r = c0 + tid + (uint32_t)k * SORT20_THREADS;
-            e[k] = r < r1 ? rec[r] : make_uint2(0u, 0xffffffffu);
+            e[k] = r < c_end ? rec[r] : make_uint2(0u, 0xffffffffu);
         }
 #pragma unroll
         for (int k = 0; k < SORT20_UNROLL; k++)
@@ -395,7 +381,7 @@ __global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec,
         for (int k = 0; k < SORT20_UNROLL; k++)
             if (e[k].y != 0xffffffffu) stage[off[e[k].y & 0xffffu] + rk[k]] = e[k];
         __syncthreads();
-        const uint32_t m = r1 - c0 < (uint32_t)SORT20_CHUNK ? r1 - c0 : (uint32_t)SORT20_CHUNK;
+        const uint32_t m = c_end - c0 < (uint32_t)SORT20_CHUNK ? c_end - c0 : (uint32_t)SORT20_CHUNK;
         for (uint32_t p = tid; p < m; p += SORT20_THREADS) {
             const uint2 v = stage[p];
             const uint32_t b = v.y & 0xffffu;
@@ -404,6 +390,140 @@ __global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec,
         __syncthreads();
         cur[b0] += h[b0];
         cur[b1] += h[b1];
+    }
+}
+
+// bucket counts of records [a, b) into h[] (zeroed here); synchronised on return
+__device__ __forceinline__ void sort20_count_range(const uint2 *rec, uint32_t a, uint32_t b, uint32_t *h) {
+    const uint32_t tid = threadIdx.x;
+    h[2 * tid] = 0;
+    h[2 * tid + 1] = 0;
+    __syncthreads();
+    for (uint32_t base = a + tid; base < b; base += SORT20_CHUNK) {
+        uint2 e[SORT20_UNROLL];
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++) {
+            const uint32_t r = base + (uint32_t)k * SORT20_THREADS;
+            e[k] = r < b ? rec[r] : make_uint2(0u, 0xffffffffu);
+        }
+#pragma unroll
+        for (int k = 0; k < SORT20_UNROLL; k++)
+            if (e[k].y != 0xffffffffu) atomicAdd(&h[e[k].y & 0xffffu], 1u);
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec, const uint32_t *bin_base, const uint32_t *hv,
+                                                               uint32_t *entries, uint32_t *bucket_start, MsmState *st, uint32_t slots) {
+    __shared__ uint32_t h[SORT20_BUCKETS], cur[SORT20_BUCKETS], off[SORT20_BUCKETS], sc[4];
+    __shared__ uint2 stage[SORT20_CHUNK];
+    const uint32_t tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
+    const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
+    if (blockIdx.x == 0 && tid == 0) {
+        const uint32_t M = bin_base[NBINS];
+        uint32_t E = (M + slots - 1) / slots;
+        if (E < 8) E = 8;
+        st->M = M;
+        st->E = E;
+        st->ntasks = (M + E - 1) / E;
+        st->ovf_tasks = 0;
+        bucket_start[(size_t)NBINS * SORT20_BUCKETS] = M;
+    }
+    if (hv[2 + NBINS + blockIdx.x]) return;  // a heavy bin: the slice kernels sort it
+    sort20_count_range(rec, r0, r1, h);
+    {
+        const uint32_t v0 = h[b0], v1 = h[b1];
+        uint32_t tot;
+        const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
+        cur[b0] = r0 + ex;
+        cur[b1] = r0 + ex + v0;
+        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b0] = r0 + ex;
+        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b1] = r0 + ex + v0;
+    }
+    sort20_place_range(rec, r0, r1, entries, h, cur, off, sc, stage);
+}
+
+constexpr int HEAVY_MAX_SLICES = 2560, HEAVY_GRID = 1024;
+static_assert(SORT20_HV_BYTES == (SORT20_HV_WORDS + (size_t)HEAVY_MAX_SLICES * SORT20_BUCKETS) * 4 && SORT20_HV_WORDS >= 2 + 2 * NBINS, "hv layout");
+
+// the heavy bin that owns slice `id` (< hv[0]): the last bin whose first slice is <= id (bins that are not heavy share their
+// first-slice number with the next heavy one)
+__device__ __forceinline__ uint32_t heavy_bin_of(const uint32_t *hv, uint32_t id) {
+    uint32_t lo = 0, hi = NBINS;  // slice0[lo] <= id, slice0[hi] > id (hi = NBINS: sentinel)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (hv[2 + mid] <= id) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(SORT20_THREADS) void k_heavy_count20(const uint2 *rec, const uint32_t *bin_base, const uint32_t *hv, uint32_t *hcnt) {
+    __shared__ uint32_t h[SORT20_BUCKETS];
+    const uint32_t total = hv[0], SL = hv[1], tid = threadIdx.x;
+    for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+        const uint32_t bin = heavy_bin_of(hv, id), j = id - hv[2 + bin];
+        const uint32_t r0 = bin_base[bin], r1 = bin_base[bin + 1];
+        const uint32_t a = r0 + j * SL, b = a + SL < r1 ? a + SL : r1;
+        sort20_count_range(rec, a, b, h);
+        hcnt[(size_t)id * SORT20_BUCKETS + 2 * tid] = h[2 * tid];
+        hcnt[(size_t)id * SORT20_BUCKETS + 2 * tid + 1] = h[2 * tid + 1];
+        __syncthreads();
+    }
+}
+
+// one block per heavy bin, one thread per bucket: counts -> exclusive offsets over the bin's slices; bucket starts of the bin
+__global__ __launch_bounds__(SORT20_BUCKETS) void k_heavy_scan20(const uint32_t *bin_base, const uint32_t *hv, uint32_t *hcnt, uint32_t *bucket_start) {
+    __shared__ uint32_t ws[8];
+    const uint32_t bin = blockIdx.x, ns = hv[2 + NBINS + bin];
+    if (hv[0] == 0 || ns == 0) return;
+    const uint32_t s0 = hv[2 + bin], b = threadIdx.x;
+    uint32_t run = 0;
+    uint32_t j = 0;
+    for (; j + 8 <= ns; j += 8) {  // eight independent loads in flight
+        uint32_t t[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) t[k] = hcnt[(size_t)(s0 + j + k) * SORT20_BUCKETS + b];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            hcnt[(size_t)(s0 + j + k) * SORT20_BUCKETS + b] = run;
+            run += t[k];
+        }
+    }
+    for (; j < ns; j++) {
+        const uint32_t t = hcnt[(size_t)(s0 + j) * SORT20_BUCKETS + b];
+        hcnt[(size_t)(s0 + j) * SORT20_BUCKETS + b] = run;
+        run += t;
+    }
+    // exclusive scan of the 512 bucket sizes
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t u = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += u;
+    }
+    if (lane == 63) ws[wave] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll
+    for (int w = 0; w < 8; w++)
+        if (w < wave) woff += ws[w];
+    bucket_start[(size_t)bin * SORT20_BUCKETS + b] = bin_base[bin] + woff + incl - run;
+}
+
+__global__ __launch_bounds__(SORT20_THREADS) void k_heavy_place20(const uint2 *rec, const uint32_t *bin_base, const uint32_t *hv, const uint32_t *hcnt,
+                                                                  const uint32_t *bucket_start, uint32_t *entries) {
+    __shared__ uint32_t h[SORT20_BUCKETS], cur[SORT20_BUCKETS], off[SORT20_BUCKETS], sc[4];
+    __shared__ uint2 stage[SORT20_CHUNK];
+    const uint32_t total = hv[0], SL = hv[1], tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
+    for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
+        const uint32_t bin = heavy_bin_of(hv, id), j = id - hv[2 + bin];
+        const uint32_t r0 = bin_base[bin], r1 = bin_base[bin + 1];
+        const uint32_t a = r0 + j * SL, b = a + SL < r1 ? a + SL : r1;
+        cur[b0] = bucket_start[(size_t)bin * SORT20_BUCKETS + b0] + hcnt[(size_t)id * SORT20_BUCKETS + b0];
+        cur[b1] = bucket_start[(size_t)bin * SORT20_BUCKETS + b1] + hcnt[(size_t)id * SORT20_BUCKETS + b1];
+        sort20_place_range(rec, a, b, entries, h, cur, off, sc, stage);
+        __syncthreads();
     }
 }
 
@@ -433,16 +553,21 @@ int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, i
 int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
                  const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
                  uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
-                 uint32_t *segtotal) {
+                 uint32_t *segtotal, uint32_t *hv) {
     if (!ctx->attr_sort20_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter20, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER20_LDS));
         ctx->attr_sort20_set = true;
     }
     const size_t per2 = (n + G2 - 1) / G2;
     KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter20, G2, 1024, BIN_SCATTER20_LDS, (const Fr *)d_scalars, n, sfmt, per2, bins, bin_total,
-               bin_base, row_stride, idx_base, (uint2 *)rec);
-    KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort20, NBINS, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, entries, bucket_start, state,
+               bin_base, row_stride, idx_base, (uint2 *)rec, hv);
+    KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort20, NBINS, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, hv, entries, bucket_start, state,
                slots);
+    uint32_t *hcnt = hv + SORT20_HV_WORDS;
+    KZG_LAUNCH(ctx, st, "k_heavy_count", k_heavy_count20, HEAVY_GRID, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, hv, hcnt);
+    KZG_LAUNCH(ctx, st, "k_heavy_scan", k_heavy_scan20, NBINS, SORT20_BUCKETS, 0, bin_base, hv, hcnt, bucket_start);
+    KZG_LAUNCH(ctx, st, "k_heavy_place", k_heavy_place20, HEAVY_GRID, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, hv, hcnt, bucket_start,
+               entries);
     return wide_s1_layout(ctx, st, bucket_start, NBINS * SORT20_BUCKETS, state, segsums, segmaxs, segtotal, s1);
 }
 

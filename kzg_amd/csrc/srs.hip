@@ -64,15 +64,16 @@ int srs_choose_window(int opt_window_bits, size_t n) {
         // 14, 15) are avoided: every scalar then lands in the same handful of buckets of that window, which the fold handles
         // through its overflow path (correct, but a 0.2 ms serial stage).  c = 8, 10, 13, 16, 17 have 7, 5, 8, 15, 17 bits there.
         const int l = ilog2_ceil(n ? n : 1);
-        // From 2^22 points on 20 bits (13 windows, 2^19 buckets, its own two-level sort): the accumulation's 13 % fewer additions
-        // outgrow the 8x bucket reduction -- same box, batched: 2^20 397 against 432/s, 2^21 224 against 221, 2^22 118.7
-        // against 109.7 (profiles/r03_window20.txt).
-        c = l >= 22 ? 20 : l >= 17 ? 17 : l >= 14 ? 13 : l >= 12 ? 10 : 8;
+        // From 2^23 points on 20 bits (13 windows, 2^19 buckets, its own two-level sort): the accumulation's 13 % fewer additions
+        // outgrow the 8x bucket reduction -- same box, batched, full-width scalars: 2^20 397 against 432/s, 2^21 224 against 221,
+        // 2^22 +8.4 %, 2^23 +9.8 %, 2^24 +12.7 %.  u64-valued scalars (4 windows either way) only pay for the larger bucket
+        // reduction: 2^22 -13.7 %, 2^24 -4.9 % -- which is why the switch is at 2^23 and not 2^22 (profiles/r03_window20.txt).
+        c = l >= 23 ? 20 : l >= 17 ? 17 : l >= 14 ? 13 : l >= 12 ? 10 : 8;
     }
     if (c < 4) c = 4;
     // c <= 16: the 2^(c-1) u32 LDS counters fit the CU's 160 KiB; 17: same pipeline, 15 windows, a two-level sort (msm.hip);
     // 18, 19 use the two-pass ("wide") sort of msm.hip and are only taken when asked for (option window_bits); 20: two-level sort
-    // of msm_wide.hip, the default from 2^22 points on
+    // of msm_wide.hip, the default from 2^23 points on
     if (c > 20) c = 20;
     return c;
 }

@@ -79,7 +79,7 @@ def test_host_only_helpers_shard_range_and_footprint():
     assert lib.kzg_shard_range(10, 4, 4, ctypes.byref(lo), ctypes.byref(hi)) == 3   # KZG_ERR_SHAPE: rank out of range
     nbytes = ctypes.c_size_t()
     assert lib.kzg_srs_footprint(1 << 20, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 15 * 128)
-    assert lib.kzg_srs_footprint(1 << 24, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 24) * (96 + 13 * 128)   # 20-bit windows from 2^22 on
+    assert lib.kzg_srs_footprint(1 << 24, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 24) * (96 + 13 * 128)   # 20-bit windows from 2^23 on
     assert lib.kzg_srs_footprint(1 << 24, 17, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 24) * (96 + 15 * 128)
     assert lib.kzg_srs_footprint(1 << 16, 0, 0, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 16) * (96 + 20 * 128)  # c = 13
     assert lib.kzg_srs_footprint(1 << 20, 0, 3, ctypes.byref(nbytes)) == 0 and nbytes.value == (1 << 20) * (96 + 3 * 128)

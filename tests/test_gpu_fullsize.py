@@ -244,6 +244,35 @@ def test_every_window_size(engine, c):
         engine.set_option("window_bits", 0)
 
 
+def test_window20_heavy_bins_2_18(engine):
+    """The 20-bit window sort cuts a bin that holds far more than its share into slices sorted by separate blocks: u64-valued
+    scalars (the whole top window lands in the first 17 buckets = bin 0), all-equal scalars (13 buckets hold everything), a
+    mix of both with random ones, and small values (every window but the lowest empty) -- each against the known-tau identity."""
+    n = 1 << 18
+    rng = random.Random(20)
+    engine.set_option("window_bits", 20)
+    try:
+        params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+        assert params.gs.window_info() == (20, 13)
+        pw = [1]
+        for _ in range(n - 1):
+            pw.append(pw[-1] * TAU % R)
+        G = C.g1_generator()
+        eq = rng.randrange(R)
+        cases = {
+            "u64": rand_scalars(rng, n, "u64"),
+            "all_equal": [eq] * n,
+            "mixed": [eq if i % 3 == 0 else rng.getrandbits(64) if i % 3 == 1 else rng.randrange(R) for i in range(n)],
+            "small": [rng.randrange(1, 1 << 12) for _ in range(n)],
+        }
+        for name, sc in cases.items():
+            want = C.g1_mul(G, sum(s * p for s, p in zip(sc, pw)) % R)
+            assert engine.msm(params.gs, sc) == want, name
+        params.gs.free()
+    finally:
+        engine.set_option("window_bits", 0)
+
+
 @pytest.mark.parametrize("n", [5, 300, 3000, 9000, 40000, 140000])
 def test_default_window_choice(engine, n):
     """The widths the engine picks by itself (8, 10, 13, 17 by size) give the right commitment."""
@@ -339,7 +368,7 @@ def test_config5_2_24_sharded_8_ways_and_whole(engine):
     assert rc == 0 and out.raw == want
     # the whole SRS on one GPU
     params = kzg_amd.setup(engine, TAU, n, g2_len=0)
-    assert params.gs.window_info() == (20, 13)     # from 2^22 points on: 13 windows of 20 bits
+    assert params.gs.window_info() == (20, 13)     # from 2^23 points on: 13 windows of 20 bits
     assert _msm_dev(engine, params.gs, buf, n) == want
     params.gs.free()
     engine.set_option("window_bits", 17)           # and the 15-window layout at the same size
