@@ -268,26 +268,6 @@ __global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *blk_bins, int G, ui
     if (slice == 0) bin_total[bin] = tot;
 }
 
-// Level-1 record = (entry word, low 6 bucket bits).  Two encodings: 8 bytes (uint2) in general; 4 bytes when the table index
-// fits 25 bits (table rows x points <= 2^25, i.e. up to 2^21 points with 15 rows): index | sign << 25 | low bits << 26 --
-// half the record traffic of both levels.
-struct Rec8 {
-    typedef uint2 T;
-    static __device__ __forceinline__ T pack(uint32_t index, uint32_t neg, uint32_t lo) { return make_uint2(index | (neg << 31), lo); }
-    static __device__ __forceinline__ uint32_t entry(const T &r) { return r.x; }
-    static __device__ __forceinline__ uint32_t lo(const T &r) { return r.y; }
-    static __device__ __forceinline__ T invalid() { return make_uint2(0u, 0xffffffffu); }
-    static __device__ __forceinline__ bool valid(const T &r) { return r.y != 0xffffffffu; }
-};
-struct Rec4 {
-    typedef uint32_t T;
-    static __device__ __forceinline__ T pack(uint32_t index, uint32_t neg, uint32_t lo) { return index | (neg << 25) | (lo << 26); }
-    static __device__ __forceinline__ uint32_t entry(const T &r) { return (r & 0x1ffffffu) | (((r >> 25) & 1u) << 31); }
-    static __device__ __forceinline__ uint32_t lo(const T &r) { return r >> 26; }
-    static __device__ __forceinline__ T invalid() { return 0xffffffffu; }  // index 2^25 - 1 with sign and lo = 63: never packed (index < 2^25 - 1)
-    static __device__ __forceinline__ bool valid(const T &r) { return r != 0xffffffffu; }
-};
-constexpr uint64_t REC4_MAX_INDEX = (1ull << 25) - 1;  // exclusive bound on table rows x padded points for Rec4
 
 // Level 1.  A block takes its scalars in chunks of 1024 (one per thread).  Per chunk the <= 15 K records are first sorted by bin
 // inside the LDS (count -> scan -> place, one packed word per record), then written out in that order: a wave's 64 stores
@@ -447,81 +427,8 @@ __global__ __launch_bounds__(1024) void k_bin_scatter_naf(const uint32_t *recs, 
     }
 }
 
-// Level 2.  block = bin: bucket sizes -> total[], then the records -> entries[] in bucket order (order inside a bucket is
-// arbitrary, as before), again chunk-sorted in LDS first so that each bucket's share of a chunk is one run of stores.
-constexpr int BIN_SORT_THREADS = 256, BIN_SORT_UNROLL = 8, BIN_SORT_CHUNK = BIN_SORT_THREADS * BIN_SORT_UNROLL;
-template <class REC>
-__global__ __launch_bounds__(BIN_SORT_THREADS) void k_bin_sort(const typename REC::T *rec, const uint32_t *bin_base, uint32_t *entries,
-                                                               uint32_t *total) {
-    KZG_SIDE_PRIO_STMT;
-    typedef typename REC::T RT;
-    __shared__ uint32_t h[BIN_BUCKETS], cur[BIN_BUCKETS], off[BIN_BUCKETS];
-    __shared__ RT stage[BIN_SORT_CHUNK];
-    const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
-    if (threadIdx.x < BIN_BUCKETS) h[threadIdx.x] = 0;
-    __syncthreads();
-    for (uint32_t base = r0 + threadIdx.x; base < r1; base += BIN_SORT_CHUNK) {
-        RT e[BIN_SORT_UNROLL];
-#pragma unroll
-        for (int k = 0; k < BIN_SORT_UNROLL; k++) {
-            const uint32_t r = base + (uint32_t)k * BIN_SORT_THREADS;
-            e[k] = r < r1 ? rec[r] : REC::invalid();
-        }
-#pragma unroll
-        for (int k = 0; k < BIN_SORT_UNROLL; k++)
-            if (REC::valid(e[k])) atomicAdd(&h[REC::lo(e[k])], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < BIN_BUCKETS) {  // one wave
-        const uint32_t v = h[threadIdx.x];
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(incl, o, 64);
-            if ((int)threadIdx.x >= o) incl += u;
-        }
-        total[(size_t)blockIdx.x * BIN_BUCKETS + threadIdx.x] = v;
-        cur[threadIdx.x] = r0 + incl - v;
-    }
-    for (uint32_t c0 = r0; c0 < r1; c0 += BIN_SORT_CHUNK) {
-        if (threadIdx.x < BIN_BUCKETS) h[threadIdx.x] = 0;
-        __syncthreads();
-        RT e[BIN_SORT_UNROLL];
-        uint32_t rk[BIN_SORT_UNROLL];
-#pragma unroll
-        for (int k = 0; k < BIN_SORT_UNROLL; k++) {
-            const uint32_t r = c0 + threadIdx.x + (uint32_t)k * BIN_SORT_THREADS;
-            e[k] = r < r1 ? rec[r] : REC::invalid();
-        }
-#pragma unroll
-        for (int k = 0; k < BIN_SORT_UNROLL; k++)
-            if (REC::valid(e[k])) rk[k] = atomicAdd(&h[REC::lo(e[k])], 1u);
-        __syncthreads();
-        if (threadIdx.x < BIN_BUCKETS) {
-            const uint32_t v = h[threadIdx.x];
-            uint32_t incl = v;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                uint32_t u = __shfl_up(incl, o, 64);
-                if ((int)threadIdx.x >= o) incl += u;
-            }
-            off[threadIdx.x] = incl - v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < BIN_SORT_UNROLL; k++)
-            if (REC::valid(e[k])) stage[off[REC::lo(e[k])] + rk[k]] = e[k];
-        __syncthreads();
-        const uint32_t m = r1 - c0 < (uint32_t)BIN_SORT_CHUNK ? r1 - c0 : (uint32_t)BIN_SORT_CHUNK;
-        for (uint32_t p = threadIdx.x; p < m; p += BIN_SORT_THREADS) {
-            const RT v = stage[p];
-            const uint32_t b = REC::lo(v);
-            entries[cur[b] + p - off[b]] = REC::entry(v);
-        }
-        __syncthreads();
-        if (threadIdx.x < BIN_BUCKETS) cur[threadIdx.x] += h[threadIdx.x];
-    }
-}
+// Level 2 (block = bin: bucket sizes -> total[], then the records -> entries[] in bucket order, chunk-sorted in LDS first so that
+// each bucket's share of a chunk is one run of stores) lives in msm_wide.hip with the handling of oversized bins: sort2_level2.
 
 // k_scan_b for the two-level sort: block j's first bucket starts at bin_base[4 j], M = bin_base[NBINS]
 __global__ __launch_bounds__(SCAN_SEG) void k_scan_b_bins(const uint32_t *total, const uint32_t *bin_base, int B, int NB,
@@ -807,7 +714,7 @@ static MsmLayout msm_layout(const kzg_srs *srs, size_t n) {
     L.off_bin_base = take((2 * NBINS + 1) * 4);  // bin starts, then bin sizes
     L.off_recs = take(srs->naf ? (size_t)NAF_MAX_DIGITS * n * 4 : 0);  // positional tables: the digit records of the scalars
     L.off_seg = take(srs->sort20 ? 3 * 256 * 4 : 0);  // segment sums / maxima / total of the round-1 layout scan (wide_s1_layout)
-    L.off_hv = take(srs->sort20 ? SORT20_HV_BYTES : 0);   // bins sorted in slices (msm_wide.hip)
+    L.off_hv = take(srs->sort20 ? sort2_hv_bytes(SORT20_BUCKETS) : (srs->narrow17 || srs->naf) ? sort2_hv_bytes(BIN_BUCKETS) : 0);  // bins sorted in slices (msm_wide.hip)
     L.off_total = take((size_t)L.B * 4);
     L.off_local = take((size_t)L.B * 4);
     L.off_agg = take(2 * SCAN_SEG * 4 + 64);  // block aggregates + the chained flag counts
@@ -1030,12 +937,12 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
                 uint32_t *rec = (uint32_t *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter_naf<Rec4>, G2, 1024, BIN_SCATTER_LDS, recs, n, per2, bins, bin_total, bin_base,
                            (uint32_t)srs->npad, (uint32_t)offset, rec);
-                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec4>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+                KZG_TRY(sort2_level2(ctx, st, 4, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
             } else {
                 uint2 *rec = (uint2 *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter_naf<Rec8>, G2, 1024, BIN_SCATTER_LDS, recs, n, per2, bins, bin_total, bin_base,
                            (uint32_t)srs->npad, (uint32_t)offset, rec);
-                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec8>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+                KZG_TRY(sort2_level2(ctx, st, 8, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
             }
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);
@@ -1060,12 +967,12 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
                 uint32_t *rec = (uint32_t *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter<Rec4>, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total,
                            bin_base, (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
-                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec4>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+                KZG_TRY(sort2_level2(ctx, st, 4, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
             } else {
                 uint2 *rec = (uint2 *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter<Rec8>, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total,
                            bin_base, (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
-                KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort<Rec8>, NBINS, BIN_SORT_THREADS, 0, rec, bin_base, entries, total);
+                KZG_TRY(sort2_level2(ctx, st, 8, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
             }
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);

@@ -61,8 +61,14 @@ int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, 
                  const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
                  uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
                  uint32_t *segtotal, uint32_t *hv);
-// hv: descriptor of the bins sorted in slices (2 + 2 NBINS words, 256-byte padded) followed by the per-slice bucket counts
-constexpr size_t SORT20_HV_WORDS = 2112, SORT20_HV_BYTES = (SORT20_HV_WORDS + (size_t)2560 * SORT20_BUCKETS) * 4;
+// Level 2 of both two-level sorts (one block per bin) + the bins that are sorted in slices (msm_wide.hip).  kind: 4 / 8 = the
+// c = 17 records of msm.hip (64 buckets per bin; bucket sizes -> total[], k_scan_b_bins follows), 20 = c = 20 (512 buckets per
+// bin; bucket starts and the equal-split state).  bucket_start is scratch for the heavy bins in the first case as well.
+// hv: descriptor (2 + 2 NBINS words, padded) followed by the per-slice bucket counts (<= 2560 slices x buckets per bin)
+constexpr size_t SORT2_HV_WORDS = 2112;
+constexpr size_t sort2_hv_bytes(int buckets_per_bin) { return (SORT2_HV_WORDS + (size_t)2560 * buckets_per_bin) * 4; }
+int sort2_level2(kzg_ctx *ctx, hipStream_t st, int kind, const void *rec, const uint32_t *bin_base, const uint32_t *bin_total, uint32_t *hv,
+                 uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots);
 
 // msm_tail.hip: everything after the bucket accumulation (fold to one point per bucket, sum (b+1) B_b)
 struct TailLayout {

@@ -167,4 +167,33 @@ __device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t *wsum /
     return incl - v + woff;
 }
 
+// Level-1 record = (entry word, low 6 bucket bits).  Two encodings: 8 bytes (uint2) in general; 4 bytes when the table index
+// fits 25 bits (table rows x points <= 2^25, i.e. up to 2^21 points with 15 rows): index | sign << 25 | low bits << 26 --
+// half the record traffic of both levels.
+struct Rec8 {
+    typedef uint2 T;
+    static __device__ __forceinline__ T pack(uint32_t index, uint32_t neg, uint32_t lo) { return make_uint2(index | (neg << 31), lo); }
+    static __device__ __forceinline__ uint32_t entry(const T &r) { return r.x; }
+    static __device__ __forceinline__ uint32_t lo(const T &r) { return r.y; }
+    static __device__ __forceinline__ T invalid() { return make_uint2(0u, 0xffffffffu); }
+    static __device__ __forceinline__ bool valid(const T &r) { return r.y != 0xffffffffu; }
+};
+struct Rec4 {
+    typedef uint32_t T;
+    static __device__ __forceinline__ T pack(uint32_t index, uint32_t neg, uint32_t lo) { return index | (neg << 25) | (lo << 26); }
+    static __device__ __forceinline__ uint32_t entry(const T &r) { return (r & 0x1ffffffu) | (((r >> 25) & 1u) << 31); }
+    static __device__ __forceinline__ uint32_t lo(const T &r) { return r >> 26; }
+    static __device__ __forceinline__ T invalid() { return 0xffffffffu; }  // index 2^25 - 1 with sign and lo = 63: never packed (index < 2^25 - 1)
+    static __device__ __forceinline__ bool valid(const T &r) { return r != 0xffffffffu; }
+};
+constexpr uint64_t REC4_MAX_INDEX = (1ull << 25) - 1;  // exclusive bound on table rows x padded points for Rec4
+// c = 20 (msm_wide.hip): (entry word, low 9 bucket bits | bin << 16): the bin rides along so that level 1 can stage finished records
+struct Rec20 {
+    typedef uint2 T;
+    static __device__ __forceinline__ uint32_t entry(const T &r) { return r.x; }
+    static __device__ __forceinline__ uint32_t lo(const T &r) { return r.y & 0xffffu; }
+    static __device__ __forceinline__ T invalid() { return make_uint2(0u, 0xffffffffu); }
+    static __device__ __forceinline__ bool valid(const T &r) { return r.y != 0xffffffffu; }
+};
+
 }  // namespace kzg

@@ -276,30 +276,17 @@ __global__ __launch_bounds__(1024) void k_bin_hist20(const Fr *scalars, size_t n
 constexpr int BIN_SCATTER20_LDS = (3 * NBINS + 16) * 4 + SORT20_W * 1024 * 8;
 __global__ __launch_bounds__(1024) void k_bin_scatter20(const Fr *scalars, size_t n, int sfmt, size_t per_block, const uint32_t *blk_off,
                                                         const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride,
-                                                        uint32_t idx_base, uint2 *rec, uint32_t *hv) {
+                                                        uint32_t idx_base, uint2 *rec) {
     uint32_t *cur = lds_u32, *cnt = cur + NBINS, *off = cnt + NBINS, *wsum = off + NBINS;
     uint2 *stage = reinterpret_cast<uint2 *>(wsum + 16);
     const uint32_t tid = threadIdx.x;
     {   // bin_base = exclusive scan of the bin sizes (every block computes it; block 0 publishes it for the later kernels)
         uint32_t tot;
-        const uint32_t size = bin_total[tid];
-        const uint32_t ex = block_scan_1024(size, wsum, &tot);
+        const uint32_t ex = block_scan_1024(bin_total[tid], wsum, &tot);
         cur[tid] = ex + blk_off[(size_t)blockIdx.x * NBINS + tid];
-        if (blockIdx.x == 0) {  // (uniform branch: the scan inside is executed by the whole block)
+        if (blockIdx.x == 0) {
             bin_base[tid] = ex;
             if (tid == 0) bin_base[NBINS] = tot;
-            // heavy bins -> slices (see k_bin_sort20)
-            uint32_t SL = (tot + 2047) / 2048;
-            if (SL < 32768u) SL = 32768u;
-            const uint32_t ns = size > 4 * SL ? (size + SL - 1) / SL : 0u;
-            uint32_t nsl;
-            const uint32_t s0 = block_scan_1024(ns, wsum, &nsl);
-            hv[2 + tid] = s0;
-            hv[2 + NBINS + tid] = ns;
-            if (tid == 0) {
-                hv[0] = nsl;
-                hv[1] = SL;
-            }
         }
     }
     const size_t i0 = (size_t)blockIdx.x * per_block;
@@ -338,88 +325,111 @@ __global__ __launch_bounds__(1024) void k_bin_scatter20(const Fr *scalars, size_
     }
 }
 
-// Level 2: one block per bin.  Counts the bin's 512 buckets (their starts = bucket_start[], two per thread), then places the
-// records chunk by chunk, each chunk sorted by bucket in LDS first.  Block 0 also sets the equal-split state.
+// Level 2 of both two-level sorts, and HEAVY bins.
 //
-// HEAVY bins.  One block per bin assumes bins of similar size.  They are not when many digits are small: u64-valued scalars put the
-// whole top window (4 bits + carry at c = 20) into the first 17 buckets = bin 0, all-equal scalars put everything into 13
-// buckets.  A bin of more than 4 SL records (SL = max(32768, M / 2048)) is therefore cut into slices of SL records that are
-// sorted by separate blocks: k_heavy_count20 (per-slice bucket counts), k_heavy_scan20 (per bucket the exclusive scan over the
-// bin's slices, then the bucket starts), k_heavy_place20.  The descriptor hv[] is written by block 0 of k_bin_scatter20:
-// hv[0] = slices in total (0: the three kernels return at once), hv[1] = SL, hv[2 + bin] = first slice of the bin,
-// hv[2 + NBINS + bin] = its slice count (0 = not heavy: k_bin_sort20 takes it).  At most M / SL + M / (4 SL) <= 2560 slices.
-constexpr int SORT20_THREADS = 256, SORT20_UNROLL = 8, SORT20_CHUNK = SORT20_THREADS * SORT20_UNROLL;
+// Level 2 sorts a bin with one block, which assumes bins of similar size.  They are not when many digits are small: scalars that
+// are bits or bytes put every entry into a handful of buckets of bin 0, u64-valued scalars at c = 20 put the whole top window
+// (4 bits + carry) there, all-equal scalars put everything into 13 / 15 buckets -- one block then places up to M records, through
+// LDS atomics on a few addresses (measured at 2^20, c = 17: k_bin_sort 0.04 ms for uniform scalars, 1.3 ms for bits, 2.6 ms for
+// all-ones).  A bin of more than 4 SL records (SL = max(32768, M / 2048)) is therefore cut into slices of SL records that
+// separate blocks sort: k_heavy_plan (descriptor hv[] from the bin sizes), k_heavy_count (per-slice bucket counts),
+// k_heavy_scan (per bucket the exclusive scan over the bin's slices; bucket sizes and starts), k_heavy_place.
+// hv[0] = slices in total (0: count / scan / place return at once), hv[1] = SL, hv[2 + bin] = first slice of the bin,
+// hv[2 + NBINS + bin] = its slice count (0 = not heavy: the one-block kernel takes it).  At most M / SL + M / (4 SL) <= 2560 slices.
+constexpr int SORT2_THREADS = 256, SORT2_UNROLL = 8, SORT2_CHUNK = SORT2_THREADS * SORT2_UNROLL;
+constexpr int HEAVY_MAX_SLICES = 2560, HEAVY_GRID = 1024;
+static_assert(SORT2_HV_WORDS >= 2 + 2 * NBINS, "hv layout");
 
-// records [c_begin, c_end) -> entries[], by bucket; cur[] = next free position per bucket (set and synchronised by the caller)
-__device__ __forceinline__ void sort20_place_range(const uint2 *rec, uint32_t c_begin, uint32_t c_end, uint32_t *entries, uint32_t *h,
-                                                   uint32_t *cur, uint32_t *off, uint32_t *sc, uint2 *stage) {
-    const uint32_t tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
-    for (uint32_t c0 = c_begin; c0 < c_end; c0 += SORT20_CHUNK) {
-        h[b0] = 0;
-        h[b1] = 0;
-        __syncthreads();
-        uint2 e[SORT20_UNROLL];
-        uint32_t rk[SORT20_UNROLL];
-#pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++) {
-            const uint32_t r = c0 + tid + (uint32_t)k * SORT20_THREADS;
-            e[k] = r < c_end ? rec[r] : make_uint2(0u, 0xffffffffu);
-        }
-#pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++)
-            if (e[k].y != 0xffffffffu) rk[k] = atomicAdd(&h[e[k].y & 0xffffu], 1u);
-        __syncthreads();
-        {
-            const uint32_t v0 = h[b0], v1 = h[b1];
-            uint32_t tot;
-            const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
-            off[b0] = ex;
-            off[b1] = ex + v0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++)
-            if (e[k].y != 0xffffffffu) stage[off[e[k].y & 0xffffu] + rk[k]] = e[k];
-        __syncthreads();
-        const uint32_t m = c_end - c0 < (uint32_t)SORT20_CHUNK ? c_end - c0 : (uint32_t)SORT20_CHUNK;
-        for (uint32_t p = tid; p < m; p += SORT20_THREADS) {
-            const uint2 v = stage[p];
-            const uint32_t b = v.y & 0xffffu;
-            entries[cur[b] + p - off[b]] = v.x;
-        }
-        __syncthreads();
-        cur[b0] += h[b0];
-        cur[b1] += h[b1];
+// exclusive scan of h[0 .. NB) into off[] (NB = 64: one value per thread of the first wave; 512: two per thread); synchronised
+// on entry by the caller, NOT on return
+template <int NB>
+__device__ __forceinline__ void sort2_scan(const uint32_t *h, uint32_t *off, uint32_t *sc) {
+    const uint32_t tid = threadIdx.x;
+    if (NB == 512) {
+        const uint32_t v0 = h[2 * tid], v1 = h[2 * tid + 1];
+        uint32_t tot;
+        const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
+        off[2 * tid] = ex;
+        off[2 * tid + 1] = ex + v0;
+    } else {
+        const uint32_t v = tid < NB ? h[tid] : 0u;
+        uint32_t tot;
+        const uint32_t ex = block_scan_256(v, sc, &tot);
+        if (tid < NB) off[tid] = ex;
     }
 }
 
 // bucket counts of records [a, b) into h[] (zeroed here); synchronised on return
-__device__ __forceinline__ void sort20_count_range(const uint2 *rec, uint32_t a, uint32_t b, uint32_t *h) {
+template <class REC, int NB>
+__device__ __forceinline__ void sort2_count_range(const typename REC::T *rec, uint32_t a, uint32_t b, uint32_t *h) {
+    typedef typename REC::T RT;
     const uint32_t tid = threadIdx.x;
-    h[2 * tid] = 0;
-    h[2 * tid + 1] = 0;
+    for (uint32_t k = tid; k < NB; k += SORT2_THREADS) h[k] = 0;
     __syncthreads();
-    for (uint32_t base = a + tid; base < b; base += SORT20_CHUNK) {
-        uint2 e[SORT20_UNROLL];
+    for (uint32_t base = a + tid; base < b; base += SORT2_CHUNK) {
+        RT e[SORT2_UNROLL];
 #pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++) {
-            const uint32_t r = base + (uint32_t)k * SORT20_THREADS;
-            e[k] = r < b ? rec[r] : make_uint2(0u, 0xffffffffu);
+        for (int k = 0; k < SORT2_UNROLL; k++) {
+            const uint32_t r = base + (uint32_t)k * SORT2_THREADS;
+            e[k] = r < b ? rec[r] : REC::invalid();
         }
 #pragma unroll
-        for (int k = 0; k < SORT20_UNROLL; k++)
-            if (e[k].y != 0xffffffffu) atomicAdd(&h[e[k].y & 0xffffu], 1u);
+        for (int k = 0; k < SORT2_UNROLL; k++)
+            if (REC::valid(e[k])) atomicAdd(&h[REC::lo(e[k])], 1u);
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec, const uint32_t *bin_base, const uint32_t *hv,
-                                                               uint32_t *entries, uint32_t *bucket_start, MsmState *st, uint32_t slots) {
-    __shared__ uint32_t h[SORT20_BUCKETS], cur[SORT20_BUCKETS], off[SORT20_BUCKETS], sc[4];
-    __shared__ uint2 stage[SORT20_CHUNK];
-    const uint32_t tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
+// records [c_begin, c_end) -> entries[], by bucket, each chunk sorted in LDS first; cur[] = next free position per bucket (set by
+// the caller; the first barrier inside orders it)
+template <class REC, int NB>
+__device__ __forceinline__ void sort2_place_range(const typename REC::T *rec, uint32_t c_begin, uint32_t c_end, uint32_t *entries,
+                                                  uint32_t *h, uint32_t *cur, uint32_t *off, uint32_t *sc, typename REC::T *stage) {
+    typedef typename REC::T RT;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t c0 = c_begin; c0 < c_end; c0 += SORT2_CHUNK) {
+        for (uint32_t k = tid; k < NB; k += SORT2_THREADS) h[k] = 0;
+        __syncthreads();
+        RT e[SORT2_UNROLL];
+        uint32_t rk[SORT2_UNROLL];
+#pragma unroll
+        for (int k = 0; k < SORT2_UNROLL; k++) {
+            const uint32_t r = c0 + tid + (uint32_t)k * SORT2_THREADS;
+            e[k] = r < c_end ? rec[r] : REC::invalid();
+        }
+#pragma unroll
+        for (int k = 0; k < SORT2_UNROLL; k++)
+            if (REC::valid(e[k])) rk[k] = atomicAdd(&h[REC::lo(e[k])], 1u);
+        __syncthreads();
+        sort2_scan<NB>(h, off, sc);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT2_UNROLL; k++)
+            if (REC::valid(e[k])) stage[off[REC::lo(e[k])] + rk[k]] = e[k];
+        __syncthreads();
+        const uint32_t m = c_end - c0 < (uint32_t)SORT2_CHUNK ? c_end - c0 : (uint32_t)SORT2_CHUNK;
+        for (uint32_t p = tid; p < m; p += SORT2_THREADS) {
+            const RT v = stage[p];
+            const uint32_t b = REC::lo(v);
+            entries[cur[b] + p - off[b]] = REC::entry(v);
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < NB; k += SORT2_THREADS) cur[k] += h[k];
+    }
+}
+
+// One block per bin (not heavy): bucket sizes -> total[] (if asked for) and bucket starts -> bucket_start[] (if asked for), then the
+// records -> entries[].  set_state: block 0 also sets the equal-split state (the c = 20 pipeline; c = 17 does it in k_scan_b_bins).
+template <class REC, int NB>
+__global__ __launch_bounds__(SORT2_THREADS) void k_bin_sort2(const typename REC::T *rec, const uint32_t *bin_base, const uint32_t *hv,
+                                                             uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *st,
+                                                             uint32_t slots) {
+    typedef typename REC::T RT;
+    __shared__ uint32_t h[NB], cur[NB], off[NB], sc[4];
+    __shared__ RT stage[SORT2_CHUNK];
+    const uint32_t tid = threadIdx.x;
     const uint32_t r0 = bin_base[blockIdx.x], r1 = bin_base[blockIdx.x + 1];
-    if (blockIdx.x == 0 && tid == 0) {
+    if (st && blockIdx.x == 0 && tid == 0) {
         const uint32_t M = bin_base[NBINS];
         uint32_t E = (M + slots - 1) / slots;
         if (E < 8) E = 8;
@@ -427,24 +437,38 @@ __global__ __launch_bounds__(SORT20_THREADS) void k_bin_sort20(const uint2 *rec,
         st->E = E;
         st->ntasks = (M + E - 1) / E;
         st->ovf_tasks = 0;
-        bucket_start[(size_t)NBINS * SORT20_BUCKETS] = M;
+        bucket_start[(size_t)NBINS * NB] = M;
     }
     if (hv[2 + NBINS + blockIdx.x]) return;  // a heavy bin: the slice kernels sort it
-    sort20_count_range(rec, r0, r1, h);
-    {
-        const uint32_t v0 = h[b0], v1 = h[b1];
-        uint32_t tot;
-        const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
-        cur[b0] = r0 + ex;
-        cur[b1] = r0 + ex + v0;
-        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b0] = r0 + ex;
-        bucket_start[(size_t)blockIdx.x * SORT20_BUCKETS + b1] = r0 + ex + v0;
+    sort2_count_range<REC, NB>(rec, r0, r1, h);
+    sort2_scan<NB>(h, off, sc);
+    __syncthreads();
+    for (uint32_t k = tid; k < NB; k += SORT2_THREADS) {
+        const uint32_t start = r0 + off[k];
+        cur[k] = start;
+        if (total) total[(size_t)blockIdx.x * NB + k] = h[k];
+        if (bucket_start) bucket_start[(size_t)blockIdx.x * NB + k] = start;
     }
-    sort20_place_range(rec, r0, r1, entries, h, cur, off, sc, stage);
+    sort2_place_range<REC, NB>(rec, r0, r1, entries, h, cur, off, sc, stage);
 }
 
-constexpr int HEAVY_MAX_SLICES = 2560, HEAVY_GRID = 1024;
-static_assert(SORT20_HV_BYTES == (SORT20_HV_WORDS + (size_t)HEAVY_MAX_SLICES * SORT20_BUCKETS) * 4 && SORT20_HV_WORDS >= 2 + 2 * NBINS, "hv layout");
+__global__ __launch_bounds__(1024) void k_heavy_plan(const uint32_t *bin_total, uint32_t *hv) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, size = bin_total[tid];
+    uint32_t M;
+    block_scan_1024(size, wsum, &M);
+    uint32_t SL = (M + 2047) / 2048;
+    if (SL < 32768u) SL = 32768u;
+    const uint32_t ns = size > 4 * SL ? (size + SL - 1) / SL : 0u;
+    uint32_t nsl;
+    const uint32_t s0 = block_scan_1024(ns, wsum, &nsl);
+    hv[2 + tid] = s0;
+    hv[2 + NBINS + tid] = ns;
+    if (tid == 0) {
+        hv[0] = nsl;
+        hv[1] = SL;
+    }
+}
 
 // the heavy bin that owns slice `id` (< hv[0]): the last bin whose first slice is <= id (bins that are not heavy share their
 // first-slice number with the next heavy one)
@@ -457,44 +481,46 @@ __device__ __forceinline__ uint32_t heavy_bin_of(const uint32_t *hv, uint32_t id
     return lo;
 }
 
-__global__ __launch_bounds__(SORT20_THREADS) void k_heavy_count20(const uint2 *rec, const uint32_t *bin_base, const uint32_t *hv, uint32_t *hcnt) {
-    __shared__ uint32_t h[SORT20_BUCKETS];
+template <class REC, int NB>
+__global__ __launch_bounds__(SORT2_THREADS) void k_heavy_count(const typename REC::T *rec, const uint32_t *bin_base, const uint32_t *hv,
+                                                               uint32_t *hcnt) {
+    __shared__ uint32_t h[NB];
     const uint32_t total = hv[0], SL = hv[1], tid = threadIdx.x;
     for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
         const uint32_t bin = heavy_bin_of(hv, id), j = id - hv[2 + bin];
         const uint32_t r0 = bin_base[bin], r1 = bin_base[bin + 1];
         const uint32_t a = r0 + j * SL, b = a + SL < r1 ? a + SL : r1;
-        sort20_count_range(rec, a, b, h);
-        hcnt[(size_t)id * SORT20_BUCKETS + 2 * tid] = h[2 * tid];
-        hcnt[(size_t)id * SORT20_BUCKETS + 2 * tid + 1] = h[2 * tid + 1];
+        sort2_count_range<REC, NB>(rec, a, b, h);
+        for (uint32_t k = tid; k < NB; k += SORT2_THREADS) hcnt[(size_t)id * NB + k] = h[k];
         __syncthreads();
     }
 }
 
-// one block per heavy bin, one thread per bucket: counts -> exclusive offsets over the bin's slices; bucket starts of the bin
-__global__ __launch_bounds__(SORT20_BUCKETS) void k_heavy_scan20(const uint32_t *bin_base, const uint32_t *hv, uint32_t *hcnt, uint32_t *bucket_start) {
+// one block per heavy bin, one thread per bucket: counts -> exclusive offsets over the bin's slices; bucket sizes and starts
+template <int NB>
+__global__ __launch_bounds__(NB) void k_heavy_scan(const uint32_t *bin_base, const uint32_t *hv, uint32_t *hcnt, uint32_t *total,
+                                                   uint32_t *bucket_start) {
     __shared__ uint32_t ws[8];
     const uint32_t bin = blockIdx.x, ns = hv[2 + NBINS + bin];
     if (hv[0] == 0 || ns == 0) return;
     const uint32_t s0 = hv[2 + bin], b = threadIdx.x;
-    uint32_t run = 0;
-    uint32_t j = 0;
+    uint32_t run = 0, j = 0;
     for (; j + 8 <= ns; j += 8) {  // eight independent loads in flight
         uint32_t t[8];
 #pragma unroll
-        for (int k = 0; k < 8; k++) t[k] = hcnt[(size_t)(s0 + j + k) * SORT20_BUCKETS + b];
+        for (int k = 0; k < 8; k++) t[k] = hcnt[(size_t)(s0 + j + k) * NB + b];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-            hcnt[(size_t)(s0 + j + k) * SORT20_BUCKETS + b] = run;
+            hcnt[(size_t)(s0 + j + k) * NB + b] = run;
             run += t[k];
         }
     }
     for (; j < ns; j++) {
-        const uint32_t t = hcnt[(size_t)(s0 + j) * SORT20_BUCKETS + b];
-        hcnt[(size_t)(s0 + j) * SORT20_BUCKETS + b] = run;
+        const uint32_t t = hcnt[(size_t)(s0 + j) * NB + b];
+        hcnt[(size_t)(s0 + j) * NB + b] = run;
         run += t;
     }
-    // exclusive scan of the 512 bucket sizes
+    // exclusive scan of the NB bucket sizes
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = run;
 #pragma unroll
@@ -506,23 +532,25 @@ __global__ __launch_bounds__(SORT20_BUCKETS) void k_heavy_scan20(const uint32_t 
     __syncthreads();
     uint32_t woff = 0;
 #pragma unroll
-    for (int w = 0; w < 8; w++)
+    for (int w = 0; w < NB / 64; w++)
         if (w < wave) woff += ws[w];
-    bucket_start[(size_t)bin * SORT20_BUCKETS + b] = bin_base[bin] + woff + incl - run;
+    if (total) total[(size_t)bin * NB + b] = run;
+    bucket_start[(size_t)bin * NB + b] = bin_base[bin] + woff + incl - run;
 }
 
-__global__ __launch_bounds__(SORT20_THREADS) void k_heavy_place20(const uint2 *rec, const uint32_t *bin_base, const uint32_t *hv, const uint32_t *hcnt,
-                                                                  const uint32_t *bucket_start, uint32_t *entries) {
-    __shared__ uint32_t h[SORT20_BUCKETS], cur[SORT20_BUCKETS], off[SORT20_BUCKETS], sc[4];
-    __shared__ uint2 stage[SORT20_CHUNK];
-    const uint32_t total = hv[0], SL = hv[1], tid = threadIdx.x, b0 = 2 * tid, b1 = 2 * tid + 1;
+template <class REC, int NB>
+__global__ __launch_bounds__(SORT2_THREADS) void k_heavy_place(const typename REC::T *rec, const uint32_t *bin_base, const uint32_t *hv,
+                                                               const uint32_t *hcnt, const uint32_t *bucket_start, uint32_t *entries) {
+    typedef typename REC::T RT;
+    __shared__ uint32_t h[NB], cur[NB], off[NB], sc[4];
+    __shared__ RT stage[SORT2_CHUNK];
+    const uint32_t total = hv[0], SL = hv[1], tid = threadIdx.x;
     for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
         const uint32_t bin = heavy_bin_of(hv, id), j = id - hv[2 + bin];
         const uint32_t r0 = bin_base[bin], r1 = bin_base[bin + 1];
         const uint32_t a = r0 + j * SL, b = a + SL < r1 ? a + SL : r1;
-        cur[b0] = bucket_start[(size_t)bin * SORT20_BUCKETS + b0] + hcnt[(size_t)id * SORT20_BUCKETS + b0];
-        cur[b1] = bucket_start[(size_t)bin * SORT20_BUCKETS + b1] + hcnt[(size_t)id * SORT20_BUCKETS + b1];
-        sort20_place_range(rec, a, b, entries, h, cur, off, sc, stage);
+        for (uint32_t k = tid; k < NB; k += SORT2_THREADS) cur[k] = bucket_start[(size_t)bin * NB + k] + hcnt[(size_t)id * NB + k];
+        sort2_place_range<REC, NB>(rec, a, b, entries, h, cur, off, sc, stage);
         __syncthreads();
     }
 }
@@ -550,6 +578,30 @@ int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, i
     return KZG_OK;
 }
 
+// level 2 + heavy bins.  kind: 4 = Rec4, 8 = Rec8 (c = 17: NB = 64, sizes -> total[]), 20 = Rec20 (NB = 512, starts and state)
+template <class REC, int NB>
+static int sort2_level2_t(kzg_ctx *ctx, hipStream_t st, const void *rec_v, const uint32_t *bin_base, const uint32_t *bin_total, uint32_t *hv,
+                          uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots) {
+    typedef typename REC::T RT;
+    const RT *rec = (const RT *)rec_v;
+    uint32_t *hcnt = hv + SORT2_HV_WORDS;
+    KZG_LAUNCH(ctx, st, "k_heavy_plan", k_heavy_plan, 1, 1024, 0, bin_total, hv);
+    KZG_LAUNCH(ctx, st, "k_bin_sort", (k_bin_sort2<REC, NB>), NBINS, SORT2_THREADS, 0, rec, bin_base, hv, entries, total,
+               state ? bucket_start : nullptr, state, slots);
+    KZG_LAUNCH(ctx, st, "k_heavy_count", (k_heavy_count<REC, NB>), HEAVY_GRID, SORT2_THREADS, 0, rec, bin_base, hv, hcnt);
+    KZG_LAUNCH(ctx, st, "k_heavy_scan", k_heavy_scan<NB>, NBINS, NB, 0, bin_base, hv, hcnt, total, bucket_start);
+    KZG_LAUNCH(ctx, st, "k_heavy_place", (k_heavy_place<REC, NB>), HEAVY_GRID, SORT2_THREADS, 0, rec, bin_base, hv, hcnt, bucket_start,
+               entries);
+    return KZG_OK;
+}
+
+int sort2_level2(kzg_ctx *ctx, hipStream_t st, int kind, const void *rec, const uint32_t *bin_base, const uint32_t *bin_total, uint32_t *hv,
+                 uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots) {
+    if (kind == 4) return sort2_level2_t<Rec4, 64>(ctx, st, rec, bin_base, bin_total, hv, entries, total, bucket_start, nullptr, slots);
+    if (kind == 8) return sort2_level2_t<Rec8, 64>(ctx, st, rec, bin_base, bin_total, hv, entries, total, bucket_start, nullptr, slots);
+    return sort2_level2_t<Rec20, SORT20_BUCKETS>(ctx, st, rec, bin_base, bin_total, hv, entries, nullptr, bucket_start, state, slots);
+}
+
 int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
                  const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
                  uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
@@ -560,14 +612,8 @@ int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, 
     }
     const size_t per2 = (n + G2 - 1) / G2;
     KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter20, G2, 1024, BIN_SCATTER20_LDS, (const Fr *)d_scalars, n, sfmt, per2, bins, bin_total,
-               bin_base, row_stride, idx_base, (uint2 *)rec, hv);
-    KZG_LAUNCH(ctx, st, "k_bin_sort", k_bin_sort20, NBINS, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, hv, entries, bucket_start, state,
-               slots);
-    uint32_t *hcnt = hv + SORT20_HV_WORDS;
-    KZG_LAUNCH(ctx, st, "k_heavy_count", k_heavy_count20, HEAVY_GRID, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, hv, hcnt);
-    KZG_LAUNCH(ctx, st, "k_heavy_scan", k_heavy_scan20, NBINS, SORT20_BUCKETS, 0, bin_base, hv, hcnt, bucket_start);
-    KZG_LAUNCH(ctx, st, "k_heavy_place", k_heavy_place20, HEAVY_GRID, SORT20_THREADS, 0, (const uint2 *)rec, bin_base, hv, hcnt, bucket_start,
-               entries);
+               bin_base, row_stride, idx_base, (uint2 *)rec);
+    KZG_TRY(sort2_level2(ctx, st, 20, rec, bin_base, bin_total, hv, entries, nullptr, bucket_start, state, slots));
     return wide_s1_layout(ctx, st, bucket_start, NBINS * SORT20_BUCKETS, state, segsums, segmaxs, segtotal, s1);
 }
 

@@ -244,16 +244,19 @@ def test_every_window_size(engine, c):
         engine.set_option("window_bits", 0)
 
 
-def test_window20_heavy_bins_2_18(engine):
-    """The 20-bit window sort cuts a bin that holds far more than its share into slices sorted by separate blocks: u64-valued
-    scalars (the whole top window lands in the first 17 buckets = bin 0), all-equal scalars (13 buckets hold everything), a
-    mix of both with random ones, and small values (every window but the lowest empty) -- each against the known-tau identity."""
+@pytest.mark.parametrize("wb,naf", [(20, 0), (17, 0), (17, 18)])
+def test_heavy_bins_2_18(engine, wb, naf):
+    """Level 2 of the two-level sorts cuts a bin that holds far more than its share into slices sorted by separate blocks: u64-valued
+    scalars (at 20 bits the whole top window lands in the first 17 buckets = bin 0), all-equal scalars (13 / 15 buckets hold
+    everything), bits and bytes (a handful of buckets of bin 0), a mix with random ones -- each against the known-tau identity, for
+    the 20-bit and the 17-bit windows and the positional tables."""
     n = 1 << 18
-    rng = random.Random(20)
-    engine.set_option("window_bits", 20)
+    rng = random.Random(wb)
+    engine.set_option("window_bits", wb)
+    engine.set_option("naf_window", naf)
     try:
         params = kzg_amd.setup(engine, TAU, n, g2_len=0)
-        assert params.gs.window_info() == (20, 13)
+        assert params.gs.window_info() == ((18, 15) if naf else (wb, 13 if wb == 20 else 15))
         pw = [1]
         for _ in range(n - 1):
             pw.append(pw[-1] * TAU % R)
@@ -264,6 +267,9 @@ def test_window20_heavy_bins_2_18(engine):
             "all_equal": [eq] * n,
             "mixed": [eq if i % 3 == 0 else rng.getrandbits(64) if i % 3 == 1 else rng.randrange(R) for i in range(n)],
             "small": [rng.randrange(1, 1 << 12) for _ in range(n)],
+            "bits": [rng.randrange(2) for _ in range(n)],
+            "bytes": [rng.randrange(256) for _ in range(n)],
+            "all_ones": [1] * n,
         }
         for name, sc in cases.items():
             want = C.g1_mul(G, sum(s * p for s, p in zip(sc, pw)) % R)
@@ -271,6 +277,7 @@ def test_window20_heavy_bins_2_18(engine):
         params.gs.free()
     finally:
         engine.set_option("window_bits", 0)
+        engine.set_option("naf_window", 0)
 
 
 @pytest.mark.parametrize("n", [5, 300, 3000, 9000, 40000, 140000])

@@ -121,7 +121,7 @@ def test_naf_equals_window_tables_2_17(engine):
 def test_naf_is_opt_in(engine):
     """kzg_srs_footprint follows the default policy: window tables (positional tables only with option naf_window = 18)."""
     b = ctypes.c_size_t()
-    for log_n, rows in ((16, 20), (17, 15), (20, 15), (24, 15)):
+    for log_n, rows in ((16, 20), (17, 15), (20, 15), (22, 15), (23, 13), (24, 13)):
         assert engine.lib.kzg_srs_footprint(1 << log_n, 0, 0, ctypes.byref(b)) == 0
         assert b.value == (1 << log_n) * (96 + rows * 128), (log_n, b.value)
     p = kzg_amd.setup(engine, TAU, 1 << 17, g2_len=0)
