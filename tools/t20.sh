@@ -1,3 +1,7 @@
 cd /root/repo
-timeout 1200 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_naf.py tests/test_gpu_golden.py tests/test_gpu_msm.py -x -q -m gpu 2>&1 | tail -5
-SKEW_PROF=1 python3 tools/skew_probe.py 20 2>&1 | tail -20
+for r in 1 2; do for o in "" "--opt naf_window=18"; do
+  echo -n "round $r [$o] -> "
+  timeout 400 python3 bench.py $o --no-cpu-baseline --no-paths --steps 8 --warmup 2 --check 2>/dev/null < /dev/null | python3 -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['single_commit_latency_ms'], d.get('all_results_match_known_tau'))"
+done; done
