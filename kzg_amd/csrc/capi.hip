@@ -144,9 +144,14 @@ int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int of
             // (emit.h, compiled for the host): a CPU core does the Fq inversion of to_affine in a few microseconds, one GPU lane
             // needs ~90 us for it, and this sits on the critical path of every blocking commit / create_witness.
             KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned, d_pt, sizeof(MsmPoint), hipMemcpyDeviceToHost, st));
+            // with it the lane's last sort plan (slices of oversized bins: what the next calls decide on, common.h h_heavy)
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned + 512, ctx->d_lane_heavy + lane, 4, hipMemcpyDeviceToHost, st));
             KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
             MsmPoint pt;
             memcpy(&pt, ctx->lanes[lane].pinned, sizeof pt);
+            uint32_t hseq;
+            memcpy(&hseq, ctx->lanes[lane].pinned + 512, 4);
+            ctx->h_heavy[lane] = ctx->lanes[lane].heavy_seq != 0 && hseq == ctx->lanes[lane].heavy_seq;
             alignas(16) uint8_t buf[144];
             emit_one(pt, buf, ofmt);
             memcpy(out, buf, psz);
@@ -254,6 +259,13 @@ extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
         delete ctx;
         return KZG_ERR_HIP;
     }
+    if (hipMalloc((void **)&ctx->d_lane_heavy, KZG_MAX_LANES * 4) != hipSuccess ||
+        hipMemset(ctx->d_lane_heavy, 0, KZG_MAX_LANES * 4) != hipSuccess) {
+        if (ctx->d_lane_heavy) hipFree(ctx->d_lane_heavy);
+        hipStreamDestroy(ctx->lanes[0].stream);
+        delete ctx;
+        return KZG_ERR_ALLOC;
+    }
     *out = ctx;
     return KZG_OK;
 }
@@ -283,6 +295,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
     for (auto st : ctx->accum_streams)
         if (st) hipStreamDestroy(st);
     if (ctx->batch_out) hipFree(ctx->batch_out);
+    if (ctx->d_lane_heavy) hipFree(ctx->d_lane_heavy);
     for (auto &ct : ctx->coset_tabs)
         if (ct.second) hipFree(ct.second);
     ntt_plans_free(ctx);
@@ -341,6 +354,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
         ctx->pipe_planned = false;
     } else if (k == "host_affine") {
         ctx->opt_host_affine = value != 0;
+    } else if (k == "heavy_bins") {
+        if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "heavy_bins: 0 (adaptive), 1 (always slice oversized sort bins), 2 (never)");
+        ctx->opt_heavy_bins = (int)value;
     } else if (k == "sort_single_pass") {
         ctx->opt_sort_single = value != 0;
     } else if (k == "tail_quads") {
@@ -752,6 +768,13 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
         hipError_t e = hipMemcpy(out, bp.d_out, out_bytes, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
     }
+#if !defined(KZG_TIMING_NO_PICKUP)
+    if (rc == KZG_OK) {  // the lanes' last sort plans (common.h h_heavy)
+        uint32_t hv[KZG_MAX_LANES];
+        if (hipMemcpy(hv, ctx->d_lane_heavy, sizeof hv, hipMemcpyDeviceToHost) == hipSuccess)
+            for (int l = 0; l < bp.nl; l++) ctx->h_heavy[l] = ctx->lanes[l].heavy_seq != 0 && hv[l] == ctx->lanes[l].heavy_seq;
+    }
+#endif
     if (ctx->prof) prof_collect(ctx);
     return rc;
 }

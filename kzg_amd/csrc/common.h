@@ -50,6 +50,7 @@ struct Lane {
     char *arena = nullptr;
     size_t arena_bytes = 0;
     size_t arena_used = 0;
+    uint32_t heavy_seq = 0;  // MSMs sorted on this lane (kzg_ctx::d_lane_heavy)
     char *pinned = nullptr;  // small pinned host staging buffer for results
     size_t pinned_bytes = 0;
 };
@@ -131,6 +132,7 @@ struct kzg_ctx {
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
     int opt_sort_threads_batch = 1024; // ... for batched MSMs
     int opt_host_affine = 1;           // a lone result bound for host memory is converted to affine / serialised on the host (emit.h)
+    int opt_heavy_bins = 0;            // level 2 of the two-level sorts: 0 = slices for oversized bins once such bins have been seen (below), 1 = always, 2 = never
     int opt_sort_single = 0;           // 1: c = 17 sorts in one pass (2^16 cursors, two walks) instead of the two-level sort
     int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
     int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
@@ -147,6 +149,12 @@ struct kzg_ctx {
     kzg::FixedBaseTable *fixed_base = nullptr;
     // distribute_powers (coset NTTs): per coset generator g two device tables g^j and g^(1024 j), j < 1024 (witness.hip)
     std::vector<std::pair<std::array<uint32_t, 8>, void *>> coset_tabs;
+    // Oversized sort bins (msm_wide.hip).  A level-2 block that finds its bin oversized writes the MSM's sequence number (per lane,
+    // Lane::heavy_seq) into the lane's word of d_lane_heavy; the host picks the words up with the results (finish_point,
+    // batch_end): h_heavy[lane] = the lane's last MSM had such a bin.  The three slice kernels are only enqueued while that holds
+    // for some lane (or option heavy_bins = 1): enqueued for nothing they cost uniform scalars 0.8 % of the batched rate.
+    uint8_t h_heavy[kzg::KZG_MAX_LANES] = {};
+    uint32_t *d_lane_heavy = nullptr;
     void *batch_out = nullptr;  // device staging of kzg_msm_g1_batch results (grow-only)
     size_t batch_out_bytes = 0;
 };

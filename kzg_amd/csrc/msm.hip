@@ -921,6 +921,13 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     const int rows = srs->naf ? W : srs->rows, passes = (W + rows - 1) / rows;  // positional tables: one pass, always
     MsmPoint *pass_res = (MsmPoint *)(base + L.off_pass);
     const uint32_t slots = (uint32_t)mm.accum_blocks * 256u;  // resident threads k_accum_affine is split over
+    uint32_t *hvp = (uint32_t *)(base + L.off_hv);
+    const uint32_t heavy_seq = ++ctx->lanes[lane].heavy_seq;  // (the lane is leased: no other thread touches it)
+    uint32_t *lane_heavy = ctx->d_lane_heavy + lane;
+    // oversized sort bins in slices: always / never by option, otherwise while some lane's last plan had any
+    bool sliced = ctx->opt_heavy_bins == 1;
+    if (ctx->opt_heavy_bins == 0)
+        for (int l = 0; l < KZG_MAX_LANES; l++) sliced = sliced || ((const volatile uint8_t *)ctx->h_heavy)[l] != 0;
     for (int p = 0; p < passes; p++) {
         const int w_lo = p * rows, w_hi = (p + 1) * rows < W ? (p + 1) * rows : W;
         if (srs->naf) {
@@ -937,12 +944,12 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
                 uint32_t *rec = (uint32_t *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter_naf<Rec4>, G2, 1024, BIN_SCATTER_LDS, recs, n, per2, bins, bin_total, bin_base,
                            (uint32_t)srs->npad, (uint32_t)offset, rec);
-                KZG_TRY(sort2_level2(ctx, st, 4, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
+                KZG_TRY(sort2_level2(ctx, st, 4, rec, bin_base, bin_total, hvp, entries, total, bucket_start, nullptr, slots, sliced, lane_heavy, heavy_seq));
             } else {
                 uint2 *rec = (uint2 *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter_naf<Rec8>, G2, 1024, BIN_SCATTER_LDS, recs, n, per2, bins, bin_total, bin_base,
                            (uint32_t)srs->npad, (uint32_t)offset, rec);
-                KZG_TRY(sort2_level2(ctx, st, 8, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
+                KZG_TRY(sort2_level2(ctx, st, 8, rec, bin_base, bin_total, hvp, entries, total, bucket_start, nullptr, slots, sliced, lane_heavy, heavy_seq));
             }
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);
@@ -954,7 +961,7 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
             KZG_TRY(sort20_hist(ctx, st, sc, n, sfmt, G2, bins));
             KZG_LAUNCH(ctx, st, "k_bin_scan", k_bin_scan, NBINS / 64, 1024, 0, bins, G2, bin_total, ready);
             KZG_TRY(sort20_place(ctx, st, sc, n, sfmt, G2, bins, bin_total, bin_base, (uint32_t)srs->npad, (uint32_t)offset, blk_hist, entries,
-                                 bucket_start, s1, state, slots, seg, seg + 256, seg + 512, (uint32_t *)(base + L.off_hv)));
+                                 bucket_start, s1, state, slots, seg, seg + 256, seg + 512, hvp, sliced, lane_heavy, heavy_seq));
         } else if (srs->narrow17 && !ctx->opt_sort_single) {
             const int G2 = L.G2;
             const size_t per2 = (n + G2 - 1) / G2;
@@ -967,12 +974,12 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
                 uint32_t *rec = (uint32_t *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter<Rec4>, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total,
                            bin_base, (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
-                KZG_TRY(sort2_level2(ctx, st, 4, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
+                KZG_TRY(sort2_level2(ctx, st, 4, rec, bin_base, bin_total, hvp, entries, total, bucket_start, nullptr, slots, sliced, lane_heavy, heavy_seq));
             } else {
                 uint2 *rec = (uint2 *)blk_hist;
                 KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter<Rec8>, G2, 1024, BIN_SCATTER_LDS, sc, n, sfmt, per2, bins, bin_total,
                            bin_base, (uint32_t)srs->npad, (uint32_t)offset, rec, w_lo, w_hi);
-                KZG_TRY(sort2_level2(ctx, st, 8, rec, bin_base, bin_total, (uint32_t *)(base + L.off_hv), entries, total, bucket_start, nullptr, slots));
+                KZG_TRY(sort2_level2(ctx, st, 8, rec, bin_base, bin_total, hvp, entries, total, bucket_start, nullptr, slots, sliced, lane_heavy, heavy_seq));
             }
             KZG_LAUNCH(ctx, st, "k_scan_b_bins", k_scan_b_bins, B / SCAN_SEG, SCAN_SEG, 0, total, bin_base, B, B / SCAN_SEG, bucket_start, s1,
                        state, slots, ready);

@@ -60,15 +60,18 @@ int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, i
 int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
                  const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
                  uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
-                 uint32_t *segtotal, uint32_t *hv);
+                 uint32_t *segtotal, uint32_t *hv, bool sliced, uint32_t *lane_heavy, uint32_t heavy_seq);
 // Level 2 of both two-level sorts (one block per bin) + the bins that are sorted in slices (msm_wide.hip).  kind: 4 / 8 = the
 // c = 17 records of msm.hip (64 buckets per bin; bucket sizes -> total[], k_scan_b_bins follows), 20 = c = 20 (512 buckets per
 // bin; bucket starts and the equal-split state).  bucket_start is scratch for the heavy bins in the first case as well.
-// hv: descriptor (2 + 2 NBINS words, padded) followed by the per-slice bucket counts (<= 2560 slices x buckets per bin)
+// hv: descriptor (2 + 2 NBINS words, padded; written by block 0 of k_heavy_count) followed by the per-slice bucket counts
+// (<= 2560 slices x buckets per bin).  sliced = false: every bin is sorted by its own block and the slice kernels are not enqueued.
+// A block that meets an oversized bin writes heavy_seq to *lane_heavy either way (kzg_ctx::d_lane_heavy).
 constexpr size_t SORT2_HV_WORDS = 2112;
 constexpr size_t sort2_hv_bytes(int buckets_per_bin) { return (SORT2_HV_WORDS + (size_t)2560 * buckets_per_bin) * 4; }
 int sort2_level2(kzg_ctx *ctx, hipStream_t st, int kind, const void *rec, const uint32_t *bin_base, const uint32_t *bin_total, uint32_t *hv,
-                 uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots);
+                 uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots, bool sliced, uint32_t *lane_heavy,
+                 uint32_t heavy_seq);
 
 // msm_tail.hip: everything after the bucket accumulation (fold to one point per bucket, sum (b+1) B_b)
 struct TailLayout {

@@ -332,12 +332,15 @@ __global__ __launch_bounds__(1024) void k_bin_scatter20(const Fr *scalars, size_
 // (4 bits + carry) there, all-equal scalars put everything into 13 / 15 buckets -- one block then places up to M records, through
 // LDS atomics on a few addresses (measured at 2^20, c = 17: k_bin_sort 0.04 ms for uniform scalars, 1.3 ms for bits, 2.6 ms for
 // all-ones).  A bin of more than 4 SL records (SL = max(32768, M / 2048)) is therefore cut into slices of SL records that
-// separate blocks sort: k_heavy_plan (descriptor hv[] from the bin sizes), k_heavy_count (per-slice bucket counts),
+// separate blocks sort: k_heavy_count (every block derives the plan from the bin starts, block 0 publishes it as hv[]; per-slice bucket counts),
 // k_heavy_scan (per bucket the exclusive scan over the bin's slices; bucket sizes and starts), k_heavy_place.
 // hv[0] = slices in total (0: count / scan / place return at once), hv[1] = SL, hv[2 + bin] = first slice of the bin,
 // hv[2 + NBINS + bin] = its slice count (0 = not heavy: the one-block kernel takes it).  At most M / SL + M / (4 SL) <= 2560 slices.
 constexpr int SORT2_THREADS = 256, SORT2_UNROLL = 8, SORT2_CHUNK = SORT2_THREADS * SORT2_UNROLL;
-constexpr int HEAVY_MAX_SLICES = 2560, HEAVY_GRID = 1024;
+#ifndef KZG_HEAVY_GRID
+#define KZG_HEAVY_GRID 256
+#endif
+constexpr int HEAVY_MAX_SLICES = 2560, HEAVY_GRID = KZG_HEAVY_GRID, HEAVY_SCAN_GRID = 64;
 static_assert(SORT2_HV_WORDS >= 2 + 2 * NBINS, "hv layout");
 
 // exclusive scan of h[0 .. NB) into off[] (NB = 64: one value per thread of the first wave; 512: two per thread); synchronised
@@ -420,10 +423,17 @@ __device__ __forceinline__ void sort2_place_range(const typename REC::T *rec, ui
 
 // One block per bin (not heavy): bucket sizes -> total[] (if asked for) and bucket starts -> bucket_start[] (if asked for), then the
 // records -> entries[].  set_state: block 0 also sets the equal-split state (the c = 20 pipeline; c = 17 does it in k_scan_b_bins).
+// slice length and "this bin is sorted in slices" from the sizes alone (every block of every kernel derives the same plan)
+__device__ __forceinline__ uint32_t heavy_slice_len(uint32_t M) {
+    const uint32_t SL = (M + 2047) / 2048;
+    return SL < 32768u ? 32768u : SL;
+}
+__device__ __forceinline__ uint32_t heavy_slices(uint32_t size, uint32_t SL) { return size > 4 * SL ? (size + SL - 1) / SL : 0u; }
+
 template <class REC, int NB>
-__global__ __launch_bounds__(SORT2_THREADS) void k_bin_sort2(const typename REC::T *rec, const uint32_t *bin_base, const uint32_t *hv,
-                                                             uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *st,
-                                                             uint32_t slots) {
+__global__ __launch_bounds__(SORT2_THREADS) void k_bin_sort2(const typename REC::T *rec, const uint32_t *bin_base, uint32_t *entries,
+                                                             uint32_t *total, uint32_t *bucket_start, MsmState *st, uint32_t slots,
+                                                             int sliced, uint32_t *lane_heavy, uint32_t heavy_seq) {
     typedef typename REC::T RT;
     __shared__ uint32_t h[NB], cur[NB], off[NB], sc[4];
     __shared__ RT stage[SORT2_CHUNK];
@@ -439,7 +449,10 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_bin_sort2(const typename REC:
         st->ovf_tasks = 0;
         bucket_start[(size_t)NBINS * NB] = M;
     }
-    if (hv[2 + NBINS + blockIdx.x]) return;  // a heavy bin: the slice kernels sort it
+    if (heavy_slices(r1 - r0, heavy_slice_len(bin_base[NBINS]))) {  // an oversized bin
+        if (tid == 0) *lane_heavy = heavy_seq;  // what the host decides the NEXT calls on
+        if (sliced) return;                     // the slice kernels sort it
+    }
     sort2_count_range<REC, NB>(rec, r0, r1, h);
     sort2_scan<NB>(h, off, sc);
     __syncthreads();
@@ -450,24 +463,6 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_bin_sort2(const typename REC:
         if (bucket_start) bucket_start[(size_t)blockIdx.x * NB + k] = start;
     }
     sort2_place_range<REC, NB>(rec, r0, r1, entries, h, cur, off, sc, stage);
-}
-
-__global__ __launch_bounds__(1024) void k_heavy_plan(const uint32_t *bin_total, uint32_t *hv) {
-    __shared__ uint32_t wsum[16];
-    const uint32_t tid = threadIdx.x, size = bin_total[tid];
-    uint32_t M;
-    block_scan_1024(size, wsum, &M);
-    uint32_t SL = (M + 2047) / 2048;
-    if (SL < 32768u) SL = 32768u;
-    const uint32_t ns = size > 4 * SL ? (size + SL - 1) / SL : 0u;
-    uint32_t nsl;
-    const uint32_t s0 = block_scan_1024(ns, wsum, &nsl);
-    hv[2 + tid] = s0;
-    hv[2 + NBINS + tid] = ns;
-    if (tid == 0) {
-        hv[0] = nsl;
-        hv[1] = SL;
-    }
 }
 
 // the heavy bin that owns slice `id` (< hv[0]): the last bin whose first slice is <= id (bins that are not heavy share their
@@ -482,12 +477,38 @@ __device__ __forceinline__ uint32_t heavy_bin_of(const uint32_t *hv, uint32_t id
 }
 
 template <class REC, int NB>
-__global__ __launch_bounds__(SORT2_THREADS) void k_heavy_count(const typename REC::T *rec, const uint32_t *bin_base, const uint32_t *hv,
+__global__ __launch_bounds__(SORT2_THREADS) void k_heavy_count(const typename REC::T *rec, const uint32_t *bin_base, uint32_t *hv,
                                                                uint32_t *hcnt) {
-    __shared__ uint32_t h[NB];
-    const uint32_t total = hv[0], SL = hv[1], tid = threadIdx.x;
+    __shared__ uint32_t h[NB], plan[2 + 2 * NBINS], sc[4];
+    const uint32_t tid = threadIdx.x;
+    {   // the plan: slices per bin, their exclusive scan (four bins per thread)
+        const uint32_t SL = heavy_slice_len(bin_base[NBINS]);
+        uint32_t ns[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t bin = 4 * tid + k;
+            ns[k] = heavy_slices(bin_base[bin + 1] - bin_base[bin], SL);
+            sum += ns[k];
+        }
+        uint32_t tot;
+        uint32_t run = block_scan_256(sum, sc, &tot);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            plan[2 + 4 * tid + k] = run;
+            plan[2 + NBINS + 4 * tid + k] = ns[k];
+            run += ns[k];
+        }
+        if (tid == 0) {
+            plan[0] = tot;
+            plan[1] = SL;
+        }
+        __syncthreads();
+        if (blockIdx.x == 0)
+            for (uint32_t k = tid; k < 2 + 2 * NBINS; k += SORT2_THREADS) hv[k] = plan[k];
+    }
+    const uint32_t total = plan[0], SL = plan[1];
     for (uint32_t id = blockIdx.x; id < total; id += gridDim.x) {
-        const uint32_t bin = heavy_bin_of(hv, id), j = id - hv[2 + bin];
+        const uint32_t bin = heavy_bin_of(plan, id), j = id - plan[2 + bin];
         const uint32_t r0 = bin_base[bin], r1 = bin_base[bin + 1];
         const uint32_t a = r0 + j * SL, b = a + SL < r1 ? a + SL : r1;
         sort2_count_range<REC, NB>(rec, a, b, h);
@@ -501,8 +522,10 @@ template <int NB>
 __global__ __launch_bounds__(NB) void k_heavy_scan(const uint32_t *bin_base, const uint32_t *hv, uint32_t *hcnt, uint32_t *total,
                                                    uint32_t *bucket_start) {
     __shared__ uint32_t ws[8];
-    const uint32_t bin = blockIdx.x, ns = hv[2 + NBINS + bin];
-    if (hv[0] == 0 || ns == 0) return;
+    if (hv[0] == 0) return;
+    for (uint32_t bin = blockIdx.x; bin < NBINS; bin += gridDim.x) {
+    const uint32_t ns = hv[2 + NBINS + bin];
+    if (ns == 0) continue;  // (block-uniform)
     const uint32_t s0 = hv[2 + bin], b = threadIdx.x;
     uint32_t run = 0, j = 0;
     for (; j + 8 <= ns; j += 8) {  // eight independent loads in flight
@@ -536,6 +559,8 @@ __global__ __launch_bounds__(NB) void k_heavy_scan(const uint32_t *bin_base, con
         if (w < wave) woff += ws[w];
     if (total) total[(size_t)bin * NB + b] = run;
     bucket_start[(size_t)bin * NB + b] = bin_base[bin] + woff + incl - run;
+    __syncthreads();
+    }
 }
 
 template <class REC, int NB>
@@ -580,32 +605,35 @@ int sort20_hist(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, i
 
 // level 2 + heavy bins.  kind: 4 = Rec4, 8 = Rec8 (c = 17: NB = 64, sizes -> total[]), 20 = Rec20 (NB = 512, starts and state)
 template <class REC, int NB>
-static int sort2_level2_t(kzg_ctx *ctx, hipStream_t st, const void *rec_v, const uint32_t *bin_base, const uint32_t *bin_total, uint32_t *hv,
-                          uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots) {
+static int sort2_level2_t(kzg_ctx *ctx, hipStream_t st, const void *rec_v, const uint32_t *bin_base, uint32_t *hv, uint32_t *entries,
+                          uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots, bool sliced, uint32_t *lane_heavy,
+                          uint32_t heavy_seq) {
     typedef typename REC::T RT;
     const RT *rec = (const RT *)rec_v;
     uint32_t *hcnt = hv + SORT2_HV_WORDS;
-    KZG_LAUNCH(ctx, st, "k_heavy_plan", k_heavy_plan, 1, 1024, 0, bin_total, hv);
-    KZG_LAUNCH(ctx, st, "k_bin_sort", (k_bin_sort2<REC, NB>), NBINS, SORT2_THREADS, 0, rec, bin_base, hv, entries, total,
-               state ? bucket_start : nullptr, state, slots);
+    KZG_LAUNCH(ctx, st, "k_bin_sort", (k_bin_sort2<REC, NB>), NBINS, SORT2_THREADS, 0, rec, bin_base, entries, total,
+               state ? bucket_start : nullptr, state, slots, sliced ? 1 : 0, lane_heavy, heavy_seq);
+    if (!sliced) return KZG_OK;
     KZG_LAUNCH(ctx, st, "k_heavy_count", (k_heavy_count<REC, NB>), HEAVY_GRID, SORT2_THREADS, 0, rec, bin_base, hv, hcnt);
-    KZG_LAUNCH(ctx, st, "k_heavy_scan", k_heavy_scan<NB>, NBINS, NB, 0, bin_base, hv, hcnt, total, bucket_start);
+    KZG_LAUNCH(ctx, st, "k_heavy_scan", k_heavy_scan<NB>, HEAVY_SCAN_GRID, NB, 0, bin_base, hv, hcnt, total, bucket_start);
     KZG_LAUNCH(ctx, st, "k_heavy_place", (k_heavy_place<REC, NB>), HEAVY_GRID, SORT2_THREADS, 0, rec, bin_base, hv, hcnt, bucket_start,
                entries);
     return KZG_OK;
 }
 
 int sort2_level2(kzg_ctx *ctx, hipStream_t st, int kind, const void *rec, const uint32_t *bin_base, const uint32_t *bin_total, uint32_t *hv,
-                 uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots) {
-    if (kind == 4) return sort2_level2_t<Rec4, 64>(ctx, st, rec, bin_base, bin_total, hv, entries, total, bucket_start, nullptr, slots);
-    if (kind == 8) return sort2_level2_t<Rec8, 64>(ctx, st, rec, bin_base, bin_total, hv, entries, total, bucket_start, nullptr, slots);
-    return sort2_level2_t<Rec20, SORT20_BUCKETS>(ctx, st, rec, bin_base, bin_total, hv, entries, nullptr, bucket_start, state, slots);
+                 uint32_t *entries, uint32_t *total, uint32_t *bucket_start, MsmState *state, uint32_t slots, bool sliced, uint32_t *lane_heavy,
+                 uint32_t heavy_seq) {
+    (void)bin_total;
+    if (kind == 4) return sort2_level2_t<Rec4, 64>(ctx, st, rec, bin_base, hv, entries, total, bucket_start, nullptr, slots, sliced, lane_heavy, heavy_seq);
+    if (kind == 8) return sort2_level2_t<Rec8, 64>(ctx, st, rec, bin_base, hv, entries, total, bucket_start, nullptr, slots, sliced, lane_heavy, heavy_seq);
+    return sort2_level2_t<Rec20, SORT20_BUCKETS>(ctx, st, rec, bin_base, hv, entries, nullptr, bucket_start, state, slots, sliced, lane_heavy, heavy_seq);
 }
 
 int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, int sfmt, int G2, const uint32_t *bins,
                  const uint32_t *bin_total, uint32_t *bin_base, uint32_t row_stride, uint32_t idx_base, void *rec, uint32_t *entries,
                  uint32_t *bucket_start, uint32_t *s1, MsmState *state, uint32_t slots, uint32_t *segsums, uint32_t *segmaxs,
-                 uint32_t *segtotal, uint32_t *hv) {
+                 uint32_t *segtotal, uint32_t *hv, bool sliced, uint32_t *lane_heavy, uint32_t heavy_seq) {
     if (!ctx->attr_sort20_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_bin_scatter20, hipFuncAttributeMaxDynamicSharedMemorySize, BIN_SCATTER20_LDS));
         ctx->attr_sort20_set = true;
@@ -613,7 +641,7 @@ int sort20_place(kzg_ctx *ctx, hipStream_t st, const void *d_scalars, size_t n, 
     const size_t per2 = (n + G2 - 1) / G2;
     KZG_LAUNCH(ctx, st, "k_bin_scatter", k_bin_scatter20, G2, 1024, BIN_SCATTER20_LDS, (const Fr *)d_scalars, n, sfmt, per2, bins, bin_total,
                bin_base, row_stride, idx_base, (uint2 *)rec);
-    KZG_TRY(sort2_level2(ctx, st, 20, rec, bin_base, bin_total, hv, entries, nullptr, bucket_start, state, slots));
+    KZG_TRY(sort2_level2(ctx, st, 20, rec, bin_base, bin_total, hv, entries, nullptr, bucket_start, state, slots, sliced, lane_heavy, heavy_seq));
     return wide_s1_layout(ctx, st, bucket_start, NBINS * SORT20_BUCKETS, state, segsums, segmaxs, segtotal, s1);
 }
 

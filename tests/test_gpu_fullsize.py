@@ -271,11 +271,30 @@ def test_heavy_bins_2_18(engine, wb, naf):
             "bytes": [rng.randrange(256) for _ in range(n)],
             "all_ones": [1] * n,
         }
-        for name, sc in cases.items():
-            want = C.g1_mul(G, sum(s * p for s, p in zip(sc, pw)) % R)
-            assert engine.msm(params.gs, sc) == want, name
+        want = {name: C.g1_mul(G, sum(s * p for s, p in zip(sc, pw)) % R) for name, sc in cases.items()}
+        for mode in (1, 2):             # slices always / never (every bin sorted by one block)
+            engine.set_option("heavy_bins", mode)
+            for name, sc in cases.items():
+                assert engine.msm(params.gs, sc) == want[name], (name, mode)
+        # adaptive (the default): the slice kernels are enqueued once a plan has seen an oversized bin, and no longer after one that has not
+        engine.set_option("heavy_bins", 0)
+        uniform = rand_scalars(rng, n)
+        want_u = C.g1_mul(G, sum(s * p for s, p in zip(uniform, pw)) % R)
+        assert engine.msm(params.gs, uniform) == want_u
+        engine.prof_reset(); engine.prof_enable(True)
+        launched = []
+        for sc, w in ((cases["bits"], want["bits"]), (cases["all_ones"], want["all_ones"]), (uniform, want_u), (uniform, want_u)):
+            assert engine.msm(params.gs, sc) == w
+            launched.append(engine.prof_get("k_heavy_place")[0])
+        engine.prof_enable(False)
+        if naf:     # the short top digit of a NAF makes an oversized bin out of uniform scalars too: always in slices
+            assert launched == [1, 2, 3, 4]
+        else:       # bits: planned with nothing seen yet; all-ones: the previous plan had slices; uniform: once more (idle), then no more
+            assert launched == [0, 1, 2, 2]
         params.gs.free()
     finally:
+        engine.prof_enable(False)
+        engine.set_option("heavy_bins", 0)
         engine.set_option("window_bits", 0)
         engine.set_option("naf_window", 0)
 

@@ -40,6 +40,8 @@ cases = {
 }
 buf = e.alloc_scalars(n)
 for name, blob in cases.items():
+    if os.environ.get("SKEW_ONLY") and not name.startswith(os.environ["SKEW_ONLY"]):
+        continue
     buf.upload(blob)
     got = e.msm(params.gs, buf, n)
     want = C.g1_mul(C.g1_generator(), C.poly_eval_bytes(blob, n, TAU))
@@ -51,5 +53,5 @@ for name, blob in cases.items():
         e.prof_reset(); e.prof_enable(True)
         e.msm(params.gs, buf, n)
         e.prof_enable(False)
-        rows = sorted(e.prof_all().items(), key=lambda kv: -kv[1][1])[:6]
+        rows = sorted(e.prof_all().items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('SKEW_ROWS', '6'))]
         print("      " + "  ".join(f"{k} {v[1] / max(v[0], 1) * 1e3:.0f}us" for k, v in rows), flush=True)

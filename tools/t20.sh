@@ -1,7 +1,7 @@
 cd /root/repo
-for r in 1 2; do for o in "" "--opt naf_window=18"; do
-  echo -n "round $r [$o] -> "
-  timeout 400 python3 bench.py $o --no-cpu-baseline --no-paths --steps 8 --warmup 2 --check 2>/dev/null < /dev/null | python3 -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['value'], d['single_commit_latency_ms'], d.get('all_results_match_known_tau'))"
-done; done
+timeout 1200 python -m pytest tests/test_gpu_fullsize.py -x -q -m gpu -k "heavy or wide" 2>&1 | tail -5
+bash tools/ab_local.sh 3 prev base
+for v in prev base; do
+  if [ $v = base ]; then lib=kzg_amd/libkzg_mi355x.so; else lib=tools/bin/lib_$v.so; fi
+  echo "== $v"; SKEW_PROF=1 SKEW_ONLY=uniform python3 tools/run_with_lib.py $lib tools/skew_probe.py 20 2>&1 | tail -2
+done
