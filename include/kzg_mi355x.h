@@ -122,7 +122,8 @@ int kzg_sync(kzg_ctx *ctx);
  * thread -- the same field code compiled for the host -- instead of one GPU lane; same bytes, ~90 us less latency),
  * "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only),
  * "heavy_bins" (sort bins far above their share -- scalars that are bits, bytes, all equal -- sorted in slices by many blocks:
- *  0 = once a call has met such a bin and until one has not (default; the extra kernels cost uniform scalars 0.8 %), 1 = always, 2 = never),
+ *  0 = for the 64 MSMs after one that met such a bin (default; the extra kernels cost uniform scalars 0.8 %), 1 = always, 2 = never;
+ *  setting it clears the history),
  * "naf_window" (0 / 18, applies to SRSs created afterwards: 18 = positional tables, 2^j P for every bit position j = 255 rows of
  * 128 B per point, scalars recoded in width-18 non-adjacent form -- 13.9 instead of 15 bucket additions per scalar for 17x the
  * table: 34 GB at 2^20; measured +3.7 % batched throughput at 2^20, nothing below 2^19, +1.3 ms on a lone commit: opt-in);

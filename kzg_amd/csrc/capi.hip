@@ -144,14 +144,15 @@ int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int of
             // (emit.h, compiled for the host): a CPU core does the Fq inversion of to_affine in a few microseconds, one GPU lane
             // needs ~90 us for it, and this sits on the critical path of every blocking commit / create_witness.
             KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned, d_pt, sizeof(MsmPoint), hipMemcpyDeviceToHost, st));
-            // with it the lane's last sort plan (slices of oversized bins: what the next calls decide on, common.h h_heavy)
+            // with it the lane's last sort plan (slices of oversized bins: what the next calls decide on, common.h heavy_last)
             KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned + 512, ctx->d_lane_heavy + lane, 4, hipMemcpyDeviceToHost, st));
             KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
             MsmPoint pt;
             memcpy(&pt, ctx->lanes[lane].pinned, sizeof pt);
             uint32_t hseq;
             memcpy(&hseq, ctx->lanes[lane].pinned + 512, 4);
-            ctx->h_heavy[lane] = ctx->lanes[lane].heavy_seq != 0 && hseq == ctx->lanes[lane].heavy_seq;
+            if (ctx->lanes[lane].heavy_seq != 0 && hseq == ctx->lanes[lane].heavy_seq)
+                ctx->heavy_last.store(ctx->msm_count.load(std::memory_order_relaxed), std::memory_order_relaxed);
             alignas(16) uint8_t buf[144];
             emit_one(pt, buf, ofmt);
             memcpy(out, buf, psz);
@@ -357,6 +358,7 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "heavy_bins") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "heavy_bins: 0 (adaptive), 1 (always slice oversized sort bins), 2 (never)");
         ctx->opt_heavy_bins = (int)value;
+        ctx->heavy_last.store(0, std::memory_order_relaxed);
     } else if (k == "sort_single_pass") {
         ctx->opt_sort_single = value != 0;
     } else if (k == "tail_quads") {
@@ -769,10 +771,12 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
         if (e != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, hipGetErrorString(e));
     }
 #if !defined(KZG_TIMING_NO_PICKUP)
-    if (rc == KZG_OK) {  // the lanes' last sort plans (common.h h_heavy)
+    if (rc == KZG_OK) {  // the lanes' last sort plans (common.h heavy_last)
         uint32_t hv[KZG_MAX_LANES];
         if (hipMemcpy(hv, ctx->d_lane_heavy, sizeof hv, hipMemcpyDeviceToHost) == hipSuccess)
-            for (int l = 0; l < bp.nl; l++) ctx->h_heavy[l] = ctx->lanes[l].heavy_seq != 0 && hv[l] == ctx->lanes[l].heavy_seq;
+            for (int l = 0; l < bp.nl; l++)
+                if (ctx->lanes[l].heavy_seq != 0 && hv[l] == ctx->lanes[l].heavy_seq)
+                    ctx->heavy_last.store(ctx->msm_count.load(std::memory_order_relaxed), std::memory_order_relaxed);
     }
 #endif
     if (ctx->prof) prof_collect(ctx);

@@ -90,6 +90,7 @@ struct CtxGate {
         cv.notify_all();
     }
 };
+constexpr int KZG_HEAVY_WINDOW = 64;  // MSMs for which one oversized sort bin keeps the slice kernels enqueued (kzg_ctx::heavy_last)
 constexpr int KZG_MAX_LANES = 24;  // lanes.reserve(): leased lanes are indexed while other threads append
 
 }  // namespace kzg
@@ -151,9 +152,10 @@ struct kzg_ctx {
     std::vector<std::pair<std::array<uint32_t, 8>, void *>> coset_tabs;
     // Oversized sort bins (msm_wide.hip).  A level-2 block that finds its bin oversized writes the MSM's sequence number (per lane,
     // Lane::heavy_seq) into the lane's word of d_lane_heavy; the host picks the words up with the results (finish_point,
-    // batch_end): h_heavy[lane] = the lane's last MSM had such a bin.  The three slice kernels are only enqueued while that holds
-    // for some lane (or option heavy_bins = 1): enqueued for nothing they cost uniform scalars 0.8 % of the batched rate.
-    uint8_t h_heavy[kzg::KZG_MAX_LANES] = {};
+    // batch_end) and notes the context's MSM count at that moment in heavy_last.  The three slice kernels are only enqueued for
+    // the next KZG_HEAVY_WINDOW MSMs after such a pick-up (or option heavy_bins = 1): enqueued for nothing they cost uniform
+    // scalars 0.8 % of the batched rate.  Setting the option clears the history.
+    std::atomic<uint64_t> msm_count{0}, heavy_last{0};
     uint32_t *d_lane_heavy = nullptr;
     void *batch_out = nullptr;  // device staging of kzg_msm_g1_batch results (grow-only)
     size_t batch_out_bytes = 0;

@@ -926,8 +926,10 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     uint32_t *lane_heavy = ctx->d_lane_heavy + lane;
     // oversized sort bins in slices: always / never by option, otherwise while some lane's last plan had any
     bool sliced = ctx->opt_heavy_bins == 1;
-    if (ctx->opt_heavy_bins == 0)
-        for (int l = 0; l < KZG_MAX_LANES; l++) sliced = sliced || ((const volatile uint8_t *)ctx->h_heavy)[l] != 0;
+    {
+        const uint64_t now = ctx->msm_count.fetch_add(1, std::memory_order_relaxed) + 1, last = ctx->heavy_last.load(std::memory_order_relaxed);
+        if (ctx->opt_heavy_bins == 0 && last != 0 && now - last <= (uint64_t)KZG_HEAVY_WINDOW) sliced = true;
+    }
     for (int p = 0; p < passes; p++) {
         const int w_lo = p * rows, w_hi = (p + 1) * rows < W ? (p + 1) * rows : W;
         if (srs->naf) {

@@ -276,21 +276,24 @@ def test_heavy_bins_2_18(engine, wb, naf):
             engine.set_option("heavy_bins", mode)
             for name, sc in cases.items():
                 assert engine.msm(params.gs, sc) == want[name], (name, mode)
-        # adaptive (the default): the slice kernels are enqueued once a plan has seen an oversized bin, and no longer after one that has not
+        # adaptive (the default; setting the option clears the history): the slice kernels are enqueued for the next 64 MSMs after
+        # one that met an oversized bin
         engine.set_option("heavy_bins", 0)
         uniform = rand_scalars(rng, n)
         want_u = C.g1_mul(G, sum(s * p for s, p in zip(uniform, pw)) % R)
-        assert engine.msm(params.gs, uniform) == want_u
         engine.prof_reset(); engine.prof_enable(True)
         launched = []
-        for sc, w in ((cases["bits"], want["bits"]), (cases["all_ones"], want["all_ones"]), (uniform, want_u), (uniform, want_u)):
+        for sc, w in ((uniform, want_u), (cases["bits"], want["bits"]), (cases["all_ones"], want["all_ones"]), (uniform, want_u)):
             assert engine.msm(params.gs, sc) == w
             launched.append(engine.prof_get("k_heavy_place")[0])
+        if naf:     # the short top digit of a NAF makes an oversized bin out of uniform scalars too
+            assert launched == [0, 1, 2, 3]
+        else:       # uniform: nothing; bits: planned with nothing seen yet; then in slices, uniform ones included (idle)
+            assert launched == [0, 0, 1, 2]
+        engine.set_option("heavy_bins", 0)
+        assert engine.msm(params.gs, uniform) == want_u
+        assert engine.prof_get("k_heavy_place")[0] == launched[-1]
         engine.prof_enable(False)
-        if naf:     # the short top digit of a NAF makes an oversized bin out of uniform scalars too: always in slices
-            assert launched == [1, 2, 3, 4]
-        else:       # bits: planned with nothing seen yet; all-ones: the previous plan had slices; uniform: once more (idle), then no more
-            assert launched == [0, 1, 2, 2]
         params.gs.free()
     finally:
         engine.prof_enable(False)

@@ -36,6 +36,8 @@ def rand_scalar(kind):
     if kind == 2:
         return rng.choice([0, 1, R - 1, R - 2, 1 << 255 if (1 << 255) < R else R - 3, 0x8000, 0x7fff, 0xffff, 0x10000,
                            int("8000" * 16, 16) % R, int("7fff" * 16, 16) % R, (1 << 128) - 1])
+    if kind == 4:
+        return rng.getrandbits(rng.choice([1, 1, 8]))      # bits / bytes: a handful of buckets hold everything
     return rng.getrandbits(rng.randrange(1, 255))
 
 
@@ -47,18 +49,19 @@ while time.time() < t_end:
     e.set_option("window_rows", rows)
     naf = 18 if (wb == 0 and rows == 0 and rng.random() < 0.3) else 0   # positional tables + width-18 NAF digits (opt-in layout)
     e.set_option("naf_window", naf)
+    e.set_option("heavy_bins", rng.choice([0, 0, 1, 2]))       # oversized sort bins in slices: adaptive / always / never
     e.set_option("tail_quads", rng.randrange(2))             # latency-mode tail kernels on / off
     e.set_option("hw_queues", rng.choice([0, 0, 1, 3, 4, 6]))  # pipeline plans
     e.set_option("streams", rng.choice([1, 2, 4, 8]))
-    nmax = rng.choice([1, 2, 5, 33, 257, 1000, 4097, 20000, 70000])
+    nmax = rng.choice([1, 2, 5, 33, 257, 1000, 4097, 20000, 70000, 70000, 300000])
     params = kzg_amd.setup(e, TAU, nmax, g2_len=0)
     srs_blob = params.gs.download()
     assert srs_blob == C.setup_g1(TAU, nmax), "setup mismatch"
     for _ in range(4):
         n = rng.randrange(0, nmax + 1)
         off = rng.randrange(0, nmax - n + 1)
-        kind = rng.randrange(4)
-        sc = [rand_scalar(kind if rng.random() < 0.8 else rng.randrange(4)) for _ in range(n)]
+        kind = rng.randrange(5)
+        sc = [rand_scalar(kind if (kind == 4 or rng.random() < 0.8) else rng.randrange(4)) for _ in range(n)]
         if n and rng.random() < 0.2:
             sc = [sc[0]] * n  # all equal: one bucket per window
         elif n and rng.random() < 0.2:
