@@ -129,40 +129,53 @@ static int stage_in(kzg_ctx *ctx, int lane, const void *src, size_t bytes, int f
 
 static size_t stage_bytes(size_t bytes, int flags) { return (flags & KZG_IN_DEVICE) ? 0 : align_up(bytes + 256, 256); }
 
+// The lane's last sort with the result (oversized bins: what the next calls decide on, common.h heavy_last): 4 bytes into the
+// lane's pinned buffer before the wait, looked at after it.
+static int heavy_pickup_enqueue(kzg_ctx *ctx, int lane) {
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned + 512, ctx->d_lane_heavy + lane, 4, hipMemcpyDeviceToHost, ctx->lanes[lane].stream));
+    return KZG_OK;
+}
+static void heavy_pickup_read(kzg_ctx *ctx, int lane) {
+    uint32_t hseq;
+    memcpy(&hseq, ctx->lanes[lane].pinned + 512, 4);
+    Lane &l = ctx->lanes[lane];
+    if (l.heavy_seq == l.heavy_seen) return;  // no MSM on this lane since the last look
+    l.heavy_seen = l.heavy_seq;
+    if (hseq == l.heavy_seq) ctx->heavy_last.store(ctx->msm_count.load(std::memory_order_relaxed), std::memory_order_relaxed);
+}
+
 // result point: XYZZ on device -> ofmt at `out` (host or device)
 int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int ofmt, int flags) {
     size_t psz = point_format_bytes(ofmt);
     if (!psz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     hipStream_t st = ctx->lanes[lane].stream;
+    KZG_TRY(lane_pinned(ctx, lane, 4096));
     if (flags & KZG_OUT_DEVICE) {
         KZG_TRY(emit_point(ctx, lane, d_pt, out, ofmt));
+        KZG_TRY(heavy_pickup_enqueue(ctx, lane));
         KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     } else {
-        KZG_TRY(lane_pinned(ctx, lane, 4096));
         if (ctx->opt_host_affine) {
             // A lone result for the host: copy the XYZZ point out and convert it on the calling thread with the same code
             // (emit.h, compiled for the host): a CPU core does the Fq inversion of to_affine in a few microseconds, one GPU lane
             // needs ~90 us for it, and this sits on the critical path of every blocking commit / create_witness.
             KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned, d_pt, sizeof(MsmPoint), hipMemcpyDeviceToHost, st));
-            // with it the lane's last sort plan (slices of oversized bins: what the next calls decide on, common.h heavy_last)
-            KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned + 512, ctx->d_lane_heavy + lane, 4, hipMemcpyDeviceToHost, st));
+            KZG_TRY(heavy_pickup_enqueue(ctx, lane));
             KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
             MsmPoint pt;
             memcpy(&pt, ctx->lanes[lane].pinned, sizeof pt);
-            uint32_t hseq;
-            memcpy(&hseq, ctx->lanes[lane].pinned + 512, 4);
-            if (ctx->lanes[lane].heavy_seq != 0 && hseq == ctx->lanes[lane].heavy_seq)
-                ctx->heavy_last.store(ctx->msm_count.load(std::memory_order_relaxed), std::memory_order_relaxed);
             alignas(16) uint8_t buf[144];
             emit_one(pt, buf, ofmt);
             memcpy(out, buf, psz);
         } else {
             // the kernel writes the <= 144 bytes straight into the lane's pinned host buffer (device-mapped, coherent)
             KZG_TRY(emit_point(ctx, lane, d_pt, ctx->lanes[lane].pinned, ofmt));
+            KZG_TRY(heavy_pickup_enqueue(ctx, lane));
             KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
             memcpy(out, ctx->lanes[lane].pinned, psz);
         }
     }
+    heavy_pickup_read(ctx, lane);
     if (ctx->prof) prof_collect(ctx);
     return KZG_OK;
 }
@@ -774,9 +787,12 @@ static int batch_end(kzg_ctx *ctx, const BatchPipe &bp, int rc, void *out, size_
     if (rc == KZG_OK) {  // the lanes' last sort plans (common.h heavy_last)
         uint32_t hv[KZG_MAX_LANES];
         if (hipMemcpy(hv, ctx->d_lane_heavy, sizeof hv, hipMemcpyDeviceToHost) == hipSuccess)
-            for (int l = 0; l < bp.nl; l++)
-                if (ctx->lanes[l].heavy_seq != 0 && hv[l] == ctx->lanes[l].heavy_seq)
-                    ctx->heavy_last.store(ctx->msm_count.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            for (int l = 0; l < bp.nl; l++) {
+                Lane &ln = ctx->lanes[l];
+                if (ln.heavy_seq == ln.heavy_seen) continue;
+                ln.heavy_seen = ln.heavy_seq;
+                if (hv[l] == ln.heavy_seq) ctx->heavy_last.store(ctx->msm_count.load(std::memory_order_relaxed), std::memory_order_relaxed);
+            }
     }
 #endif
     if (ctx->prof) prof_collect(ctx);
