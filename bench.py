@@ -8,14 +8,17 @@
 N = 1 : workload = BASELINE configs[1] "degree-2^20 coeff_form commit (G1 Pippenger MSM) on 1xMI355X".
         One step = one batch of `--batch` independent commitments pipelined on the engine's HIP streams
         (kzg_msm_g1_batch); value = commitments / second.
-N > 1 : one process per GPU; the data path is the C ABI's device group (kzg_mctx_create_rank / kzg_commit_coeff_sharded_batch,
-        kzg_amd/csrc/mgpu.hip): SRS sharded contiguously, one partial point per rank and polynomial, ONE ncclAllGather of the
-        144-byte partials inside the library, local sums.  torch.distributed only carries the RCCL unique id and the barriers.
-          default (= --strong) : the SAME metric -- degree-2^20 commitments/s, each commitment's 2^20 terms sharded N ways
-                                 (2^20 / N per rank); "scaling": "strong".
+N > 1 : one process per GPU.  Commitments are independent objects and a degree-2^20 SRS is 2 GiB, so the metric shards by
+        commitment: every rank holds the full SRS and commits its own polynomials, NO data-path collective ("scaling": "weak";
+        torch.distributed only carries the barriers and the max-over-ranks time).  That is the default.  Where one commitment
+        does not fit or its latency matters, the C ABI's device group shards the commitment itself (kzg_mctx_create_rank /
+        kzg_commit_coeff_sharded_batch, kzg_amd/csrc/mgpu.hip: SRS sharded contiguously, one partial point per rank and
+        polynomial, ONE ncclAllGather of the 144-byte partials inside the library, local sums):
           --config5            : BASELINE configs[4] -- 2^21 terms per rank (degree 2^24 at N = 8); value = commitments/s of
                                  that N * 2^21-coefficient polynomial, msm_terms_per_sec beside it; "scaling": "weak".
-          --replicas           : full SRS on every GPU, different polynomials per GPU, no data-path collective.
+          --strong             : degree-2^20 commitments/s with each commitment's 2^20 terms sharded N ways (2^20 / N per
+                                 rank); "scaling": "strong" (bounded by the per-MSM sort and bucket reduction: DESIGN.md section 4).
+          --weak               : 2^log_n terms per rank.
 
 The JSON line carries `roofline` for the dominant kernel (k_accum_affine; HIP-event times measured on the engine's streams
 inside this process), `paths` (the other BASELINE configs, timed after the timed region) and `cpu_baseline` (the oracle's
@@ -386,20 +389,20 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-paths", action="store_true", help="skip the `paths` measurements after the timed region")
     ap.add_argument("--callers", action="store_true", help="with --no-paths: still measure paths.blocking_callers_16_per_s")
-    ap.add_argument("--strong", action="store_true", help="N>1 (default there): one degree-2^log_n commitment sharded N ways")
+    ap.add_argument("--strong", action="store_true", help="N>1: one degree-2^log_n commitment sharded N ways (device group, RCCL all-gather)")
     ap.add_argument("--config5", action="store_true", help="N>1: BASELINE configs[4], 2^21 terms per rank (degree 2^24 at N = 8)")
     ap.add_argument("--weak", action="store_true", help="N>1: 2^log_n terms per rank (degree N * 2^log_n)")
     ap.add_argument("--sharded", action="store_true",
                     help="use the device-group code path (sharded SRS, RCCL all-gather inside the library) even at world size 1")
     ap.add_argument("--check", action="store_true", help="verify EVERY commitment of the last step against [p(tau)]G")
     ap.add_argument("--replicas", action="store_true",
-                    help="N>1 only: data-parallel replicas (full SRS on every GPU, different polynomials per GPU, no collective)")
+                    help="N>1 (the default there): data-parallel replicas (full SRS on every GPU, different polynomials per GPU, no collective)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    sharded = (world > 1 and not args.replicas) or args.sharded
+    sharded = args.sharded or (world > 1 and (args.strong or args.config5 or args.weak) and not args.replicas)
 
     # stdout carries exactly ONE line, the JSON record.  RCCL prints a banner (ROCm version / hostname / library path) through C
     # stdio when a communicator is created, and that buffer is flushed at process exit -- after anything Python printed.  So
@@ -429,8 +432,16 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        if os.environ.get("KZG_BENCH_SHARED_GPU"):
+            # test mode for a one-GPU box: every rank on device 0, gloo for the barriers (RCCL refuses two ranks on one GPU).
+            # Exercises the N > 1 control flow of the replicas mode; the numbers mean nothing.
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+    red_dev = "cpu" if os.environ.get("KZG_BENCH_SHARED_GPU") else "cuda"   # where the timing / agreement reductions live
 
     # ---- the device group first (it decides the mode: if the group cannot be formed on this node the run degrades to
     # data-parallel replicas and says so, instead of producing no number at all)
@@ -443,7 +454,7 @@ def main():
         except Exception as e:  # noqa: BLE001
             ok, group_note = 0, f"device group could not be formed ({e}); fell back to replicas"
         if world > 1:           # all ranks agree on the outcome
-            t = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             ok = int(t.item())
         if not ok:
@@ -542,7 +553,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
