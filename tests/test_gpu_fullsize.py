@@ -177,6 +177,33 @@ def test_config4_witnesses_2_20(engine, big):
     _fresh(buf); buf.free()
 
 
+def test_commit_and_witness_2_23_default_window20(engine):
+    """The size from which the engine picks 20-bit windows by itself: commit, a single-point witness (MSM of n - 1 terms, the
+    error path) and a blocking call from a device buffer with an offset sub-range, each against the known-tau identity."""
+    n = 1 << 23
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    assert params.gs.window_info() == (20, 13)
+    buf = engine.alloc_scalars(n).fill_random(23)
+    ptau = oeval(buf, TAU)
+    G = C.g1_generator()
+    out = ctypes.create_string_buffer(96)
+    rc = engine.lib.kzg_commit_coeff(engine.ctx, params.gs.handle, buf.ptr, n, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and out.raw == C.g1_mul(G, ptau)
+    x = kzg_amd.splitmix_scalar(23, 1)
+    y = oeval(buf, x)
+    b32 = lambda v: (v % R).to_bytes(32, "little")  # noqa: E731
+    rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(x), b32(y), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and out.raw == C.g1_mul(G, (ptau - y) * pow(TAU - x, -1, R) % R)
+    rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, b32(x), b32(y + 1), buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == L.KZG_ERR_POINT_NOT_ON_POLY
+    off, m = 1234567, (1 << 22) + 89
+    sub = _view(engine, buf, 0, m)
+    rc = engine.lib.kzg_msm_g1(engine.ctx, params.gs.handle, off, sub.ptr, m, buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+    assert rc == 0 and out.raw == C.g1_mul(G, pow(TAU, off, R) * oeval(sub, TAU) % R)
+    params.gs.free()
+    _fresh(buf); buf.free()
+
+
 def test_msm_linearity_and_offsets_2_20(engine, big):
     """MSM(a) + MSM(b) == MSM(a + b); MSM over [0, n) == MSM[0, h) + MSM[h, n)."""
     n, params, _ = big

@@ -36,4 +36,5 @@ hw "KZG_SET_HW_QUEUES=1: the library's load-time constructor opts in" KZG_HW_QUE
 done > $O/hw_queues.txt 2>&1
 timeout 900 python3 tools/sweep.py 16 18 20 22 24 > $O/sweep.jsonl 2> $O/sweep.err
 timeout 200 python3 tools/fuzz_gpu.py 90 > $O/fuzz.txt 2>&1
+SKEW_PROF=1 timeout 200 python3 tools/skew_probe.py 20 > $O/skew.txt 2>&1
 ls -la $O
