@@ -329,6 +329,38 @@ def test_heavy_bins_2_18(engine, wb, naf):
         engine.set_option("naf_window", 0)
 
 
+def test_heavy_bins_2_22_wide_records(engine):
+    """The same with the 8-byte level-1 records (17-bit windows above 2^21 points: the table index no longer fits 25 bits): bits,
+    all-ones and u64-valued coefficients at 2^22, slices always / adaptive, from device buffers, against the known-tau identity."""
+    import numpy as np
+    n = 1 << 22
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    assert params.gs.window_info() == (17, 15)
+    rng = np.random.default_rng(22)
+
+    def blob(vals):
+        a = np.zeros((n, 4), dtype="<u8")
+        a[:, 0] = vals
+        return a.tobytes()
+
+    cases = {"bits": blob(rng.integers(0, 2, size=n, dtype=np.uint64)), "all_ones": blob(np.ones(n, dtype=np.uint64)),
+             "u64": blob(rng.integers(0, 1 << 63, size=n, dtype=np.uint64))}
+    buf = engine.alloc_scalars(n)
+    G = C.g1_generator()
+    try:
+        for mode in (1, 0):
+            engine.set_option("heavy_bins", mode)
+            for name, b in cases.items():
+                buf.upload(b)
+                want = C.g1_mul(G, C.poly_eval_bytes(b, n, TAU))
+                for _ in range(2):      # adaptive: the second call of a kind runs in slices
+                    assert _msm_dev(engine, params.gs, buf, n) == want, (name, mode)
+    finally:
+        engine.set_option("heavy_bins", 0)
+        params.gs.free()
+        buf.free()
+
+
 @pytest.mark.parametrize("n", [5, 300, 3000, 9000, 40000, 140000])
 def test_default_window_choice(engine, n):
     """The widths the engine picks by itself (8, 10, 13, 17 by size) give the right commitment."""
