@@ -347,6 +347,7 @@ static_assert(SORT2_HV_WORDS >= 2 + 2 * NBINS, "hv layout");
 // on entry by the caller, NOT on return
 template <int NB>
 __device__ __forceinline__ void sort2_scan(const uint32_t *h, uint32_t *off, uint32_t *sc) {
+    static_assert(NB == 64 || NB == 512, "buckets per bin");
     const uint32_t tid = threadIdx.x;
     if (NB == 512) {
         const uint32_t v0 = h[2 * tid], v1 = h[2 * tid + 1];
@@ -354,11 +355,15 @@ __device__ __forceinline__ void sort2_scan(const uint32_t *h, uint32_t *off, uin
         const uint32_t ex = block_scan_256(v0 + v1, sc, &tot);
         off[2 * tid] = ex;
         off[2 * tid + 1] = ex + v0;
-    } else {
-        const uint32_t v = tid < NB ? h[tid] : 0u;
-        uint32_t tot;
-        const uint32_t ex = block_scan_256(v, sc, &tot);
-        if (tid < NB) off[tid] = ex;
+    } else if (tid < NB) {  // NB = 64: the first wave alone, no barrier
+        const uint32_t v = h[tid];
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(incl, o, 64);
+            if ((int)tid >= o) incl += u;
+        }
+        off[tid] = incl - v;
     }
 }
 
