@@ -201,10 +201,12 @@ def timeit(f, reps=3, warm=1):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=16, calls=12):
+def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=16, calls=12, host_resident=False):
     """The reference's call shape: `threads` host threads, each looping the BLOCKING kzg_commit_coeff (KZGProver::commit,
-    src/coeff_form.rs:59-64) on ONE context and one resident SRS, device-resident coefficients (thread t commits polynomial
-    t of the timed batch).  Returns commitments per second over all threads, and whether every result matched the batch's."""
+    src/coeff_form.rs:59-64) on ONE context and one resident SRS (thread t commits polynomial t of the timed batch).
+    Coefficients device-resident, or -- host_resident -- in the caller's pageable host memory as a Rust `Polynomial` would be
+    (every call then carries its 32 MiB over PCIe).  Returns commitments per second over all threads, and whether every
+    result matched the batch's."""
     import threading
     lib, ctx = engine.lib, engine.ctx
     want = {}
@@ -213,15 +215,20 @@ def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=
         v = view(kzg_amd, scal, t * n, n)
         assert lib.kzg_commit_coeff(ctx, srs.handle, v.ptr, n, v.sfmt, L.IN_DEVICE, ref, L.G1_AFFINE_MONT) == 0, engine.last_error()
         want[t] = ref.raw
+    host = {}
+    if host_resident:
+        for t in range(threads):
+            host[t] = ctypes.create_string_buffer(view(kzg_amd, scal, (t % n_polys) * n, n).download(), 32 * n)
     ok = [True] * threads
     start = threading.Barrier(threads + 1)
 
     def work(t):
         v = view(kzg_amd, scal, (t % n_polys) * n, n)
+        src, flags = (host[t], 0) if host_resident else (v.ptr, L.IN_DEVICE)
         out = ctypes.create_string_buffer(96)
         start.wait()
         for _ in range(calls):
-            rc = lib.kzg_commit_coeff(ctx, srs.handle, v.ptr, n, v.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            rc = lib.kzg_commit_coeff(ctx, srs.handle, src, n, v.sfmt, flags, out, L.G1_AFFINE_MONT)
             if rc != 0 or out.raw != want[t % n_polys]:
                 ok[t] = False
 
@@ -706,6 +713,9 @@ def main():
                 res["paths"]["blocking_callers_16_per_s"] = round(per_s, 2)
                 res["paths"]["blocking_callers_16_vs_value"] = round(per_s / value, 4)
                 res["paths"]["blocking_callers_16_match_batch_results"] = same
+                per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch, calls=8, host_resident=True)
+                res["paths"]["blocking_callers_16_host_resident_per_s"] = round(per_s, 2)   # 32 MiB over PCIe per call (pageable memory)
+                res["paths"]["blocking_callers_16_host_resident_match"] = same
                 if args.log_n == 20 and not args.u64:
                     res["paths"].update(measure_spots(kzg_amd, L, engine, lambda: time.perf_counter() - t_extra < 45.0))
             except Exception as e:
@@ -714,6 +724,9 @@ def main():
             per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch)
             res["paths"] = {"blocking_callers_16_per_s": round(per_s, 2), "blocking_callers_16_vs_value": round(per_s / value, 4),
                             "blocking_callers_16_match_batch_results": same}
+            per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch, calls=8, host_resident=True)
+            res["paths"]["blocking_callers_16_host_resident_per_s"] = round(per_s, 2)
+            res["paths"]["blocking_callers_16_host_resident_match"] = same
         if mode == "single" and not args.no_cpu_baseline:
             if cpu is not None:
                 try:
