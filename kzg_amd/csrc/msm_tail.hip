@@ -24,6 +24,14 @@
 // scalar multiplication per chunk) + 21 (seven tree-sum launches) + two fold rounds before.
 #include "msm_internal.h"
 
+// Experiment switch: the 256-thread tail kernels compiled for KZG_TAIL_WAVES waves per SIMD (VGPR budget 512 / waves), so that they
+// fit next to a 3-wave accumulation kernel (-DKZG_ACCUM_WAVES=3).  Default: no bound beyond the block size.
+#if defined(KZG_TAIL_WAVES)
+#define KZG_TAIL_LB __launch_bounds__(256, KZG_TAIL_WAVES)
+#else
+#define KZG_TAIL_LB __launch_bounds__(256)
+#endif
+
 namespace kzg {
 
 constexpr int FOLD_SEQ = 8;     // sequential additions per lane in k_fold_dense before a bucket counts as overflowing
@@ -59,7 +67,7 @@ __device__ __forceinline__ MsmPoint wave_sum(const MsmPoint *p, uint32_t lo, uin
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void k_fold_dense(const MsmPoint *part, const uint32_t *s1, int B, MsmPoint *dense, MsmState *st,
+__global__ KZG_TAIL_LB void k_fold_dense(const MsmPoint *part, const uint32_t *s1, int B, MsmPoint *dense, MsmState *st,
                                                     uint32_t *tasks, uint32_t *arrive) {
     KZG_SIDE_PRIO_STMT;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -81,7 +89,7 @@ __global__ __launch_bounds__(256) void k_fold_dense(const MsmPoint *part, const 
     if (g == 0) dense[b] = acc;
 }
 
-__global__ __launch_bounds__(256) void k_fold_overflow(const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, MsmPoint *dense,
+__global__ KZG_TAIL_LB void k_fold_overflow(const MsmPoint *part, MsmPoint *scratch, const uint32_t *s1, MsmPoint *dense,
                                                        const MsmState *st, const uint32_t *tasks, uint32_t *arrive) {
     KZG_SIDE_PRIO_STMT;
     const uint32_t T = st->ovf_tasks;
@@ -111,7 +119,7 @@ __global__ __launch_bounds__(256) void k_fold_overflow(const MsmPoint *part, Msm
     }
 }
 
-__global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
+__global__ KZG_TAIL_LB void k_rc_sums(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
     KZG_SIDE_PRIO_STMT;
     const int lane = threadIdx.x & 63;
     const int wv = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -132,7 +140,7 @@ __global__ __launch_bounds__(256) void k_rc_sums(const MsmPoint *dense, int Rn, 
 // column sum, each adding Cn / RC_LANES points in sequence before a log2(RC_LANES)-level butterfly -- 35 wave-additions per 8
 // sums instead of 72 (a butterfly level costs a full addition for half the useful work of the level before).
 constexpr int RC_LANES = 8;
-__global__ __launch_bounds__(256) void k_rc_sums_t(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
+__global__ KZG_TAIL_LB void k_rc_sums_t(const MsmPoint *dense, int Rn, int Cn, MsmPoint *rows, MsmPoint *cols) {
     KZG_SIDE_PRIO_STMT;
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int sum = gid / RC_LANES, l = gid % RC_LANES;
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void k_rc_sums_t(const MsmPoint *dense, int Rn
 }
 
 // Q[j] (j < lr): sum of rows whose index has bit j set; Q[lr + j] (j < lc): the same for the columns; Q[lr + lc]: all columns
-__global__ __launch_bounds__(256) void k_weighted_bits(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
+__global__ KZG_TAIL_LB void k_weighted_bits(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
     KZG_SIDE_PRIO_STMT;
     const int lane = threadIdx.x & 63;
     const int wv = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -306,7 +314,7 @@ __device__ __forceinline__ MsmPoint block_quad_sum(MsmPoint acc, MsmPoint *lds, 
     return quad_butterfly<WAVES>(t, role);
 }
 
-__global__ __launch_bounds__(256) void k_weighted_bits_q(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
+__global__ KZG_TAIL_LB void k_weighted_bits_q(const MsmPoint *rows, const MsmPoint *cols, int lr, int lc, MsmPoint *Q) {
     KZG_SIDE_PRIO_STMT;
     __shared__ MsmPoint lds[4];
     const int role = threadIdx.x & 3, qd = threadIdx.x >> 2;
