@@ -129,3 +129,6 @@ def test_naf_is_opt_in(engine):
     p.gs.free()
     with pytest.raises(kzg_amd.ReferencePanic):
         engine.set_option("naf_window", 7)
+    with pytest.raises(kzg_amd.ReferencePanic):
+        engine.set_option("heavy_bins", 3)
+    engine.set_option("heavy_bins", 0)
