@@ -201,20 +201,32 @@ def timeit(f, reps=3, warm=1):
     return (time.perf_counter() - t0) / reps * 1e3
 
 
-def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=16, calls=12, host_resident=False):
-    """The reference's call shape: `threads` host threads, each looping the BLOCKING kzg_commit_coeff (KZGProver::commit,
-    src/coeff_form.rs:59-64) on ONE context and one resident SRS (thread t commits polynomial t of the timed batch).
-    Coefficients device-resident, or -- host_resident -- in the caller's pageable host memory as a Rust `Polynomial` would be
-    (every call then carries its 32 MiB over PCIe).  Returns commitments per second over all threads, and whether every
-    result matched the batch's."""
+def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=16, calls=12, host_resident=False, op="commit", k=256):
+    """The reference's call shape: `threads` host threads, each looping a BLOCKING prover call on ONE context and one resident SRS
+    (thread t works on polynomial t of the timed batch).  op = "commit": kzg_commit_coeff (KZGProver::commit,
+    src/coeff_form.rs:59-64); op = "witness_batched": kzg_witness_coeff_batched with k opening points (create_witness_batched,
+    src/coeff_form.rs:83-111 -- BASELINE configs[3], primary reading).  Coefficients device-resident, or -- host_resident -- in
+    the caller's pageable host memory as a Rust `Polynomial` would be (every call then carries its 32 MiB over PCIe).  Returns
+    calls per second over all threads, and whether every result matched the same call made alone beforehand."""
     import threading
     lib, ctx = engine.lib, engine.ctx
-    want = {}
+    R = kzg_amd.api.R_MODULUS
+    want, pts = {}, {}
     ref = ctypes.create_string_buffer(96)
+    rbuf0, rlen0 = ctypes.create_string_buffer(32 * max(k, 2)), ctypes.c_size_t()
     for t in range(min(threads, n_polys)):
         v = view(kzg_amd, scal, t * n, n)
-        assert lib.kzg_commit_coeff(ctx, srs.handle, v.ptr, n, v.sfmt, L.IN_DEVICE, ref, L.G1_AFFINE_MONT) == 0, engine.last_error()
-        want[t] = ref.raw
+        if op == "commit":
+            assert lib.kzg_commit_coeff(ctx, srs.handle, v.ptr, n, v.sfmt, L.IN_DEVICE, ref, L.G1_AFFINE_MONT) == 0, engine.last_error()
+            want[t] = ref.raw
+        else:
+            xs = [kzg_amd.splitmix_scalar(700 + t, i) for i in range(k)]
+            ys = [engine.poly_eval(v, x) for x in xs]
+            pts[t] = (kzg_amd.pack_scalars(xs), kzg_amd.pack_scalars(ys))
+            rc = lib.kzg_witness_coeff_batched(ctx, srs.handle, v.ptr, n, pts[t][0], pts[t][1], k, v.sfmt, L.IN_DEVICE, ref, L.G1_AFFINE_MONT,
+                                               rbuf0, ctypes.byref(rlen0))
+            assert rc == 0, engine.last_error()
+            want[t] = ref.raw + rbuf0.raw[:32 * rlen0.value]
     host = {}
     if host_resident:
         for t in range(threads):
@@ -226,10 +238,18 @@ def measure_blocking_callers(kzg_amd, L, engine, srs, scal, n, n_polys, threads=
         v = view(kzg_amd, scal, (t % n_polys) * n, n)
         src, flags = (host[t], 0) if host_resident else (v.ptr, L.IN_DEVICE)
         out = ctypes.create_string_buffer(96)
+        rbuf, rlen = ctypes.create_string_buffer(32 * max(k, 2)), ctypes.c_size_t()
         start.wait()
         for _ in range(calls):
-            rc = lib.kzg_commit_coeff(ctx, srs.handle, src, n, v.sfmt, flags, out, L.G1_AFFINE_MONT)
-            if rc != 0 or out.raw != want[t % n_polys]:
+            if op == "commit":
+                rc = lib.kzg_commit_coeff(ctx, srs.handle, src, n, v.sfmt, flags, out, L.G1_AFFINE_MONT)
+                got = out.raw
+            else:
+                xb, yb = pts[t % n_polys]
+                rc = lib.kzg_witness_coeff_batched(ctx, srs.handle, src, n, xb, yb, k, v.sfmt, flags, out, L.G1_AFFINE_MONT, rbuf,
+                                                   ctypes.byref(rlen))
+                got = out.raw + rbuf.raw[:32 * rlen.value]
+            if rc != 0 or got != want[t % n_polys]:
                 ok[t] = False
 
     th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
@@ -716,6 +736,11 @@ def main():
                 per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch, calls=8, host_resident=True)
                 res["paths"]["blocking_callers_16_host_resident_per_s"] = round(per_s, 2)   # 32 MiB over PCIe per call (pageable memory)
                 res["paths"]["blocking_callers_16_host_resident_match"] = same
+                kb = 256 if n_poly > 512 else 4
+                per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch, calls=8, op="witness_batched", k=kb)
+                res["paths"]["blocking_callers_16_witness_batched_k%d_per_s" % kb] = round(per_s, 2)   # configs[3], primary reading
+                res["paths"]["blocking_callers_16_witness_batched_vs_value"] = round(per_s / value, 4)
+                res["paths"]["blocking_callers_16_witness_batched_match_lone_calls"] = same
                 if args.log_n == 20 and not args.u64:
                     res["paths"].update(measure_spots(kzg_amd, L, engine, lambda: time.perf_counter() - t_extra < 45.0))
             except Exception as e:
@@ -727,6 +752,11 @@ def main():
             per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch, calls=8, host_resident=True)
             res["paths"]["blocking_callers_16_host_resident_per_s"] = round(per_s, 2)
             res["paths"]["blocking_callers_16_host_resident_match"] = same
+            kb = 256 if n_poly > 512 else 4
+            per_s, same = measure_blocking_callers(kzg_amd, L, engine, srs, scal, n_poly, args.batch, calls=8, op="witness_batched", k=kb)
+            res["paths"]["blocking_callers_16_witness_batched_k%d_per_s" % kb] = round(per_s, 2)
+            res["paths"]["blocking_callers_16_witness_batched_vs_value"] = round(per_s / value, 4)
+            res["paths"]["blocking_callers_16_witness_batched_match_lone_calls"] = same
         if mode == "single" and not args.no_cpu_baseline:
             if cpu is not None:
                 try:

@@ -78,19 +78,29 @@ ProfScope::~ProfScope() {
 }
 
 void prof_collect(kzg_ctx *ctx) {
-    std::lock_guard<std::mutex> lk(ctx->prof_mu);
-    for (auto &p : ctx->prof_pending) {
-        float ms = 0.f;
-        hipEventSynchronize(p.stop);
-        if (hipEventElapsedTime(&ms, p.start, p.stop) == hipSuccess) {
-            ProfEntry &e = ctx->prof_map[p.name];
-            e.launches++;
-            e.total_ms += ms;
-        }
-        ctx->event_pool.push_back(p.start);
-        ctx->event_pool.push_back(p.stop);
+    // the pending list is taken under the lock and waited for outside it: with concurrent leased callers a thread collecting
+    // must not hold every other thread's ProfScope (and their kernels still in flight) behind prof_mu
+    std::vector<PendingEvent> pend;
+    {
+        std::lock_guard<std::mutex> lk(ctx->prof_mu);
+        pend.swap(ctx->prof_pending);
     }
-    ctx->prof_pending.clear();
+    std::vector<float> ms(pend.size(), -1.f);
+    for (size_t i = 0; i < pend.size(); i++) {
+        hipEventSynchronize(pend[i].stop);
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pend[i].start, pend[i].stop) == hipSuccess) ms[i] = t;
+    }
+    std::lock_guard<std::mutex> lk(ctx->prof_mu);
+    for (size_t i = 0; i < pend.size(); i++) {
+        if (ms[i] >= 0.f) {
+            ProfEntry &e = ctx->prof_map[pend[i].name];
+            e.launches++;
+            e.total_ms += ms[i];
+        }
+        ctx->event_pool.push_back(pend[i].start);
+        ctx->event_pool.push_back(pend[i].stop);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -514,21 +524,16 @@ static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out);
 static void set_lane_mode(kzg_ctx *ctx, int lane, bool pipelined, bool deep);
 
 // ---- leased lanes: the reference's blocking prover calls from many host threads (CtxGate, common.h) -------------------------
-struct Lease {
-    kzg_ctx *ctx = nullptr;
-    int lane = -1;
-    hipStream_t accum = nullptr;  // the FIFO accumulation stream of this call (nullptr: on the lane's own stream)
-    ~Lease() {
-        if (!ctx || lane < 0) return;
-        set_lane_mode(ctx, lane, false, false);  // exclusive callers (lane 0) find the lone-MSM shape
-        {
-            std::lock_guard<std::mutex> lk(ctx->mu.m);
-            ctx->mu.lane_busy &= ~(1u << lane);
-            ctx->mu.shared_active--;
-        }
-        ctx->mu.cv.notify_all();
+kzg::Lease::~Lease() {
+    if (!ctx || lane < 0) return;
+    set_lane_mode(ctx, lane, false, false);  // exclusive callers (lane 0) find the lone-MSM shape
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu.m);
+        ctx->mu.lane_busy &= ~(1u << lane);
+        ctx->mu.shared_active--;
     }
-};
+    ctx->mu.cv.notify_all();
+}
 
 // the pool concurrent callers lease from: `streams` lanes + the accumulation streams, planned like a batch of that depth
 static int plan_for_callers(kzg_ctx *ctx) {
@@ -540,7 +545,7 @@ static int plan_for_callers(kzg_ctx *ctx) {
     return KZG_OK;
 }
 
-static int lease_lane(kzg_ctx *ctx, Lease *ls) {
+int kzg::lease_lane(kzg_ctx *ctx, Lease *ls) {
     CtxGate &g = ctx->mu;
     std::unique_lock<std::mutex> lk(g.m);
     for (;;) {
@@ -578,7 +583,7 @@ static int lease_lane(kzg_ctx *ctx, Lease *ls) {
     return KZG_OK;
 }
 
-static int lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res) {
+int kzg::lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res) {
     if (ls.accum)
         return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res, ls.accum, ctx->sorted_events[ls.lane], ctx->accum_events[ls.lane]);
     return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res);
@@ -1030,17 +1035,19 @@ extern "C" int kzg_compute_omega(size_t d, size_t *m_out, uint32_t *exp_out, voi
 
 extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int flags) {
     if (!ctx || !data) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;  // EvaluationDomain::fft is a `&mut self` method of the caller's own vector: many threads, one context
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^28 are not supported (2^24-point two-pass transforms under one 16-point outer level)");
     size_t n = (size_t)1 << log_n;
     // above 2^24: the transposed copy of the whole vector + the inner transform's 2^24-element scratch + the outer twiddle tables
-    KZG_TRY(lane_reserve(ctx, 0, (log_n > 24 ? n * 32 + ((size_t)1 << 24) * 32 + (1 << 20) : n * 32) + stage_bytes(n * 32, flags) + 8192));
-    hipStream_t st = ctx->lanes[0].stream;
+    KZG_TRY(lane_reserve(ctx, lane, (log_n > 24 ? n * 32 + ((size_t)1 << 24) * 32 + (1 << 20) : n * 32) + stage_bytes(n * 32, flags) + 8192));
+    hipStream_t st = ctx->lanes[lane].stream;
     const void *d = nullptr;
-    KZG_TRY(stage_in(ctx, 0, data, n * 32, flags, &d));
-    KZG_TRY(ntt_run(ctx, 0, (Fr *)d, log_n, inverse));
+    KZG_TRY(stage_in(ctx, lane, data, n * 32, flags, &d));
+    KZG_TRY(ntt_run(ctx, lane, (Fr *)d, log_n, inverse));
     if (!(flags & KZG_IN_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->prof) prof_collect(ctx);
@@ -1052,18 +1059,20 @@ extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse,
 // ---------------------------------------------------------------------------------------------
 extern "C" int kzg_poly_eval(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, int sfmt, int flags, void *y_out) {
     if (!ctx || !coeffs || !x || !y_out || n == 0 || !count_ok(n)) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     Fr xm;
     KZG_TRY(host_scalar(ctx, x, sfmt, &xm));
-    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(n * 32, flags) + (n / 2048 + 4) * 64 + 65536));
-    hipStream_t st = ctx->lanes[0].stream;
+    KZG_TRY(lane_reserve(ctx, lane, stage_bytes(n * 32, flags) + (n / 2048 + 4) * 64 + 65536));
+    hipStream_t st = ctx->lanes[lane].stream;
     const void *d = nullptr;
-    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
-    Fr *dy = (Fr *)lane_alloc(ctx, 0, 256);
+    KZG_TRY(stage_in(ctx, lane, coeffs, n * 32, flags, &d));
+    Fr *dy = (Fr *)lane_alloc(ctx, lane, 256);
     if (!dy) return fail(ctx, KZG_ERR_ALLOC, "workspace");
-    KZG_TRY(poly_eval_run(ctx, 0, (const Fr *)d, n, xm, dy));
+    KZG_TRY(poly_eval_run(ctx, lane, (const Fr *)d, n, xm, dy));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(y_out, dy, 32, hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->prof) prof_collect(ctx);
@@ -1073,20 +1082,22 @@ extern "C" int kzg_poly_eval(kzg_ctx *ctx, const void *coeffs, size_t n, const v
 extern "C" int kzg_quotient_linear(kzg_ctx *ctx, const void *coeffs, size_t n, const void *x, const void *y, int sfmt,
                                    int flags, void *q_out) {
     if (!ctx || !coeffs || !x || !y || n == 0 || (!q_out && n > 1) || !count_ok(n)) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     Fr xm;
     KZG_TRY(host_scalar(ctx, x, sfmt, &xm));
-    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(n * 32, flags) * 2 + (n / 2048 + 4) * 64 + 65536));
-    hipStream_t st = ctx->lanes[0].stream;
+    KZG_TRY(lane_reserve(ctx, lane, stage_bytes(n * 32, flags) * 2 + (n / 2048 + 4) * 64 + 65536));
+    hipStream_t st = ctx->lanes[lane].stream;
     const void *d = nullptr;
-    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
+    KZG_TRY(stage_in(ctx, lane, coeffs, n * 32, flags, &d));
     bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
-    Fr *dq = out_dev ? (Fr *)q_out : (Fr *)lane_alloc(ctx, 0, n * 32);
-    Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
+    Fr *dq = out_dev ? (Fr *)q_out : (Fr *)lane_alloc(ctx, lane, n * 32);
+    Fr *dpx = (Fr *)lane_alloc(ctx, lane, 256);
     if (!dq || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
-    KZG_TRY(quotient_linear_run(ctx, 0, (const Fr *)d, n, xm, dq, dpx));
+    KZG_TRY(quotient_linear_run(ctx, lane, (const Fr *)d, n, xm, dq, dpx));
     Fr px;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
     if (!out_dev && n > 1) KZG_HIP_CHECK(ctx, hipMemcpyAsync(q_out, dq, (n - 1) * 32, hipMemcpyDeviceToHost, st));
@@ -1098,21 +1109,23 @@ extern "C" int kzg_quotient_linear(kzg_ctx *ctx, const void *coeffs, size_t n, c
 
 extern "C" int kzg_quotient_eval(kzg_ctx *ctx, const void *evals, size_t d, size_t i, int sfmt, int flags, void *q_out) {
     if (!ctx || !evals || !q_out) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
     if (i >= d) return fail(ctx, KZG_ERR_SHAPE, "evaluation index out of range (reference: index panic)");
     uint32_t log_d = (uint32_t)ilog2_ceil(d);
     if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
-    KZG_TRY(lane_reserve(ctx, 0, stage_bytes(d * 32, flags) * 2 + (d / 256 + 4) * 32 + 65536));
-    hipStream_t st = ctx->lanes[0].stream;
+    KZG_TRY(lane_reserve(ctx, lane, stage_bytes(d * 32, flags) * 2 + (d / 256 + 4) * 32 + 65536));
+    hipStream_t st = ctx->lanes[lane].stream;
     const void *de = nullptr;
-    KZG_TRY(stage_in(ctx, 0, evals, d * 32, flags, &de));
+    KZG_TRY(stage_in(ctx, lane, evals, d * 32, flags, &de));
     bool out_dev = (flags & KZG_OUT_DEVICE) != 0;
-    Fr *dq = out_dev ? (Fr *)q_out : (Fr *)lane_alloc(ctx, 0, d * 32);
+    Fr *dq = out_dev ? (Fr *)q_out : (Fr *)lane_alloc(ctx, lane, d * 32);
     if (!dq) return fail(ctx, KZG_ERR_ALLOC, "workspace");
-    KZG_TRY(quotient_eval_run(ctx, 0, (const Fr *)de, log_d, i, sfmt, dq));
+    KZG_TRY(quotient_eval_run(ctx, lane, (const Fr *)de, log_d, i, sfmt, dq));
     if (!out_dev) KZG_HIP_CHECK(ctx, hipMemcpyAsync(q_out, dq, d * 32, hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->prof) prof_collect(ctx);
@@ -1179,12 +1192,12 @@ extern "C" int kzg_witness_eval(kzg_ctx *ctx, const kzg_srs *lagrange, const voi
     return finish_point(ctx, lane, res, out, ofmt, flags);
 }
 
-static int verify_against(kzg_ctx *ctx, const MsmPoint *res, const void *commitment, int pfmt, int *ok) {
+static int verify_against(kzg_ctx *ctx, int lane, const MsmPoint *res, const void *commitment, int pfmt, int *ok) {
     size_t psz = point_format_bytes(pfmt);
     if (!psz || pfmt == KZG_G1_JACOBIAN_MONT_144)
         return fail(ctx, KZG_ERR_SHAPE, "verify_poly takes the commitment in an affine format (KZGCommitment = G1Affine)");
     uint8_t mine[96];
-    KZG_TRY(finish_point(ctx, 0, res, mine, pfmt, 0));
+    KZG_TRY(finish_point(ctx, lane, res, mine, pfmt, 0));
     *ok = memcmp(mine, commitment, psz) == 0;
     return KZG_OK;
 }
@@ -1193,38 +1206,42 @@ extern "C" int kzg_verify_poly_coeff(kzg_ctx *ctx, const kzg_srs *srs, const voi
                                      const void *coeffs, size_t n, int sfmt, int flags, int *ok) {
     // KZGVerifier::verify_poly (src/coeff_form.rs:119-124)
     if (!ctx || !srs || !commitment || !ok || (!coeffs && n)) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     if (n > srs->n) return fail(ctx, KZG_ERR_SHAPE, "polynomial longer than the SRS (reference: slice index panic)");
-    KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
+    KZG_TRY(lane_reserve(ctx, lane, msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192));
     const void *d = nullptr;
-    KZG_TRY(stage_in(ctx, 0, coeffs, n * 32, flags, &d));
+    KZG_TRY(stage_in(ctx, lane, coeffs, n * 32, flags, &d));
     MsmPoint *res = nullptr;
-    KZG_TRY(msm_run(ctx, 0, srs, 0, d, n, sfmt, &res));
-    return verify_against(ctx, res, commitment, pfmt, ok);
+    KZG_TRY(lease_msm(ctx, ls, srs, 0, d, n, sfmt, &res));
+    return verify_against(ctx, lane, res, commitment, pfmt, ok);
 }
 
 extern "C" int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const void *commitment, int pfmt,
                                     const void *evals, size_t d, int sfmt, int flags, int *ok) {
     // KZGVerifierEvalForm::verify_poly (src/eval_form.rs:162-171): ifft, then the monomial-basis MSM
     if (!ctx || !monomial || !commitment || !ok || !evals) return KZG_ERR_SHAPE;
-    Guard g(ctx);
+    Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     KZG_TRY(check_sfmt(ctx, sfmt));
     if (!is_pow2(d)) return fail(ctx, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
     if (d > monomial->n) return fail(ctx, KZG_ERR_SHAPE, "polynomial longer than the SRS (reference: slice index panic)");
     uint32_t log_d = (uint32_t)ilog2_ceil(d);
     if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
-    KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(monomial, d) + 3 * d * 32 + 65536));
-    hipStream_t st = ctx->lanes[0].stream;
-    Fr *work = (Fr *)lane_alloc(ctx, 0, d * 32);
+    KZG_TRY(lane_reserve(ctx, lane, msm_workspace_bytes(monomial, d) + 3 * d * 32 + 65536));
+    hipStream_t st = ctx->lanes[lane].stream;
+    Fr *work = (Fr *)lane_alloc(ctx, lane, d * 32);
     if (!work) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(work, evals, d * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-    KZG_TRY(ntt_run(ctx, 0, work, log_d, 1));
+    KZG_TRY(ntt_run(ctx, lane, work, log_d, 1));
     MsmPoint *res = nullptr;
-    KZG_TRY(msm_run(ctx, 0, monomial, 0, work, d, sfmt, &res));
-    return verify_against(ctx, res, commitment, pfmt, ok);
+    KZG_TRY(lease_msm(ctx, ls, monomial, 0, work, d, sfmt, &res));
+    return verify_against(ctx, lane, res, commitment, pfmt, ok);
 }
 
 #ifdef KZG_TEST_HOOKS

@@ -189,6 +189,17 @@ struct Guard {  // exclusive use of the context for the scope
     explicit Guard(kzg_ctx *c) : lk(c->mu) {}
 };
 
+// Shared use of the context for the scope: one leased lane (stream + arena).  Every blocking prover / verifier / transform call
+// that works on ONE lane takes a Lease instead of a Guard (capi.hip: lease_lane), so N host threads inside create_witness_batched,
+// commit, fft, verify_poly ... run side by side on one context, as the reference's `&self` methods do (src/coeff_form.rs:59-111).
+struct Lease {
+    kzg_ctx *ctx = nullptr;
+    int lane = -1;
+    hipStream_t accum = nullptr;  // the FIFO accumulation stream of this call (nullptr: on the lane's own stream)
+    ~Lease();
+};
+int lease_lane(kzg_ctx *ctx, Lease *ls);
+
 // validation of decoded points (what blstrs' G1Affine / G2Affine deserialisation enforces upstream):
 //   POINTS_TRUSTED   nothing (the engine's own intermediate results)
 //   POINTS_ON_CURVE  limbs canonical (< q) and on the curve
@@ -271,6 +282,8 @@ int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int of
 // accum_stream (optional): run k_accum_affine there instead of on the lane's stream, ordered by the two caller-owned events
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr, hipEvent_t accum_ev = nullptr);
+// capi.hip: one MSM on a leased lane (its accumulation kernel on the lease's FIFO stream when other calls are in flight)
+int lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res);
 // d_points: count points -> one point (plain sum)
 int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result);
 // conversions between the canonical saturated XYZZ form and MsmPoint (device arrays)

@@ -236,6 +236,9 @@ static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t coun
 
 static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, NttPlan **out) {
     uint32_t key = log_n * 2 + (inverse ? 1 : 0);
+    // leased lanes (concurrent fft / create_witness_batched / verify_poly callers) share the plans: one builder at a time, and a
+    // plan is published only after the stream that filled its tables has been synchronised
+    std::lock_guard<std::mutex> clk(ctx->cache_mu);
     auto it = ctx->ntt_plans.find(key);
     if (it != ctx->ntt_plans.end()) {
         *out = it->second;
@@ -275,6 +278,7 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
                        p->k2, p->scale, n, p->tw_full);
         }
     }
+    if (hipStreamSynchronize(st) != hipSuccess) return fail(ctx, KZG_ERR_HIP, "NTT twiddle tables");
     ctx->ntt_plans[key] = p;
     *out = p;
     return KZG_OK;

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void k_distribute_powers(Fr *data, size_t n, c
 static int coset_tables(kzg_ctx *ctx, hipStream_t st, const Fr &g, const Fr **lo_tab, const Fr **hi_tab) {
     std::array<uint32_t, 8> key;
     for (int i = 0; i < 8; i++) key[i] = g.v[i];
+    std::lock_guard<std::mutex> clk(ctx->cache_mu);  // leased lanes share the cache: one builder at a time
     for (auto &ct : ctx->coset_tabs)
         if (ct.first == key) {
             *lo_tab = (const Fr *)ct.second;
@@ -300,16 +301,18 @@ __global__ __launch_bounds__(256) void k_mul_assign(Fr *a, const Fr *b, size_t n
 extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *b, size_t nb, int sfmt, int flags, void *out) {
     // Polynomial::fft_mul (src/polynomial.rs:167-183)
     if (!ctx || !a || !b || !out || na == 0 || nb == 0) return KZG_ERR_SHAPE;
-    kzg::Guard g(ctx);
+    kzg::Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     uint32_t log_n = (uint32_t)ilog2_ceil(na + nb);   // from_coeffs(resize(n + k)) rounds up to 2^exp
     if (log_n >= FR_TWO_ADICITY || log_n > 24) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     size_t N = (size_t)1 << log_n, nout = na + nb - 1;
-    KZG_TRY(lane_reserve(ctx, 0, 8 * N * 32 + (1 << 20)));
-    hipStream_t st = ctx->lanes[0].stream;
-    Fr *A = (Fr *)lane_alloc(ctx, 0, N * 32), *Bv = (Fr *)lane_alloc(ctx, 0, N * 32), *ia = (Fr *)lane_alloc(ctx, 0, N * 32),
-       *ib = (Fr *)lane_alloc(ctx, 0, N * 32);
+    KZG_TRY(lane_reserve(ctx, lane, 8 * N * 32 + (1 << 20)));
+    hipStream_t st = ctx->lanes[lane].stream;
+    Fr *A = (Fr *)lane_alloc(ctx, lane, N * 32), *Bv = (Fr *)lane_alloc(ctx, lane, N * 32), *ia = (Fr *)lane_alloc(ctx, lane, N * 32),
+       *ib = (Fr *)lane_alloc(ctx, lane, N * 32);
     if (!A || !Bv || !ia || !ib) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     hipMemcpyKind kind = (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(ia, a, na * 32, kind, st));
@@ -317,10 +320,10 @@ extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *
     // a keeps its form; b goes to Montgomery form so that the pointwise Montgomery product preserves a's form
     KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, ia, na, A, N, 0);
     KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, ib, nb, Bv, N, sfmt == KZG_FR_CANONICAL_LE_32);
-    KZG_TRY(ntt_run(ctx, 0, A, log_n, 0));
-    KZG_TRY(ntt_run(ctx, 0, Bv, log_n, 0));
+    KZG_TRY(ntt_run(ctx, lane, A, log_n, 0));
+    KZG_TRY(ntt_run(ctx, lane, Bv, log_n, 0));
     KZG_LAUNCH(ctx, st, "k_mul_assign", k_mul_assign, gridfor(N), 256, 0, A, Bv, N);
-    KZG_TRY(ntt_run(ctx, 0, A, log_n, 1));
+    KZG_TRY(ntt_run(ctx, lane, A, log_n, 1));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, A, nout * 32, (flags & KZG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->prof) prof_collect(ctx);
@@ -329,18 +332,20 @@ extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *
 
 extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse, int sfmt, int flags) {
     if (!ctx || !data) return KZG_ERR_SHAPE;
-    kzg::Guard g(ctx);
+    kzg::Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     (void)sfmt;  // linear map with Montgomery constants: the data's form is preserved
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "coset NTT sizes above 2^24 are not supported");
     size_t n = (size_t)1 << log_n;
-    KZG_TRY(lane_reserve(ctx, 0, 2 * n * 32 + 65536));
-    hipStream_t st = ctx->lanes[0].stream;
-    Fr *d = (flags & KZG_IN_DEVICE) ? (Fr *)data : (Fr *)lane_alloc(ctx, 0, n * 32);
+    KZG_TRY(lane_reserve(ctx, lane, 2 * n * 32 + 65536));
+    hipStream_t st = ctx->lanes[lane].stream;
+    Fr *d = (flags & KZG_IN_DEVICE) ? (Fr *)data : (Fr *)lane_alloc(ctx, lane, n * 32);
     if (!d) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     if (!(flags & KZG_IN_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(d, data, n * 32, hipMemcpyHostToDevice, st));
-    KZG_TRY(coset_ntt_run(ctx, 0, d, log_n, inverse, from_u64<FrParams>(FR_MULT_GENERATOR)));
+    KZG_TRY(coset_ntt_run(ctx, lane, d, log_n, inverse, from_u64<FrParams>(FR_MULT_GENERATOR)));
     if (!(flags & KZG_IN_DEVICE)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(data, d, n * 32, hipMemcpyDeviceToHost, st));
     KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
     if (ctx->prof) prof_collect(ctx);
@@ -361,18 +366,23 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
 int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const void *coeffs, size_t n, const void *xs,
                                    const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt, void *out_r,
                                    size_t *out_r_len) {
-    kzg::Guard g(ctx);
+    // a leased lane, like commit / create_witness: interpolation, the coset-NTT division and the quotient MSM on the lane's stream
+    // and arena, the accumulation kernel on the shared FIFO streams once other calls are in flight (KZGProver is Clone + &self:
+    // N threads call create_witness_batched at once, src/coeff_form.rs:83-111)
+    kzg::Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     const kzg_srs *srs = sink.srs;
     auto sink_len = [&](size_t cnt) { return cnt <= sink.first ? (size_t)0 : (cnt - sink.first < sink.len ? cnt - sink.first : sink.len); };
     auto sink_msm = [&](Fr *q, size_t cnt, MsmPoint **res) {
         const size_t len = sink_len(cnt);
-        return msm_run(ctx, 0, srs, 0, len ? q + sink.first : q, len, KZG_FR_MONT_LE_32, res);
+        return lease_msm(ctx, ls, srs, 0, len ? q + sink.first : q, len, KZG_FR_MONT_LE_32, res);
     };
     auto sink_finish = [&](const MsmPoint *res) {
-        if (!sink.d_partial) return finish_point(ctx, 0, res, out_w, ofmt, flags);
-        KZG_TRY(emit_point(ctx, 0, res, sink.d_partial, KZG_G1_JACOBIAN_MONT_144));
-        KZG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lanes[0].stream));
+        if (!sink.d_partial) return finish_point(ctx, lane, res, out_w, ofmt, flags);
+        KZG_TRY(emit_point(ctx, lane, res, sink.d_partial, KZG_G1_JACOBIAN_MONT_144));
+        KZG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->lanes[lane].stream));
         return (int)KZG_OK;
     };
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
@@ -380,7 +390,7 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no opening points (the reference recurses without bound on an empty slice)");
     if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "create_witness_batched supports at most 4096 opening points (single-workgroup interpolation kernels)");
     const int to_m = sfmt == KZG_FR_CANONICAL_LE_32;
-    hipStream_t st = ctx->lanes[0].stream;
+    hipStream_t st = ctx->lanes[lane].stream;
 
     // ---- k == 1: the reference's interpolant is X + (y - x) (src/polynomial.rs:244-247) -----------
     if (k == 1) {
@@ -389,14 +399,14 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         KZG_TRY(hscalar(ctx, ys, sfmt, &ym));
         size_t n2 = n < 2 ? 2 : n;
         if (n2 - 1 > sink.total) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
-        KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(srs, sink_len(n2 - 1)) + 4 * n2 * 32 + (n2 / 2048 + 8) * 64 + 65536));
-        Fr *p = (Fr *)lane_alloc(ctx, 0, n2 * 32), *pin = (Fr *)lane_alloc(ctx, 0, n2 * 32), *q = (Fr *)lane_alloc(ctx, 0, n2 * 32);
-        Fr *dpx = (Fr *)lane_alloc(ctx, 0, 256);
+        KZG_TRY(lane_reserve(ctx, lane, msm_workspace_bytes(srs, sink_len(n2 - 1)) + 4 * n2 * 32 + (n2 / 2048 + 8) * 64 + 65536));
+        Fr *p = (Fr *)lane_alloc(ctx, lane, n2 * 32), *pin = (Fr *)lane_alloc(ctx, lane, n2 * 32), *q = (Fr *)lane_alloc(ctx, lane, n2 * 32);
+        Fr *dpx = (Fr *)lane_alloc(ctx, lane, 256);
         if (!p || !pin || !q || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, (flags & KZG_IN_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(n2), 256, 0, pin, n, p, n2, to_m);
         KZG_LAUNCH(ctx, st, "k_sub_linear", k_sub_linear, gridfor(n2), 256, 0, p, n2, p, n2, sub(ym, xm));
-        KZG_TRY(quotient_linear_run(ctx, 0, p, n2, xm, q, dpx));
+        KZG_TRY(quotient_linear_run(ctx, lane, p, n2, xm, q, dpx));
         Fr px;
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
         MsmPoint *res = nullptr;
@@ -423,14 +433,14 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     size_t nq = small_poly ? 0 : n - k;
     if (nq > sink.total) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
     size_t need = msm_workspace_bytes(srs, sink_len(nq) ? sink_len(nq) : 1) + 12 * N * 32 + (size_t)k * k * 32 + 64 * (k + 2) * 32 + (2 << 20);
-    KZG_TRY(lane_reserve(ctx, 0, need));
-    Fr *dx = (Fr *)lane_alloc(ctx, 0, k * 32), *dy = (Fr *)lane_alloc(ctx, 0, k * 32);
-    Fr *z0 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, 0, (k + 1) * 32);
-    Fr *den = (Fr *)lane_alloc(ctx, 0, k * 32), *deni = (Fr *)lane_alloc(ctx, 0, k * 32);
-    Fr *rows = (Fr *)lane_alloc(ctx, 0, (size_t)k * k * 32), *I = (Fr *)lane_alloc(ctx, 0, k * 32);
-    Fr *A = (Fr *)lane_alloc(ctx, 0, N * 32), *Bv = (Fr *)lane_alloc(ctx, 0, N * 32), *Cv = (Fr *)lane_alloc(ctx, 0, N * 32);
-    Fr *Ci = (Fr *)lane_alloc(ctx, 0, N * 32), *pin = (Fr *)lane_alloc(ctx, 0, N * 32);
-    int *flag = (int *)lane_alloc(ctx, 0, 256);
+    KZG_TRY(lane_reserve(ctx, lane, need));
+    Fr *dx = (Fr *)lane_alloc(ctx, lane, k * 32), *dy = (Fr *)lane_alloc(ctx, lane, k * 32);
+    Fr *z0 = (Fr *)lane_alloc(ctx, lane, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, lane, (k + 1) * 32);
+    Fr *den = (Fr *)lane_alloc(ctx, lane, k * 32), *deni = (Fr *)lane_alloc(ctx, lane, k * 32);
+    Fr *rows = (Fr *)lane_alloc(ctx, lane, (size_t)k * k * 32), *I = (Fr *)lane_alloc(ctx, lane, k * 32);
+    Fr *A = (Fr *)lane_alloc(ctx, lane, N * 32), *Bv = (Fr *)lane_alloc(ctx, lane, N * 32), *Cv = (Fr *)lane_alloc(ctx, lane, N * 32);
+    Fr *Ci = (Fr *)lane_alloc(ctx, lane, N * 32), *pin = (Fr *)lane_alloc(ctx, lane, N * 32);
+    int *flag = (int *)lane_alloc(ctx, lane, 256);
     if (!dx || !dy || !z0 || !z1 || !den || !deni || !rows || !I || !A || !Bv || !Cv || !Ci || !pin || !flag)
         return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, sizeof(int), st));
@@ -445,7 +455,7 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     // host round trip of the call, so it comes first, while the stream holds nothing but the upload of the points.
     Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = g1;
     if (!small_poly) {
-        int *cflag = (int *)lane_alloc(ctx, 0, 256);
+        int *cflag = (int *)lane_alloc(ctx, lane, 256);
         if (!cflag) return fail(ctx, KZG_ERR_ALLOC, "workspace");
         for (size_t attempt = 0;; attempt++) {
             int on = 0;
@@ -464,11 +474,11 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     {
         const uint32_t log_M = (uint32_t)ilog2_ceil(k + 1);
         const size_t Mz = (size_t)1 << log_M;
-        Fr *zev = (Fr *)lane_alloc(ctx, 0, Mz * 32), *wpow = (Fr *)lane_alloc(ctx, 0, Mz * 32);
+        Fr *zev = (Fr *)lane_alloc(ctx, lane, Mz * 32), *wpow = (Fr *)lane_alloc(ctx, lane, Mz * 32);
         if (!zev || !wpow) return fail(ctx, KZG_ERR_ALLOC, "workspace");
         KZG_TRY(pow_table(ctx, st, host_omega(log_M), Fr::one(), Mz, wpow));
         KZG_LAUNCH(ctx, st, "k_prod_diff", k_prod_diff, (unsigned)Mz, 256, 0, wpow, dx, (uint32_t)k, 0, zev);
-        KZG_TRY(ntt_run(ctx, 0, zev, log_M, 1));
+        KZG_TRY(ntt_run(ctx, lane, zev, log_M, 1));
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(z0, zev, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
     }
     KZG_LAUNCH(ctx, st, "k_prod_diff", k_prod_diff, (unsigned)k, 256, 0, dx, dx, (uint32_t)k, 1, den);
@@ -502,12 +512,12 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         // (p - I) in coefficient form, then TWO forward coset NTTs (numerator, Z) and one inverse; Z and the numerator's
         // zero padding are not scaled
         KZG_LAUNCH(ctx, st, "k_sub_prefix", k_sub_prefix, gridfor(k), 256, 0, A, I, k);
-        KZG_TRY(coset_ntt_run(ctx, 0, Cv, log_N, 0, gsh, k + 1));
+        KZG_TRY(coset_ntt_run(ctx, lane, Cv, log_N, 0, gsh, k + 1));
         KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(N), 256, 0, Cv, N, flag);
-        KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 0, gsh, n > k ? n : k));
+        KZG_TRY(coset_ntt_run(ctx, lane, A, log_N, 0, gsh, n > k ? n : k));
         KZG_TRY(batch_inverse(ctx, st, Cv, Ci, N));
         KZG_LAUNCH(ctx, st, "k_mul_inplace", k_mul_inplace, gridfor(N), 256, 0, A, Ci, N);
-        KZG_TRY(coset_ntt_run(ctx, 0, A, log_N, 1, gsh));
+        KZG_TRY(coset_ntt_run(ctx, lane, A, log_N, 1, gsh));
         // exact division <=> deg q <= N-1-k <=> the top k coefficients vanish
         KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);
         KZG_TRY(sink_msm(A, nq, &res));
@@ -565,18 +575,20 @@ extern "C" int kzg_domain_z(size_t d, const void *tau, int sfmt, void *out) {
 }
 
 static int vec_entry(kzg_ctx *ctx, void *a, const void *b, size_t n, int sfmt, int flags, int op, const Fr *scale) {
-    kzg::Guard g(ctx);
+    kzg::Lease ls;
+    KZG_TRY(lease_lane(ctx, &ls));
+    const int lane = ls.lane;
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     if (n > ((size_t)1 << 40)) return fail(ctx, KZG_ERR_SHAPE, "vector too long");
     if (n == 0) return KZG_OK;
-    hipStream_t st = ctx->lanes[0].stream;
+    hipStream_t st = ctx->lanes[lane].stream;
     const bool dev = (flags & KZG_IN_DEVICE) != 0;
-    KZG_TRY(lane_reserve(ctx, 0, dev ? 4096 : 2 * n * 32 + 8192));
+    KZG_TRY(lane_reserve(ctx, lane, dev ? 4096 : 2 * n * 32 + 8192));
     Fr *da = (Fr *)a, *db = (Fr *)b;
     if (!dev) {
-        da = (Fr *)lane_alloc(ctx, 0, n * 32);
-        db = b ? (Fr *)lane_alloc(ctx, 0, n * 32) : nullptr;
+        da = (Fr *)lane_alloc(ctx, lane, n * 32);
+        db = b ? (Fr *)lane_alloc(ctx, lane, n * 32) : nullptr;
         if (!da || (b && !db)) return fail(ctx, KZG_ERR_ALLOC, "workspace");
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(da, a, n * 32, hipMemcpyHostToDevice, st));
         if (b) KZG_HIP_CHECK(ctx, hipMemcpyAsync(db, b, n * 32, hipMemcpyHostToDevice, st));
@@ -593,10 +605,7 @@ extern "C" int kzg_divide_by_z_on_coset(kzg_ctx *ctx, void *data, uint32_t log_n
     // EvaluationDomain::divide_by_z_on_coset (src/ft.rs:192-217): every value times 1 / (g^d - 1), g = 7, d = 2^log_n.
     // A multiplication by a Montgomery-form constant preserves whichever form the data is in.
     if (!ctx || !data) return KZG_ERR_SHAPE;
-    if (log_n >= FR_TWO_ADICITY) {
-        kzg::Guard g(ctx);
-        return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
-    }
+    if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     const size_t d = (size_t)1 << log_n;
     const Fr zi = inv(sub(pow_u64(from_u64<FrParams>(FR_MULT_GENERATOR), (uint64_t)d), Fr::one()));
     return vec_entry(ctx, data, nullptr, d, sfmt, flags, 0, &zi);

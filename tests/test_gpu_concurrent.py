@@ -147,3 +147,91 @@ def test_concurrent_2_20_sixteen_threads(engine):
         for p in polys:
             p["buf"].free()
         params.gs.free()
+
+
+def test_concurrent_2_20_every_leased_call(engine):
+    """16 host threads at degree 2^20 mixing every call that leases a lane: commit, create_witness, create_witness_batched
+    (k = 256: BASELINE configs[3], primary reading), fft, verify_poly -- KZGProver is Clone + &self, so the reference allows all of
+    them at once (src/coeff_form.rs:59-111, src/ft.rs:111-140).  Every expected value from the oracle: downloaded coefficients,
+    its Horner loop, one scalar multiplication; the NTT against its serial_fft restatement."""
+    n, threads, k = 1 << 20, 16, 256
+    engine.set_option("streams", 16)
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    G = C.g1_generator()
+    polys = []
+    for t in range(4):  # four polynomials, four threads each
+        buf = engine.alloc_scalars(n).fill_random(5100 + t)
+        raw = buf.download()
+        ptau = C.poly_eval_bytes(raw, n, TAU)
+        x = kzg_amd.splitmix_scalar(53, t)
+        y = C.poly_eval_bytes(raw, n, x)
+        xs = [kzg_amd.splitmix_scalar(600 + t, i) for i in range(k)]
+        # the opening values by the engine (256 oracle evaluations at 2^20 would take half a minute per polynomial); a sample of them
+        # against the oracle here, and the witness identity below holds only if ALL of them are right (the division is exact iff
+        # I agrees with p at every opening point)
+        ys = [engine.poly_eval(buf, v) for v in xs]
+        assert all(C.poly_eval_bytes(raw, n, xs[i]) == ys[i] for i in (0, 101, 255))
+        polys.append(dict(buf=buf, raw=raw, ptau=ptau, commit=C.g1_mul(G, ptau), x=x, y=y,
+                          wit=C.g1_mul(G, (ptau - y) * pow(TAU - x, -1, R) % R), xs=xs, ys=ys,
+                          xb=kzg_amd.pack_scalars(xs), yb=kzg_amd.pack_scalars(ys), fft=C.fft_bytes(raw, 20)))
+    # the batched witness once alone: w == [(p(tau) - I(tau)) / Z(tau)] G with I from the call itself checked at the opening points
+    for p in polys:
+        out = ctypes.create_string_buffer(96)
+        rbuf, rlen = ctypes.create_string_buffer(32 * k), ctypes.c_size_t()
+        rc = engine.lib.kzg_witness_coeff_batched(engine.ctx, params.gs.handle, p["buf"].ptr, n, p["xb"], p["yb"], k, p["buf"].sfmt,
+                                                  L.IN_DEVICE, out, L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
+        assert rc == 0 and rlen.value == k, engine.last_error()
+        I = kzg_amd.unpack_scalars(rbuf.raw)
+        assert all(C.poly_eval(I, p["xs"][i]) == p["ys"][i] for i in range(0, k, 15))
+        Z = 1
+        for v in p["xs"]:
+            Z = Z * (TAU - v) % R
+        p["wb"] = C.g1_mul(G, (p["ptau"] - C.poly_eval(I, TAU)) * pow(Z, -1, R) % R)
+        assert out.raw == p["wb"]
+        p["I"] = rbuf.raw
+    work_bufs = [engine.alloc_scalars(n) for _ in range(threads)]
+
+    def work(t):
+        p = polys[t % 4]
+        lib, ctx = engine.lib, engine.ctx
+        out = ctypes.create_string_buffer(96)
+        rbuf, rlen = ctypes.create_string_buffer(32 * k), ctypes.c_size_t()
+        ok = ctypes.c_int(0)
+        for r in range(5):
+            what = (t + r) % 5
+            if what == 0:
+                rc = lib.kzg_commit_coeff(ctx, params.gs.handle, p["buf"].ptr, n, p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+                assert rc == 0 and out.raw == p["commit"], ("commit", t, r, rc)
+            elif what == 1:
+                rc = lib.kzg_witness_coeff(ctx, params.gs.handle, p["buf"].ptr, n, b32(p["x"]), b32(p["y"]), p["buf"].sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+                assert rc == 0 and out.raw == p["wit"], ("witness", t, r, rc)
+            elif what == 2:
+                rc = lib.kzg_witness_coeff_batched(ctx, params.gs.handle, p["buf"].ptr, n, p["xb"], p["yb"], k, p["buf"].sfmt, L.IN_DEVICE, out,
+                                                   L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
+                assert rc == 0 and out.raw == p["wb"] and rbuf.raw == p["I"], ("witness_batched", t, r, rc)
+            elif what == 3:
+                w = work_bufs[t]
+                w.upload(p["raw"])
+                assert lib.kzg_ntt_fr(ctx, w.ptr, 20, 0, L.IN_DEVICE) == 0
+                assert w.download() == p["fft"], ("fft", t, r)
+                assert lib.kzg_ntt_fr(ctx, w.ptr, 20, 1, L.IN_DEVICE) == 0
+                assert w.download() == p["raw"], ("ifft", t, r)
+            else:
+                rc = lib.kzg_verify_poly_coeff(ctx, params.gs.handle, p["commit"], L.G1_AFFINE_MONT, p["buf"].ptr, n, p["buf"].sfmt, L.IN_DEVICE,
+                                               ctypes.byref(ok))
+                assert rc == 0 and ok.value == 1, ("verify_poly", t, r, rc)
+                # a wrong opening value in the batch: the calling thread's own error
+                yb_bad = p["yb"][:32] + b32(p["ys"][1] + 1) + p["yb"][64:]
+                rc = lib.kzg_witness_coeff_batched(ctx, params.gs.handle, p["buf"].ptr, n, p["xb"], yb_bad, k, p["buf"].sfmt, L.IN_DEVICE, out,
+                                                   L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
+                assert rc == L.KZG_ERR_POINT_NOT_ON_POLY, ("wrong y in the batch", t, r, rc)
+
+    try:
+        _run_threads(threads, work)
+    finally:
+        engine.set_option("streams", 8)
+        for p in polys:
+            p["buf"].free()
+        for w in work_bufs:
+            w.free()
+        params.gs.free()
