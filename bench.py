@@ -401,6 +401,182 @@ def measure_spots(kzg_amd, L, engine, budget_ok):
     return res
 
 
+class Job:
+    """The ranks of one bench run.  World 1 needs no torch at all ("PyTorch is not needed"): barrier = the
+    engine's own device synchronisation.  World > 1: torch.distributed carries the barriers, the max-over-ranks time and the small
+    host objects of the checks; the data-path collective is inside the library (kzg_mctx, RCCL)."""
+
+    def __init__(self, rank, local_rank, world, use_torch):
+        self.rank, self.local_rank, self.world = rank, local_rank, world
+        self.torch = self.dist = None
+        self.red_dev = "cpu"
+        self.engines = []
+        if not use_torch:
+            return
+        import torch
+        self.torch = torch
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        import torch.distributed as dist
+        self.dist = dist
+        if os.environ.get("KZG_BENCH_SHARED_GPU"):
+            # test mode for a one-GPU box: every rank on device 0, gloo for the barriers (RCCL refuses two ranks on one GPU).
+            # Exercises the N > 1 control flow of the replicas mode; the numbers mean nothing.
+            self.local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+            self.red_dev = "cuda"   # where the timing / agreement reductions live
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.torch.cuda.synchronize()
+        for e in self.engines:      # the engine's own streams (non-blocking streams: torch's device sync covers them too)
+            e.sync()
+
+    def max_over_ranks(self, x):
+        if self.dist is None or self.world == 1:
+            return x
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_agree(self, ok):
+        if self.dist is None or self.world == 1:
+            return bool(ok)
+        t = self.torch.tensor([1 if ok else 0], dtype=self.torch.int32, device=self.red_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(int(t.item()))
+
+    def gather_objects(self, obj):
+        if self.dist is None or self.world == 1:
+            return [obj]
+        allv = [None] * self.world
+        self.dist.all_gather_object(allv, obj)
+        return allv
+
+    def broadcast_object(self, make):
+        if self.dist is None or self.world == 1:
+            return make()
+        box = [make() if self.rank == 0 else None]
+        self.dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def runtime(self, kzg_amd, L):
+        buf = ctypes.create_string_buffer(512)
+        L.load().kzg_runtime_info(buf, 512)
+        r = {"library": buf.value.decode(), "torch_imported": self.torch is not None}
+        if self.torch is not None:
+            r["torch"] = "%s (hip %s)" % (self.torch.__version__, getattr(self.torch.version, "hip", None))
+        return r
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.destroy_process_group()
+
+
+def known_tau_partials(kzg_amd, scal, n_local, lo, which):
+    """tau^lo * p_slice(tau) for the polynomials `which` of a [batch][n_local] device array, by the ORACLE (coefficients
+    downloaded, its Horner loop): this rank's share of p_b(tau)."""
+    from oracle import c_oracle as C
+    R = kzg_amd.api.R_MODULUS
+    return [pow(TAU, lo, R) * C.poly_eval_bytes(view(kzg_amd, scal, b * n_local, n_local).download(), n_local, TAU) % R if n_local else 0
+            for b in which]
+
+
+def check_known_tau(kzg_amd, job, scal, n_local, lo, out_raw, which, spans_ranks):
+    """out[b] == [p_b(tau)]G for b in `which`; p_b(tau) = sum over ranks of the slices' shares when a commitment spans the ranks.
+    The right-hand side is the oracle's alone; every rank checks, all must agree."""
+    from oracle import c_oracle as C
+    R = kzg_amd.api.R_MODULUS
+    mine = known_tau_partials(kzg_amd, scal, n_local, lo, which)
+    if spans_ranks and job.world > 1:
+        allv = job.gather_objects(mine)
+        mine = [sum(v[i] for v in allv) % R for i in range(len(which))]
+    G = C.g1_generator()
+    ok = all(out_raw[96 * b: 96 * b + 96] == C.g1_mul(G, mine[i]) for i, b in enumerate(which))
+    return job.all_agree(ok)
+
+
+def measure_sharded_block(kzg_amd, L, job, args, force_gather):
+    """What north_star names, measured in the default multi-GPU run next to the replicas: the SRS sharded over the ranks, one
+    partial point per rank and polynomial, ONE RCCL all-gather of the 144-byte partials inside the library, local sums
+    (kzg_commit_coeff_sharded_batch, kzg_amd/csrc/mgpu.hip).  (i) strong: every degree-2^log_n commitment sharded N ways;
+    (ii) config5: BASELINE configs[4], 2^21 terms per rank (degree 2^24 at N = 8).  Every commitment of the last step of each is
+    checked against [p(tau)]G by the oracle.  A group that cannot form degrades to a note."""
+    from kzg_amd.api import DeviceGroup
+    from kzg_amd.distributed import shard_range
+    rank, world = job.rank, job.world
+    res = {}
+    group, err = None, None
+    try:
+        uid = job.broadcast_object(DeviceGroup.unique_id)
+        group = DeviceGroup.for_rank(job.local_rank, rank, world, uid)
+        if force_gather:
+            group.set_option("always_gather", 1)
+    except Exception as e:  # noqa: BLE001
+        err = str(e)
+    if not job.all_agree(group is not None):
+        if group is not None:
+            group.close()
+        return {"note": "device group could not be formed (%s): sharded-SRS + RCCL modes not measured in this run" % (err or "failure on another rank")}
+    try:
+        res["rccl"] = group.info()
+        res["rccl_ranks"] = group.world
+        eng = group.engine(0)
+        if args.streams:
+            eng.set_option("streams", args.streams)
+        job.engines.append(eng)
+        batch, steps = args.sharded_batch, args.sharded_steps
+        for mode, n_poly in (("strong", 1 << args.log_n), ("config5", world << 21)):
+            lo, hi = shard_range(n_poly, rank, world)
+            n_local = hi - lo
+            scal = eng.alloc_scalars(max(n_local, 1) * batch)
+            for b in range(batch):
+                view(kzg_amd, scal, b * n_local, n_local).fill_random(SEED + 5000 + 1000 * b + 4 * lo)
+            msrs = group.setup(TAU, n_poly)
+            srs, first = msrs.shard(0)
+            assert first == lo and len(srs) == n_local
+            c, W = srs.window_info()
+            out = ctypes.create_string_buffer(96 * batch)
+            ptrs = (ctypes.c_void_p * 1)(scal.ptr.value)
+
+            def step():
+                rc = group.lib.kzg_commit_coeff_sharded_batch(group.handle, msrs.handle, ptrs, n_poly, batch, scal.sfmt, L.IN_DEVICE, out,
+                                                              L.G1_AFFINE_MONT)
+                if rc:
+                    raise RuntimeError(group.last_error())
+            step()
+            job.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            job.barrier()
+            dt = job.max_over_ranks(time.perf_counter() - t0)
+            ok = check_known_tau(kzg_amd, job, scal, n_local, lo, out.raw, list(range(batch)), spans_ranks=True)
+            v = batch * steps / dt
+            res[mode] = {"value": round(v, 3), "unit": "commitments/s", "scaling": "strong" if mode == "strong" else "weak",
+                         "polynomial_coefficients": n_poly, "terms_per_rank": n_local, "batch": batch, "steps": steps,
+                         "ms_per_step": round(dt / steps * 1e3, 4), "window_bits": c, "windows": W,
+                         "msm_terms_per_sec": round(v * n_poly, 1), "g1_adds_per_sec": round(v * world * g1_adds_per_msm(n_local, c, W), 1),
+                         "hbm_frac_algorithmic": round(BYTES_PER_TERM * n_poly * v / 1e9 / (HBM_PEAK_GBS * world), 6),
+                         "collective": "one ncclAllGather of (batch + 1) x 144 B per rank and step, inside the library",
+                         "all_results_match_known_tau": ok}
+            scal.free()
+            msrs.free()
+        job.engines.remove(eng)
+    except Exception as e:  # noqa: BLE001
+        res["error"] = str(e)
+    finally:
+        group.close()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,15 +597,22 @@ def main():
     ap.add_argument("--weak", action="store_true", help="N>1: 2^log_n terms per rank (degree N * 2^log_n)")
     ap.add_argument("--sharded", action="store_true",
                     help="use the device-group code path (sharded SRS, RCCL all-gather inside the library) even at world size 1")
-    ap.add_argument("--check", action="store_true", help="verify EVERY commitment of the last step against [p(tau)]G")
+    ap.add_argument("--check", action="store_true", help="verify EVERY commitment of the last step against [p(tau)]G (default: a sample of 4)")
     ap.add_argument("--replicas", action="store_true",
                     help="N>1 (the default there): data-parallel replicas (full SRS on every GPU, different polynomials per GPU, no collective)")
+    ap.add_argument("--sharded-block", action="store_true",
+                    help="measure the `sharded` block (strong + config5 through the device group) after the timed region even at world "
+                         "size 1 (RCCL all-gather forced on); at N > 1 the block is part of the default run")
+    ap.add_argument("--no-sharded-block", action="store_true", help="N>1: skip the `sharded` block")
+    ap.add_argument("--sharded-batch", type=int, default=16)
+    ap.add_argument("--sharded-steps", type=int, default=3)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     sharded = args.sharded or (world > 1 and (args.strong or args.config5 or args.weak) and not args.replicas)
+    want_block = (args.sharded_block or (world > 1 and not args.no_sharded_block)) and not sharded
 
     # stdout carries exactly ONE line, the JSON record.  RCCL prints a banner (ROCm version / hostname / library path) through C
     # stdio when a communicator is created, and that buffer is flushed at process exit -- after anything Python printed.  So
@@ -448,27 +631,13 @@ def main():
             cpu = None
             cpu_err = str(e)
 
-    import torch
+    # torch only where there is more than one rank (process group) or the torch-carried group hand-off is the thing under test
+    # (--sharded).  At N = 1 the library is the only thing that loads a HIP runtime: the system's.
+    job = Job(rank, local_rank, world, use_torch=(world > 1 or sharded))
+    local_rank = job.local_rank
+    dist = job.dist
     import kzg_amd
     from kzg_amd import _lib as L
-
-    dist = None
-    if world > 1 or sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        import torch.distributed as dist
-        if os.environ.get("KZG_BENCH_SHARED_GPU"):
-            # test mode for a one-GPU box: every rank on device 0, gloo for the barriers (RCCL refuses two ranks on one GPU).
-            # Exercises the N > 1 control flow of the replicas mode; the numbers mean nothing.
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
-    red_dev = "cpu" if os.environ.get("KZG_BENCH_SHARED_GPU") else "cuda"   # where the timing / agreement reductions live
 
     # ---- the device group first (it decides the mode: if the group cannot be formed on this node the run degrades to
     # data-parallel replicas and says so, instead of producing no number at all)
@@ -480,10 +649,7 @@ def main():
             group = group_from_torch(dist, local_rank, rank, world)
         except Exception as e:  # noqa: BLE001
             ok, group_note = 0, f"device group could not be formed ({e}); fell back to replicas"
-        if world > 1:           # all ranks agree on the outcome
-            t = torch.tensor([ok], dtype=torch.int32, device=red_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MIN)
-            ok = int(t.item())
+        ok = job.all_agree(ok)  # all ranks agree on the outcome
         if not ok:
             if group is not None:
                 group.close()
@@ -521,10 +687,8 @@ def main():
         key, val = kv.split("=")
         engine.set_option(key, int(val))
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+    job.engines.append(engine)
+    barrier = job.barrier
 
     # ---- inputs, resident in HBM before the timed region -----------------------------------------
     # polynomial b of the batch = elements of the counter stream seeded SEED + 1000 b (replicas: + 10^6 rank); a rank holds
@@ -578,27 +742,18 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = job.max_over_ranks(time.perf_counter() - t0)
 
-    check = None
-    if args.check:
-        # known-tau identity for EVERY commitment of the last step: C_b == [p_b(tau)]G, p_b(tau) = sum_r tau^(lo_r) p_{b,r}(tau).
-        # Checker = the oracle throughout: each rank downloads its coefficient slices, the oracle's Horner loop evaluates them,
-        # the oracle multiplies G.  No HIP kernel on the right-hand side.
-        from oracle import c_oracle as C
-        R = kzg_amd.api.R_MODULUS
-        mine = [pow(TAU, lo, R) * C.poly_eval_bytes(view(kzg_amd, scal, b * n_local, n_local).download(), n_local, TAU) % R if n_local else 0
-                for b in range(args.batch)]
-        if sharded and world > 1:
-            allv = [None] * world
-            dist.all_gather_object(allv, mine)
-            mine = [sum(v[b] for v in allv) % R for b in range(args.batch)]
-        G = C.g1_generator()
-        check = all(out.raw[96 * b: 96 * b + 96] == C.g1_mul(G, mine[b]) for b in range(args.batch))
+    # known-tau identity for the commitments of the last timed step: C_b == [p_b(tau)]G, p_b(tau) = sum_r tau^(lo_r) p_{b,r}(tau).
+    # Checker = the oracle throughout: each rank downloads its coefficient slices, the oracle's Horner loop evaluates them, the
+    # oracle multiplies G.  No HIP kernel on the right-hand side.  Always a sample of four (first, last, two in between: ~0.5 s
+    # at 2^20); --check: every commitment of the step.  Outside the timed region.
+    which = list(range(args.batch)) if args.check else sorted({0, args.batch // 3, 2 * args.batch // 3, args.batch - 1})
+    try:
+        checked_ok = check_known_tau(kzg_amd, job, scal, n_local, lo, out.raw, which, spans_ranks=sharded)
+    except Exception as e:  # noqa: BLE001
+        checked_ok = "check failed to run: %s" % e
+    check = checked_ok if args.check else None
 
     # ---- roofline of the dominant kernel: HIP events recorded on the engine's streams over the timed region ----
     roofline = None
@@ -678,6 +833,11 @@ def main():
                                          "hbm_frac": round(BYTES_PER_TERM * n_local / k_s / 1e9 / HBM_PEAK_GBS, 5),
                                          "kernel_ms_single_msm": {k: round(v[1] / l2, 4) for k, v in sorted(pa.items())}}
 
+    sharded_res = None
+    if want_block:
+        # every rank takes part (collective); rank 0 prints.  After the timed region and its check, before the single-GPU paths.
+        sharded_res = measure_sharded_block(kzg_amd, L, job, args, force_gather=(world == 1))
+
     if rank == 0:
         value = units_per_step * args.steps / dt
         workloads = {
@@ -723,8 +883,17 @@ def main():
         }
         if check is not None:
             res["all_results_match_known_tau"] = check
+        res["timed_results_checked"] = {"against": "[p(tau)]G, p(tau) by the oracle's Horner loop on the downloaded coefficients",
+                                        "commitments_of_last_step": which if len(which) <= 8 else "all %d" % len(which),
+                                        "every_rank": world > 1, "ok": checked_ok}
+        res["hip_runtime"] = job.runtime(kzg_amd, L)
         if roofline:
             res["roofline"] = roofline
+        if sharded_res is not None:
+            res["sharded"] = sharded_res
+            res["headline"] = ("value = data-parallel replicas (the throughput answer for independent degree-2^20 commitments: a 2 GiB SRS "
+                               "fits every GPU); sharded.strong / sharded.config5 = the sharded-SRS + RCCL design north_star names, "
+                               "measured in the same process")
         t_extra = time.perf_counter()
         if mode == "single" and not args.no_paths:
             try:
@@ -788,8 +957,7 @@ def main():
         group.close()
     else:
         engine.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    job.close()
     if rank == 0:
         os.write(real_stdout, (line + "\n").encode())
     os.close(real_stdout)

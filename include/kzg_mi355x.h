@@ -110,6 +110,9 @@ const char *kzg_version(void);
  * (4 queues: 3 lanes + 1 accumulation stream; loss: INTEGRATION.md section 6). */
 int kzg_init_hw_queues(int queues);
 int kzg_device_count(void);  /* usable HIP devices (0 if none) */
+/* "hip=<file of the HIP runtime this library is bound to> runtime_version=<n> driver_version=<n>": a process may hold two HIP
+ * runtimes (PyTorch wheels bundle their own); which one the library runs on follows from the host's load order. */
+int kzg_runtime_info(char *buf, size_t buflen);
 /* device: HIP device ordinal.  Fails with KZG_ERR_NO_DEVICE if no gfx950-class device is usable. */
 int kzg_ctx_create(int device, kzg_ctx **out);
 void kzg_ctx_destroy(kzg_ctx *ctx);

@@ -49,6 +49,7 @@ def load(path=None):
         "kzg_version": (ctypes.c_char_p, []),
         "kzg_init_hw_queues": (i32, [i32]),
         "kzg_device_count": (i32, []),
+        "kzg_runtime_info": (i32, [ctypes.c_char_p, sz]),
         "kzg_ctx_create": (i32, [i32, c_void_pp]),
         "kzg_ctx_destroy": (None, [vp]),
         "kzg_last_error": (ctypes.c_char_p, [vp]),

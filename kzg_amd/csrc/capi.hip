@@ -1,5 +1,7 @@
 // capi.hip -- the extern "C" boundary declared in include/kzg_mi355x.h: context / lanes / profiling
 // and the entry points that mirror KZGProver / KZGProverEvalForm / EvaluationDomain method by method.
+#include <dlfcn.h>
+
 #include <algorithm>
 
 #include "common.h"
@@ -260,6 +262,21 @@ extern "C" int kzg_init_hw_queues(int queues) {
 __attribute__((constructor)) static void kzg_optional_hw_queues() {
     const char *e = getenv("KZG_SET_HW_QUEUES");
     if (e && atoi(e) > 0) kzg_init_hw_queues(atoi(e) == 1 ? 0 : atoi(e));
+}
+
+// Which HIP runtime is this library bound to?  A process may hold two (PyTorch wheels ship their own libamdhip64 next to
+// /opt/rocm's); the dynamic loader binds this library to whichever copy with the matching SONAME was loaded first, so the answer
+// depends on the host's import order.  bench.py puts the string into its result line.
+extern "C" int kzg_runtime_info(char *buf, size_t buflen) {
+    if (!buf || !buflen) return KZG_ERR_SHAPE;
+    Dl_info di;
+    const char *file = "?";
+    if (dladdr((const void *)&hipStreamSynchronize, &di) && di.dli_fname) file = di.dli_fname;
+    int rt = 0, drv = 0;
+    hipRuntimeGetVersion(&rt);
+    hipDriverGetVersion(&drv);
+    snprintf(buf, buflen, "hip=%s runtime_version=%d driver_version=%d", file, rt, drv);
+    return KZG_OK;
 }
 
 extern "C" int kzg_device_count(void) {

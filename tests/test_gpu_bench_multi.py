@@ -17,7 +17,7 @@ def test_bench_two_ranks_replicas_on_one_gpu():
     env = dict(os.environ, KZG_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29617", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8",
-           "--log-n", "16", "--check", "--no-paths"]
+           "--log-n", "16", "--check", "--no-paths", "--no-sharded-block"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -29,3 +29,31 @@ def test_bench_two_ranks_replicas_on_one_gpu():
     assert d["value"] > 0 and d["unit"] == "commitments/s"
     # whole-job aggregate: both ranks' commitments over the slowest rank's time
     assert abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) / d["value"] < 0.02
+    assert d["timed_results_checked"]["ok"] is True and d["timed_results_checked"]["every_rank"] is True
+    assert "hip=" in d["hip_runtime"]["library"] and d["hip_runtime"]["torch_imported"] is True
+
+
+@pytest.mark.gpu
+def test_bench_sharded_block_world1_and_no_torch():
+    """The default N > 1 line carries `sharded` = {strong, config5}: the sharded-SRS + RCCL design north_star names, measured in the
+    same process after the replicas' timed region.  Here at world size 1 with the block forced on
+    (--sharded-block: RCCL all-gather forced on in a group of one): presence, the RCCL it ran on, and every commitment of each
+    mode's last step against [p(tau)]G by the oracle.  Also: the N = 1 run imports no torch (weak #11) and says which HIP runtime
+    the library is bound to; the timed region's own results are sample-checked unconditionally (weak #3)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--log-n", "16", "--no-paths",
+           "--no-cpu-baseline", "--sharded-block", "--sharded-batch", "4", "--sharded-steps", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["mode"] == "single" and d["n_gpus"] == 1
+    assert d["hip_runtime"]["torch_imported"] is False and "hip=" in d["hip_runtime"]["library"]
+    assert d["timed_results_checked"]["ok"] is True
+    sh = d["sharded"]
+    assert "note" not in sh and "error" not in sh, sh
+    assert sh["rccl_ranks"] == 1 and "rccl=" in sh["rccl"]
+    assert sh["strong"]["terms_per_rank"] == 1 << 16 and sh["strong"]["scaling"] == "strong"
+    assert sh["config5"]["terms_per_rank"] == 1 << 21 and sh["config5"]["polynomial_coefficients"] == 1 << 21
+    for mode in ("strong", "config5"):
+        assert sh[mode]["all_results_match_known_tau"] is True and sh[mode]["value"] > 0
