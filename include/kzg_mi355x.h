@@ -10,12 +10,17 @@
  *   - plain pointers and sizes only; no C++ exceptions or callbacks cross the ABI.
  *   - every call returns a kzg_status; 0 = ok, >0 = the reference's own error conditions,
  *     <0 = runtime failure (HIP).  kzg_last_error(ctx) gives a human-readable string.
- *   - a kzg_ctx is bound to one GPU and is thread-safe.  The reference's blocking prover calls -- kzg_commit_coeff,
- *     kzg_commit_eval, kzg_msm_g1, kzg_witness_coeff, kzg_witness_eval (KZGProver / KZGProverEvalForm are Clone + &self,
- *     src/coeff_form.rs:37-64) -- run CONCURRENTLY on one ctx: each call leases one of the context's lanes (option
- *     "streams", default and maximum 16), submits its kernels there and waits for its own result only, so N host threads
- *     calling commit() against one resident SRS fill the GPU like kzg_msm_g1_batch does.  Every other call takes the
- *     context exclusively (it waits for the leased lanes to drain).  A kzg_srs / kzg_srs_g2 is immutable after creation
+ *   - a kzg_ctx is bound to one GPU and is thread-safe.  The reference's blocking calls -- kzg_commit_coeff,
+ *     kzg_commit_eval, kzg_msm_g1, kzg_witness_coeff, kzg_witness_coeff_batched, kzg_witness_eval, kzg_verify_poly_coeff /
+ *     _eval, kzg_ntt_fr, kzg_coset_ntt_fr, kzg_poly_mul, kzg_poly_eval, kzg_quotient_linear / _eval, kzg_fr_vec_mul / _sub,
+ *     kzg_divide_by_z_on_coset (KZGProver / KZGProverEvalForm / KZGVerifier are Clone + &self, src/coeff_form.rs:37-124; an
+ *     EvaluationDomain is the caller's own) -- run CONCURRENTLY on one ctx: each call leases one of the context's lanes
+ *     (option "streams", default and maximum 16), submits its kernels there and waits for its own result only, so N host
+ *     threads calling commit() / create_witness_batched() against one resident SRS fill the GPU like kzg_msm_g1_batch does.
+ *     Every other call (the *_batch / *_many forms, SRS construction, the pairing verifier, options, profiling) takes the
+ *     context exclusively (it waits for the leased lanes to drain).  kzg_dev_alloc / _upload / _download take no lock at all and
+ *     are NOT ordered against calls in flight on other threads: a download sees the results of every call that has RETURNED;
+ *     reading a buffer another thread's call is still writing is the caller's race.  A kzg_srs / kzg_srs_g2 is immutable after creation
  *     and may be used from any number of threads and from every kzg_ctx on the same device.  kzg_last_error returns the
  *     calling thread's own last failure.  There is NO CPU fallback: without a usable HIP device kzg_ctx_create fails
  *     with KZG_ERR_NO_DEVICE.
@@ -182,7 +187,13 @@ int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t grou
  * RCCL (librccl.so.1) is loaded on first use; a group of one GPU needs no RCCL unless option "always_gather" is set.
  * Every entry point below is collective in the one-process-per-GPU mode: all ranks call it with the same arguments.
  * Failures stay collective too: a rank whose local phase fails still enters the exchange, its status travels with its
- * partials, and EVERY rank returns that error (no rank is left waiting inside the all-gather). */
+ * partials, and EVERY rank returns that error (no rank is left waiting inside the all-gather).  A rank-local resource failure
+ * BEFORE the exchange (growing the exchange / quotient buffers: the only allocations a call makes, and only when a call is larger
+ * than any before it) is agreed on through a status-only all-gather over buffers that exist since the group was formed.  What
+ * cannot be agreed on -- a peer process that died, a hung GPU, a rank that could not create its communicator -- is bounded by a
+ * deadline: the wait behind every exchange polls for at most "gather_timeout_ms" (kzg_mctx_set_option, default 60000, 0 = wait
+ * for ever); when it expires the communicators are aborted (ncclCommAbort), the call returns KZG_ERR_INTERNAL and the group is
+ * DEAD -- every later call on it fails at once with KZG_ERR_INTERNAL; destroy it and form a new one. */
 typedef struct kzg_mctx kzg_mctx;
 typedef struct kzg_msrs kzg_msrs;   /* an SRS sharded contiguously over the group */
 enum { KZG_UNIQUE_ID_BYTES = 128 };
@@ -199,7 +210,8 @@ int kzg_mctx_world(const kzg_mctx *m);        /* ranks in the group */
 int kzg_mctx_local_count(const kzg_mctx *m);  /* GPUs this process drives (n, or 1 in the per-process mode) */
 int kzg_mctx_rank(const kzg_mctx *m, int local_index);          /* global rank of a local GPU */
 kzg_ctx *kzg_mctx_ctx(kzg_mctx *m, int local_index);            /* its single-GPU context (NTT, scans, device memory) */
-/* options: "always_gather" (run the collective even in a group of one), plus every kzg_ctx_set_option key (applied to all) */
+/* options: "always_gather" (run the collective even in a group of one), "gather_timeout_ms" (above), plus every
+ * kzg_ctx_set_option key (applied to all) */
 int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value);
 /* rank r of `world` holds terms [lo, hi) of n: the first n % world ranks get one extra.  Host-only helper. */
 int kzg_shard_range(size_t n, int rank, int world, size_t *lo, size_t *hi);
@@ -233,6 +245,14 @@ int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coef
 int kzg_witness_coeff_batched_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *xs,
                                       const void *ys, size_t k, int sfmt, int flags, void *out_w, int ofmt, void *out_r,
                                       size_t *out_r_len);
+
+/* KZGProverEvalForm::create_witness over the group (src/eval_form.rs:124-140): `lagrange` is the Lagrange-basis SRS sharded over
+ * the group (kzg_srs_upload_g1_sharded); every rank computes div_by_omega_i of (evals - evals[index]) on its GPU (replicated O(d)
+ * pass) and reduces its slice of the quotient.  evals: d scalars in host memory, or with KZG_IN_DEVICE an array of
+ * kzg_mctx_local_count() device pointers (the whole vector resident on each local GPU).  KZG_ERR_SHAPE if index >= d, d is not a
+ * power of two or d > kzg_msrs_len (the reference's panics). */
+int kzg_witness_eval_sharded(kzg_mctx *m, const kzg_msrs *lagrange, const void *evals, size_t d, size_t index, int sfmt, int flags,
+                             void *out, int ofmt);
 
 /* ---- NTT: EvaluationDomain::fft / ifft (src/ft.rs:111-140; best_fft :274-288) --------------- */
 /* EvaluationDomain::compute_omega (src/ft.rs:55-76): m = next pow2 >= d, exp = log2 m, omega.

@@ -329,6 +329,15 @@ class ShardedKZGProver {  // KZGProver (src/coeff_form.rs:37-81) with the SRS sp
         return out;
     }
 
+    // KZGProverEvalForm::create_witness over the group (src/eval_form.rs:124-140); `lagrange` = the Lagrange-basis SRS sharded
+    // over the same group (kzg_srs_upload_g1_sharded), evals = the d evaluations
+    KZGWitness create_witness_eval(const kzg_msrs *lagrange, const std::vector<Scalar> &evals, size_t index) const {
+        G1Affine out;
+        g_.check(kzg_witness_eval_sharded(g_.handle(), lagrange, evals.data(), evals.size(), index, KZG_FR_CANONICAL_LE_32, 0,
+                                          out.bytes.data(), KZG_G1_AFFINE_MONT_96));
+        return out;
+    }
+
   private:
     const ShardedParams &params_;
     const DeviceGroup &g_;

@@ -16,6 +16,12 @@ int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *
 int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k_canonical, size_t n, void *out);
 /* the next sharded call of this group fails locally on local GPU 0 with `code` (status agreement across ranks, mgpu.hip) */
 int kzg_test_mctx_inject_failure(struct kzg_mctx *m, int code);
+/* the next growth of the group's exchange buffers fails on local GPU 0 (a rank-local allocation failure BEFORE the exchange: the
+ * ranks agree on it through the status-only all-gather instead of leaving the others inside the data all-gather) */
+int kzg_test_mctx_inject_alloc_failure(struct kzg_mctx *m);
+/* the next exchange sits behind a spin kernel of `ms` milliseconds on local GPU 0 (a peer that arrives late or never: option
+ * "gather_timeout_ms" turns it into KZG_ERR_INTERNAL and a dead group) */
+int kzg_test_mctx_inject_stall(struct kzg_mctx *m, int ms);
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,7 @@ def load(path=None):
         "kzg_commit_coeff_sharded_batch": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_witness_coeff_sharded": (i32, [vp, vp, vp, sz, vp, vp, i32, i32, vp, i32]),
         "kzg_witness_coeff_batched_sharded": (i32, [vp, vp, vp, sz, vp, vp, sz, i32, i32, vp, i32, vp, ctypes.POINTER(sz)]),
+        "kzg_witness_eval_sharded": (i32, [vp, vp, vp, sz, sz, i32, i32, vp, i32]),
         "kzg_mctx_info": (i32, [vp, ctypes.c_char_p, sz]),
         "kzg_compute_omega": (i32, [sz, ctypes.POINTER(sz), ctypes.POINTER(u32), vp, i32]),
         "kzg_ntt_fr": (i32, [vp, vp, u32, i32, i32]),

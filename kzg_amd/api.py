@@ -619,6 +619,14 @@ class DeviceGroup:
             r = [v * rinv % R_MODULUS for v in r]
         return out.raw, r
 
+    def create_witness_eval(self, lagrange_srs, evals, index, ofmt=L.G1_AFFINE_MONT):
+        """KZGProverEvalForm::create_witness over the group (src/eval_form.rs:124-140): replicated div_by_omega_i, sharded MSM
+        against the Lagrange-basis SRS `lagrange_srs` (DeviceGroup.upload of the basis)."""
+        arg, d, sfmt, flags = self._whole_poly_arg(evals)
+        out = ctypes.create_string_buffer(L.POINT_BYTES[ofmt])
+        self._check(self.lib.kzg_witness_eval_sharded(self.handle, lagrange_srs.handle, arg, d, index, sfmt, flags, out, ofmt))
+        return out.raw
+
     def info(self):
         """which RCCL / HIP runtime the group runs on (kzg_mctx_info)"""
         buf = ctypes.create_string_buffer(1024)

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <functional>
 #include <thread>
 
@@ -29,6 +30,7 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional: the time-out path (a dead peer) falls back to leaking the communicator
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
@@ -71,6 +73,7 @@ static Rccl *rccl_try(void *h, std::string *err) {
     r->GroupEnd = (decltype(r->GroupEnd))sym("ncclGroupEnd");
     r->GetErrorString = (decltype(r->GetErrorString))sym("ncclGetErrorString");
     r->GetVersion = (decltype(r->GetVersion))sym("ncclGetVersion");
+    if (ok) r->CommAbort = (decltype(r->CommAbort))dlsym(h, "ncclCommAbort");
     if (!ok) {
         delete r;
         return nullptr;
@@ -144,6 +147,15 @@ struct kzg_mctx {
     std::vector<ncclComm_t> comms;   // one per local GPU once the communicator exists
     ncclUniqueId uid;                // per-process mode: kept until the communicator is created
     bool always_gather = false;
+    // A peer that never arrives (a dead process, a hung GPU) must not hang the survivors inside the exchange: the wait behind the
+    // all-gather is a poll with this deadline (option "gather_timeout_ms", 0 = wait for ever).  When it expires the communicators
+    // are aborted (ncclCommAbort), the call returns KZG_ERR_INTERNAL and the group is DEAD: every later call on it fails at once;
+    // the host destroys it and forms a new one.
+    int64_t gather_timeout_ms = 60000;
+    bool dead = false;
+    std::vector<void *> d_stat;      // per local GPU: world x STATUS_BYTES for the status-only agreement (allocated with the group)
+    int inject_alloc_fail = 0;       // KZG_TEST_HOOKS: the next growth of the exchange buffers fails on local GPU 0
+    int inject_stall_ms = 0;         // KZG_TEST_HOOKS: the next exchange sits behind a spin kernel of this length (a late peer)
     std::mutex mu;
     std::string err;
     // grow-only exchange buffers per local GPU: partials of this GPU, partials of every rank
@@ -238,6 +250,7 @@ extern "C" int kzg_shard_range(size_t n, int rank, int world, size_t *lo, size_t
     return KZG_OK;
 }
 
+static int mctx_buffers_grow(kzg_mctx *m, size_t batch);
 static int mctx_make_ctxs(kzg_mctx *m) {
     // sized first: kzg_mctx_destroy walks these per context when a later device fails (devices = [0, 99])
     m->d_part.assign(m->nlocal(), nullptr);
@@ -246,12 +259,17 @@ static int mctx_make_ctxs(kzg_mctx *m) {
     m->d_quot.assign(m->nlocal(), nullptr);
     m->cap_quot.assign(m->nlocal(), 0);
     m->h_status.assign(m->nlocal(), nullptr);
+    m->d_stat.assign(m->nlocal(), nullptr);
     for (int i = 0; i < m->nlocal(); i++) {
         kzg_ctx *c = nullptr;
         int rc = kzg_ctx_create(m->devices[i], &c);
         if (rc != KZG_OK) return rc;
         m->ctxs.push_back(c);
     }
+    // the exchange buffers of ordinary calls (up to 64 polynomials per call) and the status-only agreement buffer exist from the
+    // start: a group that formed can always exchange statuses, whatever fails later
+    int rc = mctx_buffers_grow(m, 64);
+    if (rc != KZG_OK) return rc;
     workers_start(m);
     return KZG_OK;
 }
@@ -345,11 +363,12 @@ extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
     for (int i = 0; i < (int)m->ctxs.size(); i++) {
         hipSetDevice(m->devices[i]);
         if (m->ctxs[i]) kzg_sync(m->ctxs[i]);
-        if (i < (int)m->comms.size() && m->comms[i] && g_rccl) g_rccl->CommDestroy(m->comms[i]);
+        if (i < (int)m->comms.size() && m->comms[i] && g_rccl && !m->dead) g_rccl->CommDestroy(m->comms[i]);
         if (m->d_part[i]) hipFree(m->d_part[i]);
         if (m->d_gath[i]) hipFree(m->d_gath[i]);
         if (m->d_quot[i]) hipFree(m->d_quot[i]);
         if (m->h_status[i]) hipHostFree(m->h_status[i]);
+        if (i < (int)m->d_stat.size() && m->d_stat[i]) hipFree(m->d_stat[i]);
         if (m->ctxs[i]) kzg_ctx_destroy(m->ctxs[i]);
     }
     delete m;
@@ -391,6 +410,11 @@ extern "C" int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value) 
     std::lock_guard<std::mutex> lk(m->mu);
     if (std::string(key) == "always_gather") {
         m->always_gather = value != 0;
+        return KZG_OK;
+    }
+    if (std::string(key) == "gather_timeout_ms") {
+        if (value < 0) return mfail(m, KZG_ERR_SHAPE, "gather_timeout_ms must be >= 0 (0 = wait for ever)");
+        m->gather_timeout_ms = value;
         return KZG_OK;
     }
     for (int i = 0; i < m->nlocal(); i++) {
@@ -479,24 +503,121 @@ extern "C" void kzg_msrs_free(kzg_mctx *m, kzg_msrs *s) {
 constexpr size_t STATUS_BYTES = 16, STATUS_ALL_OFF = 256;  // pinned staging: own status at 0, every rank's from STATUS_ALL_OFF
 static size_t record_bytes(size_t batch) { return (batch + 1) * PARTIAL_BYTES; }
 
-static int mctx_buffers(kzg_mctx *m, size_t batch) {
+static int mctx_buffers_grow(kzg_mctx *m, size_t batch) {
     for (int i = 0; i < m->nlocal(); i++) {
-        if (m->cap_points[i] >= batch) continue;
+        if (m->cap_points[i] >= batch && m->d_stat[i]) continue;
         if (hipSetDevice(m->devices[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, "hipSetDevice");
         kzg_sync(m->ctxs[i]);
-        if (m->d_part[i]) hipFree(m->d_part[i]);
-        if (m->d_gath[i]) hipFree(m->d_gath[i]);
-        m->d_part[i] = m->d_gath[i] = nullptr;
-        m->cap_points[i] = 0;
-        size_t cap = batch < 64 ? 64 : batch;
-        if (hipMalloc(&m->d_part[i], record_bytes(cap)) != hipSuccess ||
-            hipMalloc(&m->d_gath[i], record_bytes(cap) * (size_t)m->world) != hipSuccess)
-            return mfail(m, KZG_ERR_ALLOC, "hipMalloc(partial-point exchange buffers)");
         if (!m->h_status[i] && hipHostMalloc(&m->h_status[i], STATUS_ALL_OFF + STATUS_BYTES * (size_t)m->world, hipHostMallocDefault) != hipSuccess)
             return mfail(m, KZG_ERR_ALLOC, "hipHostMalloc(status words)");
+        if (!m->d_stat[i] && hipMalloc(&m->d_stat[i], STATUS_BYTES * ((size_t)m->world + 1)) != hipSuccess)
+            return mfail(m, KZG_ERR_ALLOC, "hipMalloc(status agreement buffer)");
+        if (m->cap_points[i] >= batch) continue;
+#ifdef KZG_TEST_HOOKS
+        if (m->inject_alloc_fail && i == 0) {
+            m->inject_alloc_fail = 0;
+            return mfail(m, KZG_ERR_ALLOC, "hipMalloc(partial-point exchange buffers): injected failure (test hook)");
+        }
+#endif
+        size_t cap = batch < 64 ? 64 : batch;
+        void *np = nullptr, *ng = nullptr;
+        if (hipMalloc(&np, record_bytes(cap)) != hipSuccess || hipMalloc(&ng, record_bytes(cap) * (size_t)m->world) != hipSuccess) {
+            if (np) hipFree(np);  // the smaller buffers stay usable
+            return mfail(m, KZG_ERR_ALLOC, "hipMalloc(partial-point exchange buffers)");
+        }
+        if (m->d_part[i]) hipFree(m->d_part[i]);
+        if (m->d_gath[i]) hipFree(m->d_gath[i]);
+        m->d_part[i] = np;
+        m->d_gath[i] = ng;
         m->cap_points[i] = cap;
     }
     return KZG_OK;
+}
+
+// Wait for local GPU i's exchange stream, with the group's deadline.  KZG_OK, or the group is aborted and dead.
+static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
+    hipStream_t st = m->ctxs[i]->lanes[0].stream;
+    hipSetDevice(m->devices[i]);
+    if (m->gather_timeout_ms <= 0) {
+        if (hipStreamSynchronize(st) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + " failed");
+        return KZG_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        hipError_t e = hipStreamQuery(st);
+        if (e == hipSuccess) return KZG_OK;
+        if (e != hipErrorNotReady) return mfail(m, KZG_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+        const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+        if (us > m->gather_timeout_ms * 1000) break;
+        if (us > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100));  // a healthy exchange is over long before
+    }
+    // a peer never arrived: abort the communicators so that the collective kernels leave the streams, and retire the group
+    m->dead = true;
+    if (r && r->CommAbort)
+        for (auto &c : m->comms)
+            if (c) r->CommAbort(c);
+    m->comms.clear();
+    for (int j = 0; j < m->nlocal(); j++) {  // bounded: an aborted collective returns promptly; a stream that still hangs is left behind
+        hipSetDevice(m->devices[j]);
+        const auto t1 = std::chrono::steady_clock::now();
+        while (hipStreamQuery(m->ctxs[j]->lanes[0].stream) == hipErrorNotReady &&
+               std::chrono::steady_clock::now() - t1 < std::chrono::seconds(5))
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
+    return mfail(m, KZG_ERR_INTERNAL, std::string(what) + " did not complete within " + std::to_string(m->gather_timeout_ms) +
+                                          " ms: a peer is dead or stalled.  The communicators were aborted and this group is dead "
+                                          "(every further call fails; destroy it and form a new one)");
+}
+
+#ifdef KZG_TEST_HOOKS
+__global__ void k_test_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+#endif
+
+// Every rank reports `code` (its own resource status before the data exchange); all ranks return the first failing rank's code.
+// Uses only what exists since the group was formed (d_stat, h_status, the communicator), so a rank that could not grow its
+// exchange buffers can still tell the others -- nobody is left waiting inside the data all-gather of a call one rank abandoned.
+static int mctx_agree(kzg_mctx *m, int code, const char *what) {
+    const bool exchange = m->world > 1 || m->always_gather;
+    if (!exchange || !m->per_process) return code;  // every rank is in this process: the failure is known to all of them
+    Rccl *r = nullptr;
+    int crc = mctx_comm(m, &r);
+    if (crc != KZG_OK) return crc;  // no communicator: nothing can be exchanged (the peers' wait has its deadline)
+    hipStream_t st = m->ctxs[0]->lanes[0].stream;
+    hipSetDevice(m->devices[0]);
+    int32_t *hs = (int32_t *)m->h_status[0];
+    hs[0] = code;
+    hs[1] = m->ranks[0];
+    hs[2] = hs[3] = 0;
+    uint8_t *mine = (uint8_t *)m->d_stat[0], *all = mine + STATUS_BYTES;
+    int32_t *hall = (int32_t *)((uint8_t *)m->h_status[0] + STATUS_ALL_OFF);
+    if (hipMemcpyAsync(mine, hs, STATUS_BYTES, hipMemcpyHostToDevice, st) != hipSuccess) return mfail(m, KZG_ERR_HIP, "status upload");
+    ncclResult_t e = r->AllGather(mine, all, STATUS_BYTES, ncclUint8, m->comms[0], st);
+    if (e != ncclSuccess) return mfail(m, KZG_ERR_HIP, std::string("ncclAllGather(status): ") + r->GetErrorString(e));
+    if (hipMemcpyAsync(hall, all, STATUS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, st) != hipSuccess)
+        return mfail(m, KZG_ERR_HIP, "status download");
+    KZG_TRY(mctx_wait(m, r, 0, "status agreement"));
+    for (int rk = 0; rk < m->world; rk++)
+        if (hall[4 * rk] != KZG_OK) {
+            if (rk == m->ranks[0]) return code;  // this rank's own failure: its message is already in place
+            return mfail(m, hall[4 * rk], "rank " + std::to_string(rk) + " could not prepare " + what + " (status " +
+                                              std::to_string(hall[4 * rk]) + "); every rank returns this error");
+        }
+    return KZG_OK;
+}
+
+// Buffers for a call with `batch` partials per rank.  Whether they must grow is the same on every rank (same calls, same
+// history), so the ranks agree on the outcome exactly when a growth was attempted; ordinary calls pay nothing.
+static int mctx_buffers(kzg_mctx *m, size_t batch) {
+    if (m->dead) return mfail(m, KZG_ERR_INTERNAL, "this device group is dead (an earlier exchange timed out and was aborted): destroy it and form a new one");
+    bool grow = false;
+    for (int i = 0; i < m->nlocal(); i++) grow = grow || m->cap_points[i] < batch;
+    if (!grow) return KZG_OK;
+    int rc = mctx_buffers_grow(m, batch);
+    return mctx_agree(m, rc, "its exchange buffers");
 }
 
 // run f(i) for every local GPU (on the group's persistent worker threads when there are several); rcs[i] = its status
@@ -546,17 +667,28 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
     size_t count = 1, gstride = 1, istride = batch;
     if (exchange) {
         Rccl *r = nullptr;
-        KZG_TRY(mctx_comm(m, &r));
+        KZG_TRY(mctx_comm(m, &r));  // no communicator, nothing to enter (the peers' waits have their deadline)
         const size_t rec = record_bytes(batch);
+        int upload_rc = KZG_OK;
         for (int i = 0; i < m->nlocal(); i++) {  // the status block rides behind the partials, in stream order
             hipSetDevice(m->devices[i]);
+            hipStream_t st = m->ctxs[i]->lanes[0].stream;
             int32_t *hs = (int32_t *)m->h_status[i];
             hs[0] = local_rc[i];
             hs[1] = m->ranks[i];
             hs[2] = hs[3] = 0;
-            if (hipMemcpyAsync((uint8_t *)m->d_part[i] + batch * PARTIAL_BYTES, hs, STATUS_BYTES, hipMemcpyHostToDevice,
-                               m->ctxs[i]->lanes[0].stream) != hipSuccess)
-                return mfail(m, KZG_ERR_HIP, "status upload");
+            uint8_t *slot = (uint8_t *)m->d_part[i] + batch * PARTIAL_BYTES;
+            // the slot says "failed" until this rank's real status has landed in it: if the upload itself fails the rank still
+            // enters the all-gather below and its peers read a failure, not stale zeros
+            if (hipMemsetAsync(slot, 0xff, STATUS_BYTES, st) != hipSuccess ||
+                hipMemcpyAsync(slot, hs, STATUS_BYTES, hipMemcpyHostToDevice, st) != hipSuccess)
+                upload_rc = mfail(m, KZG_ERR_HIP, "status upload");
+#ifdef KZG_TEST_HOOKS
+            if (m->inject_stall_ms && i == 0) {  // a late peer: the exchange sits behind a spin kernel
+                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, st, (unsigned long long)m->inject_stall_ms * 100000ull);  // wall_clock64: 100 MHz
+                m->inject_stall_ms = 0;
+            }
+#endif
         }
         KZG_NCCL(m, r, r->GroupStart());
         for (int i = 0; i < m->nlocal(); i++) {
@@ -574,13 +706,12 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
         if (hipMemcpy2DAsync(hall, STATUS_BYTES, (const uint8_t *)m->d_gath[0] + batch * PARTIAL_BYTES, rec, STATUS_BYTES,
                              (size_t)m->world, hipMemcpyDeviceToHost, m->ctxs[0]->lanes[0].stream) != hipSuccess)
             return mfail(m, KZG_ERR_HIP, "status download");
-        for (int i = 0; i < m->nlocal(); i++) {
-            hipSetDevice(m->devices[i]);
-            if (hipStreamSynchronize(m->ctxs[i]->lanes[0].stream) != hipSuccess) return mfail(m, KZG_ERR_HIP, "all-gather failed");
-        }
+        for (int i = 0; i < m->nlocal(); i++) KZG_TRY(mctx_wait(m, r, i, "the all-gather of the partial points"));
+        if (upload_rc != KZG_OK) return upload_rc;
         for (int rk = 0; rk < m->world; rk++)
             if (hall[4 * rk] != KZG_OK) {
                 if (first_bad >= 0 && m->ranks[first_bad] == rk) return mfail_ctx(m, first_bad, local_rc[first_bad]);
+                // (a slot still holding the 0xff fill reads as -1 = KZG_ERR_HIP: that rank's status upload failed)
                 return mfail(m, hall[4 * rk], "rank " + std::to_string(rk) + " failed in its local phase (status " +
                                                   std::to_string(hall[4 * rk]) + "); every rank returns this error");
             }
@@ -639,6 +770,25 @@ static const void *whole_poly(const void *coeffs, int flags, int i) {
     return (flags & KZG_IN_DEVICE) ? ((const void *const *)coeffs)[i] : coeffs;
 }
 
+// the replicated quotient polynomial of create_witness (both forms): n scalars on every local GPU; the ranks agree when it grows
+static int mctx_quotient_buffers(kzg_mctx *m, size_t n) {
+    bool grow = false;
+    for (int i = 0; i < m->nlocal(); i++) grow = grow || m->cap_quot[i] < n;
+    if (!grow) return KZG_OK;
+    int rc = KZG_OK;
+    for (int i = 0; i < m->nlocal() && rc == KZG_OK; i++) {
+        if (m->cap_quot[i] >= n) continue;
+        hipSetDevice(m->devices[i]);
+        kzg_sync(m->ctxs[i]);
+        if (m->d_quot[i]) hipFree(m->d_quot[i]);
+        m->d_quot[i] = nullptr;
+        m->cap_quot[i] = 0;
+        if (hipMalloc(&m->d_quot[i], n * 32) != hipSuccess) rc = mfail(m, KZG_ERR_ALLOC, "hipMalloc(quotient)");
+        else m->cap_quot[i] = n;
+    }
+    return mctx_agree(m, rc, "its quotient buffer");
+}
+
 extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *x,
                                          const void *y, int sfmt, int flags, void *out, int ofmt) {
     // KZGProver::create_witness (src/coeff_form.rs:66-81): q = (p - y)/(X - x) has n - 1 coefficients; rank r reduces
@@ -650,16 +800,7 @@ extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const
     if (!point_format_bytes(ofmt)) return mfail(m, KZG_ERR_SHAPE, "unknown G1 output format");
     if (flags & KZG_OUT_DEVICE) return mfail(m, KZG_ERR_SHAPE, "sharded create_witness writes its result to host memory");
     KZG_TRY(mctx_buffers(m, 1));
-    for (int i = 0; i < m->nlocal(); i++) {
-        if (m->cap_quot[i] >= n) continue;
-        hipSetDevice(m->devices[i]);
-        kzg_sync(m->ctxs[i]);
-        if (m->d_quot[i]) hipFree(m->d_quot[i]);
-        m->d_quot[i] = nullptr;
-        m->cap_quot[i] = 0;
-        if (hipMalloc(&m->d_quot[i], n * 32) != hipSuccess) return mfail(m, KZG_ERR_ALLOC, "hipMalloc(quotient)");
-        m->cap_quot[i] = n;
-    }
+    KZG_TRY(mctx_quotient_buffers(m, n));
     const int in_dev = flags & KZG_IN_DEVICE;
     std::vector<int> off_poly(m->nlocal(), 0), rcs;
     for_each_local(m, rcs, [&](int i) {
@@ -715,7 +856,47 @@ extern "C" int kzg_witness_coeff_batched_sharded(kzg_mctx *m, const kzg_msrs *sr
     return KZG_OK;
 }
 
+extern "C" int kzg_witness_eval_sharded(kzg_mctx *m, const kzg_msrs *lagrange, const void *evals, size_t d, size_t index, int sfmt,
+                                        int flags, void *out, int ofmt) {
+    // KZGProverEvalForm::create_witness (src/eval_form.rs:124-140) over the group: every rank computes div_by_omega_i (:58-84) of
+    // (evals - evals[index]) on its GPU -- the closed form of poly.hip, replicated (an O(d) pass) -- and reduces
+    // q[lo_r, hi_r) against its shard of the Lagrange-basis SRS; one exchange of 144-byte partials.
+    if (!m || !lagrange || !evals || !out) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(m->mu);
+    if ((int)lagrange->shards.size() != m->nlocal()) return mfail(m, KZG_ERR_SHAPE, "SRS belongs to another group");
+    if (d == 0 || (d & (d - 1))) return mfail(m, KZG_ERR_SHAPE, "evaluation domain size must be a power of two");
+    if (index >= d) return mfail(m, KZG_ERR_SHAPE, "evaluation index out of range (reference: index panic)");
+    if (d > lagrange->n) return mfail(m, KZG_ERR_SHAPE, "evaluations longer than the Lagrange SRS (reference: slice panic)");
+    if (!point_format_bytes(ofmt)) return mfail(m, KZG_ERR_SHAPE, "unknown G1 output format");
+    if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return mfail(m, KZG_ERR_SHAPE, "unknown scalar format");
+    if (flags & KZG_OUT_DEVICE) return mfail(m, KZG_ERR_SHAPE, "sharded create_witness writes its result to host memory");
+    KZG_TRY(mctx_buffers(m, 1));
+    KZG_TRY(mctx_quotient_buffers(m, d));
+    const int in_dev = flags & KZG_IN_DEVICE;
+    std::vector<int> rcs;
+    for_each_local(m, rcs, [&](int i) {
+        int q = kzg_quotient_eval(m->ctxs[i], whole_poly(evals, flags, i), d, index, sfmt, in_dev | KZG_OUT_DEVICE, m->d_quot[i]);
+        if (q != KZG_OK) return q;
+        const size_t len = clip_len(lagrange->first[i], lagrange->len[i], d);
+        return msm_batch_strided(m->ctxs[i], lagrange->shards[i], 0, (const uint8_t *)m->d_quot[i] + lagrange->first[i] * 32, len, 1,
+                                 len * 32, sfmt, KZG_IN_DEVICE | KZG_OUT_DEVICE, m->d_part[i], KZG_G1_JACOBIAN_MONT_144);
+    });
+    return mctx_combine(m, 1, rcs, out, ofmt);
+}
+
 #ifdef KZG_TEST_HOOKS
+extern "C" int kzg_test_mctx_inject_alloc_failure(kzg_mctx *m) {
+    if (!m) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->inject_alloc_fail = 1;
+    return KZG_OK;
+}
+extern "C" int kzg_test_mctx_inject_stall(kzg_mctx *m, int ms) {
+    if (!m || ms < 0 || ms > 5000) return KZG_ERR_SHAPE;
+    std::lock_guard<std::mutex> lk(m->mu);
+    m->inject_stall_ms = ms;
+    return KZG_OK;
+}
 extern "C" int kzg_test_mctx_inject_failure(kzg_mctx *m, int code) {
     if (!m) return KZG_ERR_SHAPE;
     std::lock_guard<std::mutex> lk(m->mu);

@@ -30,7 +30,8 @@ class HooksEngine:
         for name, args in {"kzg_test_fr_mul": [vp, vp, vp, sz, vp], "kzg_test_fq_mul": [vp, vp, vp, sz, vp],
                            "kzg_test_fr_inv": [vp, vp, sz, vp], "kzg_test_g1_add": [vp, vp, vp, sz, vp],
                            "kzg_test_g1_mul": [vp, vp, vp, sz, vp], "kzg_ctx_create": [i32, ctypes.POINTER(vp)],
-                           "kzg_ctx_destroy": [vp], "kzg_test_mctx_inject_failure": [vp, i32]}.items():
+                           "kzg_ctx_destroy": [vp], "kzg_test_mctx_inject_failure": [vp, i32],
+                           "kzg_test_mctx_inject_alloc_failure": [vp], "kzg_test_mctx_inject_stall": [vp, i32]}.items():
             f = getattr(self.lib, name)
             f.argtypes = args
             f.restype = None if name == "kzg_ctx_destroy" else i32

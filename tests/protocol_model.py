@@ -15,17 +15,26 @@ class RankFailed(Exception):
         self.rank, self.status = rank, status
 
 
+class GroupDead(Exception):
+    """the exchange did not complete within the deadline (a peer is dead or stalled): mgpu.hip aborts the communicators and every
+    later call on the group fails at once (option gather_timeout_ms)"""
+
+
 class ProtocolModel:
     """local_msm(scalar_shards, batch) -> bytes[batch * point_bytes] (this rank's partial points; may raise);
     local_sum(slots, world, batch, stride) -> list of `batch` results, slots = the gathered bytes, partial of rank w for
     polynomial b at slot w * stride + b."""
 
-    def __init__(self, dist, rank, world, local_msm, local_sum, point_bytes=96):
+    def __init__(self, dist, rank, world, local_msm, local_sum, point_bytes=96, gather_timeout_s=None):
         self.dist, self.rank, self.world = dist, rank, world
         self.local_msm, self.local_sum, self.pb = local_msm, local_sum, point_bytes
+        self.gather_timeout_s, self.dead = gather_timeout_s, False
 
     def commit_batch(self, scalar_shards, batch):
+        import datetime
         import torch
+        if self.dead:
+            raise GroupDead("this device group is dead")
         status = 0
         try:
             mine = bytes(self.local_msm(scalar_shards, batch))
@@ -35,7 +44,17 @@ class ProtocolModel:
             mine = bytes(batch * self.pb)
         rec = mine + struct.pack("<ii", status, self.rank) + bytes(self.pb - 8)
         gathered = torch.empty(self.world * len(rec), dtype=torch.uint8)
-        self.dist.all_gather_into_tensor(gathered, torch.frombuffer(bytearray(rec), dtype=torch.uint8))
+        if self.gather_timeout_s is None:
+            self.dist.all_gather_into_tensor(gathered, torch.frombuffer(bytearray(rec), dtype=torch.uint8))
+        else:   # mctx_wait: poll with a deadline; on expiry abort and retire the group
+            work = self.dist.all_gather_into_tensor(gathered, torch.frombuffer(bytearray(rec), dtype=torch.uint8), async_op=True)
+            try:
+                done = work.wait(timeout=datetime.timedelta(seconds=self.gather_timeout_s))
+            except RuntimeError:
+                done = False
+            if done is False:
+                self.dead = True
+                raise GroupDead("the all-gather did not complete within %.1f s" % self.gather_timeout_s)
         raw = gathered.numpy().tobytes()
         stride = batch + 1
         for w in range(self.world):

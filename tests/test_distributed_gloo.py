@@ -12,7 +12,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from kzg_amd.distributed import broadcast_unique_id, shard_range
-from tests.protocol_model import ProtocolModel, RankFailed
+from tests.protocol_model import GroupDead, ProtocolModel, RankFailed
 from oracle import c_oracle as C
 from oracle import kzg_model as M
 
@@ -74,6 +74,53 @@ def _worker(rank, world, port, n, tau, seed, q):
     dist.destroy_process_group()
 
 
+def _deadline_worker(rank, world, port, q):
+    """rank 1 never enters the second exchange (a dead peer); rank 0's wait has a deadline"""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pm = ProtocolModel(dist, rank, world, lambda polys, batch: bytes(96 * batch), lambda raw, w, b, s: [raw[:96]] * b, gather_timeout_s=1.5)
+    first = pm.commit_batch([[]], 1)       # a healthy exchange under the same deadline
+    out = ("ok", first == [bytes(96)])
+    if rank == 0:
+        t0 = time.time()
+        try:
+            pm.commit_batch([[]], 1)
+            out += ("completed",)
+        except GroupDead:
+            out += ("dead after %.1f s" % (time.time() - t0),)
+        try:
+            pm.commit_batch([[]], 1)           # the group stays dead: no second wait
+            out += ("completed",)
+        except GroupDead as e:
+            out += (str(e),)
+    else:
+        time.sleep(4.0)                        # alive but never arrives
+    q.put((rank, out))
+    q.close()
+    q.join_thread()
+    os._exit(0)                                # no further collective on a retired group
+
+
+def test_exchange_deadline_world2_gloo():
+    """The time-out rule of mgpu.hip (mctx_wait / option gather_timeout_ms) at world size 2: a peer that never enters the exchange
+    turns into an error on the survivor within the deadline, and the survivor's group is dead afterwards -- no hang."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_deadline_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert results[0][:2] == ("ok", True) and results[1][:2] == ("ok", True)
+    assert results[0][2].startswith("dead after") and float(results[0][2].split()[2]) < 3.5
+    assert results[0][3] == "this device group is dead"
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 1000, 1 << 20, (1 << 24) + 5):
         for world in (1, 2, 3, 8):
@@ -85,15 +132,17 @@ def test_shard_range_partitions():
 
 def test_sharded_commit_world2_gloo():
     world, n, tau, seed = 2, 257, 0x1234ABCD, 5
+    C.build()   # before the workers start: two processes must not race to build the oracle library on a fresh checkout
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, n, tau, seed, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=120) for _ in range(world))
+    # (cold start: two torch imports and the first oracle build can take minutes on a fresh checkout)
+    results = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     rng = random.Random(seed)
     coeffs = [rng.randrange(M.R) for _ in range(n)]

@@ -239,6 +239,100 @@ def test_local_failure_is_agreed_on_not_hung(hooks_engine, per_process):
     lib.kzg_mctx_destroy(h)
 
 
+@pytest.mark.parametrize("per_process", [False, True])
+def test_resource_failure_before_the_exchange_is_agreed_on(hooks_engine, per_process):
+    """a rank-local allocation failure BEFORE the collective (growing the exchange buffers for a batch larger
+    than any before) must not leave the peers inside the data all-gather.  The ranks agree on it through the status-only
+    all-gather over buffers that exist since the group was formed; the call fails with the allocation error on every rank, the
+    smaller buffers stay in place and the group stays usable (the same batch succeeds on the next call)."""
+    lib = hooks_engine.lib
+    h = _hooks_group(hooks_engine, per_process)
+    sz, i32, vp = ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p
+    lib.kzg_commit_coeff_sharded_batch.argtypes = [vp, vp, vp, sz, sz, i32, i32, vp, i32]
+    assert lib.kzg_mctx_set_option(h, b"always_gather", 1) == 0
+    n, batch = 300, 70    # 70 > the 64 partials the buffers hold from the start
+    srs = ctypes.c_void_p()
+    assert lib.kzg_srs_setup_g1_sharded(h, (TAU % M.R).to_bytes(32, "little"), L.FR_CANONICAL, n, ctypes.byref(srs)) == 0
+    rng = random.Random(21)
+    polys = [rand_scalars(rng, n) for _ in range(batch)]
+    blob = b"".join(kzg_amd.pack_scalars(p) for p in polys)
+    out = ctypes.create_string_buffer(96 * batch)
+    assert lib.kzg_test_mctx_inject_alloc_failure(h) == 0
+    rc = lib.kzg_commit_coeff_sharded_batch(h, srs, blob, n, batch, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT)
+    assert rc == L.KZG_ERR_ALLOC and b"exchange buffers" in lib.kzg_mctx_last_error(h)
+    G = C.g1_generator()
+    want = b"".join(C.g1_mul(G, C.poly_eval(p, TAU)) for p in polys)
+    assert lib.kzg_commit_coeff_sharded_batch(h, srs, blob, n, batch, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0
+    assert out.raw == want
+    lib.kzg_msrs_free(h, srs)
+    lib.kzg_mctx_destroy(h)
+
+
+def test_exchange_deadline_kills_the_group_instead_of_hanging(hooks_engine):
+    """A peer that never arrives: the wait behind the all-gather polls with a deadline (option gather_timeout_ms).  Simulated in a
+    group of one by parking the exchange behind a 400 ms spin kernel with a 50 ms deadline: the call returns KZG_ERR_INTERNAL,
+    the communicator is aborted, and the group is dead -- every later call fails at once -- until the host destroys it."""
+    import time
+    lib = hooks_engine.lib
+    h = _hooks_group(hooks_engine, True)
+    assert lib.kzg_mctx_set_option(h, b"always_gather", 1) == 0
+    n = 200
+    srs = ctypes.c_void_p()
+    assert lib.kzg_srs_setup_g1_sharded(h, (TAU % M.R).to_bytes(32, "little"), L.FR_CANONICAL, n, ctypes.byref(srs)) == 0
+    rng = random.Random(22)
+    coeffs = rand_scalars(rng, n)
+    blob = kzg_amd.pack_scalars(coeffs)
+    out = ctypes.create_string_buffer(96)
+    want = C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU))
+    # a stall shorter than the deadline is just a slow exchange
+    assert lib.kzg_mctx_set_option(h, b"gather_timeout_ms", 2000) == 0
+    assert lib.kzg_test_mctx_inject_stall(h, 100) == 0
+    assert lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw == want
+    assert lib.kzg_mctx_set_option(h, b"gather_timeout_ms", 50) == 0
+    assert lib.kzg_test_mctx_inject_stall(h, 400) == 0
+    t0 = time.time()
+    rc = lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT)
+    assert rc == L.KZG_ERR_INTERNAL and b"did not complete within 50 ms" in lib.kzg_mctx_last_error(h)
+    assert time.time() - t0 < 6.0
+    rc = lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT)
+    assert rc == L.KZG_ERR_INTERNAL and b"group is dead" in lib.kzg_mctx_last_error(h)
+    lib.kzg_msrs_free(h, srs)
+    lib.kzg_mctx_destroy(h)
+
+
+def test_witness_eval_sharded(engine):
+    """KZGProverEvalForm::create_witness over the device group (src/eval_form.rs:124-140): Lagrange-basis SRS sharded, quotient
+    replicated, MSM sharded; equal to the oracle's [(p(tau) - y) / (tau - w^m)]G, to the single-GPU kzg_witness_eval, host- and
+    device-resident evaluations; the reference's panics map to KZG_ERR_SHAPE."""
+    d, log_d = 1 << 11, 11
+    rng = random.Random(23)
+    coeffs = rand_scalars(rng, d)
+    evals = C.fft(coeffs)
+    _, _, omega = kzg_amd.compute_omega(d)
+    lag_single = kzg_amd.setup_lagrange(engine, TAU, d)
+    group = kzg_amd.DeviceGroup([0])
+    group.set_option("always_gather", 1)
+    lag = group.upload(lag_single.download(), d)
+    G = C.g1_generator()
+    ptau = C.poly_eval(coeffs, TAU)
+    for m in (0, 1, 777, d - 1):
+        xm = pow(omega, m, M.R)
+        want = C.g1_mul(G, (ptau - evals[m]) * pow(TAU - xm, -1, M.R) % M.R)
+        assert group.create_witness_eval(lag, evals, m) == want
+    dev = group.engine(0).alloc_scalars(d)
+    dev.upload(kzg_amd.pack_scalars(evals))
+    xm = pow(omega, 5, M.R)
+    assert group.create_witness_eval(lag, [dev], 5) == C.g1_mul(G, (ptau - evals[5]) * pow(TAU - xm, -1, M.R) % M.R)
+    with pytest.raises(Exception):
+        group.create_witness_eval(lag, evals, d)            # index out of range
+    with pytest.raises(Exception):
+        group.create_witness_eval(lag, evals[:d - 1], 0)    # not a power of two
+    dev.free()
+    lag.free()
+    group.close()
+    lag_single.free()
+
+
 def test_rccl_load_failure_is_an_error_not_a_crash():
     """ADVICE r2: dlerror() read twice -> std::string(nullptr).  With RCCL unloadable (forced in a child process, hooks build)
     kzg_mctx_unique_id and a forced all-gather return the 'cannot load RCCL' error."""
