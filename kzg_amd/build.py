@@ -1,8 +1,9 @@
 """Builds libkzg_mi355x.so (hand-written HIP for gfx950) in-tree with hipcc.  No torch involved.
 
-msm.hip (the bucket-accumulation kernel) goes through its assembly: hipcc -S for the device side, tools-free post-processing
-(strip_asm_nops below), then assembler, lld and the offload bundler exactly as hipcc itself would run them, and the host side
-compiled against that device image.  Everything else is a plain `hipcc -c`."""
+msm.hip (the bucket-accumulation kernel) and ntt.hip go through their assembly: hipcc -S for the device side, tools-free
+post-processing (strip_asm_nops below), then assembler, lld and the offload bundler exactly as hipcc itself would run them, and the
+host side compiled against that device image.  Everything else is a plain `hipcc -c`; so are those two when the compiler is not the
+one the post-processing was validated with (asm_path_ok)."""
 import os
 import re
 import subprocess
@@ -20,8 +21,27 @@ SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip
 EXTRA_FLAGS = {}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 # translation units whose device assembly is post-processed
-VIA_ASM = ["msm.hip"]
+VIA_ASM = ["msm.hip", "ntt.hip"]
 LLVM_BIN = os.environ.get("KZG_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+# the compiler the post-processing rule was validated with (its own nop placement and hazard model); any other compiler, or a
+# missing assembler / linker / bundler, gets the plain `hipcc -c` path with the nops in place
+LLVM_VALIDATED = "roc-7.2.0"
+_asm_path_ok = None
+
+
+def asm_path_ok(hipcc):
+    global _asm_path_ok
+    if _asm_path_ok is None:
+        try:
+            ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout
+        except OSError:
+            ver = ""
+        tools = all(os.path.exists(os.path.join(LLVM_BIN, t)) for t in ("clang", "lld", "clang-offload-bundler"))
+        _asm_path_ok = (LLVM_VALIDATED in ver) and tools
+        if not _asm_path_ok:
+            sys.stderr.write("kzg_amd.build: compiler is not the validated %s (or LLVM tools missing under %s): msm.hip / ntt.hip are "
+                             "built without the s_nop post-processing\n" % (LLVM_VALIDATED, LLVM_BIN))
+    return _asm_path_ok
 
 
 def strip_asm_nops(text):
@@ -30,13 +50,29 @@ def strip_asm_nops(text):
     mul30_gfx950.inc end in v_mad_i64_i32, which has no such hazard (the compiler itself follows its own v_mad_i64_i32 with a
     dependent v_ashrrev_i64 without a wait state), so those 250 nops per bucket addition -- each costs the wave an issue
     slot, measured 0.6 of a multiply-add at two waves per SIMD (profiles/r03_issue_cost.txt) -- are removed.  Only a nop that
-    directly follows a block whose last instruction is v_mad_i64_i32 / v_mad_u64_u32 goes; returns (text, removed)."""
+    directly follows a block whose last instruction is v_mad_i64_i32 / v_mad_u64_u32 goes, and only when the NEXT instruction is a
+    plain VALU / SALU / LDS / memory instruction: in front of anything that reads VGPRs across lanes or with a sub-dword selector
+    (v_readlane / v_readfirstlane / v_writelane / v_permlane*, DPP and SDWA forms) the nop stays -- there the wait state could be a
+    real hazard of another kind.  Returns (text, removed).  Validated for the hipcc of ROCm 7.2 (LLVM_VALIDATED below):
+    with another compiler the build keeps the nops and says so."""
     lines = text.split("\n")
     out, removed = [], 0
     last_asm_insn = None       # last instruction line seen inside the current / most recent asm block
     in_asm = False
     just_ended = False
-    for ln in lines:
+
+    def next_insn(k):
+        for m in range(k + 1, min(k + 40, len(lines))):
+            u = lines[m].strip()
+            if u and not u.startswith((";", ".")) and not u.endswith(":"):
+                return u
+        return ""
+
+    def crosses_lanes(u):
+        return u.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_mov_b32_dpp", "ds_swizzle", "ds_bpermute",
+                             "ds_permute")) or "_dpp" in u.split()[0] or "_sdwa" in u.split()[0] or " dpp" in u or "quad_perm" in u or "row_" in u
+
+    for k, ln in enumerate(lines):
         t = ln.strip()
         if t.startswith(";;#ASMSTART"):
             in_asm, last_asm_insn, just_ended = True, None, False
@@ -46,7 +82,8 @@ def strip_asm_nops(text):
             if t and not t.startswith(";"):
                 last_asm_insn = t
         else:
-            if just_ended and re.match(r"s_nop\s+0\s*$", t) and last_asm_insn and last_asm_insn.startswith(("v_mad_i64_i32", "v_mad_u64_u32")):
+            if (just_ended and re.match(r"s_nop\s+0\s*$", t) and last_asm_insn and last_asm_insn.startswith(("v_mad_i64_i32", "v_mad_u64_u32"))
+                    and not crosses_lanes(next_insn(k))):
                 removed += 1
                 just_ended = False
                 continue
@@ -112,7 +149,7 @@ def build(force=False, verbose=False, out=None, defines=(), strip_nops=True, tag
         obj = os.path.join(objdir, s.replace(".hip", ".o"))
         extra = EXTRA_FLAGS.get(s, [])
         if force or _stale(obj, [src] + hdrs):
-            if s in VIA_ASM:
+            if s in VIA_ASM and asm_path_ok(hipcc):
                 jobs.append(("asm", src, obj, extra))
             else:
                 jobs.append(("cc", [hipcc] + flags + extra + ["-c", src, "-o", obj]))

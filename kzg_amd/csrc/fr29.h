@@ -100,6 +100,85 @@ KZG_HD Fr29 mul29r(const Fr29 &a, const Fr29 &b) { return mul29r_asm(a, b); }
 KZG_HD Fr29 mul29r(const Fr29 &a, const Fr29 &b) { return mul29r_inline(a, b); }
 #endif
 
+// ---- multiplication by a CONSTANT (Shoup / Harvey): the NTT's twiddles are all constants ------------------------------------
+// A twiddle is stored as the pair (w, wp): w < r in plain form (no Montgomery factor) and wp = floor(w 2^261 / r), nine 29-bit
+// limbs each.  x * w mod r for any x < 2^261 with limbs below 1.5 * 2^30 (unnormalised sums of a butterfly are fine):
+//   q~ = floor(high part of x * wp / 2^261): columns 7..16 of the product scan only -- the dropped columns 0..6 are worth less than
+//        2^-24 of a unit of q, so q~ is floor(x w / r) or one less (x w'/2^261 > x w / r - x / 2^261);
+//   result = low 261 bits of x * w - q~ * r, computed in ONE signed column chain: the true value lies in [0, (1 + x / 2^261) r)
+//        < 2r, far below 2^261, so the low nine limbs ARE the value.
+// 53 + 45 + 45 = 143 multiply-adds, 19 shifts and 18 masks; the Montgomery product above needs 154 + 9 adds by r_0 = 1, 17 shifts,
+// 18 masks and nine quotient digits (negate + mask).  Column bounds: 9 * (1.5 * 2^30) * 2^29 = 2^62.75 (unsigned and signed chain).
+// The data keeps whatever form it is in (canonical or blst_fr Montgomery): x * w is the plain product.
+KZG_HD Fr29 mulshoup29_inline(const Fr29 &x, const Fr29 &w, const Fr29 &wp) {
+    uint32_t q[R29_N];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 7; k < 2 * R29_N - 1; k++) {
+#pragma unroll
+        for (int i = 0; i < R29_N; i++)
+            if (k - i >= 0 && k - i < R29_N) acc += (uint64_t)x.v[i] * wp.v[k - i];
+        if (k >= R29_N) q[k - R29_N] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    q[R29_N - 1] = (uint32_t)acc;
+    Fr29 r;
+    int64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < R29_N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            s += (int64_t)((uint64_t)x.v[i] * w.v[k - i]);
+            s -= (int64_t)((uint64_t)q[i] * Fr29Consts::mod(k - i));
+        }
+        r.v[k] = (uint32_t)s & F29_MASK;
+        s >>= 29;
+    }
+    return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_C_MUL29R) && !defined(KZG_OOL_MUL29R)
+KZG_HD Fr29 mulshoup29(const Fr29 &x, const Fr29 &w, const Fr29 &wp) { return mulshoup29_asm(x, w, wp); }
+#else
+KZG_HD Fr29 mulshoup29(const Fr29 &x, const Fr29 &w, const Fr29 &wp) { return mulshoup29_inline(x, w, wp); }
+#endif
+
+// low 261 bits of a * b (table construction only)
+KZG_HD Fr29 fr29_lowmul(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < R29_N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)a.v[i] * b.v[k - i];
+        r.v[k] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    return r;
+}
+
+// radix-2 butterfly on a Shoup product t (< 2r, limbs < 2^29): s = u + t, d = u - t + 4r.  NOT normalised: limbs grow by at most
+// 2^29 (s) / 2^30 (d), values by 2r / 4r; a value that is multiplied next is reduced by the product, the others are normalised
+// when they are stored (fr29_normalize), once per radix-4 stage pair instead of after every butterfly.
+KZG_HD void fr29_butterfly_lazy(const Fr29 &u, const Fr29 &t, Fr29 &s_out, Fr29 &d_out) {
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        const uint32_t ui = u.v[i], ti = t.v[i];
+        s_out.v[i] = ui + ti;
+        d_out.v[i] = ui + Fr29Consts::sub4(i) - ti;
+    }
+}
+// the same with 8r: t is an unmultiplied, NORMALISED sum of two raw 256-bit inputs (below 4.5 r): the first stage pair of a tile,
+// whose stage-one twiddle is 1
+KZG_HD void fr29_butterfly_lazy8(const Fr29 &u, const Fr29 &t, Fr29 &s_out, Fr29 &d_out) {
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        const uint32_t ui = u.v[i], ti = t.v[i];
+        s_out.v[i] = ui + ti;
+        d_out.v[i] = ui + Fr29Consts::sub8(i) - ti;
+    }
+}
+
 // butterfly: (u, t) -> (u + t, u - t + 2r), t a twiddle product (normalised, < 1.4 r); outputs normalised
 KZG_HD void fr29_butterfly(Fr29 &u, Fr29 &v_out, const Fr29 &t) {
     Fr29 s, d;
@@ -146,10 +225,22 @@ KZG_HD Fr fr29_pack_canonical(const Fr29 &x) {
     return borrow ? r : t;
 }
 
-// x < 26 r, normalised (limbs below 2^29, the excess in the top limb)  ->  the same residue below 2r.
+// x < 2^256, normalised -> 8 x 32-bit words, as it is (the scratch between the two passes: any representative will do)
+KZG_HD Fr fr29_pack_raw(const Fr29 &x) {
+    Fr r = Fr::zero();
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) {
+        int bit = 29 * i, w = bit >> 5, sh = bit & 31;
+        if (w < 8) r.v[w] |= x.v[i] << sh;
+        if (sh > 3 && w + 1 < 8) r.v[w + 1] |= x.v[i] >> (32 - sh);
+    }
+    return r;
+}
+
+// x < 64 r, normalised (limbs below 2^29, the excess in the top limb)  ->  the same residue below 2r.
 // q = floor(top / (r_top + 1)) with top = x >> 232 never exceeds floor(x / r) and falls short of it by at most 1
-// ((top + r_top + 1) / (r_top (r_top + 1)) < 4e-6), so x - q r lies in [0, 2r): ~50 instructions instead of a
-// Montgomery multiplication by one.
+// ((top + r_top + 1) / (r_top (r_top + 1)) < 9e-6 for top <= 64 r_top), so x - q r lies in [0, 2r): ~50 instructions instead of a
+// multiplication by one.
 KZG_HD Fr29 fr29_reduce_below_2r(const Fr29 &x) {
     constexpr uint32_t R_TOP = 0x73eda7u;  // r >> 232
     const uint32_t q = x.v[R29_N - 1] / (R_TOP + 1);
@@ -166,6 +257,19 @@ KZG_HD Fr29 fr29_reduce_below_2r(const Fr29 &x) {
         }
     }
     return r;
+}
+
+// (w, wp) of a twiddle from its Montgomery-29 form t = w 2^261 mod r (canonical limbs: what fr29_twiddle_from_mont returns):
+// w = t / 2^261 mod r (a Montgomery product with the integer 1), and since w 2^261 = wp r + t, wp = (-t) r^-1 mod 2^261.
+KZG_HD void fr29_shoup_from_twiddle(const Fr29 &t, Fr29 &w, Fr29 &wp) {
+    Fr29 one;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) one.v[i] = i == 0 ? 1u : 0u;
+    w = fr29_unpack(fr29_pack_canonical(mul29r(t, one)));
+    Fr29 nr;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) nr.v[i] = Fr29Consts::neg_rinv(i);
+    wp = fr29_lowmul(t, nr);
 }
 
 KZG_HD Fr29 fr29_one() {

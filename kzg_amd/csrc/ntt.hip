@@ -19,16 +19,25 @@
 
 namespace kzg {
 
+// A twiddle table: entry i is the constant c_i as the pair (w[i], wp[i]) = (c_i, floor(c_i 2^261 / r)) in 9 x 29-bit limbs -- what
+// the Shoup product of fr29.h multiplies by (mulshoup29).  Two arrays of 36-byte elements.
+struct Tw29 {
+    Fr29 *w = nullptr, *wp = nullptr;
+};
+
 struct NttPlan {
     uint32_t log_n = 0, k1 = 0, k2 = 0;
     int inverse = 0;
-    Fr29 *tw1 = nullptr;   // w_{n1}^i, i < n1/2 (or w_n^i for the single-tile case), as w * 2^261 in 29-bit limbs
-    Fr29 *tw2 = nullptr;   // w_{n2}^i, i < n2/2
-    Fr29 *tw_lo = nullptr; // w_n^i, i < 2^lo_bits
-    Fr29 *tw_hi = nullptr; // w_n^(i << lo_bits)
+    Tw29 tw1;    // w_{n1}^i, i < n1/2 (or w_n^i for the single-tile case)
+    Tw29 tw2;    // w_{n2}^i, i < n2/2
+    Tw29 tw_lo;  // w_n^i, i < 2^lo_bits
+    Tw29 tw_hi;  // w_n^(i << lo_bits)
     uint32_t lo_bits = 0;
-    Fr29 *tw_full = nullptr;  // log_n <= 21: w_n^(j2*k1) * scale at [k1*n2 + j2] -- ONE inter-pass multiply, scale folded in
-    Fr29 scale;            // d^-1 for the inverse, one otherwise (twiddle form)
+    // log_n <= 21: w_n^(j2*k1) * scale at [k1*n2 + j2] -- ONE inter-pass multiply, scale folded in.  This one table stays in the
+    // Montgomery-29 form (w 2^261 mod r, 36 B per element, multiplied by mul29r): pass 1's epilogue is where the kernel waits for
+    // HBM, and the (w, wp) pair would double what it reads there (same-box: 63 -> 68 us for pass 1 at 2^20 with the pair)
+    Fr29 *tw_full = nullptr;
+    Fr29 scale, scale_p;  // d^-1 for the inverse, one otherwise (pair)
 };
 
 Fr host_omega(uint32_t exp) {
@@ -49,23 +58,28 @@ int pow_table(kzg_ctx *ctx, hipStream_t stream, const Fr &base_mont, const Fr &s
     return KZG_OK;
 }
 
-// twiddle tables for the kernels: base^i as w * 2^261 in 29-bit limbs
-__global__ __launch_bounds__(256) void k_pow_table29(Fr base, size_t count, Fr29 *out) {
+// twiddle tables for the kernels: base^i as the pair (w, floor(w 2^261 / r)) in 29-bit limbs
+__global__ __launch_bounds__(256) void k_pow_table29(Fr base, size_t count, Fr29 *out_w, Fr29 *out_wp) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    out[i] = fr29_twiddle_from_mont(pow_u64(base, (uint64_t)i));
+    Fr29 w, wp;
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(pow_u64(base, (uint64_t)i)), w, wp);
+    out_w[i] = w;
+    out_wp[i] = wp;
 }
 
-// full inter-pass twiddle table: out[k1*n2 + j2] = w_n^(j2*k1) * scale (HBM has an order of magnitude of slack in these
-// kernels, the VALU has none: one 36-byte read replaces one of the two inter-pass multiplications)
-__global__ __launch_bounds__(256) void k_twiddle_full(const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits, uint32_t k2,
-                                                      Fr29 scale, size_t n, Fr29 *out) {
+// full inter-pass twiddle table: entry [k1*n2 + j2] = w_n^(j2*k1) * scale * 2^261 mod r (one 36-byte read replaces one of the two
+// inter-pass multiplications)
+__global__ __launch_bounds__(256) void k_twiddle_full(Tw29 tw_lo, Tw29 tw_hi, uint32_t lo_bits, uint32_t k2, Fr scale_mont, size_t n,
+                                                      Fr29 *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t ex = (uint64_t)(i & (((size_t)1 << k2) - 1)) * (uint64_t)(i >> k2);
-    Fr29 w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & ((1u << lo_bits) - 1)]);
-    w = mul29r(w, scale);
-    out[i] = fr29_unpack(fr29_pack_canonical(w));  // canonical limbs: usable as the small operand of mul29r
+    // (table construction: through the Montgomery-29 form of the product, then to the pair)
+    const size_t ih = ex >> lo_bits, il = ex & ((1u << lo_bits) - 1);
+    Fr29 t = mulshoup29(fr29_twiddle_from_mont(scale_mont), tw_hi.w[ih], tw_hi.wp[ih]);   // scale 2^261 w_hi (mod r), below 2r
+    t = mulshoup29(t, tw_lo.w[il], tw_lo.wp[il]);
+    out[i] = fr29_unpack(fr29_pack_canonical(t));  // canonical limbs: usable as the small operand of mul29r
 }
 
 extern __shared__ __attribute__((aligned(16))) Fr29 lds_fr29[];
@@ -109,17 +123,21 @@ __device__ __forceinline__ uint32_t swz(uint32_t idx, uint64_t masks) {
 // input already in bit-reversed position order.  Stage pairs
 // (s, s+1) are fused: a thread takes the 4 elements {p, p+m, p+2m, p+3m}, m = 2^s, through both stages in
 // registers (radix-4), halving the LDS round trips and barriers; an odd t starts with one radix-2 stage.
-// Butterflies are lazy (fr29.h): values grow by < 2r per stage and are reduced by the next twiddle product.
-__device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t vec, const Fr29 *tw, uint64_t sw) {
+// Lazy arithmetic (fr29.h): twiddle products are Shoup products (below 2r, normalised); the butterflies' sums and differences
+// (u + t, u - t + 4r) stay UNnormalised through the pair -- a sum that is multiplied next goes into the product as it is -- and the
+// four results are normalised once, when they are stored.  Values grow by at most 8r per pair along the element chain that is
+// never multiplied (12.4 r in the first pair, whose unmultiplied sum needs 8r): below 53 r after the six pairs of the largest
+// tile, against the 70 r = 2^261 the product accepts (tests/test_host_math.py drives exactly this chain).
+__device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t vec, const Tw29 tw, uint64_t sw) {
     uint32_t s = 0;
-    if (t & 1) {  // radix-2, twiddle 1
+    if (t & 1) {  // radix-2, twiddle 1; both inputs are raw 256-bit loads
         const uint32_t total = vec << (t - 1);
         for (uint32_t b = threadIdx.x; b < total; b += blockDim.x) {
             uint32_t p0 = swz(b << 1, sw), p1 = p0 ^ 1;
-            Fr29 u = lds[p0], w = lds[p1], d;
-            fr29_butterfly(u, d, w);
-            lds[p0] = u;
-            lds[p1] = d;
+            Fr29 u = lds[p0], w = lds[p1], sm, df;
+            fr29_butterfly_lazy(u, w, sm, df);
+            lds[p0] = fr29_normalize(sm);
+            lds[p1] = fr29_normalize(df);
         }
         __syncthreads();
         s = 1;
@@ -136,51 +154,60 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
             const uint32_t p0 = swz((v << t) | (((i >> s) << (s + 2)) | j), sw);
             const uint32_t p1 = p0 ^ d1, p2 = p0 ^ d2, p3 = p1 ^ d2;
             Fr29 x0 = lds[p0], x1 = lds[p1], x2 = lds[p2], x3 = lds[p3];
-            if (s != 0) {  // stage s: twiddle w_{2m}^j on the odd halves (1 when s == 0)
-                Fr29 a = tw[j << (t - 1 - s)];
-                x1 = mul29r(x1, a);
-                x3 = mul29r(x3, a);
+            Fr29 s0, y1, s2, y3, z0, z1, z2, z3;
+            if (s != 0) {
+                // stage s: twiddle w_{2m}^j on the odd halves; stage s+1: w_{4m}^j and w_{4m}^(j+m)
+                const uint32_t ia = j << (t - 1 - s), ib = j << (t - 2 - s), ic = (j + m) << (t - 2 - s);
+                const Fr29 a = tw.w[ia], ap = tw.wp[ia];
+                x1 = mulshoup29(x1, a, ap);
+                x3 = mulshoup29(x3, a, ap);
+                fr29_butterfly_lazy(x0, x1, s0, y1);
+                fr29_butterfly_lazy(x2, x3, s2, y3);
+                s2 = mulshoup29(s2, tw.w[ib], tw.wp[ib]);
+                y3 = mulshoup29(y3, tw.w[ic], tw.wp[ic]);
+                fr29_butterfly_lazy(s0, s2, z0, z2);
+                fr29_butterfly_lazy(y1, y3, z1, z3);
+            } else {
+                // first pair of a tile (raw inputs, j = 0): stage-0 twiddles are 1, stage 1 has 1 and w_4
+                const uint32_t ic = m << (t - 2);
+                fr29_butterfly_lazy(x0, x1, s0, y1);
+                fr29_butterfly_lazy(x2, x3, s2, y3);
+                s2 = fr29_normalize(s2);                        // below 4.5 r, unmultiplied: the 8r butterfly
+                y3 = mulshoup29(y3, tw.w[ic], tw.wp[ic]);
+                fr29_butterfly_lazy8(s0, s2, z0, z2);
+                fr29_butterfly_lazy(y1, y3, z1, z3);
             }
-            Fr29 y1, y3;
-            fr29_butterfly(x0, y1, x1);
-            fr29_butterfly(x2, y3, x3);
-            // stage s+1: twiddles w_{4m}^j and w_{4m}^(j+m)
-            if (s != 0) x2 = mul29r(x2, tw[j << (t - 2 - s)]);
-            y3 = mul29r(y3, tw[(j + m) << (t - 2 - s)]);
-            Fr29 z2, z3;
-            fr29_butterfly(x0, z2, x2);
-            fr29_butterfly(y1, z3, y3);
-            lds[p0] = x0;
-            lds[p1] = y1;
-            lds[p2] = z2;
-            lds[p3] = z3;
+            lds[p0] = fr29_normalize(z0);
+            lds[p1] = fr29_normalize(z1);
+            lds[p2] = fr29_normalize(z2);
+            lds[p3] = fr29_normalize(z3);
         }
         __syncthreads();
     }
 }
 
 // Whole transform in one tile (log_n <= 12).
-__global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const Fr29 *tw, Fr29 scale, uint64_t sw) {
+__global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const Tw29 tw, Fr29 scale, Fr29 scale_p, uint64_t sw) {
     const uint32_t n = 1u << t;
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) lds_fr29[swz(bitrev(i, t), sw)] = fr29_unpack(data[i]);
     __syncthreads();
     if (t == 1) {
         if (threadIdx.x == 0) {
-            Fr29 u = lds_fr29[0], d;
-            fr29_butterfly(u, d, lds_fr29[1]);
-            lds_fr29[0] = u;
-            lds_fr29[1] = d;
+            Fr29 u = lds_fr29[0], w = lds_fr29[1], sm, df;
+            fr29_butterfly_lazy(u, w, sm, df);
+            lds_fr29[0] = fr29_normalize(sm);
+            lds_fr29[1] = fr29_normalize(df);
         }
         __syncthreads();
     } else if (t >= 2) {
         lds_ntt_stages29(lds_fr29, t, 1, tw, sw);
     }
-    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) data[i] = fr29_pack_canonical(mul29r(lds_fr29[swz(i, sw)], scale));
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) data[i] = fr29_pack_canonical(mulshoup29(lds_fr29[swz(i, sw)], scale, scale_p));
 }
 
 // pass 1: columns j2 = blockIdx.x*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
 __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr29 *tw1, const Fr29 *tw_lo, const Fr29 *tw_hi, uint32_t lo_bits,
+                                                    const Tw29 tw1, const Tw29 tw_lo, const Tw29 tw_hi, uint32_t lo_bits,
                                                     const Fr29 *tw_full, uint64_t sw) {
     const uint32_t n1 = 1u << k1, vec = 1u << vec_log;
     const uint32_t j2_0 = blockIdx.x << vec_log;
@@ -195,20 +222,23 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk1 = e >> vec_log;
         uint32_t j2 = j2_0 + v;
-        Fr29 w;
+        Fr29 x = lds_fr29[swz((v << k1) | kk1, sw)];
         if (tw_full) {
-            w = tw_full[((size_t)kk1 << k2) + j2];
+            x = mul29r(x, tw_full[((size_t)kk1 << k2) + j2]);  // Montgomery-29 product: below 1.4 r for x < 64 r
         } else {
-            uint64_t ex = (uint64_t)j2 * kk1;  // < n
-            w = mul29r(tw_hi[ex >> lo_bits], tw_lo[ex & lo_mask]);
+            const uint64_t ex = (uint64_t)j2 * kk1;  // < n
+            const size_t ih = ex >> lo_bits, il = ex & lo_mask;
+            x = mulshoup29(x, tw_hi.w[ih], tw_hi.wp[ih]);
+            x = mulshoup29(x, tw_lo.w[il], tw_lo.wp[il]);
         }
-        out[((size_t)kk1 << k2) + j2] = fr29_pack_canonical(mul29r(lds_fr29[swz((v << k1) | kk1, sw)], w));
+        // below 2r < 2^256: the scratch keeps this representative (pass 2 unpacks any 256-bit integer); no canonicalisation
+        out[((size_t)kk1 << k2) + j2] = fr29_pack_raw(x);
     }
 }
 
 // pass 2: rows k1 = blockIdx.x*vec .. +vec-1; row k1 contiguous at in[k1*n2 ..]; out[k1 + n1*k2]
 __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Fr29 *tw2, Fr29 scale, int scale_folded, uint64_t sw) {
+                                                    const Tw29 tw2, Fr29 scale, Fr29 scale_p, int scale_folded, uint64_t sw) {
     const uint32_t n2 = 1u << k2, vec = 1u << vec_log;
     const uint32_t r0 = blockIdx.x << vec_log;
     const uint32_t total = n2 << vec_log;
@@ -221,16 +251,55 @@ __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint3
     for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
         uint32_t v = e & (vec - 1), kk2 = e >> vec_log;  // consecutive threads -> consecutive k1
         Fr29 x = lds_fr29[swz((v << k2) | kk2, sw)];
-        // the scale already sits in the inter-pass table: only canonicalise (x < 26 r) -- no multiplication
-        x = scale_folded ? fr29_reduce_below_2r(x) : mul29r(x, scale);
+        // the scale already sits in the inter-pass table: only canonicalise (x < 64 r) -- no multiplication
+        x = scale_folded ? fr29_reduce_below_2r(x) : mulshoup29(x, scale, scale_p);
         out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(x);
     }
 }
 
-static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t count, Fr29 **out) {
+static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t count, Tw29 *out) {
     if (!count) count = 1;
-    KZG_HIP_CHECK(ctx, hipMalloc((void **)out, count * sizeof(Fr29)));
-    KZG_LAUNCH(ctx, st, "k_pow_table29", k_pow_table29, (unsigned)((count + 255) / 256), 256, 0, base, count, *out);
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&out->w, count * sizeof(Fr29)));
+    KZG_HIP_CHECK(ctx, hipMalloc((void **)&out->wp, count * sizeof(Fr29)));
+    KZG_LAUNCH(ctx, st, "k_pow_table29", k_pow_table29, (unsigned)((count + 255) / 256), 256, 0, base, count, out->w, out->wp);
+    return KZG_OK;
+}
+
+static void plan_free(NttPlan *p) {
+    for (Tw29 *t : {&p->tw1, &p->tw2, &p->tw_lo, &p->tw_hi}) {
+        if (t->w) hipFree(t->w);
+        if (t->wp) hipFree(t->wp);
+    }
+    if (p->tw_full) hipFree(p->tw_full);
+    delete p;
+}
+
+static int ntt_plan_build(kzg_ctx *ctx, hipStream_t st, NttPlan *p) {
+    const uint32_t log_n = p->log_n;
+    Fr w = host_omega(log_n);
+    if (p->inverse) w = inv(w);
+    size_t n = (size_t)1 << log_n;
+    Fr scale = p->inverse ? inv(from_u64<FrParams>((uint64_t)n)) : Fr::one();
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(scale), p->scale, p->scale_p);
+    if (log_n <= 12) {
+        p->k1 = log_n;
+        p->k2 = 0;
+        return pow_table29(ctx, st, w, log_n ? (n >> 1) : 1, &p->tw1);
+    }
+    p->k1 = (log_n + 1) / 2;
+    p->k2 = log_n - p->k1;
+    size_t n1 = (size_t)1 << p->k1, n2 = (size_t)1 << p->k2;
+    p->lo_bits = p->k1;
+    size_t nlo = (size_t)1 << p->lo_bits, nhi = (size_t)1 << (log_n - p->lo_bits);
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n2), n1 >> 1, &p->tw1));  // w_{n1}
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n1), n2 >> 1, &p->tw2));  // w_{n2}
+    KZG_TRY(pow_table29(ctx, st, w, nlo, &p->tw_lo));
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)nlo), nhi, &p->tw_hi));
+    if (log_n <= 21) {  // 36 B per element, 38 MB at 2^20 per direction; measured -7.5 % at 2^20, nothing at 2^22
+        KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw_full, n * sizeof(Fr29)));
+        KZG_LAUNCH(ctx, st, "k_twiddle_full", k_twiddle_full, (unsigned)((n + 255) / 256), 256, 0, p->tw_lo, p->tw_hi, p->lo_bits, p->k2,
+                   scale, n, p->tw_full);
+    }
     return KZG_OK;
 }
 
@@ -253,44 +322,20 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
     NttPlan *p = new NttPlan();
     p->log_n = log_n;
     p->inverse = inverse;
-    Fr w = host_omega(log_n);
-    if (inverse) w = inv(w);
-    size_t n = (size_t)1 << log_n;
-    Fr scale = inverse ? inv(from_u64<FrParams>((uint64_t)n)) : Fr::one();
-    p->scale = fr29_twiddle_from_mont(scale);
-    if (log_n <= 12) {
-        p->k1 = log_n;
-        p->k2 = 0;
-        KZG_TRY(pow_table29(ctx, st, w, log_n ? (n >> 1) : 1, &p->tw1));
-    } else {
-        p->k1 = (log_n + 1) / 2;
-        p->k2 = log_n - p->k1;
-        size_t n1 = (size_t)1 << p->k1, n2 = (size_t)1 << p->k2;
-        p->lo_bits = p->k1;
-        size_t nlo = (size_t)1 << p->lo_bits, nhi = (size_t)1 << (log_n - p->lo_bits);
-        KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n2), n1 >> 1, &p->tw1));  // w_{n1}
-        KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)n1), n2 >> 1, &p->tw2));  // w_{n2}
-        KZG_TRY(pow_table29(ctx, st, w, nlo, &p->tw_lo));
-        KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)nlo), nhi, &p->tw_hi));
-        if (log_n <= 21) {  // 36 B per element, 38 MB at 2^20 per direction; measured -7.5 % at 2^20, nothing at 2^22
-            KZG_HIP_CHECK(ctx, hipMalloc((void **)&p->tw_full, n * sizeof(Fr29)));
-            KZG_LAUNCH(ctx, st, "k_twiddle_full", k_twiddle_full, (unsigned)((n + 255) / 256), 256, 0, p->tw_lo, p->tw_hi, p->lo_bits,
-                       p->k2, p->scale, n, p->tw_full);
-        }
+    int rc = ntt_plan_build(ctx, st, p);
+    if (rc == KZG_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "NTT twiddle tables");
+    if (rc != KZG_OK) {  // nothing half-built stays behind
+        hipStreamSynchronize(st);
+        plan_free(p);
+        return rc;
     }
-    if (hipStreamSynchronize(st) != hipSuccess) return fail(ctx, KZG_ERR_HIP, "NTT twiddle tables");
     ctx->ntt_plans[key] = p;
     *out = p;
     return KZG_OK;
 }
 
 void ntt_plans_free(kzg_ctx *ctx) {
-    for (auto &kv : ctx->ntt_plans) {
-        NttPlan *p = kv.second;
-        for (Fr29 *t : {p->tw1, p->tw2, p->tw_lo, p->tw_hi, p->tw_full})
-            if (t) hipFree(t);
-        delete p;
-    }
+    for (auto &kv : ctx->ntt_plans) plan_free(kv.second);
     ctx->ntt_plans.clear();
 }
 
@@ -403,7 +448,7 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     if (log_n <= 12) {
         size_t n = (size_t)1 << log_n;
         unsigned threads = n >= 4096 ? 1024 : (n >= 256 ? (unsigned)(n / 4) : 64);
-        KZG_LAUNCH(ctx, st, "k_ntt_single", k_ntt_single, 1, threads, n * sizeof(Fr29), d_data, log_n, p->tw1, p->scale,
+        KZG_LAUNCH(ctx, st, "k_ntt_single", k_ntt_single, 1, threads, n * sizeof(Fr29), d_data, log_n, p->tw1, p->scale, p->scale_p,
                    LDS_SWIZZLE[log_n][0]);
         return KZG_OK;
     }
@@ -420,7 +465,7 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     unsigned th1 = std::min(1024u, 1u << (p->k1 + vec1 - 2)), th2 = std::min(1024u, 1u << (p->k2 + vec2 - 2));
     KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, th1, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
                p->tw_hi, p->lo_bits, p->tw_full, LDS_SWIZZLE[p->k1][vec1]);
-    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
+    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale, p->scale_p,
                p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2]);
     return KZG_OK;
 }

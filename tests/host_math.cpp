@@ -115,6 +115,43 @@ void hm_fr29_butterflies(const uint32_t *u, const uint32_t *v, const uint32_t *w
     Fr zu = fr29_pack_canonical(mul29r(U, fr29_one())), zv = fr29_pack_canonical(mul29r(V, fr29_one()));
     memcpy(ou, zu.v, 32); memcpy(ov, zv.v, 32); }
 }
+extern "C" {
+// the Shoup product of the NTT kernels: x (9 raw limbs, possibly unnormalised: any u32 values the caller supplies) times the
+// constant w (Montgomery form in), through fr29_shoup_from_twiddle -> (w, wp) -> mulshoup29; returns the 9 raw result limbs and (w, wp)
+void hm_fr29_shoup_raw(const uint32_t *x_limbs, const uint32_t *w_mont, uint32_t *out_limbs, uint32_t *w_out, uint32_t *wp_out) {
+    Fr w; memcpy(w.v, w_mont, 32);
+    Fr29 x, W, WP; memcpy(x.v, x_limbs, 36);
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(w), W, WP);
+    Fr29 r = mulshoup29(x, W, WP);
+    memcpy(out_limbs, r.v, 36); memcpy(w_out, W.v, 36); memcpy(wp_out, WP.v, 36); }
+// `pairs` radix-4 stage pairs of the LDS transform on the element chain that is never multiplied (role x0 of every pair) with
+// the other three inputs fresh each time: exactly lds_ntt_stages29's register code -- lazy butterflies, products of unnormalised
+// sums, one normalisation per pair; then the closing canonicalisation of pass 2.  x0..x3: 256-bit integers; which = which of the
+// four outputs continues as the next pair's x0 (0..3: 3 = z3, the fastest-growing).  Returns the canonical chain value.
+void hm_fr29_radix4_chain(const uint32_t *x0, const uint32_t *xs, const uint32_t *w_mont, int pairs, int which, uint32_t *o) {
+    Fr a; memcpy(a.v, x0, 32);
+    Fr29 X0 = fr29_unpack(a);
+    for (int p = 0; p < pairs; p++) {
+        Fr b1, b2, b3, w1, w2, w3;
+        memcpy(b1.v, xs + 24 * p, 32); memcpy(b2.v, xs + 24 * p + 8, 32); memcpy(b3.v, xs + 24 * p + 16, 32);
+        memcpy(w1.v, w_mont + 24 * p, 32); memcpy(w2.v, w_mont + 24 * p + 8, 32); memcpy(w3.v, w_mont + 24 * p + 16, 32);
+        Fr29 A, AP, B, BP, Cw, CP;
+        fr29_shoup_from_twiddle(fr29_twiddle_from_mont(w1), A, AP);
+        fr29_shoup_from_twiddle(fr29_twiddle_from_mont(w2), B, BP);
+        fr29_shoup_from_twiddle(fr29_twiddle_from_mont(w3), Cw, CP);
+        Fr29 x1 = fr29_unpack(b1), x2 = fr29_unpack(b2), x3 = fr29_unpack(b3);
+        Fr29 t1 = mulshoup29(x1, A, AP), t3 = mulshoup29(x3, A, AP);
+        Fr29 s0, y1, s2, y3;
+        fr29_butterfly_lazy(X0, t1, s0, y1);
+        fr29_butterfly_lazy(x2, t3, s2, y3);
+        Fr29 t2 = mulshoup29(s2, B, BP), t3b = mulshoup29(y3, Cw, CP);
+        Fr29 z0, z2, z1, z3;
+        fr29_butterfly_lazy(s0, t2, z0, z2);
+        fr29_butterfly_lazy(y1, t3b, z1, z3);
+        X0 = fr29_normalize(which == 0 ? z0 : which == 1 ? z1 : which == 2 ? z2 : z3);
+    }
+    Fr z = fr29_pack_canonical(fr29_reduce_below_2r(X0)); memcpy(o, z.v, 32); }
+}
 #include "../kzg_amd/csrc/emit.h"
 extern "C" {
 // emit.h on the host (what capi.hip runs for a lone host-bound MSM result): k * P as a de-normalised XYZZ point in the signed

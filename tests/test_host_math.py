@@ -326,6 +326,65 @@ def test_fr29_ntt_arithmetic(L):
             assert int.from_bytes(ou.raw, "little") == U and int.from_bytes(ov.raw, "little") == V
 
 
+def test_fr29_shoup_multiply_and_lazy_radix4(L):
+    """fr29.h, the NTT's multiplication by constants (Shoup: w with wp = floor(w 2^261 / r)) and the lazy radix-4 butterflies:
+    (w, wp) from the table builder against big-integer arithmetic; the product exact mod r and below 2r for normalised inputs,
+    for unnormalised sums with every limb at the 1.5 * 2^30 bound, and for values up to 2^261 - 1; then six stage pairs (the 12
+    stages of the largest LDS tile) along the never-multiplied element chain taking the fastest-growing output each time."""
+    rng = random.Random(29)
+    R, R256, B261 = M.R, 1 << 256, 1 << 261
+    MASK = (1 << 29) - 1
+
+    def limbs(v):
+        return (ctypes.c_uint32 * 9)(*[(v >> (29 * i)) & MASK for i in range(9)])
+
+    def val(ls):
+        return sum(int(x) << (29 * i) for i, x in enumerate(ls))
+
+    for it in range(400):
+        w = rng.randrange(R) if it > 3 else [0, 1, R - 1, 7][it]
+        out, wl, wpl = (ctypes.c_uint32 * 9)(), (ctypes.c_uint32 * 9)(), (ctypes.c_uint32 * 9)()
+        kind = it % 4
+        if kind == 0:      # normalised, below 2^256 (what a tile load produces)
+            x = rng.randrange(R256)
+            xl = limbs(x)
+        elif kind == 1:    # any value below 2^261
+            x = rng.randrange(B261) if it > 8 else B261 - 1
+            xl = limbs(x)
+        elif kind == 2:    # unnormalised: every limb up to 1.5 * 2^30 (u + 4r - t), value kept below 2^261
+            raw = [rng.randrange(3 << 29) for _ in range(8)] + [rng.randrange(1 << 27)]
+            if it < 12:
+                raw = [(3 << 29) - 1] * 8 + [(1 << 27) - 1]
+            xl = (ctypes.c_uint32 * 9)(*raw)
+            x = val(raw)
+            assert x < B261
+        else:
+            x = rng.randrange(R)
+            xl = limbs(x)
+        L.hm_fr29_shoup_raw(xl, b(w * R256 % R, 32), out, wl, wpl)
+        assert val(wl) == w and val(wpl) == (w << 261) // R
+        assert all(v <= MASK for v in out)
+        got = val(out)
+        assert got % R == x * w % R and got < 2 * R, (it, kind)
+    for which in (3, 0, 1, 2):
+        for pairs in (1, 5, 6):
+            for _ in range(6):
+                x0 = rng.randrange(R256)
+                xs = [rng.randrange(R256) for _ in range(3 * pairs)]
+                ws = [rng.randrange(R) for _ in range(3 * pairs)]
+                o = ctypes.create_string_buffer(32)
+                L.hm_fr29_radix4_chain(b(x0, 32), b"".join(b(v, 32) for v in xs), b"".join(b(v * R256 % R, 32) for v in ws), pairs, which, o)
+                X0 = x0
+                for p in range(pairs):
+                    x1, x2, x3 = xs[3 * p: 3 * p + 3]
+                    a, bb, c = ws[3 * p: 3 * p + 3]
+                    t1, t3 = x1 * a, x3 * a
+                    s0, y1, s2, y3 = X0 + t1, X0 - t1, x2 + t3, x2 - t3
+                    t2, t3b = s2 * bb, y3 * c
+                    X0 = [s0 + t2, y1 + t3b, s0 - t2, y1 - t3b][which] % R
+                assert int.from_bytes(o.raw, "little") == X0
+
+
 def test_naf18_recoding(L):
     """naf.h: the width-18 NAF digits of the positional tables.  k = sum d 2^p exactly, digits odd with |d| < 2^17, positions at
     least 18 apart and below 255, at most 15 of them, sign combined with the flip of a balanced scalar; edge patterns: 0, 1, runs
