@@ -338,13 +338,16 @@ void eval_tabs_free(kzg_ctx *ctx);   // poly.hip
 void fixed_base_free(kzg_ctx *ctx);  // srs.hip
 
 // ntt.hip
-int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse);
+int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, size_t nnz = (size_t)-1);  // nnz: d_data[nnz ..) is zero (assumed, not read)
+bool ntt_short_input_ok(uint32_t log_n, size_t nnz);  // ntt_run(..., nnz) will not read d_data[nnz ..)
 int pow_table(kzg_ctx *ctx, hipStream_t stream, const Fr &base_mont, const Fr &scale_mont, size_t count, Fr *d_out);
 Fr host_omega(uint32_t exp);  // Montgomery-form 2^exp-th root of unity per compute_omega (src/ft.rs:73)
 
 // poly.hip
 int fr_convert(kzg_ctx *ctx, hipStream_t stream, Fr *d_data, size_t n, int to_mont);  // in place
 int batch_inverse(kzg_ctx *ctx, hipStream_t stream, const Fr *d_in, Fr *d_out, size_t n);
+// d_a[i] *= 1 / d_c[i] (zeros of c: a[i] = 0 and *d_flag |= 1); d_tmp: n elements of scratch
+int batch_inverse_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_c, Fr *d_a, Fr *d_tmp, size_t n, int *d_flag);
 // Horner machinery: eval and linear quotient. d_coeffs in Montgomery or canonical form (linear ops:
 // the result is in the same form provided x_mont is Montgomery).
 int poly_eval_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_y_out);

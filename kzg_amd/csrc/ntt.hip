@@ -209,22 +209,42 @@ __global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const
 __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
                                                     const Tw29 tw1, const Tw29 tw_lo, const Tw29 tw_hi, uint32_t lo_bits,
                                                     const Fr29 *tw_full, uint64_t sw) {
-    const uint32_t n1 = 1u << k1, vec = 1u << vec_log;
+    const uint32_t vec = 1u << vec_log;
     const uint32_t j2_0 = blockIdx.x << vec_log;
-    const uint32_t total = n1 << vec_log;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-        uint32_t v = e & (vec - 1), j1 = e >> vec_log;  // consecutive threads -> consecutive columns
-        lds_fr29[swz((v << k1) | bitrev(j1, k1), sw)] = fr29_unpack(in[((size_t)j1 << k2) + j2_0 + v]);
+    // every thread moves exactly four elements (the launch uses total / 4 threads): all four loads are issued before the first
+    // is unpacked, so a wave waits for HBM once, not four times
+    {
+        Fr raw[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = threadIdx.x + i * blockDim.x;
+            raw[i] = in[((size_t)(e >> vec_log) << k2) + j2_0 + (e & (vec - 1))];  // consecutive threads -> consecutive columns
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = threadIdx.x + i * blockDim.x;
+            lds_fr29[swz(((e & (vec - 1)) << k1) | bitrev(e >> vec_log, k1), sw)] = fr29_unpack(raw[i]);
+        }
     }
     __syncthreads();
     lds_ntt_stages29(lds_fr29, k1, vec, tw1, sw);
     const uint32_t lo_mask = (1u << lo_bits) - 1;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+    Fr29 twf[4];
+    if (tw_full) {  // the four table entries of this thread, requested together
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = threadIdx.x + i * blockDim.x;
+            twf[i] = tw_full[((size_t)(e >> vec_log) << k2) + j2_0 + (e & (vec - 1))];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t e = threadIdx.x + i * blockDim.x;
         uint32_t v = e & (vec - 1), kk1 = e >> vec_log;
         uint32_t j2 = j2_0 + v;
         Fr29 x = lds_fr29[swz((v << k1) | kk1, sw)];
         if (tw_full) {
-            x = mul29r(x, tw_full[((size_t)kk1 << k2) + j2]);  // Montgomery-29 product: below 1.4 r for x < 64 r
+            x = mul29r(x, twf[i]);  // Montgomery-29 product: below 1.4 r for x < 64 r
         } else {
             const uint64_t ex = (uint64_t)j2 * kk1;  // < n
             const size_t ih = ex >> lo_bits, il = ex & lo_mask;
@@ -237,18 +257,57 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
 }
 
 // pass 2: rows k1 = blockIdx.x*vec .. +vec-1; row k1 contiguous at in[k1*n2 ..]; out[k1 + n1*k2]
+// SHORT: the transform's input has at most n2 non-zero leading elements (a zero-padded short polynomial: Z = prod (X - x_i) on the
+// evaluation coset of create_witness_batched).  Only row 0 of the n1 x n2 matrix is non-zero, so every column transform of pass 1
+// returns its one input in all n1 positions and pass 1 collapses to the inter-pass twiddle: row k1 of pass 2's input is
+// x[j2] * w_n^(j2 k1) * scale for j2 < nnz and zero beyond.  The tile load computes that from the nnz inputs (`in` = a private copy
+// of them) and pass 1 is not launched at all.
+template <bool SHORT>
 __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
-                                                    const Tw29 tw2, Fr29 scale, Fr29 scale_p, int scale_folded, uint64_t sw) {
+                                                    const Tw29 tw2, Fr29 scale, Fr29 scale_p, int scale_folded, uint64_t sw,
+                                                    uint32_t nnz, const Fr29 *tw_full, const Tw29 tw_lo, const Tw29 tw_hi, uint32_t lo_bits) {
     const uint32_t n2 = 1u << k2, vec = 1u << vec_log;
     const uint32_t r0 = blockIdx.x << vec_log;
-    const uint32_t total = n2 << vec_log;
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
-        uint32_t j2 = e & (n2 - 1), v = e >> k2;  // consecutive threads -> consecutive row elements
-        lds_fr29[swz((v << k2) | bitrev(j2, k2), sw)] = fr29_unpack(in[((size_t)(r0 + v) << k2) + j2]);
+    if (!SHORT) {
+        Fr raw[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = threadIdx.x + i * blockDim.x;
+            raw[i] = in[((size_t)(r0 + (e >> k2)) << k2) + (e & (n2 - 1))];  // consecutive threads -> consecutive row elements
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = threadIdx.x + i * blockDim.x;
+            lds_fr29[swz(((e >> k2) << k2) | bitrev(e & (n2 - 1), k2), sw)] = fr29_unpack(raw[i]);
+        }
+    } else {
+        const uint32_t lo_mask = (1u << lo_bits) - 1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t e = threadIdx.x + i * blockDim.x;
+            const uint32_t j2 = e & (n2 - 1), row = r0 + (e >> k2);
+            Fr29 x;
+#pragma unroll
+            for (int l = 0; l < R29_N; l++) x.v[l] = 0;
+            if (j2 < nnz) {
+                x = fr29_unpack(in[j2]);
+                if (tw_full) {
+                    x = mul29r(x, tw_full[((size_t)row << k2) + j2]);
+                } else {
+                    const uint64_t ex = (uint64_t)j2 * row;
+                    const size_t ih = ex >> lo_bits, il = ex & lo_mask;
+                    x = mulshoup29(x, tw_hi.w[ih], tw_hi.wp[ih]);
+                    x = mulshoup29(x, tw_lo.w[il], tw_lo.wp[il]);
+                }
+            }
+            lds_fr29[swz(((e >> k2) << k2) | bitrev(j2, k2), sw)] = x;
+        }
     }
     __syncthreads();
     lds_ntt_stages29(lds_fr29, k2, vec, tw2, sw);
-    for (uint32_t e = threadIdx.x; e < total; e += blockDim.x) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const uint32_t e = threadIdx.x + i * blockDim.x;
         uint32_t v = e & (vec - 1), kk2 = e >> vec_log;  // consecutive threads -> consecutive k1
         Fr29 x = lds_fr29[swz((v << k2) | kk2, sw)];
         // the scale already sits in the inter-pass table: only canonicalise (x < 64 r) -- no multiplication
@@ -316,7 +375,8 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
     if (!ctx->attr_ntt_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_single, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
-        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         ctx->attr_ntt_set = true;
     }
     NttPlan *p = new NttPlan();
@@ -399,8 +459,6 @@ __global__ __launch_bounds__(256) void k_ntt_outer_transpose(const Fr *in, Fr *o
     for (int k1 = 0; k1 < A; k1++) out[(size_t)A * k2 + k1] = in[(size_t)k1 * B + k2];
 }
 
-int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse);
-
 static int ntt_run_large(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     const uint32_t la = log_n - 24;
     const size_t B = (size_t)1 << 24, n = (size_t)1 << log_n, A = (size_t)1 << la;
@@ -438,7 +496,13 @@ static int ntt_run_large(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int
     return KZG_OK;
 }
 
-int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
+// does ntt_run take the short-input path for a transform of 2^log_n points whose input has nnz leading non-zero elements?  (Then
+// d_data[nnz ..) is never read and need not be zero-filled.)
+bool ntt_short_input_ok(uint32_t log_n, size_t nnz) { return log_n > 12 && log_n <= 24 && nnz <= ((size_t)1 << (log_n / 2)); }
+
+// nnz: the caller vouches that d_data[nnz ..) is zero (it need not even be written): a zero-padded short polynomial.  With
+// nnz <= n2 the column pass is skipped (k_ntt_pass2<true>).
+int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, size_t nnz) {
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^28 are not supported (2^24-point two-pass transforms under one 16-point outer level)");
     if (log_n > 24) return ntt_run_large(ctx, lane, d_data, log_n, inverse);
@@ -458,15 +522,24 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
     // vec adjacent columns/rows per block: as many as fit the LDS (4096 elements x 36 B = 144 KiB), at most 4
     const uint32_t vmax = (uint32_t)ctx->opt_ntt_vec_log;
     uint32_t vec1 = 12 - p->k1 < vmax ? 12 - p->k1 : vmax;
-    uint32_t vec2 = 12 - p->k2 < vmax ? 12 - p->k2 : vmax;
+    // rows are contiguous, so narrower pass-2 tiles cost no coalescing and two blocks share a CU: one loads / stores while the
+    // other computes (same-box at 2^20: 58.2 -> 54.2 us); pass 1 needs its 128-byte column segments
+    const uint32_t vmax2 = vmax < 1 ? vmax : 1;
+    uint32_t vec2 = 12 - p->k2 < vmax2 ? 12 - p->k2 : vmax2;
     size_t lds1 = ((size_t)1 << (p->k1 + vec1)) * sizeof(Fr29), lds2 = ((size_t)1 << (p->k2 + vec2)) * sizeof(Fr29);
     unsigned g1 = 1u << (p->k2 - vec1), g2 = 1u << (p->k1 - vec2);
     // one radix-4 butterfly per thread and stage; smaller tiles leave room for a second block per CU
     unsigned th1 = std::min(1024u, 1u << (p->k1 + vec1 - 2)), th2 = std::min(1024u, 1u << (p->k2 + vec2 - 2));
+    if (nnz <= ((size_t)1 << p->k2)) {
+        if (nnz) KZG_HIP_CHECK(ctx, hipMemcpyAsync(scratch, d_data, nnz * sizeof(Fr), hipMemcpyDeviceToDevice, st));  // pass 2 writes d_data
+        KZG_LAUNCH(ctx, st, "k_ntt_pass2_short", k_ntt_pass2<true>, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
+                   p->scale_p, p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2], (uint32_t)nnz, p->tw_full, p->tw_lo, p->tw_hi, p->lo_bits);
+        return KZG_OK;
+    }
     KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, th1, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
                p->tw_hi, p->lo_bits, p->tw_full, LDS_SWIZZLE[p->k1][vec1]);
-    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale, p->scale_p,
-               p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2]);
+    KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2<false>, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale, p->scale_p,
+               p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2], 0u, (const Fr29 *)nullptr, Tw29(), Tw29(), 0u);
     return KZG_OK;
 }
 

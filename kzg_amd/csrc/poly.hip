@@ -55,6 +55,43 @@ __global__ __launch_bounds__(256) void k_batch_inverse(const Fr *in, Fr *out, si
     }
 }
 
+// a[i] *= 1 / c[i]: the same two sweeps with the quotient formed in the second one (no separate pass over the inverses); a zero
+// divisor sets flag bit 0 and zeroes the quotient
+__global__ __launch_bounds__(256) void k_batch_inverse_mul(const Fr *c, Fr *a, Fr *tmp, size_t n, size_t T, int *flag) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T || t >= n) return;
+    Fr prod = Fr::one();
+    size_t last = t;
+    bool zero = false;
+    for (size_t i = t; i < n; i += T) {
+        tmp[i] = prod;
+        Fr v = c[i];
+        if (!v.is_zero()) prod = mul(prod, v);
+        else zero = true;
+        last = i;
+    }
+    if (zero) atomicOr(flag, 1);
+    Fr iv = inv(prod);
+    for (size_t i = last;; i -= T) {
+        Fr v = c[i];
+        if (v.is_zero()) {
+            a[i] = Fr::zero();
+        } else {
+            a[i] = mul(a[i], mul(iv, tmp[i]));
+            iv = mul(iv, v);
+        }
+        if (i < T) break;  // i == t
+    }
+}
+
+int batch_inverse_mul(kzg_ctx *ctx, hipStream_t stream, const Fr *d_c, Fr *d_a, Fr *d_tmp, size_t n, int *d_flag) {
+    if (!n) return KZG_OK;
+    size_t T = (n + BI_K - 1) / BI_K;
+    T = (T + 255) / 256 * 256;
+    KZG_LAUNCH(ctx, stream, "k_batch_inverse_mul", k_batch_inverse_mul, (unsigned)(T / 256), 256, 0, d_c, d_a, d_tmp, n, T, d_flag);
+    return KZG_OK;
+}
+
 int batch_inverse(kzg_ctx *ctx, hipStream_t stream, const Fr *d_in, Fr *d_out, size_t n) {
     if (!n) return KZG_OK;
     size_t T = (n + BI_K - 1) / BI_K;

@@ -36,6 +36,27 @@ __global__ __launch_bounds__(256) void k_distribute_powers(Fr *data, size_t n, c
     }
 }
 
+// The numerator of create_witness_batched on its way to the coset: A[i] = (p[i] - I[i]) * g^i for i < n (I has k < n coefficients,
+// p is converted to Montgomery form on the fly when `to_m`), zero for n <= i < N.  One pass instead of three (zero-padded load,
+// prefix subtraction, distribute_powers); same thread / element mapping as k_distribute_powers.
+__global__ __launch_bounds__(256) void k_numerator_on_coset(const Fr *p, size_t n, const Fr *I, size_t k, Fr *A, size_t N, int to_m,
+                                                            const Fr *lo_tab, const Fr *hi_tab, Fr gT, size_t T) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T || t >= N) return;
+    Fr u = mul(hi_tab[t >> 10], lo_tab[t & (DP_TAB - 1)]);
+    for (size_t i = t; i < N; i += T) {
+        if (i < n) {
+            Fr v = p[i];
+            if (to_m) v = to_mont(v);
+            if (i < k) v = sub(v, I[i]);
+            A[i] = mul(v, u);
+            u = mul(u, gT);
+        } else {
+            A[i] = Fr::zero();
+        }
+    }
+}
+
 // device tables for the coset generator g, built once per context and generator (7, its inverse, and the rare 7^k of
 // kzg_witness_coeff_batched when opening points lie on the coset)
 static int coset_tables(kzg_ctx *ctx, hipStream_t st, const Fr &g, const Fr **lo_tab, const Fr **hi_tab) {
@@ -64,6 +85,18 @@ static int coset_tables(kzg_ctx *ctx, hipStream_t st, const Fr &g, const Fr **lo
     return KZG_OK;
 }
 
+static int numerator_on_coset(kzg_ctx *ctx, hipStream_t st, const Fr *p, size_t n, const Fr *I, size_t k, Fr *A, size_t N, int to_m,
+                              const Fr &g) {
+    size_t T = (N + DP_E - 1) / DP_E;
+    T = (T + 255) / 256 * 256;
+    if (T > DP_TAB * DP_TAB) T = DP_TAB * DP_TAB;
+    const Fr *lo_tab = nullptr, *hi_tab = nullptr;
+    KZG_TRY(coset_tables(ctx, st, g, &lo_tab, &hi_tab));
+    KZG_LAUNCH(ctx, st, "k_numerator_on_coset", k_numerator_on_coset, (unsigned)(T / 256), 256, 0, p, n, I, k, A, N, to_m, lo_tab, hi_tab,
+               pow_u64(g, (uint64_t)T), T);
+    return KZG_OK;
+}
+
 static int distribute_powers(kzg_ctx *ctx, hipStream_t st, Fr *d, size_t n, const Fr &g) {
     if (!n) return KZG_OK;
     size_t T = (n + DP_E - 1) / DP_E;
@@ -83,7 +116,7 @@ static int coset_ntt_run(kzg_ctx *ctx, int lane, Fr *d, uint32_t log_n, int inve
     size_t n = (size_t)1 << log_n;
     if (!inverse) {
         KZG_TRY(distribute_powers(ctx, st, d, nnz < n ? nnz : n, g));
-        return ntt_run(ctx, lane, d, log_n, 0);
+        return ntt_run(ctx, lane, d, log_n, 0, nnz);
     }
     KZG_TRY(ntt_run(ctx, lane, d, log_n, 1));
     return distribute_powers(ctx, st, d, n, inv(g));
@@ -318,10 +351,13 @@ extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(ia, a, na * 32, kind, st));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(ib, b, nb * 32, kind, st));
     // a keeps its form; b goes to Montgomery form so that the pointwise Montgomery product preserves a's form
-    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, ia, na, A, N, 0);
-    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, ib, nb, Bv, N, sfmt == KZG_FR_CANONICAL_LE_32);
-    KZG_TRY(ntt_run(ctx, lane, A, log_n, 0));
-    KZG_TRY(ntt_run(ctx, lane, Bv, log_n, 0));
+    // a short operand (a low-degree factor times a long polynomial) takes the transform's short-input path: no zero padding, no
+    // column pass
+    const bool sa = ntt_short_input_ok(log_n, na), sb = ntt_short_input_ok(log_n, nb);
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(sa ? na : N), 256, 0, ia, na, A, sa ? na : N, 0);
+    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(sb ? nb : N), 256, 0, ib, nb, Bv, sb ? nb : N, sfmt == KZG_FR_CANONICAL_LE_32);
+    KZG_TRY(ntt_run(ctx, lane, A, log_n, 0, sa ? na : (size_t)-1));
+    KZG_TRY(ntt_run(ctx, lane, Bv, log_n, 0, sb ? nb : (size_t)-1));
     KZG_LAUNCH(ctx, st, "k_mul_assign", k_mul_assign, gridfor(N), 256, 0, A, Bv, N);
     KZG_TRY(ntt_run(ctx, lane, A, log_n, 1));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(out, A, nout * 32, (flags & KZG_OUT_DEVICE) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, st));
@@ -499,24 +535,25 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin, coeffs, n * 32, hipMemcpyHostToDevice, st));
         psrc = pin;
     }
-    KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, psrc, n, A, N, to_m);
     MsmPoint *res = nullptr;
     int hflag = 0;
     if (small_poly) {
+        KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, psrc, n, A, N, to_m);
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, I, k, Bv, N, 0);
         // deg I <= k-1 and deg p <= n-1 <= k-1: the quotient is zero and the division is exact iff p == I
         KZG_LAUNCH(ctx, st, "k_any_diff", k_any_diff, gridfor(N), 256, 0, A, Bv, N, flag);
         KZG_TRY(sink_msm(A, 0, &res));  // identity
     } else {
-        KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
-        // (p - I) in coefficient form, then TWO forward coset NTTs (numerator, Z) and one inverse; Z and the numerator's
-        // zero padding are not scaled
-        KZG_LAUNCH(ctx, st, "k_sub_prefix", k_sub_prefix, gridfor(k), 256, 0, A, I, k);
+        // Z on the coset: its k + 1 coefficients times g^j, then a transform whose input is short -- when the k + 1 values fit the
+        // first row of the four-step matrix the column pass is skipped and nothing beyond them is read (no zero padding)
+        if (ntt_short_input_ok(log_N, k + 1)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(Cv, z0, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
+        else KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
         KZG_TRY(coset_ntt_run(ctx, lane, Cv, log_N, 0, gsh, k + 1));
-        KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(N), 256, 0, Cv, N, flag);
-        KZG_TRY(coset_ntt_run(ctx, lane, A, log_N, 0, gsh, n > k ? n : k));
-        KZG_TRY(batch_inverse(ctx, st, Cv, Ci, N));
-        KZG_LAUNCH(ctx, st, "k_mul_inplace", k_mul_inplace, gridfor(N), 256, 0, A, Ci, N);
+        // (p - I) g^i in one pass over p, then its transform; the pointwise division by Z's values (one batch inversion; a zero
+        // among them would be an opening point on the coset, excluded above) inside the inversion's second sweep
+        KZG_TRY(numerator_on_coset(ctx, st, psrc, n, I, k, A, N, to_m, gsh));
+        KZG_TRY(ntt_run(ctx, lane, A, log_N, 0));
+        KZG_TRY(batch_inverse_mul(ctx, st, Cv, A, Ci, N, flag));
         KZG_TRY(coset_ntt_run(ctx, lane, A, log_N, 1, gsh));
         // exact division <=> deg q <= N-1-k <=> the top k coefficients vanish
         KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);

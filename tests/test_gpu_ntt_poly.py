@@ -153,6 +153,34 @@ def test_fft_mul_polynomial_arith(engine):
     assert got.slice_coeffs() == want.slice_coeffs()
 
 
+def test_fft_mul_short_operand_takes_the_short_input_transform(engine):
+    """A low-degree factor times a long polynomial (the shape of Z = prod (X - x_i) against a degree-2^20 numerator): the short
+    operand's transform skips the column pass and reads nothing beyond its coefficients (k_ntt_pass2<SHORT>, ntt.hip).  Product
+    against the model's naive Mul at 2^13..2^15 (both table kinds of the inter-pass twiddle are used below 2^21), by oracle
+    evaluation at 2^17 and at 2^22 (two-level twiddles), operand lengths at and around the first-row limit 2^floor(log_n / 2)."""
+    rng = random.Random(77)
+    for na, nb in ((1, 5000), (2, 8000), (63, 8100), (64, 8100), (65, 8100), (90, 16000), (128, 30000), (181, 32500)):
+        a, b = rand_scalars(rng, na), rand_scalars(rng, nb)
+        want = M.Polynomial(a, na - 1).mul_naive(M.Polynomial(b, nb - 1))
+        assert engine.poly_mul(a, b) == want.coeffs, (na, nb)
+        assert engine.poly_mul(b, a) == want.coeffs, (nb, na)
+    for na, nb in ((257, (1 << 17) - 300), (2048, (1 << 22) - 3000)):
+        a = rand_scalars(rng, na)
+        bb = engine.alloc_scalars(nb).fill_random(600 + na)
+        braw = bb.download()
+        ab = engine.alloc_scalars(na)
+        ab.upload(kzg_amd.pack_scalars(a))
+        out = engine.alloc_scalars(na + nb - 1)
+        rc = engine.lib.kzg_poly_mul(engine.ctx, ab.ptr, na, bb.ptr, nb, ab.sfmt, L.IN_DEVICE | L.OUT_DEVICE, out.ptr)
+        assert rc == 0, engine.last_error()
+        got = out.download()
+        for _ in range(3):
+            x = rng.randrange(M.R)
+            assert C.poly_eval_bytes(got, na + nb - 1, x) == C.poly_eval(a, x) * C.poly_eval_bytes(braw, nb, x) % M.R
+        for buf in (bb, ab, out):
+            buf.free()
+
+
 def test_evaluation_domain_remaining_ops(engine):
     """EvaluationDomain::z / divide_by_z_on_coset / mul_assign / sub_assign (src/ft.rs:180-271) against the model, and the
     workflow they exist for: with a = b * Z_H + c on the domain H, (coset values of a - c) / Z on the coset are b's coset values."""
