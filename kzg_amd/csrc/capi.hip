@@ -401,6 +401,8 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
         ctx->heavy_last.store(0, std::memory_order_relaxed);
     } else if (k == "sort_single_pass") {
         ctx->opt_sort_single = value != 0;
+    } else if (k == "defer_tail") {
+        ctx->opt_no_defer_tail = value == 0;
     } else if (k == "tail_quads") {
         ctx->opt_tail_quads = value != 0;
     } else if (k == "hw_queues") {
@@ -754,7 +756,7 @@ static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
     }
     if (getenv("KZG_DEBUG")) fprintf(stderr, "kzg: pipeline plan: %d lanes + %d accumulation streams\n", nl, nas);
     KZG_TRY(ensure_lanes(ctx, nl));
-    while (nas && (int)ctx->sorted_events.size() < nl) {
+    while (nas && (int)ctx->sorted_events.size() < 2 * nl) {  // [0, nl): the lanes' own; [nl, 2 nl): their second MSM in flight (batch_msm)
         hipEvent_t e1 = nullptr, e2 = nullptr;
         KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
         KZG_HIP_CHECK(ctx, hipEventCreateWithFlags(&e2, hipEventDisableTiming));
@@ -788,13 +790,16 @@ static int batch_begin(kzg_ctx *ctx, size_t batch, size_t out_bytes, void *out, 
 }
 
 static int batch_msm(kzg_ctx *ctx, const BatchPipe &bp, size_t b, int lane, const kzg_srs *srs, size_t offset, const void *d_sc,
-                     size_t n, int sfmt, MsmPoint **res) {
+                     size_t n, int sfmt, MsmPoint **res, MsmPending *defer = nullptr) {
     // (Staggering the first round -- lane b starting its sort when lane b - 2 has sorted, so that the first accumulation kernel
     // does not wait for sixteen contending sorts -- measured 460 against 472 commitments/s same-box, profiles/r03_ab_kernel.txt:
     // the up-front burst of sorts is the better start.)
-    if (bp.nas)
-        return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res, ctx->accum_streams[b % bp.nas], ctx->sorted_events[lane],
-                       ctx->accum_events[lane]);
+    if (bp.nas) {
+        // a lane's two MSMs in flight (deferred tails) use different events
+        const int ev = defer ? lane + (int)((b / (size_t)bp.nl) & 1) * bp.nl : lane;
+        return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res, ctx->accum_streams[b % bp.nas], ctx->sorted_events[ev], ctx->accum_events[ev],
+                       defer);
+    }
     return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res);
 }
 
@@ -835,18 +840,40 @@ int msm_batch_strided(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const voi
     if (batch == 0) return KZG_OK;
     BatchPipe bp;
     KZG_TRY(batch_begin(ctx, batch, batch * psz, out, flags, &bp));
-    size_t per = msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192;
+    size_t per = align_up(msm_workspace_bytes(srs, n) + stage_bytes(n * 32, flags) + 8192, 4096);
     int rc = KZG_OK;
-    for (int l = 0; l < bp.nl && rc == KZG_OK; l++) rc = lane_reserve(ctx, l, per);
+    // Software pipelining inside a lane (deep batches on FIFO accumulation streams): MSM b's tail is enqueued AFTER the sort of the
+    // lane's next MSM (b + nl), so the accumulation queue gets its next kernel before the lane spends milliseconds in latency-bound
+    // tail kernels.  Two MSMs of a lane are in flight then: two workspaces (the arena's halves) and two event pairs per lane.
+    const bool defer = bp.nas > 0 && batch > (size_t)bp.nl && !ctx->opt_no_defer_tail;
+    std::vector<MsmPending> pend(defer ? 2 * (size_t)bp.nl : 0);
+    for (int l = 0; l < bp.nl && rc == KZG_OK; l++) rc = lane_reserve(ctx, l, defer ? 2 * per : per);
+    auto finish = [&](size_t b) {
+        const int l = (int)(b % bp.nl);
+        MsmPoint *res = nullptr;
+        int r = msm_finish(ctx, pend[(size_t)l + ((b / (size_t)bp.nl) & 1) * (size_t)bp.nl], &res);
+        if (r == KZG_OK) r = emit_point(ctx, l, res, bp.d_out + b * psz, ofmt);
+        return r;
+    };
     for (size_t b = 0; b < batch && rc == KZG_OK; b++) {
         int l = (int)(b % bp.nl);
-        ctx->lanes[l].arena_used = 0;  // stream order makes re-use of the lane arena safe
+        const size_t half = defer ? ((b / (size_t)bp.nl) & 1) : 0;
+        ctx->lanes[l].arena_used = half * per;  // stream order makes re-use of the lane arena (of this half) safe
         const void *d_sc = nullptr;
         rc = stage_in(ctx, l, (const uint8_t *)scalars + b * stride_bytes, n * 32, flags, &d_sc);
         MsmPoint *res = nullptr;
+        if (defer) {
+            MsmPending &pd = pend[(size_t)l + half * (size_t)bp.nl];
+            if (rc == KZG_OK) rc = batch_msm(ctx, bp, b, l, srs, offset, d_sc, n, sfmt, &res, &pd);
+            if (rc == KZG_OK && !pd.active) pd.result = res;  // (not deferred: multi-pass / wide path) finish() emits it
+            if (rc == KZG_OK && b >= (size_t)bp.nl) rc = finish(b - bp.nl);
+            continue;
+        }
         if (rc == KZG_OK) rc = batch_msm(ctx, bp, b, l, srs, offset, d_sc, n, sfmt, &res);
         if (rc == KZG_OK) rc = emit_point(ctx, l, res, bp.d_out + b * psz, ofmt);
     }
+    if (defer)
+        for (size_t b = batch > (size_t)bp.nl ? batch - bp.nl : 0; b < batch && rc == KZG_OK; b++) rc = finish(b);
     return batch_end(ctx, bp, rc, out, batch * psz);
 }
 }  // namespace kzg

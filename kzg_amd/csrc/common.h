@@ -134,6 +134,7 @@ struct kzg_ctx {
     int opt_sort_threads_batch = 1024; // ... for batched MSMs
     int opt_host_affine = 1;           // a lone result bound for host memory is converted to affine / serialised on the host (emit.h)
     int opt_heavy_bins = 0;            // level 2 of the two-level sorts: 0 = slices for oversized bins once such bins have been seen (below), 1 = always, 2 = never
+    bool opt_no_defer_tail = false;    // option defer_tail = 0: kzg_msm_g1_batch enqueues every MSM's tail right behind its accumulation (A/B)
     int opt_sort_single = 0;           // 1: c = 17 sorts in one pass (2^16 cursors, two walks) instead of the two-level sort
     int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
     int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
@@ -280,8 +281,28 @@ size_t msm_workspace_bytes(const kzg_srs *srs, size_t n);
 int finish_point(kzg_ctx *ctx, int lane, const MsmPoint *d_pt, void *out, int ofmt, int flags);
 // d_scalars: device pointer to n scalars (sfmt); result: one device MsmPoint in the lane arena
 // accum_stream (optional): run k_accum_affine there instead of on the lane's stream, ordered by the two caller-owned events
+// `defer` (batched pipeline): when the accumulation kernel went to a FIFO stream, the part behind it (wait for it, fold, bucket
+// reduction) is NOT enqueued: it is described in *defer and enqueued later by msm_finish -- after the lane's NEXT sort, so that the
+// accumulation queue is fed before the lane's latency-bound tail kernels run (two MSMs in flight per lane, two workspaces).
+struct MsmPending {
+    bool active = false;
+    hipStream_t st = nullptr;
+    hipEvent_t accum_ev = nullptr;
+    MsmMode mm;
+    const MsmPoint *part = nullptr;
+    MsmPoint *scratch = nullptr, *result = nullptr;
+    const uint32_t *s1 = nullptr;
+    int B = 0;
+    size_t expected = 0;
+    void *state = nullptr;
+    char *tail_base = nullptr;
+    size_t tail_off[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // TailLayout (msm_internal.h), opaque here
+    bool odd = false;
+};
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-            MsmPoint **d_result, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr, hipEvent_t accum_ev = nullptr);
+            MsmPoint **d_result, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr, hipEvent_t accum_ev = nullptr,
+            MsmPending *defer = nullptr);
+int msm_finish(kzg_ctx *ctx, MsmPending &pd, MsmPoint **d_result);  // the deferred part of an MSM (its result if it was not deferred)
 // capi.hip: one MSM on a leased lane (its accumulation kernel on the lease's FIFO stream when other calls are in flight)
 int lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res);
 // d_points: count points -> one point (plain sum)

@@ -883,7 +883,7 @@ __global__ __launch_bounds__(64) void k_combine_passes(const MsmPoint *S, int pa
 // One MSM on the lane's stream: counting sort, bucket accumulation (on `accum_stream` when the batched pipeline runs every
 // accumulation kernel on dedicated streams: then `sorted_ev` / `accum_ev` order the two), tail (msm_tail.hip).
 static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-                          MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
+                          MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev, MsmPending *defer) {
     hipStream_t st = ctx->lanes[lane].stream;
     const MsmMode mm = ctx->lanes[lane].mode;
     MsmLayout L = msm_layout(srs, n ? n : 1);
@@ -1006,6 +1006,24 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
             KZG_LAUNCH(ctx, accum_stream, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
                        (const uint4 *)srs->table30, bufA, state);
             KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, accum_stream));
+            if (defer && passes == 1) {  // the caller enqueues the wait and the tail later (msm_finish)
+                static_assert(sizeof(TailLayout) == sizeof(defer->tail_off), "MsmPending::tail_off mirrors TailLayout");
+                defer->active = true;
+                defer->st = st;
+                defer->accum_ev = accum_ev;
+                defer->mm = mm;
+                defer->part = bufA;
+                defer->scratch = bufB;
+                defer->s1 = s1;
+                defer->B = B;
+                defer->expected = expected_partials(L.M_max, slots, B);
+                defer->state = state;
+                defer->tail_base = base + L.off_tail;
+                memcpy(defer->tail_off, &L.tail, sizeof(TailLayout));
+                defer->odd = srs->naf != 0;
+                *d_result = nullptr;
+                return KZG_OK;
+            }
             KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
         } else {
             KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries, bucket_start, s1, B,
@@ -1025,15 +1043,28 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     return KZG_OK;
 }
 
+int msm_finish(kzg_ctx *ctx, MsmPending &pd, MsmPoint **d_result) {
+    if (!pd.active) {
+        *d_result = pd.result;
+        return KZG_OK;
+    }
+    pd.active = false;
+    KZG_HIP_CHECK(ctx, hipStreamWaitEvent(pd.st, pd.accum_ev, 0));
+    TailLayout tl;
+    memcpy(&tl, pd.tail_off, sizeof tl);
+    return msm_tail_run(ctx, pd.st, pd.mm, pd.part, pd.scratch, pd.s1, pd.B, pd.expected, (MsmState *)pd.state, pd.tail_base, tl, d_result, pd.odd);
+}
+
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-            MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
+            MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev, MsmPending *defer) {
+    if (defer) defer->active = false;
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if (srs->c > 16 && !srs->narrow17 && !(srs->sort20 && !ctx->opt_sort_single))
         return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
     if ((uint64_t)srs->rows * srs->npad >= (1ull << 31))
         return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (table rows * points < 2^31)");
     if (srs->naf && offset + n > srs->npad) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
-    return msm_run_narrow(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result, accum_stream, sorted_ev, accum_ev);
+    return msm_run_narrow(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result, accum_stream, sorted_ev, accum_ev, defer);
 }
 
 }  // namespace kzg
