@@ -35,6 +35,10 @@ hw "nobody asks: the runtime's default pool (4 queues), engine narrows the pipel
 hw "KZG_SET_HW_QUEUES=1: the library's load-time constructor opts in" KZG_HW_QUEUES=0 KZG_SET_HW_QUEUES=1
 done > $O/hw_queues.txt 2>&1
 timeout 900 python3 tools/sweep.py 16 18 20 22 24 > $O/sweep.jsonl 2> $O/sweep.err
+# round 4: the concurrent-callers mix (every leased call, oracle-checked), the NTT probe, N > 1 block at world size 1
+timeout 300 python3 tools/stress_callers.py 60 18 16 > $O/stress_callers.txt 2>&1
+timeout 200 python3 tools/ntt_probe.py 16 18 20 22 24 > $O/ntt_probe.txt 2>&1
+timeout 400 python3 bench.py --no-cpu-baseline --no-paths --sharded-block --steps 4 > $O/bench_sharded_block_world1.json 2>> $O/bench.err
 timeout 200 python3 tools/fuzz_gpu.py 90 > $O/fuzz.txt 2>&1
 SKEW_PROF=1 timeout 200 python3 tools/skew_probe.py 20 > $O/skew.txt 2>&1
 ls -la $O

@@ -30,6 +30,12 @@ cp("pmc_fetch.summary.json", "pmc_fetch.json")
 cp("pmc_write.summary.json", "pmc_write.json")
 cp("pmc_sq.summary.json", "pmc_sq_single_msm.json")
 cp("sweep.jsonl", "sweep.jsonl")
+for a, b in (("stress_callers.txt", "stress_callers.txt"), ("ntt_probe.txt", "ntt_probe.txt"), ("bench_sharded_block_world1.json", "bench_sharded_block_world1.json"),
+             ("pmc_ntt_sq.summary.json", "pmc_ntt_2e20_sq.json"), ("pmc_ntt_lds.summary.json", "pmc_ntt_2e20_lds.json"),
+             ("pmc_ntt_fetch.summary.json", "pmc_ntt_2e20_fetch.json"), ("pmc_ntt_write.summary.json", "pmc_ntt_2e20_write.json"),
+             ("fuzz.txt", "fuzz.txt"), ("skew.txt", "skewed_scalars.txt")):
+    if os.path.exists(os.path.join(src, a)):
+        cp(a, b)
 hw = os.path.join(dst, f"{rnd}_hw_queues.txt")
 head = [ln for ln in open(hw).read().splitlines() if ln.startswith("#")] if os.path.exists(hw) else []
 open(hw, "w").write("\n".join(head + open(os.path.join(src, "hw_queues.txt")).read().splitlines()) + "\n")
