@@ -422,6 +422,11 @@ class Job:
             return
         import torch
         self.torch = torch
+        # order matters: torch first (its wheel bundles a HIP runtime under the system's SONAME and must bring it in), then the
+        # library (binds to that runtime and asks for the hardware queues: kzg_init_hw_queues sets GPU_MAX_HW_QUEUES), and only then
+        # the first HIP call of the process (set_device below), which is when the runtime sizes its queue pool
+        import kzg_amd
+        kzg_amd.load()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
