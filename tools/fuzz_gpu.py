@@ -23,7 +23,8 @@ e = kzg_amd.Engine(0)
 TAU = rng.getrandbits(64)
 t_end = time.time() + budget
 fails = 0
-cases = {"msm": 0, "msm_batch": 0, "ntt": 0, "witness": 0, "witness_batched": 0, "eval_form": 0, "group": 0, "lagrange_intt": 0}
+cases = {"msm": 0, "msm_batch": 0, "ntt": 0, "witness": 0, "witness_batched": 0, "eval_form": 0, "group": 0, "lagrange_intt": 0, "poly_mul": 0,
+         "group_witness_eval": 0}
 group = kzg_amd.DeviceGroup([0])
 group.set_option("always_gather", 1)
 
@@ -53,6 +54,7 @@ while time.time() < t_end:
     e.set_option("tail_quads", rng.randrange(2))             # latency-mode tail kernels on / off
     e.set_option("hw_queues", rng.choice([0, 0, 1, 3, 4, 6]))  # pipeline plans
     e.set_option("streams", rng.choice([1, 2, 4, 8]))
+    e.set_option("defer_tail", rng.choice([1, 1, 0]))           # batched MSMs: a lane's tail behind the sort of its next MSM / right away
     nmax = rng.choice([1, 2, 5, 33, 257, 1000, 4097, 20000, 70000, 70000, 300000])
     params = kzg_amd.setup(e, TAU, nmax, g2_len=0)
     srs_blob = params.gs.download()
@@ -75,7 +77,7 @@ while time.time() < t_end:
             print("MSM MISMATCH", dict(window_bits=wb, rows=rows, naf=naf, nmax=nmax, n=n, off=off, kind=kind, seed=seed), flush=True)
     if nmax >= 33:
         n = rng.randrange(1, min(nmax, 3000) + 1)
-        batch = rng.randrange(1, 12)
+        batch = rng.randrange(1, 12) if rng.random() < 0.7 else rng.randrange(12, 40)   # deep batches: two MSMs in flight per lane
         sc = [rand_scalar(rng.randrange(4)) for _ in range(n * batch)]
         got = e.msm_batch(params.gs, sc, n, batch)
         cases["msm_batch"] += 1
@@ -105,8 +107,11 @@ while time.time() < t_end:
         except kzg_amd.PointNotOnPolynomial:
             pass
         # batched witness: r == the interpolant, w == [(p(tau) - I(tau)) / Z(tau)] G  (known-tau identity)
-        n = rng.randrange(2, min(nmax, 2000) + 1)
-        k = rng.randrange(1, min(n + 2, 24))
+        # (one round in three: a long polynomial, where the division's transforms are two-pass and Z's takes the short-input path
+        # or not depending on k against the first-row limit 2^floor(log N / 2))
+        big = rng.random() < 0.34 and nmax >= 20000
+        n = rng.randrange(9000, min(nmax, 70000) + 1) if big else rng.randrange(2, min(nmax, 2000) + 1)
+        k = rng.choice([rng.randrange(1, 24), rng.randrange(60, 70), rng.randrange(120, 135), rng.randrange(250, 262)]) if big else rng.randrange(1, min(n + 2, 24))
         coeffs = [rand_scalar(rng.randrange(2)) for _ in range(n)]
         coeffs[-1] = coeffs[-1] or 1
         poly = kzg_amd.Polynomial(coeffs)
@@ -178,6 +183,31 @@ while time.time() < t_end:
         fails += 1
         print("GROUP COMMIT MISMATCH", dict(n=n, m=len(coeffs), seed=seed), flush=True)
     gsrs.free()
+    # KZGProverEvalForm::create_witness over the group
+    if rng.random() < 0.4:
+        dd = 1 << rng.randrange(1, 12)
+        lag1 = kzg_amd.setup_lagrange(e, TAU, dd)
+        glag = group.upload(lag1.download(), dd)
+        cf = [rand_scalar(rng.randrange(2)) for _ in range(dd)]
+        evs = C.fft(cf)
+        mm = rng.randrange(dd)
+        wmm = pow(kzg_amd.compute_omega(dd)[2], mm, R)
+        cases["group_witness_eval"] += 1
+        if (TAU - wmm) % R and group.create_witness_eval(glag, evs, mm) != C.g1_mul(C.g1_generator(), (C.poly_eval(cf, TAU) - evs[mm]) * pow(TAU - wmm, -1, R) % R):
+            fails += 1
+            print("GROUP EVAL WITNESS MISMATCH", dict(d=dd, m=mm, seed=seed), flush=True)
+        glag.free(); lag1.free()
+    # fft_mul with a short operand (short-input transform) and with two long ones: product checked by oracle evaluation
+    if rng.random() < 0.5:
+        na = rng.choice([1, 2, 17, 64, 65, 129, 300, 5000])
+        nb = rng.choice([100, 5000, 9000, 33000, 120000])
+        pa, pb = [rand_scalar(rng.randrange(2)) for _ in range(na)], [rand_scalar(0) for _ in range(nb)]
+        prod = e.poly_mul(pa, pb) if rng.random() < 0.5 else e.poly_mul(pb, pa)
+        cases["poly_mul"] += 1
+        xx = rand_scalar(0)
+        if len(prod) != na + nb - 1 or C.poly_eval(prod, xx) != C.poly_eval(pa, xx) * C.poly_eval(pb, xx) % R:
+            fails += 1
+            print("POLY_MUL MISMATCH", dict(na=na, nb=nb, seed=seed), flush=True)
     # compute_lagrange_basis from the monomial SRS alone (group iNTT) == the known-tau closed form
     if rng.random() < 0.3:
         d = 1 << rng.randrange(0, 12)
@@ -220,6 +250,7 @@ while time.time() < t_end:
         print("NTT MISMATCH", dict(log_n=log_n, seed=seed), flush=True)
 e.set_option("window_bits", 0)
 e.set_option("sort_single_pass", 0)
+e.set_option("defer_tail", 1)
 group.close()
 summary = "seed %d, %.0f s: fuzz done %s failures: %d" % (seed, budget, cases, fails)
 print(summary, flush=True)
