@@ -59,7 +59,9 @@ extern "C" {
 /* Limits (each returns KZG_ERR_SHAPE with a message in kzg_last_error; tests/test_gpu_validation.py):
  *   kzg_ntt_fr                              log_n <= 28                      (2^24: two LDS passes of <= 2^12 points; above: one
  *                                                                             more four-step level of <= 16 around them)
- *   coset NTT / verify_poly_eval / poly_mul / create_witness_batched         log_n <= 24
+ *   kzg_coset_ntt_fr                        log_n <= 28;  kzg_poly_mul: products of up to 2^27 coefficients;
+ *   kzg_witness_coeff_batched               polynomials of up to 2^26 coefficients (the SRS with its window tables is 118 GB there);
+ *   kzg_verify_poly_eval                    as far as the monomial SRS goes (MSM limit below)
  *   kzg_witness_coeff_batched,
  *   kzg_verify_eval_batched                 k <= 4096 opening points          (single-workgroup interpolation kernels)
  *   kzg_srs_lagrange_from_monomial_g1       d <= 2^24;  _g2: d <= 1024

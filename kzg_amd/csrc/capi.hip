@@ -1087,7 +1087,7 @@ extern "C" int kzg_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int inverse,
     if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^28 are not supported (2^24-point two-pass transforms under one 16-point outer level)");
     size_t n = (size_t)1 << log_n;
     // above 2^24: the transposed copy of the whole vector + the inner transform's 2^24-element scratch + the outer twiddle tables
-    KZG_TRY(lane_reserve(ctx, lane, (log_n > 24 ? n * 32 + ((size_t)1 << 24) * 32 + (1 << 20) : n * 32) + stage_bytes(n * 32, flags) + 8192));
+    KZG_TRY(lane_reserve(ctx, lane, ntt_workspace_bytes(log_n) + stage_bytes(n * 32, flags) + 8192));
     hipStream_t st = ctx->lanes[lane].stream;
     const void *d = nullptr;
     KZG_TRY(stage_in(ctx, lane, data, n * 32, flags, &d));
@@ -1277,7 +1277,7 @@ extern "C" int kzg_verify_poly_eval(kzg_ctx *ctx, const kzg_srs *monomial, const
     if (d > monomial->n) return fail(ctx, KZG_ERR_SHAPE, "polynomial longer than the SRS (reference: slice index panic)");
     uint32_t log_d = (uint32_t)ilog2_ceil(d);
     if (log_d >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "domain too large");
-    KZG_TRY(lane_reserve(ctx, lane, msm_workspace_bytes(monomial, d) + 3 * d * 32 + 65536));
+    KZG_TRY(lane_reserve(ctx, lane, msm_workspace_bytes(monomial, d) + d * 32 + ntt_workspace_bytes(log_d) + 65536));
     hipStream_t st = ctx->lanes[lane].stream;
     Fr *work = (Fr *)lane_alloc(ctx, lane, d * 32);
     if (!work) return fail(ctx, KZG_ERR_ALLOC, "workspace");

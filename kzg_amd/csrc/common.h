@@ -360,6 +360,12 @@ void fixed_base_free(kzg_ctx *ctx);  // srs.hip
 
 // ntt.hip
 int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, size_t nnz = (size_t)-1);  // nnz: d_data[nnz ..) is zero (assumed, not read)
+// arena bytes ONE ntt_run of 2^log_n points takes from its lane (never returned before the call ends): the two-pass scratch; above
+// 2^24 the transposed copy, the inner transform's scratch and the outer twiddle tables
+inline size_t ntt_workspace_bytes(uint32_t log_n) {
+    const size_t n = (size_t)1 << log_n;
+    return log_n > 24 ? n * 32 + ((size_t)1 << 24) * 32 + (2 << 20) : n * 32 + 4096;
+}
 bool ntt_short_input_ok(uint32_t log_n, size_t nnz);  // ntt_run(..., nnz) will not read d_data[nnz ..)
 int pow_table(kzg_ctx *ctx, hipStream_t stream, const Fr &base_mont, const Fr &scale_mont, size_t count, Fr *d_out);
 Fr host_omega(uint32_t exp);  // Montgomery-form 2^exp-th root of unity per compute_omega (src/ft.rs:73)

@@ -340,9 +340,10 @@ extern "C" int kzg_poly_mul(kzg_ctx *ctx, const void *a, size_t na, const void *
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     uint32_t log_n = (uint32_t)ilog2_ceil(na + nb);   // from_coeffs(resize(n + k)) rounds up to 2^exp
-    if (log_n >= FR_TWO_ADICITY || log_n > 24) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    if (log_n > 27) return fail(ctx, KZG_ERR_SHAPE, "kzg_poly_mul: products of up to 2^27 coefficients");
     size_t N = (size_t)1 << log_n, nout = na + nb - 1;
-    KZG_TRY(lane_reserve(ctx, lane, 8 * N * 32 + (1 << 20)));
+    KZG_TRY(lane_reserve(ctx, lane, 4 * N * 32 + 3 * ntt_workspace_bytes(log_n) + (1 << 20)));
     hipStream_t st = ctx->lanes[lane].stream;
     Fr *A = (Fr *)lane_alloc(ctx, lane, N * 32), *Bv = (Fr *)lane_alloc(ctx, lane, N * 32), *ia = (Fr *)lane_alloc(ctx, lane, N * 32),
        *ib = (Fr *)lane_alloc(ctx, lane, N * 32);
@@ -374,9 +375,9 @@ extern "C" int kzg_coset_ntt_fr(kzg_ctx *ctx, void *data, uint32_t log_n, int in
     KZG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
     (void)sfmt;  // linear map with Montgomery constants: the data's form is preserved
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
-    if (log_n > 24) return fail(ctx, KZG_ERR_SHAPE, "coset NTT sizes above 2^24 are not supported");
+    if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "coset NTT sizes above 2^28 are not supported (as kzg_ntt_fr)");
     size_t n = (size_t)1 << log_n;
-    KZG_TRY(lane_reserve(ctx, lane, 2 * n * 32 + 65536));
+    KZG_TRY(lane_reserve(ctx, lane, ((flags & KZG_IN_DEVICE) ? 0 : n * 32) + ntt_workspace_bytes(log_n) + 65536));
     hipStream_t st = ctx->lanes[lane].stream;
     Fr *d = (flags & KZG_IN_DEVICE) ? (Fr *)data : (Fr *)lane_alloc(ctx, lane, n * 32);
     if (!d) return fail(ctx, KZG_ERR_ALLOC, "workspace");
@@ -464,11 +465,13 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     // ---- k >= 2 -----------------------------------------------------------------------------------
     const bool small_poly = k >= n;  // deg I = k-1 >= deg p: quotient is zero iff I == p
     uint32_t log_N = (uint32_t)ilog2_ceil(n > k + 1 ? n : k + 1);
-    if (log_N >= FR_TWO_ADICITY || log_N > 24) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    if (log_N >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
+    if (log_N > 26) return fail(ctx, KZG_ERR_SHAPE, "create_witness_batched: polynomials of up to 2^26 coefficients (the SRS with its window tables is 118 GB there)");
     size_t N = (size_t)1 << log_N;
     size_t nq = small_poly ? 0 : n - k;
     if (nq > sink.total) return fail(ctx, KZG_ERR_SHAPE, "quotient longer than the SRS (reference: slice index panic)");
-    size_t need = msm_workspace_bytes(srs, sink_len(nq) ? sink_len(nq) : 1) + 12 * N * 32 + (size_t)k * k * 32 + 64 * (k + 2) * 32 + (2 << 20);
+    size_t need = msm_workspace_bytes(srs, sink_len(nq) ? sink_len(nq) : 1) + 5 * N * 32 + 4 * ntt_workspace_bytes(log_N) + (size_t)k * k * 32 +
+                  64 * (k + 2) * 32 + (4 << 20);
     KZG_TRY(lane_reserve(ctx, lane, need));
     Fr *dx = (Fr *)lane_alloc(ctx, lane, k * 32), *dy = (Fr *)lane_alloc(ctx, lane, k * 32);
     Fr *z0 = (Fr *)lane_alloc(ctx, lane, (k + 1) * 32), *z1 = (Fr *)lane_alloc(ctx, lane, (k + 1) * 32);

@@ -144,3 +144,66 @@ def test_ntt_above_2_24(engine, log_n, full):
     inv_n = pow(n, -1, R)
     assert int.from_bytes(buf.download(1, offset=(n - i) % n), "little") == got[i] * inv_n % R
     buf.free()
+
+
+def test_coset_ntt_and_fft_mul_above_2_24(engine):
+    """coset_fft / icoset_fft (src/ft.rs:168-178) and fft_mul (src/polynomial.rs:167-183) beyond 2^24 (the reference's bound is
+    2^31; here 2^28 / 2^27 since round 4): at 2^25, coset outputs against direct Horner evaluation at 7 w^i by the oracle, the
+    round trip, and a product of two 2^24-coefficient polynomials checked by oracle evaluation."""
+    log_n = 25
+    n = 1 << log_n
+    buf = engine.alloc_scalars(n).fill_random(925)
+    a0 = buf.download()
+    assert engine.lib.kzg_coset_ntt_fr(engine.ctx, buf.ptr, log_n, 0, buf.sfmt, L.IN_DEVICE) == 0, engine.last_error()
+    _, _, omega = kzg_amd.compute_omega(n)
+    for i in (3, (n >> 1) + 7):
+        assert int.from_bytes(buf.download(1, offset=i), "little") == C.poly_eval_bytes(a0, n, 7 * pow(omega, i, R) % R), i
+    assert engine.lib.kzg_coset_ntt_fr(engine.ctx, buf.ptr, log_n, 1, buf.sfmt, L.IN_DEVICE) == 0, engine.last_error()
+    assert buf.download() == a0
+    # (p * q)(x) == p(x) q(x): p = the first 2^24 coefficients, q = the rest minus a few (the product has 2^25 - 9 coefficients)
+    na, nb = 1 << 24, (1 << 24) - 8
+    out = engine.alloc_scalars(na + nb - 1)
+    pa = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    pa.engine, pa.n, pa.sfmt, pa.ptr = engine, na, buf.sfmt, buf.ptr
+    pb = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+    pb.engine, pb.n, pb.sfmt, pb.ptr = engine, nb, buf.sfmt, ctypes.c_void_p(buf.ptr.value + 32 * na)
+    rc = engine.lib.kzg_poly_mul(engine.ctx, pa.ptr, na, pb.ptr, nb, buf.sfmt, L.IN_DEVICE | L.OUT_DEVICE, out.ptr)
+    assert rc == 0, engine.last_error()
+    prod = out.download()
+    x = kzg_amd.splitmix_scalar(926, 0)
+    assert C.poly_eval_bytes(prod, na + nb - 1, x) == C.poly_eval_bytes(a0[:32 * na], na, x) * C.poly_eval_bytes(a0[32 * na:32 * (na + nb)], nb, x) % R
+    out.free()
+    buf.free()
+
+
+def test_create_witness_batched_2_25(engine):
+    """create_witness_batched (src/coeff_form.rs:83-111) above the old 2^24 bound: degree 2^25 - 1, 64 opening points; the division's
+    transforms take the extra four-step level (ntt_run_large).  w == [(p(tau) - I(tau)) / Z(tau)]G with p(tau) by the oracle's Horner
+    loop on the downloaded coefficients; the opening values by the engine, two of them against the oracle (the identity holds only if
+    all are right); a wrong value is refused."""
+    TAU = 0x5EED5EED5EED5EED
+    n, k = 1 << 25, 64
+    params = kzg_amd.setup(engine, TAU, n, g2_len=0)
+    buf = engine.alloc_scalars(n).fill_random(2525)
+    raw = buf.download()
+    xs = [kzg_amd.splitmix_scalar(2526, i) for i in range(k)]
+    ys = [engine.poly_eval(buf, v) for v in xs]
+    assert all(C.poly_eval_bytes(raw, n, xs[i]) == ys[i] for i in (0, 63))
+    out = ctypes.create_string_buffer(96)
+    rbuf, rlen = ctypes.create_string_buffer(32 * k), ctypes.c_size_t()
+    rc = engine.lib.kzg_witness_coeff_batched(engine.ctx, params.gs.handle, buf.ptr, n, kzg_amd.pack_scalars(xs), kzg_amd.pack_scalars(ys), k,
+                                              buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
+    assert rc == 0 and rlen.value == k, engine.last_error()
+    I = kzg_amd.unpack_scalars(rbuf.raw)
+    assert all(C.poly_eval(I, xs[i]) == ys[i] for i in range(0, k, 9))
+    Z = 1
+    for v in xs:
+        Z = Z * (TAU - v) % R
+    ptau = C.poly_eval_bytes(raw, n, TAU)
+    assert out.raw == C.g1_mul(C.g1_generator(), (ptau - C.poly_eval(I, TAU)) * pow(Z, -1, R) % R)
+    ys[5] = (ys[5] + 1) % R
+    rc = engine.lib.kzg_witness_coeff_batched(engine.ctx, params.gs.handle, buf.ptr, n, kzg_amd.pack_scalars(xs), kzg_amd.pack_scalars(ys), k,
+                                              buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT, rbuf, ctypes.byref(rlen))
+    assert rc == L.KZG_ERR_POINT_NOT_ON_POLY
+    buf.free()
+    params.gs.free()

@@ -172,12 +172,13 @@ def test_documented_limits_return_shape_errors(engine):
     lib, ctx = engine.lib, engine.ctx
     buf = ctypes.create_string_buffer(64)
     # NTT: log_n < 32 by the field (PolynomialDegreeTooLarge), <= 28 by the engine (two LDS passes under one outer level of 16);
-    # the coset transform stops at 2^24
+    # so is the coset transform (round 4; 2^24 before)
     assert lib.kzg_ntt_fr(ctx, buf, 32, 0, 0) == L.KZG_ERR_DEGREE_TOO_LARGE
     assert lib.kzg_ntt_fr(ctx, buf, 29, 0, L.IN_DEVICE) == L.KZG_ERR_SHAPE
     assert "2^28" in engine.last_error()
-    assert lib.kzg_coset_ntt_fr(ctx, buf, 25, 0, L.FR_CANONICAL, L.IN_DEVICE) == L.KZG_ERR_SHAPE
-    assert "2^24" in engine.last_error()
+    assert lib.kzg_coset_ntt_fr(ctx, buf, 29, 0, L.FR_CANONICAL, L.IN_DEVICE) == L.KZG_ERR_SHAPE
+    assert "2^28" in engine.last_error()
+    assert lib.kzg_coset_ntt_fr(ctx, buf, 32, 0, L.FR_CANONICAL, L.IN_DEVICE) == L.KZG_ERR_DEGREE_TOO_LARGE
     # create_witness_batched: at most 4096 opening points
     params = kzg_amd.setup(engine, TAU, 8, g2_len=0)
     k = 4097
