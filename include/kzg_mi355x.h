@@ -63,7 +63,7 @@ extern "C" {
  *   kzg_witness_coeff_batched               polynomials of up to 2^26 coefficients (the SRS with its window tables is 118 GB there);
  *   kzg_verify_poly_eval                    as far as the monomial SRS goes (MSM limit below)
  *   kzg_witness_coeff_batched,
- *   kzg_verify_eval_batched                 k <= 4096 opening points          (single-workgroup interpolation kernels)
+ *   kzg_verify_eval_batched                 k <= 16384 opening points         (the interpolation works on a k x k matrix: 8.6 GB there)
  *   kzg_srs_lagrange_from_monomial_g1       d <= 2^24;  _g2: d <= 1024
  *   MSM                                     table rows x points < 2^31       (the sorted entry is a 31-bit table index + sign);
  *                                           window_bits 18, 19 (option), and 20 with option sort_single_pass: windows x points < 2^27
@@ -348,7 +348,7 @@ int kzg_verify_eval(kzg_ctx *ctx, const kzg_srs *gs, const kzg_srs_g2 *hs, const
                     const void *commitments, const void *witnesses, int pfmt, size_t count, uint8_t *ok);
 /* KZGVerifier::verify_eval_batched (src/coeff_form.rs:144-182): z = prod (X - xs[i]), hz = MSM(hs, z),
  * gr = MSM(gs, r) with r = witness.r (r_len = num_coeffs), *ok = e(w, hz) == e(C - gr, hs[0]).
- * KZG_ERR_SHAPE if k + 1 > len(hs) or r_len > len(gs) (slice index panics), k = 0, or k > 4096. */
+ * KZG_ERR_SHAPE if k + 1 > len(hs) or r_len > len(gs) (slice index panics), k = 0, or k > 16384. */
 int kzg_verify_eval_batched(kzg_ctx *ctx, const kzg_srs *gs, const kzg_srs_g2 *hs, const void *xs, size_t k,
                             const void *r_coeffs, size_t r_len, int sfmt, const void *commitment, const void *witness,
                             int pfmt, int *ok);

@@ -832,7 +832,7 @@ extern "C" int kzg_witness_coeff_batched_sharded(kzg_mctx *m, const kzg_msrs *sr
     if ((int)srs->shards.size() != m->nlocal()) return mfail(m, KZG_ERR_SHAPE, "SRS belongs to another group");
     if (!point_format_bytes(ofmt)) return mfail(m, KZG_ERR_SHAPE, "unknown G1 output format");
     if (flags & KZG_OUT_DEVICE) return mfail(m, KZG_ERR_SHAPE, "sharded create_witness_batched writes its result to host memory");
-    if (k == 0 || k > 4096) return mfail(m, KZG_ERR_SHAPE, "1 <= opening points <= 4096");
+    if (k == 0 || k > 16384) return mfail(m, KZG_ERR_SHAPE, "1 <= opening points <= 16384");
     KZG_TRY(mctx_buffers(m, 1));
     const size_t rl = k == 1 ? 2 : k;
     std::vector<std::vector<uint8_t>> rbuf(m->nlocal(), std::vector<uint8_t>(rl * 32));

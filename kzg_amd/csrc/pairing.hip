@@ -684,7 +684,7 @@ extern "C" int kzg_verify_eval_batched(kzg_ctx *ctx, const kzg_srs *gs, const kz
     size_t psz = point_format_bytes(pfmt);
     if (!psz || pfmt == KZG_G1_JACOBIAN_MONT_144) return fail(ctx, KZG_ERR_SHAPE, "commitment / witness are affine (G1Affine)");
     if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no points (reference: op_tree over an empty set panics)");
-    if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "batched verification is limited to 4096 points");
+    if (k > 16384) return fail(ctx, KZG_ERR_SHAPE, "batched verification is limited to 16384 points");
     if (k >= hs->n) return fail(ctx, KZG_ERR_SHAPE, "z longer than hs (reference: slice index panic)");
     if (r_len > gs->n) return fail(ctx, KZG_ERR_SHAPE, "witness.r longer than gs (reference: slice index panic)");
     KZG_TRY(lane_reserve(ctx, 0, msm_workspace_bytes(gs, r_len) + (k + 2) * (3 * 32 + sizeof(G2Jacobian)) + 64 * sizeof(G2Jacobian) +

@@ -123,7 +123,7 @@ static int coset_ntt_run(kzg_ctx *ctx, int lane, Fr *d, uint32_t log_n, int inve
 }
 
 // ---------------------------------------------------------------------------------------------
-// interpolation through k points (single workgroup kernels; k <= 4096)
+// interpolation through k points (k <= 16384: the k x k matrix of scaled quotients Z / (X - x_i) is 8.6 GB there)
 // ---------------------------------------------------------------------------------------------
 // Z = prod_i (X - x_i): z has k+1 coefficients.  One block of 1024 threads, ping-pong in global memory.
 __global__ __launch_bounds__(1024) void k_vanishing_poly(const Fr *xs, uint32_t k, Fr *z0, Fr *z1) {
@@ -237,9 +237,9 @@ __global__ __launch_bounds__(256) void k_inverse_each(const Fr *in, Fr *out, siz
 // division of k_bary_rows cut into chunks of CH coefficients.  One block per i, one thread per chunk c of the index range [0, k]:
 // local Horner value of the chunk (CH steps), suffix Horner over the chunks above (<= (k+1)/CH steps, X = x_i^CH) = the carry
 // entering the chunk, then the chunk's CH quotient coefficients: depth ~3 sqrt(k) instead of k.
-__global__ __launch_bounds__(128) void k_bary_rows_chunked(const Fr *xs, const Fr *ys, const Fr *den_inv, const Fr *z, uint32_t k,
+__global__ __launch_bounds__(256) void k_bary_rows_chunked(const Fr *xs, const Fr *ys, const Fr *den_inv, const Fr *z, uint32_t k,
                                                            uint32_t CH, uint32_t nch, Fr *rows) {
-    __shared__ Fr B[128];
+    __shared__ Fr B[256];
     const uint32_t i = blockIdx.x, c = threadIdx.x;
     const Fr xi = xs[i];
     const Fr ci = mul(ys[i], den_inv[i]);
@@ -425,7 +425,7 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     if (sfmt != KZG_FR_MONT_LE_32 && sfmt != KZG_FR_CANONICAL_LE_32) return fail(ctx, KZG_ERR_SHAPE, "unknown scalar format");
     if (!point_format_bytes(ofmt)) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 output format");
     if (k == 0) return fail(ctx, KZG_ERR_SHAPE, "no opening points (the reference recurses without bound on an empty slice)");
-    if (k > 4096) return fail(ctx, KZG_ERR_SHAPE, "create_witness_batched supports at most 4096 opening points (single-workgroup interpolation kernels)");
+    if (k > 16384) return fail(ctx, KZG_ERR_SHAPE, "create_witness_batched supports at most 16384 opening points (the interpolation works on a k x k matrix)");
     const int to_m = sfmt == KZG_FR_CANONICAL_LE_32;
     hipStream_t st = ctx->lanes[lane].stream;
 
@@ -526,10 +526,10 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     {
         uint32_t CH = 1;
         while ((uint64_t)CH * CH * 4 <= k) CH *= 2;             // CH = 2^floor(log2(k) / 2): 16 at k = 256, 64 at 4096
-        const uint32_t nch = (uint32_t)((k + 1 + CH - 1) / CH);  // <= 128 for k <= 4096 (k = 4095: CH = 32, nch = 128)
-        if (nch > 128) return fail(ctx, KZG_ERR_INTERNAL, "interpolation chunk count exceeds the kernel's LDS array (B[128])");
-        KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, nch <= 64 ? 64 : 128, 0, dx, dy, deni, z0, (uint32_t)k, CH, nch,
-                   rows);
+        const uint32_t nch = (uint32_t)((k + 1 + CH - 1) / CH);  // <= 256 for k <= 16384 (k = 16383: CH = 64, nch = 256)
+        if (nch > 256) return fail(ctx, KZG_ERR_INTERNAL, "interpolation chunk count exceeds the kernel's LDS array (B[256])");
+        KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, nch <= 64 ? 64 : (nch <= 128 ? 128 : 256), 0, dx, dy, deni, z0,
+                   (uint32_t)k, CH, nch, rows);
     }
     KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, rows, (uint32_t)k, I);
     // numerator and divisor on the coset g*H

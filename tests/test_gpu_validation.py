@@ -179,14 +179,14 @@ def test_documented_limits_return_shape_errors(engine):
     assert lib.kzg_coset_ntt_fr(ctx, buf, 29, 0, L.FR_CANONICAL, L.IN_DEVICE) == L.KZG_ERR_SHAPE
     assert "2^28" in engine.last_error()
     assert lib.kzg_coset_ntt_fr(ctx, buf, 32, 0, L.FR_CANONICAL, L.IN_DEVICE) == L.KZG_ERR_DEGREE_TOO_LARGE
-    # create_witness_batched: at most 4096 opening points
+    # create_witness_batched: at most 16384 opening points
     params = kzg_amd.setup(engine, TAU, 8, g2_len=0)
-    k = 4097
+    k = 16385
     xs = kzg_amd.pack_scalars(list(range(1, k + 1)))
     rlen = ctypes.c_size_t()
     rc = lib.kzg_witness_coeff_batched(ctx, params.gs.handle, kzg_amd.pack_scalars([1] * 8), 8, xs, xs, k, L.FR_CANONICAL, 0, buf,
                                        L.G1_AFFINE_MONT, ctypes.create_string_buffer(32 * k), ctypes.byref(rlen))
-    assert rc == L.KZG_ERR_SHAPE and "4096" in engine.last_error()
+    assert rc == L.KZG_ERR_SHAPE and "16384" in engine.last_error()
     # MSM range beyond the SRS, with an offset that would wrap in size_t
     out = ctypes.create_string_buffer(96)
     rc = lib.kzg_msm_g1(ctx, params.gs.handle, ctypes.c_size_t(2 ** 64 - 2), kzg_amd.pack_scalars([1] * 4), 4, L.FR_CANONICAL, 0, out,

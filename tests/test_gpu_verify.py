@@ -9,6 +9,7 @@ import pytest
 
 import kzg_amd
 from kzg_amd import _lib as L
+from oracle import c_oracle as C
 from oracle import kzg_model as M, pairing_model as P
 from tests.gpu_common import engine  # noqa: F401
 
@@ -237,5 +238,35 @@ def test_verify_eval_degenerate_secret(engine):
     assert w == g1b(wP)
     for pt in [(x, y), (x, (y + 1) % M.R), (0, 7), (0, 8)]:
         assert verifier.verify_eval(pt, c, w) == ov.verify_eval(pt, cP, wP), pt
+    params.gs.free()
+    params.hs.free()
+
+
+def test_batched_opening_5000_points_prover_and_verifier(engine):
+    """create_witness_batched + verify_eval_batched (src/coeff_form.rs:83-111, :144-182) with 5000 opening points -- above the 4096 the
+    interpolation kernels took until round 4 (limit now 16384).  The witness against the known-tau identity with p(tau), I(tau) by the
+    oracle; the interpolant at sampled opening points; the pairing check accepts it and rejects a shifted point set."""
+    rng = random.Random(71)
+    tau = rng.getrandbits(64)
+    n, k = 6000, 5000
+    params = kzg_amd.setup(engine, tau, n, g2_len=k + 1)
+    prover, verifier = kzg_amd.KZGProver(params), kzg_amd.KZGVerifier(params)
+    coeffs = [rng.randrange(M.R) for _ in range(n)]
+    p = kzg_amd.Polynomial(coeffs)
+    c = prover.commit(p)
+    xs = [rng.randrange(M.R) for _ in range(k)]
+    ys = [C.poly_eval(coeffs, x) for x in xs]
+    w = prover.create_witness_batched(p, xs, ys)
+    I = list(w.r.coeffs)
+    assert len(I) == k and all(C.poly_eval(I, xs[i]) == ys[i] for i in range(0, k, 499))
+    Z = 1
+    for x in xs:
+        Z = Z * (tau - x) % M.R
+    assert w.w == C.g1_mul(C.g1_generator(), (C.poly_eval(coeffs, tau) - C.poly_eval(I, tau)) * pow(Z, -1, M.R) % M.R)
+    assert verifier.verify_eval_batched(xs, c, w)
+    assert not verifier.verify_eval_batched([(x + 1) % M.R for x in xs], c, w)
+    ys[1234] = (ys[1234] + 1) % M.R
+    with pytest.raises(kzg_amd.PointNotOnPolynomial):
+        prover.create_witness_batched(p, xs, ys)
     params.gs.free()
     params.hs.free()
