@@ -381,7 +381,9 @@ int kzg_dev_download(kzg_ctx *ctx, void *dst_host, const void *src_dev, size_t b
  * `u64_valued` != 0 mirrors the reference benches' u64-valued coefficients,
  * benches/commit_coeff_form.rs:16-21).  Output canonical or Montgomery per sfmt. */
 int kzg_fill_random_fr(kzg_ctx *ctx, void *dst_dev, size_t n, uint64_t seed, int u64_valued, int sfmt);
-/* Per-kernel HIP-event timing on the stream the kernels run on (for bench.py's roofline line). */
+/* Per-kernel HIP-event timing on the stream the kernels run on (for bench.py's roofline line).  on = 1: every kernel; on = 2: the
+ * bucket-accumulation kernel only (two events per launch of all ~14 kernels of an MSM cost 1.4 % of the batched rate, one pair per
+ * MSM does not); 0: off. */
 int kzg_prof_enable(kzg_ctx *ctx, int on);
 int kzg_prof_reset(kzg_ctx *ctx);
 int kzg_prof_get(kzg_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms);

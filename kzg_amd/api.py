@@ -151,7 +151,8 @@ class Engine:
 
     # --- profiling ---
     def prof_enable(self, on=True):
-        self.lib.kzg_prof_enable(self.ctx, 1 if on else 0)
+        """True / 1: HIP events around every kernel; 2: around the bucket-accumulation kernel only; False / 0: off"""
+        self.lib.kzg_prof_enable(self.ctx, int(on))
 
     def prof_reset(self):
         self.lib.kzg_prof_reset(self.ctx)

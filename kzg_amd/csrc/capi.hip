@@ -64,6 +64,7 @@ static hipEvent_t get_event(kzg_ctx *ctx) {  // prof_mu held
 
 ProfScope::ProfScope(kzg_ctx *c, hipStream_t s, const char *n) : ctx(c), stream(s), name(n) {
     if (!ctx->prof) return;
+    if (ctx->prof_only_accum && strcmp(n, "k_accum_affine") != 0) return;  // kzg_prof_enable(ctx, 2): the dominant kernel only
     {
         std::lock_guard<std::mutex> lk(ctx->prof_mu);
         start = get_event(ctx);
@@ -464,6 +465,7 @@ extern "C" int kzg_prof_enable(kzg_ctx *ctx, int on) {
     if (!ctx) return KZG_ERR_SHAPE;
     Guard g(ctx);
     ctx->prof = on != 0;
+    ctx->prof_only_accum = on == 2;
     return KZG_OK;
 }
 extern "C" int kzg_prof_reset(kzg_ctx *ctx) {

@@ -142,6 +142,7 @@ struct kzg_ctx {
     std::atomic<bool> attr_msm_set{false}, attr_ntt_set{false}, attr_wide_set{false}, attr_sort20_set{false};  // > 64 KiB dynamic-LDS opt-in done for this device
     // profiling
     bool prof = false;
+    bool prof_only_accum = false;  // events around k_accum_affine only (bench.py's timed region: two events per kernel launch cost 1.4 % there)
     std::map<std::string, kzg::ProfEntry> prof_map;
     std::vector<kzg::PendingEvent> prof_pending;
     std::vector<hipEvent_t> event_pool;

@@ -122,7 +122,7 @@ __global__ __launch_bounds__(SCAN_SEG) void k_scan_b(const uint32_t *total, cons
     }
     __syncthreads();
     uint32_t E = (M + slots - 1) / slots;
-    if (E < 8) E = 8;
+    if (E < KZG_ACCUM_MIN_CHUNK) E = KZG_ACCUM_MIN_CHUNK;
     const double rcp_e = 1.0 / (double)E;
     const int b = blockIdx.x * SCAN_SEG + threadIdx.x;
     uint32_t start = 0, f = 0;
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(SCAN_SEG) void k_scan_b_bins(const uint32_t *total,
     const uint32_t M = bin_base[NBINS];
     const uint32_t my_prefix = bin_base[blockIdx.x * (SCAN_SEG / BIN_BUCKETS)];
     uint32_t E = (M + slots - 1) / slots;
-    if (E < 8) E = 8;
+    if (E < KZG_ACCUM_MIN_CHUNK) E = KZG_ACCUM_MIN_CHUNK;
     const double rcp_e = 1.0 / (double)E;
     const int b = blockIdx.x * SCAN_SEG + threadIdx.x;
     const uint32_t cnt = b < B ? total[b] : 0u;
@@ -780,7 +780,7 @@ static WideLayout wide_layout(const kzg_srs *srs, size_t n) {
 
 // round-1 partials the equal split is expected to emit (one per thread that gets work + one per bucket boundary inside a chunk)
 static size_t expected_partials(size_t M_max, uint32_t slots, int B) {
-    size_t thr = M_max / 8 + 1 < (size_t)slots ? M_max / 8 + 1 : (size_t)slots;
+    size_t thr = M_max / KZG_ACCUM_MIN_CHUNK + 1 < (size_t)slots ? M_max / KZG_ACCUM_MIN_CHUNK + 1 : (size_t)slots;
     return thr + (size_t)B;
 }
 
@@ -829,7 +829,7 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     KZG_TRY(wide_sort_pass2(ctx, st, entries1, state, nhi, blockcnt, binbase, lo_start, B_lo, entries2, bucket_start));
     // equal-split layout of round 1 over the full bucket set
     KZG_TRY(wide_s1_layout(ctx, st, bucket_start, Btot, state, segsums, segmaxs, segtotal, s1));
-    size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
+    size_t thr1 = L.M_max / KZG_ACCUM_MIN_CHUNK + 1 < (size_t)slots ? L.M_max / KZG_ACCUM_MIN_CHUNK + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
     KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, s1, Btot,
                (const uint4 *)srs->table30, bufA, state);
@@ -995,7 +995,7 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
                        bucket_start, (uint32_t)srs->npad, (uint32_t)offset, entries, mode, w_lo, w_hi);
         }
         // grid covers ceil(M/E) <= max(ACC_SLOTS, M_max/8) threads
-        size_t thr1 = L.M_max / 8 + 1 < (size_t)slots ? L.M_max / 8 + 1 : (size_t)slots;
+        size_t thr1 = L.M_max / KZG_ACCUM_MIN_CHUNK + 1 < (size_t)slots ? L.M_max / KZG_ACCUM_MIN_CHUNK + 1 : (size_t)slots;
         unsigned grid1 = (unsigned)((thr1 + 255) / 256);
         if (accum_stream && accum_stream != st) {
             // wait / launch / record on the shared FIFO stream is one unit: with concurrent callers the three must not

@@ -16,6 +16,13 @@
 #define KZG_SIDE_PRIO_STMT ((void)0)
 #endif
 
+// Fewest sorted entries one thread of k_accum_affine folds (the equal-split chunk E = max(ceil(M / resident threads), this)): a thread
+// pays a bucket search, its first gathers and a 224-byte partial whatever its share, and every thread beyond the first of a bucket is
+// one more addition for the fold.
+#ifndef KZG_ACCUM_MIN_CHUNK
+#define KZG_ACCUM_MIN_CHUNK 8
+#endif
+
 namespace kzg {
 
 constexpr uint32_t ACC_SLOTS = 256 * 4 * KZG_ACCUM_WAVES * 64;  // resident threads of k_accum_affine: 256 CUs x 4 SIMDs x waves/SIMD x 64

@@ -447,7 +447,7 @@ __global__ __launch_bounds__(SORT2_THREADS) void k_bin_sort2(const typename REC:
     if (st && blockIdx.x == 0 && tid == 0) {
         const uint32_t M = bin_base[NBINS];
         uint32_t E = (M + slots - 1) / slots;
-        if (E < 8) E = 8;
+        if (E < KZG_ACCUM_MIN_CHUNK) E = KZG_ACCUM_MIN_CHUNK;
         st->M = M;
         st->E = E;
         st->ntasks = (M + E - 1) / E;

@@ -10,7 +10,6 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 lib_path = os.path.abspath(sys.argv[1])
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[2:]
-import torch  # noqa: E402,F401  (first: PyTorch must bring its own HIP runtime in before the library pulls the system one)
 from kzg_amd import _lib as L  # noqa: E402
 
 L.load(lib_path)
