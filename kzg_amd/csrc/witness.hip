@@ -43,14 +43,18 @@ __global__ __launch_bounds__(256) void k_numerator_on_coset(const Fr *p, size_t 
                                                             const Fr *lo_tab, const Fr *hi_tab, Fr gT, size_t T) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T || t >= N) return;
-    Fr u = mul(hi_tab[t >> 10], lo_tab[t & (DP_TAB - 1)]);
+    const bool scale = lo_tab != nullptr;  // nullptr: the shift is 1 (plain domain), nothing to multiply by
+    Fr u = scale ? mul(hi_tab[t >> 10], lo_tab[t & (DP_TAB - 1)]) : Fr::one();
     for (size_t i = t; i < N; i += T) {
         if (i < n) {
             Fr v = p[i];
             if (to_m) v = to_mont(v);
             if (i < k) v = sub(v, I[i]);
-            A[i] = mul(v, u);
-            u = mul(u, gT);
+            if (scale) {
+                v = mul(v, u);
+                u = mul(u, gT);
+            }
+            A[i] = v;
         } else {
             A[i] = Fr::zero();
         }
@@ -91,7 +95,7 @@ static int numerator_on_coset(kzg_ctx *ctx, hipStream_t st, const Fr *p, size_t 
     T = (T + 255) / 256 * 256;
     if (T > DP_TAB * DP_TAB) T = DP_TAB * DP_TAB;
     const Fr *lo_tab = nullptr, *hi_tab = nullptr;
-    KZG_TRY(coset_tables(ctx, st, g, &lo_tab, &hi_tab));
+    if (!(g == Fr::one())) KZG_TRY(coset_tables(ctx, st, g, &lo_tab, &hi_tab));
     KZG_LAUNCH(ctx, st, "k_numerator_on_coset", k_numerator_on_coset, (unsigned)(T / 256), 256, 0, p, n, I, k, A, N, to_m, lo_tab, hi_tab,
                pow_u64(g, (uint64_t)T), T);
     return KZG_OK;
@@ -114,12 +118,13 @@ static int distribute_powers(kzg_ctx *ctx, hipStream_t st, Fr *d, size_t n, cons
 static int coset_ntt_run(kzg_ctx *ctx, int lane, Fr *d, uint32_t log_n, int inverse, const Fr &g, size_t nnz = (size_t)-1) {
     hipStream_t st = ctx->lanes[lane].stream;
     size_t n = (size_t)1 << log_n;
+    const bool unit = g == Fr::one();  // the "coset" 1 * H: the plain transform (create_witness_batched's first choice of a shift)
     if (!inverse) {
-        KZG_TRY(distribute_powers(ctx, st, d, nnz < n ? nnz : n, g));
+        if (!unit) KZG_TRY(distribute_powers(ctx, st, d, nnz < n ? nnz : n, g));
         return ntt_run(ctx, lane, d, log_n, 0, nnz);
     }
     KZG_TRY(ntt_run(ctx, lane, d, log_n, 1));
-    return distribute_powers(ctx, st, d, n, inv(g));
+    return unit ? (int)KZG_OK : distribute_powers(ctx, st, d, n, inv(g));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -489,10 +494,11 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         KZG_TRY(fr_convert(ctx, st, dx, k, 1));
         KZG_TRY(fr_convert(ctx, st, dy, k, 1));
     }
-    // pick a coset shift on which Z has no root: g = 7, then 7^2, ...  An opening point inside g*H (x = 7 is
-    // one) would make Z vanish there; the cosets 7^j*H are pairwise distinct, so at most k candidates fail.  This is the one
-    // host round trip of the call, so it comes first, while the stream holds nothing but the upload of the points.
-    Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = g1;
+    // pick a shift g on whose coset g*H Z has no root: g = 1 first -- H itself, no scaling passes at all (two passes over N elements
+    // saved whenever no opening point is an N-th root of unity) --, then 7, 7^2, ...  An opening point inside g*H (x = 1 or a power of
+    // omega for H, x = 7 for 7*H) would make Z vanish there; the cosets 7^j*H are pairwise distinct, so at most k + 1 candidates fail.
+    // This is the one host round trip of the call, so it comes first, while the stream holds nothing but the upload of the points.
+    Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = Fr::one();
     if (!small_poly) {
         int *cflag = (int *)lane_alloc(ctx, lane, 256);
         if (!cflag) return fail(ctx, KZG_ERR_ALLOC, "workspace");
@@ -503,7 +509,7 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
             KZG_HIP_CHECK(ctx, hipMemcpyAsync(&on, cflag, sizeof(int), hipMemcpyDeviceToHost, st));
             KZG_HIP_CHECK(ctx, hipStreamSynchronize(st));
             if (!on) break;
-            if (attempt > k) return fail(ctx, KZG_ERR_INTERNAL, "no usable coset shift");
+            if (attempt > k + 1) return fail(ctx, KZG_ERR_INTERNAL, "no usable coset shift");
             gsh = mul(gsh, g1);
         }
     }

@@ -243,11 +243,43 @@ def test_create_witness_batched_edge_cases(engine):
     # opening points ON the cosets 7*H, 7^2*H the (p - I)/Z division would evaluate on (7 = the coset shift itself):
     # the engine must move to a coset without roots of Z; results equal the oracle's schoolbook division
     w16 = pow(M.FR_ROOT_OF_UNITY, 1 << (M.FR_S - 4), M.R)
-    for xs in ([5, 6, 7], [7, 49, 7 * w16 % M.R], [49 * w16 % M.R, 343, 11]):
+    # (round 4: the first choice is the plain domain H itself -- no scaling passes -- so openings AT roots of unity, the usual case
+    # of an evaluation-form protocol, are the ones that move on: x = 1, w^3, both together with 7 and 49 -> 7^3 * H)
+    for xs in ([5, 6, 7], [7, 49, 7 * w16 % M.R], [49 * w16 % M.R, 343, 11], [1, 5, 6], [pow(w16, 3, M.R), 2, 3], [1, 7, w16, 49 * w16 % M.R],
+               [w16, pow(w16, 2, M.R), pow(w16, 15, M.R)]):
         ys = [C.poly_eval(coeffs, x) for x in xs]
         wit = prover.create_witness_batched(p, xs, ys)
         Ir, w = _batched_oracle(coeffs, xs, ys, tau)
         assert wit.elem() == w and wit.polynomial().coeffs == Ir.coeffs, xs
+    params.gs.free()
+
+
+def test_create_witness_batched_openings_at_roots_of_unity_2_17(engine):
+    """Openings at points of the evaluation domain itself (x_i = w^(m_i), what an evaluation-form protocol opens at): Z vanishes on
+    H, so the division moves to the coset 7 * H; a second polynomial opened at random points stays on H.  Both against the known-tau
+    identity with oracle-evaluated p(tau), I(tau); two-pass transforms, Z through the short-input path."""
+    n, k = 1 << 17, 40
+    tau = 0x1234567
+    params = kzg_amd.setup(engine, tau, n, g2_len=0)
+    prover = kzg_amd.KZGProver(params)
+    buf = engine.alloc_scalars(n).fill_random(1717)
+    raw = buf.download()
+    coeffs = kzg_amd.unpack_scalars(raw)
+    _, _, omega = kzg_amd.compute_omega(n)
+    rng = random.Random(1718)
+    G = C.g1_generator()
+    ptau = C.poly_eval_bytes(raw, n, tau)
+    for xs in ([pow(omega, rng.randrange(n), M.R) for _ in range(k)], rand_scalars(rng, k)):
+        xs = list(dict.fromkeys(xs))
+        ys = [C.poly_eval_bytes(raw, n, x) for x in xs]
+        wit = prover.create_witness_batched(kzg_amd.Polynomial(coeffs), xs, ys)
+        I = list(wit.polynomial().coeffs)
+        assert all(C.poly_eval(I, x) == y for x, y in zip(xs, ys))
+        Z = 1
+        for x in xs:
+            Z = Z * (tau - x) % M.R
+        assert wit.elem() == C.g1_mul(G, (ptau - C.poly_eval(I, tau)) * pow(Z, -1, M.R) % M.R)
+    buf.free()
     params.gs.free()
 
 
