@@ -618,6 +618,7 @@ def main():
     ap.add_argument("--no-sharded-block", action="store_true", help="N>1: skip the `sharded` block")
     ap.add_argument("--sharded-batch", type=int, default=16)
     ap.add_argument("--sharded-steps", type=int, default=3)
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds the sharded block may take before the line is printed without it")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -858,11 +859,6 @@ def main():
                                          "hbm_frac": round(BYTES_PER_TERM * n_local / k_s / 1e9 / HBM_PEAK_GBS, 5),
                                          "kernel_ms_single_msm": {k: round(v[1] / l2, 4) for k, v in sorted(pa.items())}}
 
-    sharded_res = None
-    if want_block:
-        # every rank takes part (collective); rank 0 prints.  After the timed region and its check, before the single-GPU paths.
-        sharded_res = measure_sharded_block(kzg_amd, L, job, args, force_gather=(world == 1))
-
     if rank == 0:
         value = units_per_step * args.steps / dt
         workloads = {
@@ -914,11 +910,6 @@ def main():
         res["hip_runtime"] = job.runtime(kzg_amd, L)
         if roofline:
             res["roofline"] = roofline
-        if sharded_res is not None:
-            res["sharded"] = sharded_res
-            res["headline"] = ("value = data-parallel replicas (the throughput answer for independent degree-2^20 commitments: a 2 GiB SRS "
-                               "fits every GPU); sharded.strong / sharded.config5 = the sharded-SRS + RCCL design north_star names, "
-                               "measured in the same process")
         t_extra = time.perf_counter()
         if mode == "single" and not args.no_paths:
             try:
@@ -967,6 +958,29 @@ def main():
         line = json.dumps(res)
     if cpu is not None:
         cpu.close()
+    if want_block:
+        # The sharded-SRS + RCCL modes, measured by every rank together after everything else (collective).  `value` above is already
+        # final: if forming the group or an exchange hangs (a dead peer, a broken fabric), a watchdog prints the line without the
+        # block after --sharded-timeout seconds and ends the process on every rank -- the default multi-GPU run never loses its
+        # number to the extra measurement.  (Inside the library every exchange has its own deadline: gather_timeout_ms.)
+        import threading
+
+        def bail():
+            if rank == 0:
+                res["sharded"] = {"note": "the sharded block did not finish within %d s (group formation or an exchange hung); not measured" % args.sharded_timeout}
+                os.write(real_stdout, (json.dumps(res) + "\n").encode())
+            os._exit(0)
+        dog = threading.Timer(args.sharded_timeout, bail)
+        dog.daemon = True
+        dog.start()
+        sharded_res = measure_sharded_block(kzg_amd, L, job, args, force_gather=(world == 1))
+        dog.cancel()
+        if rank == 0:
+            res["sharded"] = sharded_res
+            res["headline"] = ("value = data-parallel replicas (the throughput answer for independent degree-2^20 commitments: a 2 GiB SRS "
+                               "fits every GPU); sharded.strong / sharded.config5 = the sharded-SRS + RCCL design north_star names, "
+                               "measured in the same process")
+            line = json.dumps(res)
     # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's own
     # output when a process exits: every rank flushes it before the last barrier, so that rank 0's JSON line ends the output
     sys.stdout.flush()
