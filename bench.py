@@ -408,6 +408,64 @@ def measure_spots(kzg_amd, L, engine, budget_ok):
     return res
 
 
+def pmc_child(log_n):
+    """The workload a `rocprofv3 --kernel-trace --pmc <counter> -- python3 bench.py --pmc-child <log_n>` pass of THIS script
+    profiles (measure_traffic_pmc below starts it as a child process): a few lone degree-2^log_n commitments on uniform scalars
+    resident in HBM -- k_accum_affine launches of exactly the shape the timed region runs."""
+    import kzg_amd
+    from kzg_amd import _lib as L
+    e = kzg_amd.Engine(0)
+    n = 1 << log_n
+    params = kzg_amd.setup(e, TAU, n, g2_len=0)
+    sc = e.alloc_scalars(n).fill_random(SEED)
+    out = ctypes.create_string_buffer(96)
+    for _ in range(4):
+        assert e.lib.kzg_msm_g1(e.ctx, params.gs.handle, 0, sc.ptr, n, sc.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT) == 0, e.last_error()
+    sc.free()
+    params.gs.free()
+    e.close()
+
+
+def measure_traffic_pmc(log_n, timeout_s=150):
+    """HBM bytes per k_accum_affine launch from the PMC counters, collected the way MI355X_MICROARCH.md prescribes: two separate
+    rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE, then WRITE_SIZE: they do not fit one pass on gfx950) of a child process
+    running pmc_child, FETCH_SIZE doubled (gfx950 tallies the 128-byte requests of wide loads at 64 bytes), units of KB.  Returns
+    (dict or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rp:
+        return None, "rocprofv3 not found"
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="kzg_pmc_", dir="/tmp")
+        try:
+            cmd = [rp, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--", sys.executable,
+                   os.path.join(ROOT, "bench.py"), "--pmc-child", str(log_n)]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=timeout_s)
+            tot, cnt = 0.0, 0
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_accum_affine" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        tot += float(row["Counter_Value"])
+                        cnt += 1
+            if not cnt:
+                return None, "%s pass produced no k_accum_affine rows (rc %d): %s" % (ctr, r.returncode, (r.stderr or "")[-200:])
+            vals[ctr] = (tot / cnt, cnt)
+        except Exception as e:  # noqa: BLE001
+            return None, "%s pass failed: %s" % (ctr, e)
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    f_kb, w_kb = vals["FETCH_SIZE"][0], vals["WRITE_SIZE"][0]
+    return {"bytes_per_launch": int(round((2 * f_kb + w_kb) * 1024)), "raw_fetch_kb": round(f_kb, 1), "raw_write_kb": round(w_kb, 1),
+            "launches_sampled": vals["FETCH_SIZE"][1],
+            "method": "two rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE, WRITE_SIZE) of a child process running lone 2^%d commitments, "
+                      "collected during this bench run; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB (gfx950 correction of "
+                      "MI355X_MICROARCH.md)" % log_n}, None
+
+
 class Job:
     """The ranks of one bench run.  World 1 needs no torch at all ("PyTorch is not needed"): barrier = the
     engine's own device synchronisation.  World > 1: torch.distributed carries the barriers, the max-over-ranks time and the small
@@ -618,8 +676,13 @@ def main():
     ap.add_argument("--no-sharded-block", action="store_true", help="N>1: skip the `sharded` block")
     ap.add_argument("--sharded-batch", type=int, default=16)
     ap.add_argument("--sharded-steps", type=int, default=3)
+    ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: the workload of measure_traffic_pmc's rocprofv3 passes
+    ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds the sharded block may take before the line is printed without it")
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args.pmc_child)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -942,6 +1005,20 @@ def main():
             res["paths"]["blocking_callers_16_witness_batched_k%d_per_s" % kb] = round(per_s, 2)
             res["paths"]["blocking_callers_16_witness_batched_vs_value"] = round(per_s / value, 4)
             res["paths"]["blocking_callers_16_witness_batched_match_lone_calls"] = same
+        if mode == "single" and roofline and not args.no_paths and not args.no_traffic and not args.u64:
+            tr, note = measure_traffic_pmc(args.log_n)
+            if tr is not None:
+                alg = BYTES_PER_TERM * n_local
+                tr["ratio_to_algorithmic"] = round(tr["bytes_per_launch"] / alg, 2)
+                res["roofline"]["traffic"] = tr["bytes_per_launch"]
+                res["roofline"]["hbm"]["traffic"] = tr["bytes_per_launch"]
+                res["roofline"]["traffic_measured"] = tr
+                alone = res["roofline"].get("alone")
+                if alone:
+                    alone["hbm_real_gbs"] = round(tr["bytes_per_launch"] / (alone["avg_kernel_ms"] / 1e3) / 1e9, 1)
+                    alone["hbm_real_frac"] = round(tr["bytes_per_launch"] / (alone["avg_kernel_ms"] / 1e3) / 1e9 / HBM_PEAK_GBS, 4)
+            else:
+                res["roofline"]["traffic_note"] = note
         if mode == "single" and not args.no_cpu_baseline:
             if cpu is not None:
                 try:

@@ -57,3 +57,21 @@ def test_bench_sharded_block_world1_and_no_torch():
     assert sh["config5"]["terms_per_rank"] == 1 << 21 and sh["config5"]["polynomial_coefficients"] == 1 << 21
     for mode in ("strong", "config5"):
         assert sh[mode]["all_results_match_known_tau"] is True and sh[mode]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_live_pmc_traffic():
+    """roofline.traffic: HBM bytes per launch of the dominant kernel from the PMC counters, collected DURING the bench run by two
+    child rocprofv3 passes (FETCH_SIZE, WRITE_SIZE; gfx950 correction) -- not a number copied from profiles/.  Small size here;
+    the figure must be a positive byte count of the order of (table rows x 128 B + 4 B) per sorted entry."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8", "--log-n", "16", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    rf = d["roofline"]
+    assert isinstance(rf["traffic"], int) and rf["traffic"] > 0, rf.get("traffic_note")
+    tm = rf["traffic_measured"]
+    assert tm["launches_sampled"] >= 1 and "rocprofv3" in tm["method"]
+    entries = (1 << 16) * d["config"]["windows"]
+    assert 64 * entries < rf["traffic"] < 512 * entries
+    assert rf["frac_of_nominal"] > 0 and d["paths"]["ntt_2e16_ms"] > 0
