@@ -674,7 +674,7 @@ def main():
                     help="measure the `sharded` block (strong + config5 through the device group) after the timed region even at world "
                          "size 1 (RCCL all-gather forced on); at N > 1 the block is part of the default run")
     ap.add_argument("--no-sharded-block", action="store_true", help="N>1: skip the `sharded` block")
-    ap.add_argument("--sharded-batch", type=int, default=16)
+    ap.add_argument("--sharded-batch", type=int, default=64, help="commitments per step of the sharded block (as --batch)")
     ap.add_argument("--sharded-steps", type=int, default=3)
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: the workload of measure_traffic_pmc's rocprofv3 passes
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
@@ -1035,12 +1035,19 @@ def main():
         line = json.dumps(res)
     if cpu is not None:
         cpu.close()
+    main_closed = False
     if want_block:
         # The sharded-SRS + RCCL modes, measured by every rank together after everything else (collective).  `value` above is already
         # final: if forming the group or an exchange hangs (a dead peer, a broken fabric), a watchdog prints the line without the
         # block after --sharded-timeout seconds and ends the process on every rank -- the default multi-GPU run never loses its
         # number to the extra measurement.  (Inside the library every exchange has its own deadline: gather_timeout_ms.)
         import threading
+        # the main engine goes first: its 16 lanes + 2 accumulation streams hold hardware queues the group's own context needs (two
+        # contexts' streams on one queue pool: the second one measures the sharing and narrows its pipeline, -12 % at world 1)
+        job.engines.remove(engine)
+        scal.free()
+        engine.close()
+        main_closed = True
 
         def bail():
             if rank == 0:
@@ -1067,11 +1074,12 @@ def main():
         pass
     if dist is not None:
         dist.barrier()
-    scal.free()
     if group is not None:
+        scal.free()
         msrs.free()
         group.close()
-    else:
+    elif not main_closed:
+        scal.free()
         engine.close()
     job.close()
     if rank == 0:
