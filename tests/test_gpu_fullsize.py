@@ -106,14 +106,19 @@ def test_sort_variants_and_batch_tail_agree_2_20(engine, big):
             v = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
             v.engine, v.n, v.sfmt, v.ptr = engine, n, rep.sfmt, ctypes.c_void_p(rep.ptr.value + 32 * n * j)
             v.upload(hipcpy)
-        out = ctypes.create_string_buffer(96 * 6)
-        rc = engine.lib.kzg_msm_g1_batch(engine.ctx, params.gs.handle, 0, rep.ptr, n, 6, rep.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
-        assert rc == 0, engine.last_error()
-        assert [out.raw[96 * j:96 * j + 96] for j in range(6)] == [want[j % 3] for j in range(6)]
+        # (deferred tails, round 4: with more MSMs than lanes a lane's tail is enqueued after the sort of its next MSM -- two in flight
+        # per lane, the arena's two halves; and the same batch with every tail right behind its accumulation)
+        for defer in (1, 0):
+            engine.set_option("defer_tail", defer)
+            out = ctypes.create_string_buffer(96 * 6)
+            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, params.gs.handle, 0, rep.ptr, n, 6, rep.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+            assert rc == 0, engine.last_error()
+            assert [out.raw[96 * j:96 * j + 96] for j in range(6)] == [want[j % 3] for j in range(6)], defer
         rep.free()
     finally:
         engine.set_option("sort_single_pass", 0)
         engine.set_option("tail_quads", 1)
+        engine.set_option("defer_tail", 1)
         engine.set_option("streams", 8)
     for b in bufs:
         _fresh(b); b.free()
