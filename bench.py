@@ -471,7 +471,7 @@ class Job:
     engine's own device synchronisation.  World > 1: torch.distributed carries the barriers, the max-over-ranks time and the small
     host objects of the checks; the data-path collective is inside the library (kzg_mctx, RCCL)."""
 
-    def __init__(self, rank, local_rank, world, use_torch):
+    def __init__(self, rank, local_rank, world, use_torch, backend="gloo"):
         self.rank, self.local_rank, self.world = rank, local_rank, world
         self.torch = self.dist = None
         self.red_dev = "cpu"
@@ -491,16 +491,20 @@ class Job:
         os.environ.setdefault("WORLD_SIZE", "1")
         import torch.distributed as dist
         self.dist = dist
-        if os.environ.get("KZG_BENCH_SHARED_GPU"):
-            # test mode for a one-GPU box: every rank on device 0, gloo for the barriers (RCCL refuses two ranks on one GPU).
-            # Exercises the N > 1 control flow of the replicas mode; the numbers mean nothing.
+        # The process group is the CONTROL plane only (barriers, the max-over-ranks time, the small host objects of the checks): gloo
+        # on CPU tensors.  The data-path collective is the library's own RCCL communicator (kzg_mctx), and a second, idle NCCL
+        # communicator of torch's on the same GPU costs it dearly: with torch's nccl process group alive the device-group path
+        # measured 361 commitments/s against 454 without (one GPU, RCCL all-gather forced on; profiles/r04_torch_pg_interference.txt),
+        # while the plain path is unaffected.  --torch-backend nccl restores the old control plane.
+        shared = bool(os.environ.get("KZG_BENCH_SHARED_GPU"))   # test mode for a one-GPU box: every rank on device 0
+        if shared:
             self.local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), rank=rank, world_size=world)
+        torch.cuda.set_device(self.local_rank)
+        if backend == "nccl" and not shared:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", self.local_rank), rank=rank, world_size=world)
             self.red_dev = "cuda"   # where the timing / agreement reductions live
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     def barrier(self):
         if self.dist is not None:
@@ -677,6 +681,9 @@ def main():
     ap.add_argument("--sharded-batch", type=int, default=64, help="commitments per step of the sharded block (as --batch)")
     ap.add_argument("--sharded-steps", type=int, default=3)
     ap.add_argument("--pmc-child", type=int, default=0, help=argparse.SUPPRESS)   # internal: the workload of measure_traffic_pmc's rocprofv3 passes
+    ap.add_argument("--torch-backend", default="gloo", choices=["gloo", "nccl"],
+                    help="N>1: backend of the torch process group that carries barriers and timing reductions (the data-path collective is the "
+                         "library's own RCCL communicator either way)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
     ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds the sharded block may take before the line is printed without it")
     args = ap.parse_args()
@@ -709,7 +716,7 @@ def main():
 
     # torch only where there is more than one rank (process group) or the torch-carried group hand-off is the thing under test
     # (--sharded).  At N = 1 the library is the only thing that loads a HIP runtime: the system's.
-    job = Job(rank, local_rank, world, use_torch=(world > 1 or sharded))
+    job = Job(rank, local_rank, world, use_torch=(world > 1 or sharded), backend=args.torch_backend)
     local_rank = job.local_rank
     dist = job.dist
     import kzg_amd
@@ -750,6 +757,8 @@ def main():
     if sharded:
         if world == 1:
             group.set_option("always_gather", 1)     # --sharded at N = 1 exercises the RCCL exchange
+        if os.environ.get("KZG_GATHER_TIMEOUT_MS"):  # experiments: the exchange wait's deadline (0 = plain hipStreamSynchronize)
+            group.set_option("gather_timeout_ms", int(os.environ["KZG_GATHER_TIMEOUT_MS"]))
         engine = group.engine(0)
     else:
         engine = kzg_amd.Engine(local_rank)
