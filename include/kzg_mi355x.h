@@ -131,6 +131,7 @@ int kzg_sync(kzg_ctx *ctx);
  * lone MSM), "host_affine" (1 / 0: a lone result bound for host memory is converted to affine and serialised by the calling
  * thread -- the same field code compiled for the host -- instead of one GPU lane; same bytes, ~90 us less latency),
  * "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only),
+ * "defer_tail" (1 / 0: kzg_msm_g1_batch enqueues a lane's tail kernels after the sort of the lane's next MSM; default 1),
  * "heavy_bins" (sort bins far above their share -- scalars that are bits, bytes, all equal -- sorted in slices by many blocks:
  *  0 = for the 64 MSMs after one that met such a bin (default; the extra kernels cost uniform scalars 0.8 %), 1 = always, 2 = never;
  *  setting it clears the history),
@@ -167,7 +168,8 @@ void kzg_srs_free(kzg_ctx *ctx, kzg_srs *srs);
 int kzg_msm_g1(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n, int sfmt,
                int flags, void *out, int ofmt);
 /* `batch` scalar vectors (each n scalars, contiguous, stride n*32 B) against one SRS; out gets
- * `batch` points.  Throughput mode: independent MSMs are pipelined on several HIP streams. */
+ * `batch` points.  Throughput mode: independent MSMs are pipelined on several HIP streams, two in flight per lane (option
+ * "defer_tail"): the context's workspace grows to 2 x `streams` MSM workspaces (2 x 16 x ~0.25 GB at 2^20, 17-bit windows). */
 int kzg_msm_g1_batch(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const void *scalars, size_t n,
                      size_t batch, int sfmt, int flags, void *out, int ofmt);
 /* sum of `count` G1 points (multi-GPU combine of per-rank partial MSMs). points in pfmt. */
