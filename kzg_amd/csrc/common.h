@@ -42,8 +42,9 @@ struct MsmMode {
 };
 
 // One independent execution lane: a HIP stream plus a bump-allocated scratch arena in HBM.
-// Exclusive calls use lane 0; kzg_msm_g1_batch pipelines independent MSMs over several lanes; concurrent blocking callers
-// (commit / create_witness from many host threads) each lease one lane for the duration of their call.
+// Exclusive calls use lane 0; kzg_msm_g1_batch pipelines independent MSMs over several lanes (two in flight per lane); concurrent
+// blocking callers (commit / create_witness / create_witness_batched / fft ... from many host threads) each lease one lane for the
+// duration of their call.
 struct Lane {
     MsmMode mode;
     hipStream_t stream = nullptr;
@@ -60,13 +61,15 @@ struct FixedBaseTable;
 struct EvalDomainTables;
 
 // Who may use the context when.  Two kinds of callers:
-//   exclusive  everything that works on lane 0 / the shared caches / all lanes at once (NTT, polynomial helpers, SRS setup,
-//              the batched entry points, options): one at a time, as before.  lock() / unlock() -- the type is a BasicLockable,
-//              so std::lock_guard<CtxGate> is the old "Guard".
-//   shared     the reference's blocking prover calls (KZGProver::commit / create_witness, both forms, src/coeff_form.rs:59-81,
-//              src/eval_form.rs:114-140: `&self` methods of a Clone type, callable from many threads).  Each leases a free lane
-//              under this short lock, submits its kernels there (accumulation kernels on the shared FIFO streams) and waits for
-//              its own stream only -- N host threads calling commit() keep the pipeline as full as kzg_msm_g1_batch does.
+//   exclusive  everything that works on all lanes at once or rebuilds shared state (the *_batch / *_many entry points, SRS
+//              construction, the pairing verifier, options, profiling, kzg_sync / kzg_dev_free): one at a time.  lock() / unlock() --
+//              the type is a BasicLockable, so std::lock_guard<CtxGate> is the old "Guard".
+//   shared     every blocking call of the reference that works on ONE lane (KZGProver::commit / create_witness /
+//              create_witness_batched, both forms, verify_poly, EvaluationDomain::fft and friends: `&self` methods of Clone types,
+//              src/coeff_form.rs:59-124, src/eval_form.rs:114-171, src/ft.rs:111-271).  Each leases a free lane under this short lock
+//              (kzg::Lease), submits its kernels there (accumulation kernels on the shared FIFO streams) and waits for its own
+//              stream only -- N host threads keep the pipeline as full as kzg_msm_g1_batch does.  The caches such calls share (NTT
+//              plans, coset tables, evaluation-domain tables) are guarded by kzg_ctx::cache_mu.
 // Exclusive callers wait for the leased lanes to drain and hold new leases off while they wait (no starvation).
 struct CtxGate {
     std::mutex m;
@@ -100,7 +103,7 @@ struct kzg_ctx {
     kzg::CtxGate mu;
     std::mutex err_mu;   // err
     std::mutex prof_mu;  // prof_map, prof_pending, event_pool
-    std::mutex cache_mu; // eval_tabs (the other caches are touched by exclusive callers only)
+    std::mutex cache_mu; // ntt_plans, coset_tabs, eval_tabs: built by one leased caller at a time, published after the builder's stream is synchronised
     std::mutex accum_mu; // wait / launch / record on a shared accumulation stream is one unit
     std::atomic<uint32_t> accum_rr{0};  // round robin over the accumulation streams (leased lanes)
     bool pipe_planned = false;          // lanes + accumulation streams created, probed and ordered for concurrent callers
