@@ -1020,7 +1020,10 @@ int g1_sum_batch_strided(kzg_ctx *ctx, const void *points, size_t count, size_t 
     size_t psz = point_format_bytes(pfmt), osz = point_format_bytes(ofmt);
     if (!psz || !osz) return fail(ctx, KZG_ERR_SHAPE, "unknown G1 point format");
     if (count > (1u << 20) || groups > (1u << 24)) return fail(ctx, KZG_ERR_SHAPE, "kzg_g1_sum_batch: count <= 2^20, groups <= 2^24");
-    size_t total = count * groups;
+    // every source slot the strides reach: count * groups of them for dense groups, more when the records carry other slots
+    // between the points -- the gathered [world][batch + 1] records of a device group (mgpu.hip) hold a status slot after each
+    // rank's batch partials, so rank r's partial of polynomial b sits at r (batch + 1) + b
+    size_t total = count && groups ? (groups - 1) * gstride + (count - 1) * istride + 1 : 0;
     KZG_TRY(lane_reserve(ctx, 0, stage_bytes(total * psz, flags) + total * sizeof(G1Xyzz) + (total + groups + 4) * sizeof(MsmPoint) + groups * 144 + 65536));
     hipStream_t st = ctx->lanes[0].stream;
     G1Xyzz *dec = (G1Xyzz *)lane_alloc(ctx, 0, total * sizeof(G1Xyzz));

@@ -20,6 +20,7 @@
 #include "common.h"
 #ifdef KZG_TEST_HOOKS
 #include "../../include/kzg_mi355x_test.h"
+#include "test_transport.h"
 #endif
 
 namespace kzg {
@@ -93,6 +94,25 @@ static Rccl *rccl_load(std::string *err) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl) return g_rccl;
     const std::string mine = object_of((const void *)&hipStreamSynchronize);
+#ifdef KZG_TEST_HOOKS
+    if (getenv("KZG_TEST_SHM_TRANSPORT")) {  // tests: world > 1 on ONE GPU, which RCCL refuses (test_transport.h)
+        Rccl *r = new Rccl();
+        r->GetUniqueId = shmt::get_unique_id;
+        r->CommInitRank = shmt::comm_init_rank;
+        r->CommInitAll = shmt::comm_init_all;
+        r->CommDestroy = shmt::comm_destroy;
+        r->CommAbort = shmt::comm_destroy;
+        r->AllGather = shmt::all_gather;
+        r->GroupStart = shmt::group_start;
+        r->GroupEnd = shmt::group_end;
+        r->GetVersion = shmt::get_version;
+        r->GetErrorString = shmt::error_string;
+        r->path = "test-shm-transport";
+        r->hip_path = mine;
+        g_rccl = r;
+        return r;
+    }
+#endif
     const char *names[] = {nullptr, "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
     std::string load_err = "not found", mismatches;
     bool any = false;
@@ -161,6 +181,8 @@ struct kzg_mctx {
     // grow-only exchange buffers per local GPU: partials of this GPU, partials of every rank
     std::vector<void *> d_part, d_gath;
     std::vector<size_t> cap_points;
+    size_t agreed_points = 64;       // the batch every rank is known to hold buffers for (grown only by a successful agreement)
+    size_t agreed_quot = 0;          // ... and the quotient length
     std::vector<void *> d_quot;      // create_witness: the quotient polynomial on each GPU
     std::vector<size_t> cap_quot;
     std::vector<void *> h_status;    // pinned: the status words of all ranks after the exchange, per local GPU
@@ -301,7 +323,11 @@ static int mctx_comm(kzg_mctx *m, Rccl **out) {
 
 extern "C" int kzg_mctx_create(const int *devices, int n, kzg_mctx **out) {
     if (!out || !devices || n < 1 || n > 64) return KZG_ERR_SHAPE;
-    for (int i = 0; i < n; i++)
+    bool distinct = true;
+#ifdef KZG_TEST_HOOKS
+    distinct = !getenv("KZG_TEST_SHM_TRANSPORT");  // tests: several ranks of a one-process group on one GPU (test_transport.h)
+#endif
+    for (int i = 0; i < n && distinct; i++)
         for (int j = 0; j < i; j++)
             if (devices[i] == devices[j]) return KZG_ERR_SHAPE;
     kzg_mctx *m = new kzg_mctx();
@@ -609,15 +635,17 @@ static int mctx_agree(kzg_mctx *m, int code, const char *what) {
     return KZG_OK;
 }
 
-// Buffers for a call with `batch` partials per rank.  Whether they must grow is the same on every rank (same calls, same
-// history), so the ranks agree on the outcome exactly when a growth was attempted; ordinary calls pay nothing.
+// Buffers for a call with `batch` partials per rank.  Whether the ranks must agree is decided by what they last AGREED on
+// (agreed_points: the same on every rank -- same calls, same outcomes), not by a rank's own capacity: after a growth that failed on
+// one rank only, the others hold larger buffers than that rank, and on the next call all of them must still enter the agreement the
+// failed rank enters (tests/test_gpu_mgpu_world.py runs exactly that at world 2..8).  Ordinary calls pay nothing.
 static int mctx_buffers(kzg_mctx *m, size_t batch) {
     if (m->dead) return mfail(m, KZG_ERR_INTERNAL, "this device group is dead (an earlier exchange timed out and was aborted): destroy it and form a new one");
-    bool grow = false;
-    for (int i = 0; i < m->nlocal(); i++) grow = grow || m->cap_points[i] < batch;
-    if (!grow) return KZG_OK;
-    int rc = mctx_buffers_grow(m, batch);
-    return mctx_agree(m, rc, "its exchange buffers");
+    if (batch <= m->agreed_points) return KZG_OK;
+    int rc = mctx_buffers_grow(m, batch);  // (a no-op on a rank that already grew in a round another rank failed)
+    rc = mctx_agree(m, rc, "its exchange buffers");
+    if (rc == KZG_OK) m->agreed_points = batch;
+    return rc;
 }
 
 // run f(i) for every local GPU (on the group's persistent worker threads when there are several); rcs[i] = its status
@@ -772,9 +800,7 @@ static const void *whole_poly(const void *coeffs, int flags, int i) {
 
 // the replicated quotient polynomial of create_witness (both forms): n scalars on every local GPU; the ranks agree when it grows
 static int mctx_quotient_buffers(kzg_mctx *m, size_t n) {
-    bool grow = false;
-    for (int i = 0; i < m->nlocal(); i++) grow = grow || m->cap_quot[i] < n;
-    if (!grow) return KZG_OK;
+    if (n <= m->agreed_quot) return KZG_OK;  // (what the ranks agreed on, not this rank's own capacity: see mctx_buffers)
     int rc = KZG_OK;
     for (int i = 0; i < m->nlocal() && rc == KZG_OK; i++) {
         if (m->cap_quot[i] >= n) continue;
@@ -786,7 +812,9 @@ static int mctx_quotient_buffers(kzg_mctx *m, size_t n) {
         if (hipMalloc(&m->d_quot[i], n * 32) != hipSuccess) rc = mfail(m, KZG_ERR_ALLOC, "hipMalloc(quotient)");
         else m->cap_quot[i] = n;
     }
-    return mctx_agree(m, rc, "its quotient buffer");
+    rc = mctx_agree(m, rc, "its quotient buffer");
+    m->agreed_quot = rc == KZG_OK ? n : 0;  // after a failure (the failing rank has no buffer left) the next call agrees again
+    return rc;
 }
 
 extern "C" int kzg_witness_coeff_sharded(kzg_mctx *m, const kzg_msrs *srs, const void *coeffs, size_t n, const void *x,
