@@ -2,6 +2,12 @@
  * kzg_mi355x_test.h -- unit-test hooks: device arithmetic exercised directly.  NOT part of the product ABI: they exist only in
  * the -DKZG_TEST_HOOKS build of the library (kzg_amd/libkzg_mi355x_hooks.so, built by `python -m kzg_amd.build` next to the
  * product library and loaded by tests/ only).
+ *
+ * The hooks build also honours two environment variables (read when the library first needs RCCL):
+ *   KZG_TEST_NO_RCCL=1        RCCL is "not installed": the load-failure path on a host that has it
+ *   KZG_TEST_SHM_TRANSPORT=1  the eight RCCL entry points are replaced by a shared-memory stand-in (kzg_amd/csrc/test_transport.h)
+ *                             and kzg_mctx_create accepts the same device several times: device groups of world size > 1 on a
+ *                             one-GPU box (RCCL refuses two ranks per GPU).  tests/test_gpu_mgpu_world.py, tools/bench_shared_gpu.sh.
  */
 #ifndef KZG_MI355X_TEST_H
 #define KZG_MI355X_TEST_H

@@ -34,11 +34,12 @@ c_void_pp = ctypes.POINTER(ctypes.c_void_p)
 
 
 def load(path=None):
-    """Load the shared library.  `path` (tools/ab_libs.py only) selects another build of the same ABI for A/B runs."""
+    """Load the shared library.  `path` (tools/ab_libs.py only) or the environment variable KZG_AMD_LIBRARY (tests: the hooks
+    build under torch.distributed.run) selects another build of the same ABI."""
     global _lib
     if _lib is not None:
         return _lib
-    so = path or SO_PATH
+    so = path or os.environ.get("KZG_AMD_LIBRARY") or SO_PATH
     if not os.path.exists(so):
         raise ImportError(
             f"{so} not found: build it with `python -m kzg_amd.build` (hipcc --offload-arch=gfx950). "

@@ -75,3 +75,47 @@ def test_bench_line_carries_live_pmc_traffic():
     entries = (1 << 16) * d["config"]["windows"]
     assert 64 * entries < rf["traffic"] < 512 * entries
     assert rf["frac_of_nominal"] > 0 and d["paths"]["ntt_2e16_ms"] > 0
+
+
+def _torchrun(nproc, port, bench_args, timeout=900):
+    """bench.py under torch.distributed.run with `nproc` ranks on the one GPU: gloo control plane, and the device group over the
+    hooks build's test transport (kzg_amd/csrc/test_transport.h -- RCCL refuses two ranks on one GPU)."""
+    env = dict(os.environ, KZG_BENCH_SHARED_GPU="1", MASTER_ADDR="127.0.0.1", KZG_TEST_SHM_TRANSPORT="1",
+               KZG_AMD_LIBRARY=os.path.join(ROOT, "kzg_amd", "libkzg_mi355x_hooks.so"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + bench_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_default_line_at_two_ranks_carries_the_sharded_block():
+    """What the driver's `bench.py --gpus N` run prints at N > 1, executed with two ranks: value = replicas, and the `sharded` block
+    (strong: each commitment split over the ranks; config5: 2^21 terms per rank) measured through the device group at world 2 with
+    every commitment of each mode's last step checked against [p(tau)]G."""
+    d = _torchrun(2, 29641, ["--steps", "2", "--warmup", "1", "--batch", "8", "--log-n", "16", "--no-paths", "--sharded-batch", "4",
+                             "--sharded-steps", "2"])
+    assert d["n_gpus"] == 2 and d["config"]["mode"] == "replicas"
+    assert d["timed_results_checked"]["ok"] is True and d["timed_results_checked"]["every_rank"] is True   # the unconditional sample
+    sh = d["sharded"]
+    assert "note" not in sh and "error" not in sh, sh
+    assert sh["rccl_ranks"] == 2 and "test-shm-transport" in sh["rccl"]
+    assert sh["strong"]["terms_per_rank"] == 1 << 15 and sh["strong"]["scaling"] == "strong"
+    assert sh["config5"]["terms_per_rank"] == 1 << 21 and sh["config5"]["polynomial_coefficients"] == 1 << 22
+    for mode in ("strong", "config5"):
+        assert sh[mode]["all_results_match_known_tau"] is True and sh[mode]["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,flag", [(4, "--strong"), (2, "--weak")])
+def test_bench_sharded_modes_as_the_timed_region(nproc, flag):
+    """--strong / --weak at N > 1: the device group IS the timed region (one commitment sharded over the ranks, the exchange inside
+    every step), every commitment of the last step checked on every rank."""
+    d = _torchrun(nproc, 29643 + nproc, ["--steps", "2", "--warmup", "1", "--batch", "4", "--log-n", "16", "--no-paths", "--check", flag])
+    assert d["n_gpus"] == nproc and d["config"]["mode"] == flag[2:]
+    assert d["scaling"] == ("strong" if flag == "--strong" else "weak")
+    assert d["all_results_match_known_tau"] is True and d["timed_results_checked"]["ok"] is True
+    assert d["value"] > 0
