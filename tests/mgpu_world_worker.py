@@ -135,6 +135,19 @@ def scenario(group, rank_of_failure, seed):
     out["after_alloc_failure_66"] = all(b.hex() == want_small for b in group.commit_batch(srs, bflat[:66 * 777 * 32], 777, 66))
     out["last_commit"] = group.commit(srs, polys[N]).hex()
     srs.free()
+    # --- an SRS shorter than the group: ranks >= 3 hold EMPTY shards and contribute the identity to every exchange ---
+    tiny = group.setup(TAU, 3)
+    tp = [rng.randrange(R) for _ in range(3)]
+    t = {"shards": [[tiny.shard(i)[1], len(tiny.shard(i)[0])] for i in range(group.local_count)],
+         "commit": {str(m): group.commit(tiny, tp[:m]).hex() for m in (3, 2, 1, 0)}}
+    tx = rng.randrange(R)
+    t["witness"] = group.create_witness(tiny, tp, (tx, horner(tp, tx))).hex()
+    for k in (1, 2):
+        pts = [(v, horner(tp, v)) for v in [rng.randrange(R) for _ in range(k)]]
+        w, r = group.create_witness_batched(tiny, tp, pts)
+        t["batched_%d" % k] = [w.hex(), [hex(c) for c in r], [[hex(a), hex(b)] for a, b in pts]]
+    out["tiny"] = t
+    tiny.free()
     return out
 
 

@@ -85,6 +85,11 @@ def _expected(seed):
     exp["witness_eval"] = {str(m): C.g1_mul(G, (petau - evals[m]) * pow(TAU - pow(omega, m, M.R), -1, M.R) % M.R).hex()
                            for m in (0, 1, 777, D - 1)}
     exp["commit_eval"] = C.g1_mul(G, petau).hex()
+    tp = [rng.randrange(M.R) for _ in range(3)]
+    exp["tiny_commit"] = {str(m): C.g1_mul(G, C.poly_eval(tp[:m], TAU) if m else 0).hex() for m in (3, 2, 1, 0)}
+    tx = rng.randrange(M.R)
+    exp["tiny_witness"] = C.g1_mul(G, (C.poly_eval(tp, TAU) - _horner(tp, tx)) * pow(TAU - tx, -1, M.R) % M.R).hex()
+    exp["tiny_poly"] = tp
     return exp
 
 
@@ -116,6 +121,27 @@ def _check(res, exp, world):
     assert res["alloc_failure"][0] == "EngineError" and "-3" in res["alloc_failure"][2], res["alloc_failure"]
     assert res["after_alloc_failure"] is True and res["after_alloc_failure_66"] is True
     assert res["last_commit"] == exp["commit"][str(N)]
+    # the SRS of 3 points: ranks from 3 on hold empty shards
+    t = res["tiny"]
+    for (first, ln), rk in zip(t["shards"], res["ranks"]):
+        lo, hi = shard_range(3, rk, world)
+        assert (first, ln) == (lo, hi - lo)
+    assert t["commit"] == exp["tiny_commit"] and t["witness"] == exp["tiny_witness"]
+    tp = exp["tiny_poly"]
+    ptau = C.poly_eval(tp, TAU)
+    for k in (1, 2):
+        w_hex, r_hex, pts = t["batched_%d" % k]
+        r = [int(c, 16) for c in r_hex]
+        pts = [(int(a, 16), int(b, 16)) for a, b in pts]
+        assert len(r) == (2 if k == 1 else k)       # the one-point interpolant is X + (y - x), degree 1
+        z = 1
+        for x, y in pts:
+            z = z * (TAU - x) % M.R
+            if k > 1:
+                assert _horner(r, x) == y
+        if k == 1:
+            assert r == [(pts[0][1] - pts[0][0]) % M.R, 1]
+        assert w_hex == C.g1_mul(G, (ptau - _horner(r, TAU)) * pow(z, -1, M.R) % M.R).hex()
 
 
 def _unique_id():
