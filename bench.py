@@ -972,7 +972,7 @@ def main():
             **({"note": group_note} if group_note else {}),
             "g1_adds_per_sec": round(value * (world if mode != "replicas" else 1) * g1_adds_per_msm(n_local, c, digits), 1),
             "msm_terms_per_sec": round(value * n_poly, 1),
-            "parity_pin": "fr-literal+known-tau",   # G1 layer: no literal vector in the reference
+            "parity_pin": "fr-literal+known-tau+published-points",   # G1 layer: no literal vector in the reference
             "single_commit_latency_ms": None if latency_ms is None else round(latency_ms, 4),
             "blocking_commit_per_s": None if latency_ms is None else round(1e3 / latency_ms, 2),
         }

@@ -15,7 +15,8 @@ PARITY STATUS
     (blstrs git rev b98fc83 -> supranational blst; pairing 0.21.0 -> group/ff; Cargo.toml:23,27).
     The published BLS12-381 definition is restated here (curve y^2 = x^3 + 4 over Fq, standard
     generator, zcash serialisation) and pinned by: generator-on-curve, r*G = infinity, the well
-    known compressed generator encoding 97f1d3a7...c6bb, and the known-tau identities
+    known compressed generator encoding 97f1d3a7...c6bb, the published compressed [2]G and [3]G
+    (tests/test_oracle_reference_vectors.py, [upstream-memory]), and the known-tau identities
     commit(p) == [p(tau)]G etc..
 
 Every function cites the reference file:line it follows.  Scalars are python ints in [0, r).

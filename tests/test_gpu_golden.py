@@ -151,3 +151,31 @@ def test_golden_production_path_witness(engine):
     assert out.raw.hex() == w["witness"]
     buf.free()
     params.gs.free()
+
+
+def test_published_points_through_the_engine(engine):
+    """The only literals in the repository that were not produced by its own oracle (tests/test_oracle_reference_vectors.py:
+    compressed [1]G, [2]G, [3]G and the G2 generator as published, [upstream-memory]): the engine's SRS generation, MSM, point sum,
+    affine conversion and zcash serialisation reproduce them -- commit of the constant polynomial k against setup(tau, n).gs, the
+    sum G + G and 2G + G, [2]H through the G2 multi-exponentiation."""
+    import kzg_amd
+    from kzg_amd import _lib as L
+    from tests.test_oracle_reference_vectors import PUBLISHED_2G2_PREFIX, PUBLISHED_G1, PUBLISHED_G2_GENERATOR
+    params = kzg_amd.setup(engine, 0x1234567, 4, g2_len=2)
+    for k, hexv in PUBLISHED_G1.items():
+        assert engine.msm(params.gs, [k], ofmt=L.G1_ZCASH_COMPRESSED).hex() == hexv             # gs[0] = G
+        assert engine.msm(params.gs, [k, 0, 0, 0], ofmt=L.G1_ZCASH_COMPRESSED).hex() == hexv
+    g = params.gs.download(0, 1)
+    assert engine.g1_sum([g, g], ofmt=L.G1_ZCASH_COMPRESSED).hex() == PUBLISHED_G1[2]
+    assert engine.g1_sum([g, g, g], ofmt=L.G1_ZCASH_COMPRESSED).hex() == PUBLISHED_G1[3]
+    assert params.hs.download(0, 1, pfmt=L.G2_COMPRESSED).hex() == PUBLISHED_G2_GENERATOR           # hs[0] = H
+    assert params.hs.msm([2], ofmt=L.G2_COMPRESSED).hex().startswith(PUBLISHED_2G2_PREFIX)
+    # uploading the published bytes gives the same resident points as generating them
+    up = kzg_amd.Srs.upload(engine, bytes.fromhex(PUBLISHED_G1[1] + PUBLISHED_G1[2] + PUBLISHED_G1[3]), 3, pfmt=L.G1_ZCASH_COMPRESSED)
+    one = kzg_amd.setup(engine, 1, 1, g2_len=0)
+    assert up.download(0, 1) == one.gs.download(0, 1)
+    assert engine.msm(up, [1, 1, 1], ofmt=L.G1_ZCASH_COMPRESSED) == engine.msm(params.gs, [6], ofmt=L.G1_ZCASH_COMPRESSED)
+    up.free()
+    one.gs.free()
+    params.gs.free()
+    params.hs.free()

@@ -131,3 +131,51 @@ def test_known_tau_identities_small():  # replaces the pairing checks
     pe = M.KZGParams(M.setup_g1(tau, 8))
     lag = M.compute_lagrange_basis_g1(pe)
     assert lag == M.lagrange_basis_g1_known_tau(tau, 8)
+
+
+# Compressed encodings of [1]G, [2]G, [3]G on BLS12-381 G1 as they circulate in public test material (the Ethereum consensus
+# "interop" validator public keys of the secret keys 1, 2 and 3; the first one is the generator of the zkcrypto / IETF
+# pairing-friendly-curves documents).  [upstream-memory]: written down from memory of that public material, not read from a file in
+# this image -- the reference crate holds no literal G1 value and blstrs is absent.  They are the only values in this
+# repository that were not produced by the oracle's own author: 48 bytes each that an implementation with a wrong doubling,
+# addition, Montgomery constant, sign convention or serialisation rule would not reproduce.
+PUBLISHED_G1 = {
+    1: "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb",
+    2: "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e",
+    3: "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224",
+}
+
+
+def test_g1_layer_against_published_points():
+    """The oracle's G1 law and zcash serialisation (python model and C oracle) reproduce the published [k]G; so do the commitment
+    of the constant polynomial k and the sums G + G, 2G + G -- doubling, addition and scalar multiplication each pinned."""
+    from oracle import c_oracle as C
+    G = M.G1
+    for k, hexv in PUBLISHED_G1.items():
+        want = bytes.fromhex(hexv)
+        assert M.g1_to_compressed(M.g1_mul(G, k)) == want
+        assert M.g1_to_compressed(C.blob_to_point(C.g1_mul(C.g1_generator(), k))) == want
+        assert M.g1_to_compressed(C.blob_to_point(C.msm_g1(C.setup_g1(12345, 1), [k]))) == want   # commit of the constant k
+    assert M.g1_to_compressed(M.g1_add(G, G)) == bytes.fromhex(PUBLISHED_G1[2])
+    assert M.g1_to_compressed(M.g1_add(M.g1_mul(G, 2), G)) == bytes.fromhex(PUBLISHED_G1[3])
+    # decompression of the published bytes gives points on the curve and in the subgroup that re-encode to themselves
+    for k, hexv in PUBLISHED_G1.items():
+        Pk = M.g1_from_compressed(bytes.fromhex(hexv))
+        assert M.g1_is_on_curve(Pk) and M.g1_to_compressed(Pk) == bytes.fromhex(hexv)
+        assert M.g1_mul(Pk, M.R) is None   # the identity: in the r-torsion subgroup
+
+
+# The same for G2: the compressed generator as published (zkcrypto / IETF pairing-friendly-curves, Ethereum), in full, and the
+# leading 8 bytes of [2]G2 as they appear in public BLS12-381 precompile test material.  [upstream-memory], as above.
+PUBLISHED_G2_GENERATOR = ("93e02b6052719f607dacd3a088274f65596bd0d09920b61ab5da61bbdc7f5049334cf11213945d57e5ac7d055d042b7e"
+                          "024aa2b2f08f0a91260805272dc51051c6e47ad4fa403b02b4510b647ae3d1770bac0326a805bbefd48056c8c121bdb8")
+PUBLISHED_2G2_PREFIX = "aa4edef9c1ed7f72"
+
+
+def test_g2_layer_against_published_points():
+    from oracle import pairing_model as PM
+    assert PM.g2_to_compressed(PM.G2).hex() == PUBLISHED_G2_GENERATOR
+    assert PM.g2_to_compressed(PM.g2_mul(PM.G2, 2)).hex().startswith(PUBLISHED_2G2_PREFIX)
+    assert PM.g2_to_compressed(PM.g2_add(PM.G2, PM.G2)).hex().startswith(PUBLISHED_2G2_PREFIX)
+    P = PM.g2_from_compressed(bytes.fromhex(PUBLISHED_G2_GENERATOR))
+    assert PM.g2_is_on_curve(P) and P == PM.G2
