@@ -179,3 +179,44 @@ def test_published_points_through_the_engine(engine):
     one.gs.free()
     params.gs.free()
     params.hs.free()
+
+
+def test_published_montgomery_constants_through_the_engine(engine):
+    """The zero-copy formats are what they claim to be: KZG_G1_AFFINE_MONT_96 / KZG_G1_JACOBIAN_MONT_144 hold the generator exactly as
+    the public implementations' `G1Affine::generator()` / blst_p1 do (x, y[, z] as 6 little-endian u64 limbs, Montgomery radix 2^384),
+    KZG_FR_MONT_LE_32 holds 1 as their `Scalar::one()` (radix 2^256), and the NTT's twiddles are the published roots of unity.
+    Literals: tests/test_oracle_reference_vectors.py ([upstream-memory] of public material, not produced by this repository)."""
+    import ctypes
+    import kzg_amd
+    from kzg_amd import _lib as L
+    from oracle import kzg_model as M
+    from tests import test_oracle_reference_vectors as V
+    one = kzg_amd.setup(engine, 0xABCDEF, 2, g2_len=0)
+    assert one.gs.download(0, 1) == V.PUBLISHED_G1_GENERATOR_MONT                                      # gs[0] = G, resident form
+    # a scalar handed over in Montgomery form: the published R is 1, R2 is 2^256 mod r
+    out = ctypes.create_string_buffer(48)
+    for blob, k in ((V.PUBLISHED_FR_ONE_MONT, 1), (V.PUBLISHED_FR_R2, (1 << 256) % M.R)):
+        rc = engine.lib.kzg_msm_g1(engine.ctx, one.gs.handle, 0, blob, 1, L.FR_MONT, 0, out, L.G1_ZCASH_COMPRESSED)
+        assert rc == 0, engine.last_error()
+        assert out.raw == engine.msm(one.gs, [k], ofmt=L.G1_ZCASH_COMPRESSED)
+        if k == 1:
+            assert out.raw.hex() == V.PUBLISHED_G1[1]
+    # blst_p1 of the generator = (x, y, 1) in Montgomery form: uploads to the same resident point; the engine's own Jacobian output
+    # of [1]G normalises to it
+    up = kzg_amd.Srs.upload(engine, V.PUBLISHED_G1_GENERATOR_MONT + V.PUBLISHED_FQ_ONE_MONT, 1, pfmt=L.G1_JACOBIAN_MONT)
+    assert up.download(0, 1) == V.PUBLISHED_G1_GENERATOR_MONT
+    assert engine.msm(up, [3], ofmt=L.G1_ZCASH_COMPRESSED).hex() == V.PUBLISHED_G1[3]
+    aff = engine.msm(one.gs, [1], ofmt=L.G1_AFFINE_MONT)
+    assert aff == V.PUBLISHED_G1_GENERATOR_MONT
+    # roots of unity: compute_omega and the transform itself
+    for k in (2, 3):
+        assert kzg_amd.compute_omega(1 << k)[2] == V.PUBLISHED_ROOTS_OF_UNITY[k]
+    w4, w8 = V.PUBLISHED_ROOTS_OF_UNITY[2], V.PUBLISHED_ROOTS_OF_UNITY[3]
+    assert engine.ntt([0, 1, 0, 0], 2) == [1, w4, M.R - 1, M.R - w4]                                    # fft(X) = (w^i)_i
+    assert engine.ntt([0, 1] + [0] * 6, 3) == [pow(w8, i, M.R) for i in range(8)]
+    assert pow(w8, 2, M.R) == w4 and pow(w4, 2, M.R) == M.R - 1
+    # the 2^32-th root: 2^27 squarings away from the 32-point transform's twiddle
+    w32pt = engine.ntt([0, 1] + [0] * 30, 5)[1]
+    assert w32pt == pow(V.PUBLISHED_ROOTS_OF_UNITY[32], 1 << 27, M.R)
+    up.free()
+    one.gs.free()

@@ -179,3 +179,45 @@ def test_g2_layer_against_published_points():
     assert PM.g2_to_compressed(PM.g2_add(PM.G2, PM.G2)).hex().startswith(PUBLISHED_2G2_PREFIX)
     P = PM.g2_from_compressed(bytes.fromhex(PUBLISHED_G2_GENERATOR))
     assert PM.g2_is_on_curve(P) and P == PM.G2
+
+
+# Constants of the public BLS12-381 implementations in their IN-MEMORY (Montgomery) form, [upstream-memory] like the points above:
+# zkcrypto bls12_381 `Scalar` / `Fp` (R = 2^256 resp. 2^384, little-endian u64 limbs -- the radix and limb order blst's blst_fr /
+# blst_fp use) and `G1Affine::generator()`; the 2^k-th roots of unity as c-kzg-4844 tabulates them (SCALE2_ROOT_OF_UNITY[k]).
+# They pin what the zero-copy formats KZG_FR_MONT_LE_32 and KZG_G1_AFFINE_MONT_96 claim to be.
+def _limbs(*w):
+    return b"".join(int(x).to_bytes(8, "little") for x in w)
+
+
+PUBLISHED_FR_ONE_MONT = _limbs(0x00000001fffffffe, 0x5884b7fa00034802, 0x998c4fefecbc4ff5, 0x1824b159acc5056f)      # Scalar R
+PUBLISHED_FR_R2 = _limbs(0xc999e990f3f29c6d, 0x2b6cedcb87925c23, 0x05d314967254398f, 0x0748d9d99f59ff11)            # Scalar R2
+PUBLISHED_FR_ROOT_OF_UNITY_MONT = _limbs(0xb9b58d8c5f0e466a, 0x5b1b4c801819d7ec, 0x0af53ae352a31e64, 0x5bf3adda19e9b27b)
+PUBLISHED_FQ_ONE_MONT = _limbs(0x760900000002fffd, 0xebf4000bc40c0002, 0x5f48985753c758ba, 0x77ce585370525745,
+                               0x5c071a97a256ec6d, 0x15f65ec3fa80e493)                                                # Fp R
+PUBLISHED_G1_GENERATOR_MONT = (_limbs(0x5cb38790fd530c16, 0x7817fc679976fff5, 0x154f95c7143ba1c1, 0xf0ae6acdf3d0e747,
+                                      0xedce6ecc21dbf440, 0x120177419e0bfb75) +
+                               _limbs(0xbaac93d50ce72271, 0x8c22631a7918fd8e, 0xdd595f13570725ce, 0x51ac582950405194,
+                                      0x0e1c8c3fad0059c0, 0x0bbc3efc5008a26a))
+PUBLISHED_ROOTS_OF_UNITY = {    # 2^k-th roots, canonical
+    2: 0x0000000000000000_8d51ccce760304d0_ec03000276030000_0001000000000000,
+    3: 0x345766f603fa66e7_8c0625cd70d77ce2_b38b21c28713b700_7228fd3397743f7a,
+    32: 0x16a2a19edfe81f20_d09b681922c813b4_b63683508c2280b9_3829971f439f0d2b,
+}
+PUBLISHED_MONT_INV = {"fr": 0xfffffffeffffffff, "fq": 0x89f3fffcfffcfffd}    # -p^-1 mod 2^64
+
+
+def test_montgomery_layouts_against_published_constants():
+    from oracle import c_oracle as C
+    assert M.fr_to_mont_le(1) == PUBLISHED_FR_ONE_MONT
+    assert M.fr_to_mont_le(1 << 256) == PUBLISHED_FR_R2                     # R2 = 2^512 mod r is the Montgomery form of 2^256
+    assert M.fr_to_mont_le(M.FR_ROOT_OF_UNITY) == PUBLISHED_FR_ROOT_OF_UNITY_MONT
+    assert ((1 << 384) % M.Q).to_bytes(48, "little") == PUBLISHED_FQ_ONE_MONT
+    assert M.g1_to_affine_mont(M.G1) == PUBLISHED_G1_GENERATOR_MONT
+    assert C.g1_generator() == PUBLISHED_G1_GENERATOR_MONT                  # the C oracle's 96-byte affine-Montgomery blob
+    assert M.FR_ROOT_OF_UNITY == PUBLISHED_ROOTS_OF_UNITY[32]
+    for k, w in PUBLISHED_ROOTS_OF_UNITY.items():
+        assert pow(M.FR_ROOT_OF_UNITY, 1 << (32 - k), M.R) == w
+        if k < 32:
+            assert M.compute_omega(1 << k)[2] == w         # src/ft.rs:55-76
+    assert (-pow(M.R, -1, 1 << 64)) % (1 << 64) == PUBLISHED_MONT_INV["fr"]
+    assert (-pow(M.Q, -1, 1 << 64)) % (1 << 64) == PUBLISHED_MONT_INV["fq"]
