@@ -25,16 +25,50 @@ class ProtocolModel:
     local_sum(slots, world, batch, stride) -> list of `batch` results, slots = the gathered bytes, partial of rank w for
     polynomial b at slot w * stride + b."""
 
-    def __init__(self, dist, rank, world, local_msm, local_sum, point_bytes=96, gather_timeout_s=None):
+    def __init__(self, dist, rank, world, local_msm, local_sum, point_bytes=96, gather_timeout_s=None, grow=None):
         self.dist, self.rank, self.world = dist, rank, world
         self.local_msm, self.local_sum, self.pb = local_msm, local_sum, point_bytes
         self.gather_timeout_s, self.dead = gather_timeout_s, False
+        # exchange buffers (mctx_buffers): `cap` is this rank's own capacity, `agreed` the batch every rank is KNOWN to hold buffers
+        # for.  grow(batch) stands for the rank's allocations and may raise; `collectives` logs what this rank entered.
+        self.cap = self.agreed = 64
+        self.grow = grow or (lambda batch: None)
+        self.collectives = []
+
+    def _agree(self, code):
+        """mctx_agree: a status-only all-gather over buffers that exist since the group was formed; every rank returns the first
+        failing rank's code"""
+        import torch
+        mine = torch.tensor([code, self.rank], dtype=torch.int32)
+        allv = torch.empty(2 * self.world, dtype=torch.int32)
+        self.collectives.append(("agree", 8))
+        self.dist.all_gather_into_tensor(allv, mine)
+        for w in range(self.world):
+            if int(allv[2 * w]) != 0:
+                raise RankFailed(w, int(allv[2 * w]))
+
+    def _buffers(self, batch):
+        """The decision to agree follows what the ranks last AGREED on -- the same on every rank -- not a rank's own capacity: after a
+        growth that failed on one rank only, the others hold larger buffers than that rank, and deciding by capacity would send the
+        failed rank into the agreement while the others go straight to the data exchange (the bug tests/test_gpu_mgpu_world.py found)."""
+        if batch <= self.agreed:
+            return
+        code = 0
+        if self.cap < batch:
+            try:
+                self.grow(batch)
+                self.cap = batch
+            except Exception as e:  # noqa: BLE001
+                code = getattr(e, "status", -3)
+        self._agree(code)
+        self.agreed = batch
 
     def commit_batch(self, scalar_shards, batch):
         import datetime
         import torch
         if self.dead:
             raise GroupDead("this device group is dead")
+        self._buffers(batch)
         status = 0
         try:
             mine = bytes(self.local_msm(scalar_shards, batch))
@@ -44,6 +78,7 @@ class ProtocolModel:
             mine = bytes(batch * self.pb)
         rec = mine + struct.pack("<ii", status, self.rank) + bytes(self.pb - 8)
         gathered = torch.empty(self.world * len(rec), dtype=torch.uint8)
+        self.collectives.append(("gather", len(rec)))
         if self.gather_timeout_s is None:
             self.dist.all_gather_into_tensor(gathered, torch.frombuffer(bytearray(rec), dtype=torch.uint8))
         else:   # mctx_wait: poll with a deadline; on expiry abort and retire the group

@@ -151,3 +151,57 @@ def test_sharded_commit_world2_gloo():
     assert results[0][0] == results[1][0] == want
     assert results[0][1] == results[1][1] == (1, -3)
     assert results[0][2] == results[1][2] == want[:1]
+
+
+def _growth_worker(rank, world, port, q):
+    """rank 1's allocation fails once when the exchange buffers must grow (batch 70 > the 64 held from the start)"""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fails = [1 if rank == 1 else 0]
+
+    class NoMemory(Exception):
+        status = -3
+
+    def grow(batch):
+        if fails[0]:
+            fails[0] -= 1
+            raise NoMemory()
+
+    pm = ProtocolModel(dist, rank, world, lambda polys, batch: bytes([rank + 1]) * (96 * batch),
+                       lambda raw, w, b, stride: [bytes(raw[96 * (r * stride + i)] for r in range(w)) for i in range(b)], grow=grow)
+    out = [pm.commit_batch(None, 3)]                    # ordinary call: no agreement
+    try:
+        pm.commit_batch(None, 70)
+        out.append("no error")
+    except RankFailed as e:
+        out.append((e.rank, e.status))
+    caps = (pm.cap, pm.agreed)                          # the ranks now differ in capacity, not in what they agreed on
+    out.append(pm.commit_batch(None, 70)[:2])           # every rank enters the agreement again (a no-op growth where it already grew)
+    out.append(pm.commit_batch(None, 66)[:1])           # below what was agreed: straight to the exchange on every rank
+    q.put((rank, (out, caps, pm.collectives)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_growth_failure_on_one_rank_keeps_the_collective_sequence_world3_gloo():
+    """mctx_buffers' rule at world size 3: whether to run the status-only agreement is decided by what the ranks last agreed on, so
+    the ranks enter the same collectives in the same order even after a growth that failed on one of them only."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_growth_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want_row = bytes([1, 2, 3])                          # slot r * (batch + 1) + i holds rank r's fill byte
+    for r in range(world):
+        out, caps, coll = results[r]
+        assert out[0] == [want_row] * 3 and out[1] == (1, -3) and out[2] == [want_row] * 2 and out[3] == [want_row]
+        assert caps == ((64, 64) if r == 1 else (70, 64))
+        assert coll == results[0][2]                     # the same collectives, in the same order, on every rank
+    assert [c[0] for c in results[0][2]] == ["gather", "agree", "agree", "gather", "gather"]
