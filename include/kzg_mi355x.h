@@ -193,7 +193,8 @@ int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t grou
  * Failures stay collective too: a rank whose local phase fails still enters the exchange, its status travels with its
  * partials, and EVERY rank returns that error (no rank is left waiting inside the all-gather).  A rank-local resource failure
  * BEFORE the exchange (growing the exchange / quotient buffers: the only allocations a call makes, and only when a call is larger
- * than any before it) is agreed on through a status-only all-gather over buffers that exist since the group was formed.  What
+ * than any the ranks have agreed on before) is agreed on through a status-only all-gather over buffers that exist since the group
+ * was formed; after such a failure the failing call may simply be repeated.  What
  * cannot be agreed on -- a peer process that died, a hung GPU, a rank that could not create its communicator -- is bounded by a
  * deadline: the wait behind every exchange polls for at most "gather_timeout_ms" (kzg_mctx_set_option, default 60000, 0 = wait
  * for ever); when it expires the communicators are aborted (ncclCommAbort), the call returns KZG_ERR_INTERNAL and the group is
