@@ -20,6 +20,8 @@ int kzg_test_fq_mul(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *
 int kzg_test_fr_inv(kzg_ctx *ctx, const void *a, size_t n, void *out);
 int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_t n, void *out);   /* affine mont 96 */
 int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k_canonical, size_t n, void *out);
+/* pretend `srs` is resident on GPU `device` (the "SRS of another GPU" error of every MSM entry point, on a one-GPU box) */
+int kzg_test_srs_set_device(struct kzg_srs *srs, int device);
 /* the next sharded call of this group fails locally on local GPU 0 with `code` (status agreement across ranks, mgpu.hip) */
 int kzg_test_mctx_inject_failure(struct kzg_mctx *m, int code);
 /* the next growth of the group's exchange buffers fails on local GPU 0 (a rank-local allocation failure BEFORE the exchange: the

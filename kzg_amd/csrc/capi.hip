@@ -1346,6 +1346,12 @@ extern "C" int kzg_test_g1_add(kzg_ctx *ctx, const void *a, const void *b, size_
                            (G1Affine *)dout);
     }, n, 96, 2, a, b, 96, out, 96);
 }
+// pretend an SRS lives on another GPU (one-GPU test boxes): the device check of msm_run
+extern "C" int kzg_test_srs_set_device(kzg_srs *srs, int device) {
+    if (!srs) return KZG_ERR_SHAPE;
+    srs->device = device;
+    return KZG_OK;
+}
 extern "C" int kzg_test_g1_mul(kzg_ctx *ctx, const void *p, const void *k, size_t n, void *out) {
     if (!ctx || !n) return KZG_ERR_SHAPE;
     unsigned grid = (unsigned)((n + 255) / 256);

@@ -1058,6 +1058,9 @@ int msm_finish(kzg_ctx *ctx, MsmPending &pd, MsmPoint **d_result) {
 int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
             MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev, MsmPending *defer) {
     if (defer) defer->active = false;
+    if (srs->device != ctx->device)  // (every MSM of every entry point passes here; a kernel on this GPU cannot read another GPU's table)
+        return fail(ctx, KZG_ERR_SHAPE, "the SRS is resident on GPU " + std::to_string(srs->device) + ", this context runs on GPU " +
+                                            std::to_string(ctx->device) + ": upload or generate it through this context");
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if (srs->c > 16 && !srs->narrow17 && !(srs->sort20 && !ctx->opt_sort_single))
         return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);

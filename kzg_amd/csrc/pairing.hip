@@ -515,6 +515,7 @@ extern "C" void kzg_srs_g2_free(kzg_ctx *ctx, kzg_srs_g2 *srs) {
 // sum_i scalars[i] * srs[offset + i] on the device -> one affine point at d_out
 static int g2_msm_device(kzg_ctx *ctx, const kzg_srs_g2 *srs, size_t offset, const Fr *d_scalars, size_t n, int is_mont,
                          G2Affine *d_out) {
+    if (srs->device != ctx->device) return fail(ctx, KZG_ERR_SHAPE, "the G2 points are resident on another GPU than this context's");
     hipStream_t st = ctx->lanes[0].stream;
     G2Jacobian *terms = (G2Jacobian *)lane_alloc(ctx, 0, (n + 64) * sizeof(G2Jacobian));
     if (!terms) return fail(ctx, KZG_ERR_ALLOC, "workspace");

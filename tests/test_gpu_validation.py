@@ -227,3 +227,39 @@ def test_window_rows_low_memory_srs(engine, rows):
         finally:
             engine.set_option("window_rows", 0)
             engine.set_option("window_bits", 0)
+
+
+def test_srs_of_another_gpu_is_refused():
+    """An SRS is resident on ONE GPU; handing it to a context on another one (a host with several kzg_ctx, one per GPU, mixing up its
+    handles) must be an error at the door, not a kernel on GPU a chasing pointers into GPU b.  Every MSM of every entry point passes
+    msm_run's check.  One-GPU box: the SRS's device field is changed through the hooks build."""
+    from tests.gpu_common import HooksEngine
+    h = HooksEngine(0)
+    lib = h.lib
+    vp, sz, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
+    lib.kzg_srs_setup_g1.argtypes = [vp, vp, i32, sz, ctypes.POINTER(vp)]
+    lib.kzg_msm_g1.argtypes = [vp, vp, sz, vp, sz, i32, i32, vp, i32]
+    lib.kzg_msm_g1_batch.argtypes = [vp, vp, sz, vp, sz, sz, i32, i32, vp, i32]
+    lib.kzg_witness_coeff.argtypes = [vp, vp, vp, sz, vp, vp, i32, i32, vp, i32]
+    lib.kzg_test_srs_set_device.argtypes = [vp, i32]
+    lib.kzg_srs_free.argtypes = [vp, vp]
+    srs = vp()
+    n = 300
+    assert lib.kzg_srs_setup_g1(h.ctx, (TAU % M.R).to_bytes(32, "little"), L.FR_CANONICAL, n, ctypes.byref(srs)) == 0
+    rng = random.Random(31)
+    coeffs = rand_scalars(rng, n)
+    blob = kzg_amd.pack_scalars(coeffs)
+    out = ctypes.create_string_buffer(96 * 4)
+    want = C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU))
+    assert lib.kzg_msm_g1(h.ctx, srs, 0, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw[:96] == want
+    assert lib.kzg_test_srs_set_device(srs, 5) == 0
+    assert lib.kzg_msm_g1(h.ctx, srs, 0, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == L.KZG_ERR_SHAPE
+    assert "resident on GPU 5" in h.last_error()
+    assert lib.kzg_msm_g1_batch(h.ctx, srs, 0, blob * 2, n, 2, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == L.KZG_ERR_SHAPE
+    x = (7).to_bytes(32, "little")
+    y = C.poly_eval(coeffs, 7).to_bytes(32, "little")
+    assert lib.kzg_witness_coeff(h.ctx, srs, blob, n, x, y, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == L.KZG_ERR_SHAPE
+    assert lib.kzg_test_srs_set_device(srs, 0) == 0                      # and the context is fine afterwards
+    assert lib.kzg_msm_g1(h.ctx, srs, 0, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw[:96] == want
+    lib.kzg_srs_free(h.ctx, srs)
+    h.close()
