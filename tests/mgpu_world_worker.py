@@ -74,6 +74,19 @@ def scenario(group, rank_of_failure, seed):
     out["batch_device"] = [b.hex() for b in group.commit_batch(srs, bufs, N, batch)]
     for b in bufs:
         b.free()
+    # device-resident polynomials SHORTER than the SRS (4000 of 5003 coefficients): a rank holds [batch][its terms below 4000], the
+    # last ranks hold fewer terms than their shard or none
+    short, bufs = 4000, []
+    for i in range(group.local_count):
+        lo, hi = shard_range(N, group.rank(i), group.world)
+        lo, hi = min(lo, short), min(hi, short)
+        b = group.engine(i).alloc_scalars(max(hi - lo, 1) * batch)
+        if hi > lo:
+            b.upload(kzg_amd.pack_scalars([c for p in bp for c in p[lo:hi]]))
+        bufs.append(b)
+    out["batch_device_short"] = [b.hex() for b in group.commit_batch(srs, bufs, short, batch)]
+    for b in bufs:
+        b.free()
     # create_witness: on the polynomial, off it (the reference's error, after the exchange), a polynomial of one coefficient
     p = polys[N]
     x = rng.randrange(R)

@@ -65,6 +65,7 @@ def _expected(seed):
     bp = [[rng.randrange(M.R) for _ in range(N)] for _ in range(3)] + [[0] * N, [M.R - 1] * N]
     exp["batch"] = [C.g1_mul(G, C.poly_eval(p, TAU)).hex() for p in bp]
     exp["batch_compressed"] = [M.g1_to_compressed(C.blob_to_point(bytes.fromhex(b))).hex() for b in exp["batch"]]
+    exp["batch_short"] = [C.g1_mul(G, C.poly_eval(p[:4000], TAU)).hex() for p in bp]
     p = polys[N]
     x = rng.randrange(M.R)
     y = _horner(p, x)
@@ -103,6 +104,7 @@ def _check(res, exp, world):
     assert res["commit"] == exp["commit"]
     assert res["batch_host"] == exp["batch"] and res["batch_device"] == exp["batch"]
     assert res["batch_compressed"] == exp["batch_compressed"]
+    assert res["batch_device_short"] == exp["batch_short"]
     assert res["witness"] == exp["witness"] and res["witness_device"] == exp["witness"]
     assert res["witness_off_poly"] == "PointNotOnPolynomial"
     # create_witness_batched: the interpolant passes through the points with degree < k, and w = [(p(tau) - I(tau)) / Z(tau)]G
