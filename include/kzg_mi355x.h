@@ -132,6 +132,9 @@ int kzg_sync(kzg_ctx *ctx);
  * thread -- the same field code compiled for the host -- instead of one GPU lane; same bytes, ~90 us less latency),
  * "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only),
  * "defer_tail" (1 / 0: kzg_msm_g1_batch enqueues a lane's tail kernels after the sort of the lane's next MSM; default 1),
+ * "accum_blocks_small" / "accum_streams_small" / "small_entries" (MSMs of at most small_entries sorted entries -- windows x terms,
+ *  default 2^21: up to 2^17 points -- inside a pipeline take a 160-block accumulation grid and are spread over 4 accumulation
+ *  streams instead of 480 blocks on 2: +20 % at 2^16, +50 % at 2^14; accum_blocks_small = 0 switches the rule off),
  * "heavy_bins" (sort bins far above their share -- scalars that are bits, bytes, all equal -- sorted in slices by many blocks:
  *  0 = for the 64 MSMs after one that met such a bin (default; the extra kernels cost uniform scalars 0.8 %), 1 = always, 2 = never;
  *  setting it clears the history),

@@ -394,6 +394,17 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
         if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams must be 0..4");
         ctx->opt_accum_streams = (int)value;
         ctx->pipe_planned = false;
+    } else if (k == "accum_streams_small") {
+        if (value < 0 || value > 4) return fail(ctx, KZG_ERR_SHAPE, "accum_streams_small must be 0..4");
+        ctx->opt_accum_streams_small = (int)value;
+        ctx->pipe_planned = false;
+    } else if (k == "accum_blocks_small") {
+        if (value != 0 && (value < 64 || value > 256 * KZG_ACCUM_WAVES)) return fail(ctx, KZG_ERR_SHAPE, "accum_blocks_small must be 0 (off) or 64..256 x waves per SIMD");
+        ctx->opt_accum_blocks_small = (int)value;
+        ctx->pipe_planned = false;
+    } else if (k == "small_entries") {
+        if (value < 0) return fail(ctx, KZG_ERR_SHAPE, "small_entries must be >= 0");
+        ctx->opt_small_entries = value;
     } else if (k == "host_affine") {
         ctx->opt_host_affine = value != 0;
     } else if (k == "heavy_bins") {
@@ -600,13 +611,25 @@ int kzg::lease_lane(kzg_ctx *ctx, Lease *ls) {
     // flight the call is one stage of a pipeline: batch-sized grid on a FIFO accumulation stream, lane-time tail
     const bool pipelined = others > 0 && ctx->pipe_planned;
     set_lane_mode(ctx, lane, pipelined, others >= 3);
-    if (pipelined && ctx->pipe_accum > 0) ls->accum = ctx->accum_streams[ctx->accum_rr.fetch_add(1) % (uint32_t)ctx->pipe_accum];
+    if (pipelined && ctx->pipe_accum > 0) {
+        ls->pipelined = true;
+        ls->slot = ctx->accum_rr.fetch_add(1);
+    }
     return KZG_OK;
 }
 
+// how many of the `planned` accumulation streams MSMs of this size are spread over (small ones: all; common.h opt_accum_streams_small)
+static int accum_streams_for(kzg_ctx *ctx, int planned, const kzg_srs *srs, size_t n) {
+    if (planned <= 0) return 1;
+    if (ctx->msm_small((size_t)srs->W * n)) return planned;
+    return planned < ctx->opt_accum_streams ? planned : (ctx->opt_accum_streams > 0 ? ctx->opt_accum_streams : 1);
+}
+
 int kzg::lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res) {
-    if (ls.accum)
-        return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res, ls.accum, ctx->sorted_events[ls.lane], ctx->accum_events[ls.lane]);
+    if (ls.pipelined) {
+        hipStream_t accum = ctx->accum_streams[ls.slot % (uint32_t)accum_streams_for(ctx, ctx->pipe_accum, srs, n)];
+        return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res, accum, ctx->sorted_events[ls.lane], ctx->accum_events[ls.lane]);
+    }
     return msm_run(ctx, ls.lane, srs, offset, d_sc, n, sfmt, res);
 }
 
@@ -719,7 +742,9 @@ static void set_lane_mode(kzg_ctx *ctx, int lane, bool pipelined, bool deep) {
 // than lanes + accumulation streams the pipeline is narrowed to fit (measured on 4 queues: 3 lanes + 1 accumulation stream
 // 392/s, 2 + 2: 330/s, 4 + 0: 383/s, against 405/s with 18 queues; profiles/r02_hw_queues.txt).
 static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
+    // (small MSMs are spread over more accumulation streams than large ones: the plan holds the larger number)
     int nl = want, nas = want > 1 ? ctx->opt_accum_streams : 0;
+    if (nas > 0 && ctx->opt_accum_blocks_small > 0 && ctx->opt_accum_streams_small > nas) nas = ctx->opt_accum_streams_small;
     if (want > 1) {
         KZG_TRY(ensure_lanes(ctx, want));
         for (int i = 0; i < nas; i++)
@@ -799,8 +824,8 @@ static int batch_msm(kzg_ctx *ctx, const BatchPipe &bp, size_t b, int lane, cons
     if (bp.nas) {
         // a lane's two MSMs in flight (deferred tails) use different events
         const int ev = defer ? lane + (int)((b / (size_t)bp.nl) & 1) * bp.nl : lane;
-        return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res, ctx->accum_streams[b % bp.nas], ctx->sorted_events[ev], ctx->accum_events[ev],
-                       defer);
+        return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res, ctx->accum_streams[b % (size_t)accum_streams_for(ctx, bp.nas, srs, n)],
+                       ctx->sorted_events[ev], ctx->accum_events[ev], defer);
     }
     return msm_run(ctx, lane, srs, offset, d_sc, n, sfmt, res);
 }

@@ -131,6 +131,15 @@ struct kzg_ctx {
     // (rocprofv3 kernel trace); two FIFO streams keep exactly the next one or two queued behind the running one: +3.5 %.
     // Needs its own hardware queues (GPU_MAX_HW_QUEUES >= lanes + 2): sharing a queue with a lane serialises them (-10 %).
     int opt_accum_streams = 2;
+    // Small MSMs in a pipeline (sorted entries W * n <= opt_small_entries: up to 2^17 points): the per-thread costs of the equal
+    // split (a partial sum written and folded per thread and per bucket boundary) weigh more the shorter a thread's chunk, so such
+    // an MSM gets a smaller accumulation grid and the pipeline more accumulation streams to keep the chip full -- measured
+    // (profiles/r04_small_grid_ab.txt) 160 blocks on 4 streams against 480 on 2: +49 % at 2^14, +39 % at 2^15, +20 % at 2^16, +9 % at
+    // 2^17; at 2^20 four streams measure -1 %, so larger MSMs keep two.
+    int opt_accum_streams_small = 4;
+    int opt_accum_blocks_small = 160;
+    int64_t opt_small_entries = 2 << 20;
+    bool msm_small(size_t entries) const { return opt_accum_blocks_small > 0 && (int64_t)entries <= opt_small_entries; }
     hipStream_t accum_streams[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> sorted_events, accum_events;  // per lane
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
@@ -200,7 +209,8 @@ struct Guard {  // exclusive use of the context for the scope
 struct Lease {
     kzg_ctx *ctx = nullptr;
     int lane = -1;
-    hipStream_t accum = nullptr;  // the FIFO accumulation stream of this call (nullptr: on the lane's own stream)
+    bool pipelined = false;  // others were in flight when the lane was leased: the call's accumulation goes to a FIFO accumulation stream
+    uint32_t slot = 0;       // ... which one: slot modulo the number of streams MSMs of its size are spread over (lease_msm)
     ~Lease();
 };
 int lease_lane(kzg_ctx *ctx, Lease *ls);

@@ -920,7 +920,11 @@ static int msm_run_narrow(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t off
     // rows == W (the default): one pass, no doubling chain.
     const int rows = srs->naf ? W : srs->rows, passes = (W + rows - 1) / rows;  // positional tables: one pass, always
     MsmPoint *pass_res = (MsmPoint *)(base + L.off_pass);
-    const uint32_t slots = (uint32_t)mm.accum_blocks * 256u;  // resident threads k_accum_affine is split over
+    // resident threads k_accum_affine is split over; a small MSM inside a pipeline takes a smaller grid (common.h opt_accum_blocks_small)
+    const bool in_pipeline = accum_stream && accum_stream != st;
+    const int acc_blocks = in_pipeline && ctx->msm_small(L.M_max) && ctx->opt_accum_blocks_small < mm.accum_blocks ? ctx->opt_accum_blocks_small
+                                                                                                                   : mm.accum_blocks;
+    const uint32_t slots = (uint32_t)acc_blocks * 256u;
     uint32_t *hvp = (uint32_t *)(base + L.off_hv);
     const uint32_t heavy_seq = ++ctx->lanes[lane].heavy_seq;  // (the lane is leased: no other thread touches it)
     uint32_t *lane_heavy = ctx->d_lane_heavy + lane;
