@@ -34,7 +34,7 @@ hw "host exports GPU_MAX_HW_QUEUES=24 itself, library sets nothing" KZG_HW_QUEUE
 hw "nobody asks: the runtime's default pool (4 queues), engine narrows the pipeline" KZG_HW_QUEUES=0
 hw "KZG_SET_HW_QUEUES=1: the library's load-time constructor opts in" KZG_HW_QUEUES=0 KZG_SET_HW_QUEUES=1
 done > $O/hw_queues.txt 2>&1
-timeout 900 python3 tools/sweep.py 16 18 20 22 24 > $O/sweep.jsonl 2> $O/sweep.err
+timeout 900 python3 tools/sweep.py 14 16 17 18 19 20 21 22 23 24 > $O/sweep.jsonl 2> $O/sweep.err
 # round 4: the concurrent-callers mix (every leased call, oracle-checked), the NTT probe, N > 1 block at world size 1
 timeout 300 python3 tools/stress_callers.py 60 18 16 > $O/stress_callers.txt 2>&1
 timeout 200 python3 tools/ntt_probe.py 16 18 20 22 24 > $O/ntt_probe.txt 2>&1

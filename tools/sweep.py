@@ -18,12 +18,13 @@ R = kzg_amd.api.R_MODULUS
 
 
 def main():
-    logs = [int(a) for a in sys.argv[1:]] or [16, 18, 20, 22]
+    logs = [int(a) for a in sys.argv[1:]] or [16, 17, 18, 19, 20, 21, 22, 23, 24]
     e = kzg_amd.Engine(0)
     rows = []
     for log_n in logs:
         n = 1 << log_n
-        batch = 4 if log_n <= 22 else 2
+        # the pipeline's depth where memory allows: 64 commitments per call up to 2^20, 2 GiB of resident scalars above
+        batch = int(os.environ.get("KZG_SWEEP_BATCH", "0")) or (64 if log_n <= 20 else max(2, 64 >> (log_n - 20)))
         t0 = time.perf_counter()
         params = kzg_amd.setup(e, TAU, n, g2_len=0)
         t_setup = time.perf_counter() - t0
@@ -36,7 +37,7 @@ def main():
                 rc = e.lib.kzg_msm_g1_batch(e.ctx, params.gs.handle, 0, scal.ptr, n, batch, scal.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
                 assert rc == 0, e.last_error()
             step()
-            reps = 5 if log_n <= 20 else 2
+            reps = 8 if log_n <= 18 else (4 if log_n <= 21 else 2)
             t0 = time.perf_counter()
             for _ in range(reps):
                 step()
