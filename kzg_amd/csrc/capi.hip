@@ -790,6 +790,7 @@ static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
         ctx->sorted_events.push_back(e1);
         ctx->accum_events.push_back(e2);
     }
+    ctx->planned_accum = nas;
     *nl_out = nl;
     *nas_out = nas;
     return KZG_OK;

@@ -139,7 +139,9 @@ struct kzg_ctx {
     int opt_accum_streams_small = 4;
     int opt_accum_blocks_small = 160;
     int64_t opt_small_entries = 2 << 20;
-    bool msm_small(size_t entries) const { return opt_accum_blocks_small > 0 && (int64_t)entries <= opt_small_entries; }
+    int planned_accum = 0;   // accumulation streams of the current plan (plan_pipeline): with fewer than three (a process short of
+                             // hardware queues narrows the pipeline) the small grid would leave most of the chip idle, so the rule is off
+    bool msm_small(size_t entries) const { return opt_accum_blocks_small > 0 && planned_accum >= 3 && (int64_t)entries <= opt_small_entries; }
     hipStream_t accum_streams[4] = {nullptr, nullptr, nullptr, nullptr};
     std::vector<hipEvent_t> sorted_events, accum_events;  // per lane
     int opt_sort_threads = 1024;       // threads per k_hist / k_scatter block for a single MSM (one block per CU: 128 KiB of LDS)
