@@ -33,9 +33,16 @@ cp("sweep.jsonl", "sweep.jsonl")
 for a, b in (("stress_callers.txt", "stress_callers.txt"), ("ntt_probe.txt", "ntt_probe.txt"), ("bench_sharded_block_world1.json", "bench_sharded_block_world1.json"),
              ("pmc_ntt_sq.summary.json", "pmc_ntt_2e20_sq.json"), ("pmc_ntt_lds.summary.json", "pmc_ntt_2e20_lds.json"),
              ("pmc_ntt_fetch.summary.json", "pmc_ntt_2e20_fetch.json"), ("pmc_ntt_write.summary.json", "pmc_ntt_2e20_write.json"),
-             ("fuzz.txt", "fuzz.txt"), ("skew.txt", "skewed_scalars.txt")):
+             ("skew.txt", "skewed_scalars.txt")):
     if os.path.exists(os.path.join(src, a)):
         cp(a, b)
+# the fuzz record is a history of runs (seeds, durations, builds): the collection's run is appended, never replaces it
+fz = os.path.join(src, "fuzz.txt")
+if os.path.exists(fz):
+    last = [ln for ln in open(fz).read().splitlines() if "fuzz done" in ln][-1:]
+    with open(os.path.join(dst, f"{rnd}_fuzz.txt"), "a") as f:
+        f.write("# collection %s:\n%s\n" % (tag, "\n".join(last)))
+    print("profiles/%s_fuzz.txt (appended)" % rnd)
 hw = os.path.join(dst, f"{rnd}_hw_queues.txt")
 head = [ln for ln in open(hw).read().splitlines() if ln.startswith("#")] if os.path.exists(hw) else []
 open(hw, "w").write("\n".join(head + open(os.path.join(src, "hw_queues.txt")).read().splitlines()) + "\n")
