@@ -659,7 +659,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="commitments per step (pipelined on the engine's HIP streams)")
-    ap.add_argument("--streams", type=int, default=16, help="HIP streams the engine pipelines a batch over (0 = engine default)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="lanes the engine pipelines a batch over (0 = the engine's default: 16, or 14 for a device group's contexts, which "
+                         "leave hardware queues to the RCCL communicator in the process)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks_batch (0 = default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (kzg_ctx_set_option), repeatable")
     ap.add_argument("--log-n", type=int, default=LOG_N)

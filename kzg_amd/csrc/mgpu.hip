@@ -287,6 +287,12 @@ static int mctx_make_ctxs(kzg_mctx *m) {
         int rc = kzg_ctx_create(m->devices[i], &c);
         if (rc != KZG_OK) return rc;
         m->ctxs.push_back(c);
+        // A group's context shares the process' hardware-queue pool with the RCCL communicator: with 16 lanes + 4 accumulation
+        // streams the exchange's kernels end up behind the pipeline's on shared queues (measured at world 1, all-gather forced on:
+        // 400 against 482 commitments/s); 14 + 4 costs the plain pipeline <= 1 % and leaves RCCL its queues
+        // (profiles/r04_group_queues_ab.txt).  kzg_mctx_set_option(m, "streams", ...) overrides.
+        rc = kzg_ctx_set_option(c, "streams", 14);
+        if (rc != KZG_OK) return rc;
     }
     // the exchange buffers of ordinary calls (up to 64 polynomials per call) and the status-only agreement buffer exist from the
     // start: a group that formed can always exchange statuses, whatever fails later
