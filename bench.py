@@ -770,6 +770,8 @@ def main():
         engine.set_option("window_bits", args.window_bits)
     if args.streams:
         engine.set_option("streams", args.streams)
+    elif world > 1 and args.torch_backend == "nccl" and not sharded:
+        engine.set_option("streams", 14)     # torch's own communicator on this GPU needs hardware queues too
     if args.accum_blocks:
         engine.set_option("accum_blocks_batch", args.accum_blocks)
     for kv in args.opt:
