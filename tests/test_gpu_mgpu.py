@@ -368,3 +368,24 @@ print("ok")
     env = dict(os.environ, KZG_TEST_NO_RCCL="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_group_context_leaves_hardware_queues_to_rccl():
+    """A device group's context shares the process' hardware-queue pool (24) with the RCCL communicator: it pipelines over 14 lanes
+    (+ 4 accumulation streams = 18 streams), not the plain context's 16 -- with 20 streams beside RCCL the group path measured 400
+    against 471-482 commitments/s (profiles/r04_group_queues_ab.txt).  Read from the engine's KZG_DEBUG plan line, in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import kzg_amd\n"
+            "g = kzg_amd.DeviceGroup([0]); g.set_option('always_gather', 1); n = 1 << 12\n"
+            "srs = g.setup(12345, n); flat = kzg_amd.pack_scalars(list(range(1, n + 1)) * 40)\n"
+            "out = g.commit_batch(srs, flat, n, 40); assert len(set(out)) == 1; srs.free(); g.close()\n"
+            "e = kzg_amd.Engine(0); p = kzg_amd.setup(e, 12345, n, g2_len=0); buf = e.alloc_scalars(n * 40); buf.upload(flat)\n"
+            "assert e.msm_batch(p.gs, buf, n, 40)[0] == out[0]; print('DONE')\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_DEBUG="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "DONE" in r.stdout, r.stderr[-2000:]
+    plans = [ln for ln in r.stderr.splitlines() if "pipeline plan" in ln]
+    assert any("14 lanes + 4 accumulation streams" in ln for ln in plans), plans      # the group's context
+    assert any("16 lanes + 4 accumulation streams" in ln for ln in plans), plans      # a plain context in the same process
