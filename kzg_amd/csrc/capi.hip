@@ -405,8 +405,6 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "small_entries") {
         if (value < 0) return fail(ctx, KZG_ERR_SHAPE, "small_entries must be >= 0");
         ctx->opt_small_entries = value;
-    } else if (k == "wide_in_lane") {
-        ctx->opt_wide_in_lane = value != 0;
     } else if (k == "host_affine") {
         ctx->opt_host_affine = value != 0;
     } else if (k == "heavy_bins") {

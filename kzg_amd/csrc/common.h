@@ -139,7 +139,6 @@ struct kzg_ctx {
     int opt_accum_streams_small = 4;
     int opt_accum_blocks_small = 160;
     int64_t opt_small_entries = 2 << 20;
-    bool opt_wide_in_lane = false;  // option wide_in_lane = 1: the 18..20-bit-window path keeps its accumulation kernel on the lane's own stream (A/B)
     int planned_accum = 0;   // accumulation streams of the current plan (plan_pipeline): with fewer than three (a process short of
                              // hardware queues narrows the pipeline) the small grid would leave most of the chip idle, so the rule is off
     bool msm_small(size_t entries) const { return opt_accum_blocks_small > 0 && planned_accum >= 3 && (int64_t)entries <= opt_small_entries; }

@@ -785,7 +785,7 @@ static size_t expected_partials(size_t M_max, uint32_t slots, int B) {
 }
 
 static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const void *d_scalars, size_t n, int sfmt,
-                        MsmPoint **d_result, hipStream_t accum_stream, hipEvent_t sorted_ev, hipEvent_t accum_ev) {
+                        MsmPoint **d_result) {
     if ((uint64_t)srs->W * srs->npad >= (1ull << WIDE_HI_SHIFT))
         return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the wide-window entry encoding (window_bits 18..20: W * n < 2^27)");
     hipStream_t st = ctx->lanes[lane].stream;
@@ -831,20 +831,8 @@ static int msm_run_wide(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offse
     KZG_TRY(wide_s1_layout(ctx, st, bucket_start, Btot, state, segsums, segmaxs, segtotal, s1));
     size_t thr1 = L.M_max / KZG_ACCUM_MIN_CHUNK + 1 < (size_t)slots ? L.M_max / KZG_ACCUM_MIN_CHUNK + 1 : (size_t)slots;
     unsigned grid1 = (unsigned)((thr1 + 255) / 256);
-    if (accum_stream && accum_stream != st && !ctx->opt_wide_in_lane) {
-        // inside a pipeline the accumulation goes to a FIFO accumulation stream, as on the narrow path: the next MSM's sort and this
-        // one's tail (2^19 buckets) then run beside the neighbours' accumulation kernels instead of between them
-        KZG_HIP_CHECK(ctx, hipEventRecord(sorted_ev, st));
-        std::lock_guard<std::mutex> alk(ctx->accum_mu);
-        KZG_HIP_CHECK(ctx, hipStreamWaitEvent(accum_stream, sorted_ev, 0));
-        KZG_LAUNCH(ctx, accum_stream, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, s1, Btot,
-                   (const uint4 *)srs->table30, bufA, state);
-        KZG_HIP_CHECK(ctx, hipEventRecord(accum_ev, accum_stream));
-        KZG_HIP_CHECK(ctx, hipStreamWaitEvent(st, accum_ev, 0));
-    } else {
-        KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, s1, Btot,
-                   (const uint4 *)srs->table30, bufA, state);
-    }
+    KZG_LAUNCH(ctx, st, "k_accum_affine", k_accum_affine, grid1, 256, 0, entries2, bucket_start, s1, Btot,
+               (const uint4 *)srs->table30, bufA, state);
     return msm_tail_run(ctx, st, mm, bufA, bufB, s1, Btot, expected_partials(L.M_max, slots, Btot), state, base + L.off_tail, L.tail,
                         d_result);
 }
@@ -1079,7 +1067,7 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
                                             std::to_string(ctx->device) + ": upload or generate it through this context");
     if (n > srs->n || offset > srs->n - n) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS (reference: slice index panic)");
     if (srs->c > 16 && !srs->narrow17 && !(srs->sort20 && !ctx->opt_sort_single))
-        return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result, accum_stream, sorted_ev, accum_ev);
+        return msm_run_wide(ctx, lane, srs, offset, d_scalars, n, sfmt, d_result);
     if ((uint64_t)srs->rows * srs->npad >= (1ull << 31))
         return fail(ctx, KZG_ERR_SHAPE, "SRS too large for the 31-bit entry index (table rows * points < 2^31)");
     if (srs->naf && offset + n > srs->npad) return fail(ctx, KZG_ERR_SHAPE, "MSM range exceeds the SRS");
