@@ -192,6 +192,8 @@ int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t grou
  *   - one process per GPU:  rank 0 calls kzg_mctx_unique_id, the host distributes the 128 bytes by any means (MPI, a TCP
  *     store, torch.distributed), every rank calls kzg_mctx_create_rank(device, rank, world, id)   (ncclCommInitRank).
  * RCCL (librccl.so.1) is loaded on first use; a group of one GPU needs no RCCL unless option "always_gather" is set.
+ * A group's contexts pipeline over 14 lanes instead of 16 (option "streams" through kzg_mctx_set_option): the communicator's kernels
+ * need hardware queues from the same per-process pool as the contexts' streams.
  * Every entry point below is collective in the one-process-per-GPU mode: all ranks call it with the same arguments.
  * Failures stay collective too: a rank whose local phase fails still enters the exchange, its status travels with its
  * partials, and EVERY rank returns that error (no rank is left waiting inside the all-gather).  A rank-local resource failure
