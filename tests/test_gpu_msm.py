@@ -345,3 +345,46 @@ def test_concurrent_callers(engine, srs_small):
     for e, s in zip(engines, srss):
         s.free()
         e.close()
+
+
+@pytest.mark.parametrize("log_n", [12, 16, 17])
+def test_small_msm_pipeline_shapes_agree(engine, log_n):
+    """MSMs of up to 2^17 points inside a pipeline take a 160-block accumulation grid on four accumulation streams (round 4); the old
+    shape (accum_blocks_small = 0: the batch grid on two streams), other grids, a narrowed stream plan and the lone call must all give
+    the same bytes -- uniform, u64-valued, all-equal and sparse coefficients -- each equal to the oracle's [p(tau)]G."""
+    import kzg_amd
+    from kzg_amd import _lib as L
+    n, batch, tau = 1 << log_n, 36, 0x5151ABCD
+    params = kzg_amd.setup(engine, tau, n, g2_len=0)
+    scal = engine.alloc_scalars(n * batch)
+    views = []
+    for b in range(batch):
+        v = kzg_amd.DeviceBuffer.__new__(kzg_amd.DeviceBuffer)
+        v.engine, v.n, v.sfmt, v.ptr = engine, n, scal.sfmt, ctypes.c_void_p(scal.ptr.value + 32 * n * b)
+        views.append(v)
+        if b % 4 == 0:
+            v.fill_random(900 + b)
+        elif b % 4 == 1:
+            v.fill_random(900 + b, u64_valued=True)
+        elif b % 4 == 2:
+            v.upload(M.fr_to_le((0xABCDEF0123456789 << 100) % M.R) * n)                     # all equal: one bucket per window
+        else:
+            v.upload(b"".join(M.fr_to_le(7 if i % 997 == 0 else 0) for i in range(n)))      # sparse
+    G = C.g1_generator()
+    want = [C.g1_mul(G, C.poly_eval_bytes(v.download(), n, tau)) for v in views[:8]]
+    try:
+        ref = engine.msm_batch(params.gs, scal, n, batch)
+        assert ref[:8] == want
+        for opts in ({"accum_blocks_small": 0}, {"accum_blocks_small": 64}, {"accum_blocks_small": 256, "accum_streams_small": 3},
+                     {"small_entries": 0}, {"accum_streams": 1, "accum_streams_small": 0}, {"defer_tail": 0}):
+            for k, val in opts.items():
+                engine.set_option(k, val)
+            assert engine.msm_batch(params.gs, scal, n, batch) == ref, opts
+            for k, val in {"accum_blocks_small": 160, "accum_streams_small": 4, "small_entries": 2 << 20, "accum_streams": 2, "defer_tail": 1}.items():
+                engine.set_option(k, val)
+        assert [engine.msm(params.gs, v) for v in views[:6]] == ref[:6]                     # lone calls
+    finally:
+        for k, val in {"accum_blocks_small": 160, "accum_streams_small": 4, "small_entries": 2 << 20, "accum_streams": 2, "defer_tail": 1}.items():
+            engine.set_option(k, val)
+        scal.free()
+        params.gs.free()
