@@ -376,6 +376,47 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
         t_many = timeit(witness_many, reps=1, warm=1)
         res["witness_many_k%d_per_s" % k] = round(k / t_many * 1e3, 1)
         res["witness_many_all_on_poly"] = all(v == 0 for v in st)
+    # config 3 at pipeline speed: 16 host threads, each taking coefficient vectors to evaluation form (EvaluationDomain::fft, in
+    # place on its own device buffer) and committing them against the Lagrange-basis SRS (KZGProverEvalForm::commit) -- every
+    # commitment must equal the coefficient-form commitment of the same polynomial
+    if time.perf_counter() - t_start < budget_s * 0.7:
+        try:
+            import threading
+            threads, calls = 16, 4
+            bufs = [[engine.alloc_scalars(n) for _ in range(calls + 1)] for _ in range(threads)]
+            for t in range(threads):
+                for b in bufs[t]:
+                    b.upload(host_coeffs)
+            ok = [True] * threads
+
+            def work(t, which, barrier):
+                o = ctypes.create_string_buffer(96)
+                barrier.wait()
+                for b in which(bufs[t]):
+                    rc = lib.kzg_ntt_fr(ctx, b.ptr, log_n, 0, L.IN_DEVICE)
+                    rc = rc or lib.kzg_commit_eval(ctx, lag.handle, b.ptr, n, b.sfmt, L.IN_DEVICE, o, L.G1_AFFINE_MONT)
+                    if rc != 0 or o.raw != commitment:
+                        ok[t] = False
+
+            def round_(which):
+                bar = threading.Barrier(threads + 1)
+                th = [threading.Thread(target=work, args=(t, which, bar)) for t in range(threads)]
+                for x in th:
+                    x.start()
+                bar.wait()
+                t0 = time.perf_counter()
+                for x in th:
+                    x.join()
+                return time.perf_counter() - t0
+            round_(lambda bs: bs[:1])          # untimed: lanes, plans, arenas
+            dt = round_(lambda bs: bs[1:])
+            res["blocking_callers_16_fft_commit_eval_per_s"] = round(threads * calls / dt, 2)   # configs[2] from many threads
+            res["blocking_callers_16_fft_commit_eval_match_commit_coeff"] = all(ok)
+            for bl in bufs:
+                for b in bl:
+                    b.free()
+        except Exception as e:  # noqa: BLE001
+            res["blocking_callers_16_fft_commit_eval_note"] = str(e)[:200]
     ev.free()
     lag.free()
     return res

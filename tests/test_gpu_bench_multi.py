@@ -75,6 +75,9 @@ def test_bench_line_carries_live_pmc_traffic():
     entries = (1 << 16) * d["config"]["windows"]
     assert 64 * entries < rf["traffic"] < 512 * entries
     assert rf["frac_of_nominal"] > 0 and d["paths"]["ntt_2e16_ms"] > 0
+    # BASELINE configs[2] from 16 threads (fft in place, then the Lagrange-SRS commit): every commitment equals the coefficient-form one
+    assert d["paths"]["blocking_callers_16_fft_commit_eval_match_commit_coeff"] is True
+    assert d["paths"]["blocking_callers_16_fft_commit_eval_per_s"] > 0
 
 
 def _torchrun(nproc, port, bench_args, timeout=900):
