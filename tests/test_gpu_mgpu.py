@@ -378,14 +378,25 @@ def test_group_context_leaves_hardware_queues_to_rccl():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import sys; sys.path.insert(0, %r); import kzg_amd\n"
-            "g = kzg_amd.DeviceGroup([0]); g.set_option('always_gather', 1); n = 1 << 12\n"
-            "srs = g.setup(12345, n); flat = kzg_amd.pack_scalars(list(range(1, n + 1)) * 40)\n"
-            "out = g.commit_batch(srs, flat, n, 40); assert len(set(out)) == 1; srs.free(); g.close()\n"
-            "e = kzg_amd.Engine(0); p = kzg_amd.setup(e, 12345, n, g2_len=0); buf = e.alloc_scalars(n * 40); buf.upload(flat)\n"
-            "assert e.msm_batch(p.gs, buf, n, 40)[0] == out[0]; print('DONE')\n" % root)
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_DEBUG="1"), capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and "DONE" in r.stdout, r.stderr[-2000:]
-    plans = [ln for ln in r.stderr.splitlines() if "pipeline plan" in ln]
-    assert any("14 lanes + 4 accumulation streams" in ln for ln in plans), plans      # the group's context
-    assert any("16 lanes + 4 accumulation streams" in ln for ln in plans), plans      # a plain context in the same process
+    group_code = ("import sys; sys.path.insert(0, %r); import kzg_amd\n"
+                  "g = kzg_amd.DeviceGroup([0]); g.set_option('always_gather', 1); n = 1 << 12\n"
+                  "srs = g.setup(12345, n); flat = kzg_amd.pack_scalars(list(range(1, n + 1)) * 40)\n"
+                  "out = g.commit_batch(srs, flat, n, 40); assert len(set(out)) == 1; srs.free(); g.close(); print('DONE', out[0].hex())\n" % root)
+    plain_code = ("import sys; sys.path.insert(0, %r); import kzg_amd\n"
+                  "n = 1 << 12; flat = kzg_amd.pack_scalars(list(range(1, n + 1)) * 40)\n"
+                  "e = kzg_amd.Engine(0); p = kzg_amd.setup(e, 12345, n, g2_len=0); buf = e.alloc_scalars(n * 40); buf.upload(flat)\n"
+                  "print('DONE', e.msm_batch(p.gs, buf, n, 40)[0].hex())\n" % root)
+    # (one process each: what the second context of a process finds in the queue pool depends on what the first one left there)
+    res = {}
+    import re
+    for name, code, most in (("group", group_code, 14), ("plain", plain_code, 16)):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_DEBUG="1"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "DONE" in r.stdout, r.stderr[-2000:]
+        plans = [tuple(map(int, re.findall(r"(\d+) lanes \+ (\d+) accumulation", ln)[0])) for ln in r.stderr.splitlines() if "pipeline plan" in ln]
+        # (inside the whole suite the pytest process holds contexts of its own on this GPU, and a child may find the chip's queues
+        # shared and narrow its plan further: the bound is what is asserted, and the total never exceeds 18 streams for a group)
+        assert plans and all(nl <= most for nl, _ in plans), (name, plans)
+        if name == "group":
+            assert all(nl + nas <= 18 for nl, nas in plans), plans
+        res[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("DONE")][-1]
+    assert res["group"] == res["plain"]        # the same commitment through both
