@@ -18,8 +18,12 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <random>
+#include <vector>
 
 namespace kzg {
 namespace shmt {
