@@ -669,6 +669,9 @@ def measure_sharded_block(kzg_amd, L, job, args, force_gather):
                 if rc:
                     raise RuntimeError(group.last_error())
             step()
+            if "formation" not in res:      # after the first exchange: what forming the communicator cost on this rank (ms per phase)
+                res["formation"] = group.formation()
+                res["rccl"] = group.info()
             job.barrier()
             t0 = time.perf_counter()
             for _ in range(steps):
@@ -692,6 +695,119 @@ def measure_sharded_block(kzg_amd, L, job, args, force_gather):
     finally:
         group.close()
     return res
+
+
+def sharded_child_main(args):
+    """`bench.py --sharded-child`: the sharded block alone, in a fresh process per rank (started by run_sharded_block_in_children).
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* come from the parent; rank 0 prints the block as one JSON line."""
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)       # RCCL's banner and anything else native goes to stderr: stdout carries the JSON line only
+    job = Job(rank, local_rank, world, use_torch=(world > 1), backend="gloo")
+    import kzg_amd
+    from kzg_amd import _lib as L
+    res = measure_sharded_block(kzg_amd, L, job, args, force_gather=(world == 1))
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if job.dist is not None:
+        job.dist.barrier()
+    job.close()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(res) + "\n").encode())
+    os.close(real_stdout)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _tail(path_or_text, n=1500, is_path=False):
+    try:
+        t = open(path_or_text, errors="replace").read() if is_path else (path_or_text or "")
+    except OSError:
+        return ""
+    return t[-n:]
+
+
+def run_sharded_block_in_children(job, args, rank, local_rank, world):
+    """The `sharded` block in a FRESH child process per rank.  The parent holds this run's number and has touched the GPU: whatever
+    goes wrong while a device group forms over RCCL -- a bootstrap that stalls for minutes on a hostile network stack (round 4's
+    driver box), a crash inside the communicator, a dead peer -- happens in a process that can be killed, the parent's line and exit
+    status stay truthful, and the block says what happened: the library's per-phase formation times (KZG_DEBUG), the child's exit
+    code, and the tail of RCCL's own log (NCCL_DEBUG=INFO into NCCL_DEBUG_FILE from the start)."""
+    import glob
+    import signal
+    import subprocess
+    port = job.broadcast_object(_free_port)
+    log_prefix = os.path.join(tempfile.gettempdir(), "kzg_rccl_%d_r%d" % (os.getpid(), rank))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}   # (the agent-store flag would make the child look
+    #                                                                                     for torchrun's store on the new port)
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               KZG_DEBUG="1")
+    if env.get("KZG_RCCL_SINGLE_NODE_ENV", "1") != "0":     # this process is the host: the one-node RCCL knobs (kzg_amd/distributed.py)
+        from kzg_amd.distributed import SINGLE_NODE_RCCL_ENV
+        for k, v in SINGLE_NODE_RCCL_ENV.items():
+            env.setdefault(k, v)
+    if env.get("NCCL_DEBUG", "VERSION").upper() in ("VERSION", "WARN"):
+        env["NCCL_DEBUG"] = "INFO"
+        env.setdefault("NCCL_DEBUG_SUBSYS", "INIT,BOOTSTRAP,NET,ENV")
+    env.setdefault("NCCL_DEBUG_FILE", log_prefix + ".%p.log")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--sharded-child", "--gpus", str(world), "--log-n", str(args.log_n),
+           "--sharded-batch", str(args.sharded_batch), "--sharded-steps", str(args.sharded_steps), "--streams", str(args.streams)]
+    t0 = time.perf_counter()
+    p = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    timed_out = False
+    try:
+        out, err = p.communicate(timeout=args.sharded_timeout)
+    except subprocess.TimeoutExpired:
+        timed_out = True
+        try:
+            os.killpg(p.pid, signal.SIGKILL)     # exactly the process group this call started
+        except OSError:
+            pass
+        out, err = p.communicate()
+    wall = time.perf_counter() - t0
+    block = None
+    for ln in (out or "").splitlines():
+        if ln.startswith("{"):
+            try:
+                block = json.loads(ln)
+            except ValueError:
+                pass
+    child = {"rc": p.returncode, "wall_s": round(wall, 2), "timed_out": timed_out, "process": "fresh child per rank"}
+    healthy = job.all_agree(not timed_out and p.returncode == 0)
+    if rank != 0:
+        for f in glob.glob(log_prefix + "*"):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+        return None
+    if block is None:
+        block = {"note": ("the sharded block did not finish within %d s and its process was killed" % args.sharded_timeout) if timed_out
+                 else "the sharded block's process ended with code %s and no result" % p.returncode}
+    block["child"] = child
+    slow = isinstance(block.get("formation"), dict) and block["formation"].get("formation_ms", 0) > 10000
+    if timed_out or p.returncode != 0 or not healthy or slow or "error" in block or "note" in block:
+        logs = sorted(glob.glob(log_prefix + "*"))
+        block["diagnostics"] = {"stderr_tail": _tail(err, 2500), "rccl_log_tail": _tail(logs[0], 2500, is_path=True) if logs else "",
+                                "every_rank_healthy": healthy,
+                                "env": {k: v for k, v in env.items() if k.startswith(("NCCL_", "RCCL_", "KZG_", "GPU_MAX"))}}
+    for f in glob.glob(log_prefix + "*"):
+        try:
+            os.unlink(f)
+        except OSError:
+            pass
+    return block
 
 
 def main():
@@ -730,10 +846,14 @@ def main():
                     help="N>1: backend of the torch process group that carries barriers and timing reductions (the data-path collective is the "
                          "library's own RCCL communicator either way)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
-    ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds the sharded block may take before the line is printed without it")
+    ap.add_argument("--sharded-timeout", type=int, default=180, help="seconds the sharded block's child process may take before it is killed and the line printed without it")
+    ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)   # internal: the block alone (run_sharded_block_in_children)
     args = ap.parse_args()
     if args.pmc_child:
         pmc_child(args.pmc_child)
+        return
+    if args.sharded_child:
+        sharded_child_main(args)
         return
 
     rank = int(os.environ.get("RANK", "0"))
@@ -1093,33 +1213,23 @@ def main():
         cpu.close()
     main_closed = False
     if want_block:
-        # The sharded-SRS + RCCL modes, measured by every rank together after everything else (collective).  `value` above is already
-        # final: if forming the group or an exchange hangs (a dead peer, a broken fabric), a watchdog prints the line without the
-        # block after --sharded-timeout seconds and ends the process on every rank -- the default multi-GPU run never loses its
-        # number to the extra measurement.  (Inside the library every exchange has its own deadline: gather_timeout_ms.)
-        import threading
-        # the main engine goes first: its 16 lanes + 2 accumulation streams hold hardware queues the group's own context needs (two
-        # contexts' streams on one queue pool: the second one measures the sharing and narrows its pipeline, -12 % at world 1)
+        # The sharded-SRS + RCCL modes, measured by every rank together after everything else (collective) -- in a fresh child process
+        # per rank (run_sharded_block_in_children): `value` above is already final and this process keeps it whatever the device
+        # group does.  (Inside the library every exchange and the communicator's formation have their own deadlines:
+        # gather_timeout_ms, comm_timeout_ms.)  The main engine goes first: the child's group context needs the chip's hardware
+        # queues to itself (two contexts' streams on one queue pool: the second one narrows its pipeline, -12 % at world 1).
         job.engines.remove(engine)
         scal.free()
+        if params is not None:
+            params.gs.free()     # 2 GiB at 2^20: the child's group sets up its own shards
         engine.close()
         main_closed = True
-
-        def bail():
-            if rank == 0:
-                res["sharded"] = {"note": "the sharded block did not finish within %d s (group formation or an exchange hung); not measured" % args.sharded_timeout}
-                os.write(real_stdout, (json.dumps(res) + "\n").encode())
-            os._exit(0)
-        dog = threading.Timer(args.sharded_timeout, bail)
-        dog.daemon = True
-        dog.start()
-        sharded_res = measure_sharded_block(kzg_amd, L, job, args, force_gather=(world == 1))
-        dog.cancel()
+        sharded_res = run_sharded_block_in_children(job, args, rank, local_rank, world)
         if rank == 0:
             res["sharded"] = sharded_res
             res["headline"] = ("value = data-parallel replicas (the throughput answer for independent degree-2^20 commitments: a 2 GiB SRS "
                                "fits every GPU); sharded.strong / sharded.config5 = the sharded-SRS + RCCL design north_star names, "
-                               "measured in the same process")
+                               "measured by the same ranks in fresh child processes right after the timed region")
             line = json.dumps(res)
     # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's own
     # output when a process exits: every rank flushes it before the last barrier, so that rank 0's JSON line ends the output

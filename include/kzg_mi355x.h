@@ -203,7 +203,17 @@ int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t grou
  * cannot be agreed on -- a peer process that died, a hung GPU, a rank that could not create its communicator -- is bounded by a
  * deadline: the wait behind every exchange polls for at most "gather_timeout_ms" (kzg_mctx_set_option, default 60000, 0 = wait
  * for ever); when it expires the communicators are aborted (ncclCommAbort), the call returns KZG_ERR_INTERNAL and the group is
- * DEAD -- every later call on it fails at once with KZG_ERR_INTERNAL; destroy it and form a new one. */
+ * DEAD -- every later call on it fails at once with KZG_ERR_INTERNAL; destroy it and form a new one (kzg_mctx_destroy of a dead
+ * group never synchronises on a stream an aborted collective still holds: such a context is left behind, with a line on stderr).
+ * Communicator FORMATION is bounded the same way: ncclGetUniqueId / ncclCommInitRank / ncclCommInitAll / ncclCommDestroy run on
+ * a helper thread and the caller waits at most "comm_timeout_ms" (kzg_mctx_set_option for a group that forms its communicator
+ * lazily; the environment variable KZG_COMM_TIMEOUT_MS for the ones formed inside kzg_mctx_create*; default 60000, 0 = wait for
+ * ever).  RCCL bootstraps over TCP on an interface of its own choosing even on one node, and a host whose interface swallows
+ * packets stalls it for minutes.  On expiry the call returns KZG_ERR_INTERNAL with the phase timings in its message
+ * (kzg_mctx_last_error, or kzg_mctx_create_error when the group was never handed out), the group is dead, and -- because the
+ * abandoned call may hold RCCL's locks for ever -- no further communicator is formed in this process.  A one-node host should
+ * export NCCL_SOCKET_IFNAME=lo, NCCL_RAS_ENABLE=0 and NCCL_IB_DISABLE=1 before the first RCCL call (INTEGRATION.md section 5b;
+ * kzg_amd.api.DeviceGroup does).  KZG_DEBUG=1 prints every phase with its duration on stderr. */
 typedef struct kzg_mctx kzg_mctx;
 typedef struct kzg_msrs kzg_msrs;   /* an SRS sharded contiguously over the group */
 enum { KZG_UNIQUE_ID_BYTES = 128 };
@@ -212,15 +222,21 @@ int kzg_mctx_unique_id(void *id_out);
 int kzg_mctx_create_rank(int device, int rank, int world, const void *unique_id, kzg_mctx **out);
 void kzg_mctx_destroy(kzg_mctx *m);
 const char *kzg_mctx_last_error(kzg_mctx *m);
-/* "rccl=<file> version=<n> hip=<runtime file> world=.. local=.. mode=..": which RCCL the group adopted (the copy the process
- * already holds, else librccl.so.1 from the library path) and the HIP runtime it is bound to.  The library refuses an RCCL that
+/* why the calling thread's last kzg_mctx_create / kzg_mctx_create_rank / kzg_mctx_unique_id failed (no group exists to ask);
+ * "" when it did not.  Valid until the thread's next call of one of the three. */
+const char *kzg_mctx_create_error(void);
+/* "rccl=<file> version=<n> hip=<runtime file> world=.. local=.. mode=.. formation_ms=<f> phases_ms=[load=.. uid=.. init=..
+ * first_exchange=.. destroy=..] comm_timeout_ms=.. gather_timeout_ms=.. dead=0|1": which RCCL the group adopted (the copy the
+ * process already holds, else librccl.so.1 from the library path), the HIP runtime it is bound to, and what forming the
+ * communicator cost (wall-clock ms per phase: loading RCCL, ncclGetUniqueId, ncclCommInit*, the first exchange -- RCCL loads its
+ * kernels there --; -1 = has not happened).  The library refuses an RCCL that
  * is bound to a different HIP runtime than itself (streams and device pointers cross the boundary): KZG_ERR_INTERNAL. */
 int kzg_mctx_info(kzg_mctx *m, char *buf, size_t buflen);
 int kzg_mctx_world(const kzg_mctx *m);        /* ranks in the group */
 int kzg_mctx_local_count(const kzg_mctx *m);  /* GPUs this process drives (n, or 1 in the per-process mode) */
 int kzg_mctx_rank(const kzg_mctx *m, int local_index);          /* global rank of a local GPU */
 kzg_ctx *kzg_mctx_ctx(kzg_mctx *m, int local_index);            /* its single-GPU context (NTT, scans, device memory) */
-/* options: "always_gather" (run the collective even in a group of one), "gather_timeout_ms" (above), plus every
+/* options: "always_gather" (run the collective even in a group of one), "gather_timeout_ms", "comm_timeout_ms" (above), plus every
  * kzg_ctx_set_option key (applied to all) */
 int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value);
 /* rank r of `world` holds terms [lo, hi) of n: the first n % world ranks get one extra.  Host-only helper. */

@@ -183,57 +183,187 @@ pub fn fft_in_place(eng: &Mi355x, coeffs: &mut [Scalar], exp: u32, inverse: bool
     }
 }
 
-// ---- multi-GPU: the same commit with KZGParams.gs sharded over every GPU of the node ------------
+// ---- multi-GPU: the same prover with KZGParams.gs sharded over every GPU of the node -------------
+/// What a ONE-NODE host exports before the first RCCL call of the process (values already exported are kept): RCCL bootstraps
+/// every communicator over TCP on the first non-loopback interface it finds; on a host whose interface swallows packets that
+/// stalls formation for minutes.  The library bounds formation ("comm_timeout_ms", KZG_COMM_TIMEOUT_MS) but cannot choose the
+/// interface for RCCL -- the environment is the host's.
+pub fn single_node_rccl_env() {
+    for (k, v) in [("NCCL_SOCKET_IFNAME", "lo"), ("NCCL_RAS_ENABLE", "0"), ("NCCL_IB_DISABLE", "1"), ("NCCL_NET_PLUGIN", "none")] {
+        if std::env::var_os(k).is_none() {
+            std::env::set_var(k, v);
+        }
+    }
+}
+
+/// An SRS (monomial `gs` or a Lagrange basis) sharded contiguously over the group's GPUs; freed with the group that made it.
+pub struct ShardedSrs {
+    s: *mut sys::kzg_msrs,
+    m: *mut sys::kzg_mctx,
+}
+unsafe impl Send for ShardedSrs {}
+unsafe impl Sync for ShardedSrs {}
+impl ShardedSrs {
+    pub fn len(&self) -> usize {
+        unsafe { sys::kzg_msrs_len(self.s) }
+    }
+}
+impl Drop for ShardedSrs {
+    fn drop(&mut self) {
+        unsafe { sys::kzg_msrs_free(self.m, self.s) } // (drop it before the group)
+    }
+}
+
 pub struct Mi355xGroup {
     m: *mut sys::kzg_mctx,
 }
 unsafe impl Send for Mi355xGroup {}
 unsafe impl Sync for Mi355xGroup {}
 impl Mi355xGroup {
-    pub fn all_gpus() -> Self {
+    fn create_error() -> String {
+        unsafe { CStr::from_ptr(sys::kzg_mctx_create_error()) }.to_string_lossy().into_owned()
+    }
+    /// One host process driving every GPU of the node (ncclCommInitAll inside, bounded by KZG_COMM_TIMEOUT_MS).
+    pub fn all_gpus() -> Result<Self, String> {
+        single_node_rccl_env();
         let n = unsafe { sys::kzg_device_count() };
         let devs: Vec<i32> = (0..n).collect();
         let mut m = std::ptr::null_mut();
-        let rc = unsafe { sys::kzg_mctx_create(devs.as_ptr(), n, &mut m) }; // ncclCommInitAll inside
-        assert_eq!(rc, 0, "kzg_mctx_create failed");
-        Mi355xGroup { m }
+        match unsafe { sys::kzg_mctx_create(devs.as_ptr(), n, &mut m) } {
+            0 => Ok(Mi355xGroup { m }),
+            e => Err(format!("kzg_mctx_create failed with {}: {}", e, Self::create_error())),
+        }
     }
-    pub fn upload(&self, params: &KZGParams) -> *mut sys::kzg_msrs {
+    /// One process per GPU: rank 0 draws the id, the host carries the 128 bytes to the other ranks by its own means.
+    pub fn unique_id() -> Result<[u8; 128], String> {
+        single_node_rccl_env();
+        let mut id = [0u8; 128];
+        match unsafe { sys::kzg_mctx_unique_id(id.as_mut_ptr() as *mut c_void) } {
+            0 => Ok(id),
+            e => Err(format!("kzg_mctx_unique_id failed with {}: {}", e, Self::create_error())),
+        }
+    }
+    pub fn for_rank(device: i32, rank: i32, world: i32, id: &[u8; 128]) -> Result<Self, String> {
+        single_node_rccl_env();
+        let mut m = std::ptr::null_mut();
+        match unsafe { sys::kzg_mctx_create_rank(device, rank, world, id.as_ptr() as *const c_void, &mut m) } {
+            0 => Ok(Mi355xGroup { m }),
+            e => Err(format!("kzg_mctx_create_rank failed with {}: {}", e, Self::create_error())),
+        }
+    }
+    fn last_error(&self) -> String {
+        unsafe { CStr::from_ptr(sys::kzg_mctx_last_error(self.m)) }.to_string_lossy().into_owned()
+    }
+    fn fail(&self, rc: i32) -> ! {
+        // every rank returns the same status (mgpu.hip); status 3 = a condition on which the reference panics
+        panic!("kzg_mi355x group error {}: {}", rc, self.last_error())
+    }
+    /// "rccl=... formation_ms=... phases_ms=[...]": which RCCL the group runs on and what forming the communicator cost.
+    pub fn info(&self) -> String {
+        let mut buf = vec![0u8; 2048];
+        let rc = unsafe { sys::kzg_mctx_info(self.m, buf.as_mut_ptr() as *mut std::os::raw::c_char, buf.len()) };
+        if rc != 0 {
+            self.fail(rc)
+        }
+        unsafe { CStr::from_ptr(buf.as_ptr() as *const std::os::raw::c_char) }.to_string_lossy().into_owned()
+    }
+    /// `KZGParams.gs` (or `lagrange_basis_g`) sharded over the group: rank r uploads its contiguous range of the caller's vector.
+    pub fn upload(&self, gs: &[blstrs::G1Projective]) -> ShardedSrs {
         let mut s = std::ptr::null_mut();
-        let rc = unsafe {
-            sys::kzg_srs_upload_g1_sharded(self.m, params.gs.as_ptr() as *const c_void, params.gs.len(), KZG_G1_JACOBIAN_MONT_144, &mut s)
-        };
-        assert_eq!(rc, 0);
-        s
+        let rc = unsafe { sys::kzg_srs_upload_g1_sharded(self.m, gs.as_ptr() as *const c_void, gs.len(), KZG_G1_JACOBIAN_MONT_144, &mut s) };
+        if rc != 0 {
+            self.fail(rc)
+        }
+        ShardedSrs { s, m: self.m }
     }
-    pub fn commit(&self, srs: *const sys::kzg_msrs, coeffs: &[Scalar]) -> G1Affine {
+    /// KZGProver::commit over the group (src/coeff_form.rs:59-64).
+    pub fn commit(&self, srs: &ShardedSrs, coeffs: &[Scalar]) -> G1Affine {
         let mut out = G1Affine::identity();
         let rc = unsafe {
-            sys::kzg_commit_coeff_sharded(self.m, srs, coeffs.as_ptr() as *const c_void, coeffs.len(), KZG_FR_MONT_LE_32, 0,
+            sys::kzg_commit_coeff_sharded(self.m, srs.s, coeffs.as_ptr() as *const c_void, coeffs.len(), KZG_FR_MONT_LE_32, 0,
                                           &mut out as *mut G1Affine as *mut c_void, KZG_G1_AFFINE_MONT_96)
         };
         if rc != 0 {
-            let msg = unsafe { CStr::from_ptr(sys::kzg_mctx_last_error(self.m)) }.to_string_lossy().into_owned();
-            panic!("kzg_mi355x group error {}: {}", rc, msg) // every rank returns the same status (mgpu.hip)
+            self.fail(rc)
         }
         out
     }
-    pub fn create_witness(&self, srs: *const sys::kzg_msrs, coeffs: &[Scalar], x: &Scalar, y: &Scalar) -> Result<G1Affine, KZGError> {
+    /// `polys.len() / n` polynomials of n coefficients each (contiguous), one exchange for all of them: the throughput form of
+    /// KZGProver::commit (src/coeff_form.rs:59-64) -- commitments of a whole batch of blobs in one call.
+    pub fn commit_batch(&self, srs: &ShardedSrs, polys: &[Scalar], n: usize) -> Vec<G1Affine> {
+        assert!(n > 0 && polys.len() % n == 0);
+        let batch = polys.len() / n;
+        let mut out = vec![G1Affine::identity(); batch];
+        let rc = unsafe {
+            sys::kzg_commit_coeff_sharded_batch(self.m, srs.s, polys.as_ptr() as *const c_void, n, batch, KZG_FR_MONT_LE_32, 0,
+                                                out.as_mut_ptr() as *mut c_void, KZG_G1_AFFINE_MONT_96)
+        };
+        if rc != 0 {
+            self.fail(rc)
+        }
+        out
+    }
+    /// KZGProver::create_witness over the group (src/coeff_form.rs:66-81): replicated quotient scan, sharded MSM.
+    pub fn create_witness(&self, srs: &ShardedSrs, coeffs: &[Scalar], x: &Scalar, y: &Scalar) -> Result<G1Affine, KZGError> {
         let mut out = G1Affine::identity();
         let rc = unsafe {
-            sys::kzg_witness_coeff_sharded(self.m, srs, coeffs.as_ptr() as *const c_void, coeffs.len(), x as *const Scalar as *const c_void,
+            sys::kzg_witness_coeff_sharded(self.m, srs.s, coeffs.as_ptr() as *const c_void, coeffs.len(), x as *const Scalar as *const c_void,
                                            y as *const Scalar as *const c_void, KZG_FR_MONT_LE_32, 0,
                                            &mut out as *mut G1Affine as *mut c_void, KZG_G1_AFFINE_MONT_96)
         };
         match rc {
             0 => Ok(out),
             1 => Err(KZGError::PointNotOnPolynomial),
-            e => panic!("kzg_mi355x group error {}", e),
+            e => self.fail(e),
+        }
+    }
+    /// KZGProver::create_witness_batched over the group (src/coeff_form.rs:83-111): interpolant and quotient replicated on every
+    /// GPU, the quotient's MSM sharded; returns (w, coefficients of r) like the single-GPU splice 3.
+    pub fn create_witness_batched(&self, srs: &ShardedSrs, coeffs: &[Scalar], xs: &[Scalar], ys: &[Scalar])
+                                  -> Result<(G1Affine, Vec<Scalar>), KZGError> {
+        assert_eq!(xs.len(), ys.len());
+        let mut w = G1Affine::identity();
+        let mut r = vec![Scalar::from(0u64); xs.len().max(2)];
+        let mut r_len = 0usize;
+        let rc = unsafe {
+            sys::kzg_witness_coeff_batched_sharded(self.m, srs.s, coeffs.as_ptr() as *const c_void, coeffs.len(),
+                                                   xs.as_ptr() as *const c_void, ys.as_ptr() as *const c_void, xs.len(), KZG_FR_MONT_LE_32, 0,
+                                                   &mut w as *mut G1Affine as *mut c_void, KZG_G1_AFFINE_MONT_96,
+                                                   r.as_mut_ptr() as *mut c_void, &mut r_len)
+        };
+        match rc {
+            0 => {
+                r.truncate(r_len);
+                Ok((w, r))
+            }
+            1 => Err(KZGError::PointNotOnPolynomial),
+            e => self.fail(e),
+        }
+    }
+    /// KZGProverEvalForm::create_witness over the group (src/eval_form.rs:124-140): `lagrange` = upload(&lagrange_basis_g);
+    /// div_by_omega_i replicated, MSM sharded.
+    pub fn create_witness_eval(&self, lagrange: &ShardedSrs, evals: &[Scalar], i: usize) -> G1Affine {
+        let mut out = G1Affine::identity();
+        let rc = unsafe {
+            sys::kzg_witness_eval_sharded(self.m, lagrange.s, evals.as_ptr() as *const c_void, evals.len(), i, KZG_FR_MONT_LE_32, 0,
+                                          &mut out as *mut G1Affine as *mut c_void, KZG_G1_AFFINE_MONT_96)
+        };
+        if rc != 0 {
+            self.fail(rc) // status 3: index out of range / d not a power of two (the reference's panics)
+        }
+        out
+    }
+    /// e.g. ("gather_timeout_ms", 60000), ("comm_timeout_ms", 60000), ("always_gather", 1), or any kzg_ctx_set_option key
+    pub fn set_option(&self, key: &str, value: i64) {
+        let k = std::ffi::CString::new(key).unwrap();
+        let rc = unsafe { sys::kzg_mctx_set_option(self.m, k.as_ptr(), value) };
+        if rc != 0 {
+            self.fail(rc)
         }
     }
 }
 impl Drop for Mi355xGroup {
     fn drop(&mut self) {
-        unsafe { sys::kzg_mctx_destroy(self.m) }
+        unsafe { sys::kzg_mctx_destroy(self.m) } // bounded: a dead group's stuck stream is left behind, not waited for
     }
 }

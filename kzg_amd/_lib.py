@@ -76,6 +76,7 @@ def load(path=None):
         "kzg_mctx_create_rank": (i32, [i32, i32, i32, vp, c_void_pp]),
         "kzg_mctx_destroy": (None, [vp]),
         "kzg_mctx_last_error": (ctypes.c_char_p, [vp]),
+        "kzg_mctx_create_error": (ctypes.c_char_p, []),
         "kzg_mctx_world": (i32, [vp]),
         "kzg_mctx_local_count": (i32, [vp]),
         "kzg_mctx_rank": (i32, [vp, i32]),

@@ -494,31 +494,46 @@ class DeviceGroup:
     def __init__(self, devices=(0,), _handle=None):
         self.lib = L.load()
         if _handle is None:
+            self._host_env()
             arr = (ctypes.c_int * len(devices))(*devices)
             h = ctypes.c_void_p()
             rc = self.lib.kzg_mctx_create(arr, len(devices), ctypes.byref(h))
             if rc:
-                raise EngineError(f"kzg_mctx_create({list(devices)}) failed with {rc} (kzg_amd has no CPU fallback)")
+                raise EngineError(f"kzg_mctx_create({list(devices)}) failed with {rc}: {self._create_error(self.lib)} "
+                                  "(kzg_amd has no CPU fallback)")
             _handle = h
         self.handle = _handle
         self._engines = {}
 
     @staticmethod
+    def _host_env():
+        """This module is the host: the one-node RCCL knobs go into the environment before the first RCCL call."""
+        from .distributed import single_node_rccl_env
+        return single_node_rccl_env()
+
+    @staticmethod
+    def _create_error(lib):
+        return (lib.kzg_mctx_create_error() or b"").decode()
+
+    @staticmethod
     def unique_id():
         lib = L.load()
+        DeviceGroup._host_env()
         buf = ctypes.create_string_buffer(128)
         rc = lib.kzg_mctx_unique_id(buf)
         if rc:
-            raise EngineError(f"kzg_mctx_unique_id failed with {rc} (RCCL not loadable?)")
+            raise EngineError(f"kzg_mctx_unique_id failed with {rc}: {DeviceGroup._create_error(lib)}")
         return buf.raw
 
     @staticmethod
     def for_rank(device, rank, world, unique_id):
         lib = L.load()
+        DeviceGroup._host_env()
         h = ctypes.c_void_p()
         rc = lib.kzg_mctx_create_rank(device, rank, world, unique_id, ctypes.byref(h))
         if rc:
-            raise EngineError(f"kzg_mctx_create_rank(device={device}, rank={rank}/{world}) failed with {rc}")
+            raise EngineError(f"kzg_mctx_create_rank(device={device}, rank={rank}/{world}) failed with {rc}: "
+                              f"{DeviceGroup._create_error(lib)}")
         return DeviceGroup(_handle=h)
 
     def last_error(self):
@@ -629,10 +644,20 @@ class DeviceGroup:
         return out.raw
 
     def info(self):
-        """which RCCL / HIP runtime the group runs on (kzg_mctx_info)"""
-        buf = ctypes.create_string_buffer(1024)
-        self._check(self.lib.kzg_mctx_info(self.handle, buf, 1024))
+        """which RCCL / HIP runtime the group runs on and what forming its communicator cost (kzg_mctx_info)"""
+        buf = ctypes.create_string_buffer(2048)
+        self._check(self.lib.kzg_mctx_info(self.handle, buf, 2048))
         return buf.value.decode()
+
+    def formation(self):
+        """{'formation_ms': f, 'load': .., 'uid': .., 'init': .., 'first_exchange': .., 'destroy': ..} parsed from info() (ms; -1 =
+        has not happened)"""
+        import re
+        s = self.info()
+        d = {"formation_ms": float(re.search(r"formation_ms=(-?[0-9.]+)", s).group(1))}
+        for k, v in re.findall(r"(load|uid|init|first_exchange|destroy)=(-?[0-9.]+)", s):
+            d[k] = float(v)
+        return d
 
     def close(self):
         if self.handle:

@@ -69,6 +69,8 @@ def strip_asm_nops(text):
         return ""
 
     def crosses_lanes(u):
+        if not u:            # no instruction follows within reach (end of a function, directives): nothing is known, the nop stays
+            return True
         return u.startswith(("v_readlane", "v_readfirstlane", "v_writelane", "v_permlane", "v_mov_b32_dpp", "ds_swizzle", "ds_bpermute",
                              "ds_permute")) or "_dpp" in u.split()[0] or "_sdwa" in u.split()[0] or " dpp" in u or "quad_perm" in u or "row_" in u
 

@@ -13,8 +13,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <chrono>
 #include <functional>
+#include <memory>
 #include <thread>
 
 #include "common.h"
@@ -40,7 +42,78 @@ struct Rccl {
     std::string path;      // the file the adopted RCCL was loaded from
     std::string hip_path;  // the HIP runtime it is bound to
     int version = 0;
+    double load_ms = 0;    // dlopen + symbol resolution of the adopted copy (a 570 MB file on a cold box)
+    double uid_ms = -1;    // the last ncclGetUniqueId (creates the bootstrap root: the first thing that touches the network stack)
 };
+
+static double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool debug_on() {
+    static const bool on = getenv("KZG_DEBUG") != nullptr;
+    return on;
+}
+#define KZG_DBG(...)                              \
+    do {                                          \
+        if (debug_on()) {                         \
+            fprintf(stderr, "[kzg mgpu] " __VA_ARGS__); \
+            fputc('\n', stderr);                  \
+        }                                         \
+    } while (0)
+
+// RCCL's communicator calls (ncclGetUniqueId, ncclCommInitRank / ncclCommInitAll, ncclCommDestroy) have no deadline of their own:
+// the bootstrap is TCP over whatever interface RCCL picks, and on a host whose non-loopback interface swallows packets a
+// world-1 ncclCommInitRank was seen to return only after five minutes (round 4's driver box).  They therefore run on a helper
+// thread and the caller waits with a deadline.  A call that does not come back is ABANDONED: its thread is detached (it owns its
+// state through a shared_ptr), and since it may hold RCCL's internal locks for ever, every later communicator call of this
+// process fails at once (g_rccl_wedged) instead of queueing up behind it.
+static std::atomic<bool> g_rccl_wedged{false};
+static std::mutex g_wedge_mu;
+static std::string g_wedge_msg;
+
+struct BoundedState {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool done = false;
+    ncclResult_t res = ncclSuccess;
+    std::vector<ncclComm_t> comms;  // what a formation produced (copied out by the caller when it was still waiting)
+    ncclUniqueId uid;
+};
+
+// true = f returned within the deadline (*res, *ms set); false = abandoned.  timeout_ms <= 0: inline, unbounded.
+static bool run_bounded(int64_t timeout_ms, const std::shared_ptr<BoundedState> &st, std::function<ncclResult_t(BoundedState &)> f,
+                        ncclResult_t *res, double *ms) {
+    const double t0 = now_ms();
+    if (timeout_ms <= 0) {
+        *res = f(*st);
+        *ms = now_ms() - t0;
+        return true;
+    }
+    std::thread th([st, f]() {
+        ncclResult_t r = f(*st);
+        std::lock_guard<std::mutex> lk(st->mu);
+        st->res = r;
+        st->done = true;
+        st->cv.notify_all();
+    });
+    std::unique_lock<std::mutex> lk(st->mu);
+    const bool ok = st->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return st->done; });
+    lk.unlock();
+    *ms = now_ms() - t0;
+    if (ok) {
+        th.join();
+        *res = st->res;
+        return true;
+    }
+    th.detach();
+    return false;
+}
+
+static int64_t default_comm_timeout_ms() {
+    const char *e = getenv("KZG_COMM_TIMEOUT_MS");  // process-wide default (a group formed inside kzg_mctx_create* has no option call before it)
+    if (e && *e) return atoll(e) < 0 ? 0 : atoll(e);
+    return 60000;
+}
 
 // the shared object that holds `addr`
 static std::string object_of(const void *addr) {
@@ -93,6 +166,7 @@ static Rccl *rccl_try(void *h, std::string *err) {
 static Rccl *rccl_load(std::string *err) {
     std::lock_guard<std::mutex> lk(g_rccl_mu);
     if (g_rccl) return g_rccl;
+    const double t_load0 = now_ms();
     const std::string mine = object_of((const void *)&hipStreamSynchronize);
 #ifdef KZG_TEST_HOOKS
     if (getenv("KZG_TEST_SHM_TRANSPORT")) {  // tests: world > 1 on ONE GPU, which RCCL refuses (test_transport.h)
@@ -141,6 +215,8 @@ static Rccl *rccl_load(std::string *err) {
             delete r;
             continue;
         }
+        r->load_ms = now_ms() - t_load0;
+        KZG_DBG("RCCL loaded in %.1f ms: %s version %d, HIP runtime %s", r->load_ms, r->path.c_str(), r->version, r->hip_path.c_str());
         g_rccl = r;
         return r;
     }
@@ -172,6 +248,13 @@ struct kzg_mctx {
     // are aborted (ncclCommAbort), the call returns KZG_ERR_INTERNAL and the group is DEAD: every later call on it fails at once;
     // the host destroys it and forms a new one.
     int64_t gather_timeout_ms = 60000;
+    // ... and neither must communicator FORMATION (ncclCommInitRank / ncclCommInitAll): option "comm_timeout_ms" (0 = wait for
+    // ever; default 60 s or KZG_COMM_TIMEOUT_MS).  On expiry the call returns KZG_ERR_INTERNAL with the phase timings in
+    // kzg_mctx_last_error, the group is dead and the process forms no further communicators (run_bounded above).
+    int64_t comm_timeout_ms = default_comm_timeout_ms();
+    double t_init_ms = -1;           // ncclCommInit* (wall), -1 = no communicator was ever formed
+    double t_first_ms = -1;          // the first exchange: enqueue -> complete (RCCL loads its kernels' code object here)
+    double t_destroy_ms = -1;
     bool dead = false;
     std::vector<void *> d_stat;      // per local GPU: world x STATUS_BYTES for the status-only agreement (allocated with the group)
     int inject_alloc_fail = 0;       // KZG_TEST_HOOKS: the next growth of the exchange buffers fails on local GPU 0
@@ -246,6 +329,11 @@ struct kzg_msrs {
 };
 
 static std::mutex &merr_mu();
+static std::string &create_err() {  // why this thread's last kzg_mctx_create* / kzg_mctx_unique_id failed (no group to ask)
+    static thread_local std::string e;
+    return e;
+}
+extern "C" const char *kzg_mctx_create_error(void) { return create_err().c_str(); }
 static int mfail(kzg_mctx *m, int code, const std::string &msg) {
     std::lock_guard<std::mutex> lk(merr_mu());
     m->err = msg;
@@ -302,6 +390,33 @@ static int mctx_make_ctxs(kzg_mctx *m) {
     return KZG_OK;
 }
 
+static std::string phase_report(const kzg_mctx *m, const Rccl *r) {
+    char b[256];
+    snprintf(b, sizeof b, "load=%.1f uid=%.1f init=%.1f first_exchange=%.1f destroy=%.1f", r ? r->load_ms : -1.0, r ? r->uid_ms : -1.0,
+             m->t_init_ms, m->t_first_ms, m->t_destroy_ms);
+    return b;
+}
+
+static int rccl_wedged_fail(kzg_mctx *m) {
+    std::string msg;
+    {
+        std::lock_guard<std::mutex> lk(g_wedge_mu);
+        msg = g_wedge_msg;
+    }
+    if (m) {
+        m->dead = true;
+        return mfail(m, KZG_ERR_INTERNAL, "an earlier RCCL communicator call of this process never returned (" + msg +
+                                              "): no further communicators are formed in this process");
+    }
+    return KZG_ERR_INTERNAL;
+}
+
+static void rccl_mark_wedged(const std::string &msg) {
+    std::lock_guard<std::mutex> lk(g_wedge_mu);
+    g_wedge_msg = msg;
+    g_rccl_wedged = true;
+}
+
 // the communicator is created when the first collective needs it (a group of one GPU never does unless asked to)
 static int mctx_comm(kzg_mctx *m, Rccl **out) {
     std::string err;
@@ -309,21 +424,49 @@ static int mctx_comm(kzg_mctx *m, Rccl **out) {
     if (!r) return mfail(m, KZG_ERR_INTERNAL, err);
     *out = r;
     if (!m->comms.empty()) return KZG_OK;
-    m->comms.assign(m->nlocal(), nullptr);
-    if (m->per_process) {
-        if (hipSetDevice(m->devices[0]) != hipSuccess) return mfail(m, KZG_ERR_NO_DEVICE, "hipSetDevice");
-        ncclResult_t e = r->CommInitRank(&m->comms[0], m->world, m->uid, m->ranks[0]);
-        if (e != ncclSuccess) {
-            m->comms.clear();
-            return mfail(m, KZG_ERR_HIP, std::string("ncclCommInitRank: ") + r->GetErrorString(e));
-        }
-    } else {
-        ncclResult_t e = r->CommInitAll(m->comms.data(), m->nlocal(), m->devices.data());
-        if (e != ncclSuccess) {
-            m->comms.clear();
-            return mfail(m, KZG_ERR_HIP, std::string("ncclCommInitAll: ") + r->GetErrorString(e));
-        }
+    if (m->dead) return mfail(m, KZG_ERR_INTERNAL, "this device group is dead (its communicator could not be formed or an exchange timed out): destroy it and form a new one");
+    if (g_rccl_wedged) return rccl_wedged_fail(m);
+    auto st = std::make_shared<BoundedState>();
+    st->comms.assign(m->nlocal(), nullptr);
+    st->uid = m->uid;
+    const bool per_process = m->per_process;
+    const int world = m->world, rank0 = m->ranks[0];
+    const std::vector<int> devices = m->devices;
+    int64_t stall_ms = 0;
+#ifdef KZG_TEST_HOOKS
+    if (const char *e = getenv("KZG_TEST_FORMATION_STALL_MS")) stall_ms = atoll(e);  // tests: a formation that takes this long
+#endif
+    const char *what = per_process ? "ncclCommInitRank" : "ncclCommInitAll";
+    ncclResult_t e = ncclSuccess;
+    KZG_DBG("%s: world %d, %d local GPU(s), deadline %lld ms ...", what, world, m->nlocal(), (long long)m->comm_timeout_ms);
+    const bool back = run_bounded(
+        m->comm_timeout_ms, st,
+        [r, per_process, world, rank0, devices, stall_ms](BoundedState &s) -> ncclResult_t {
+            if (stall_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(stall_ms));
+            if (per_process) {
+                if (hipSetDevice(devices[0]) != hipSuccess) return ncclUnhandledCudaError;
+                return r->CommInitRank(&s.comms[0], world, s.uid, rank0);
+            }
+            return r->CommInitAll(s.comms.data(), (int)devices.size(), devices.data());
+        },
+        &e, &m->t_init_ms);
+    KZG_DBG("%s %s after %.1f ms", what, back ? (e == ncclSuccess ? "returned" : "FAILED") : "ABANDONED", m->t_init_ms);
+    if (!back) {
+        m->dead = true;
+        const std::string msg = std::string(what) + " did not return within " + std::to_string(m->comm_timeout_ms) + " ms (" +
+                                phase_report(m, r) + " ms; RCCL " + r->path + ")";
+        rccl_mark_wedged(msg);
+        return mfail(m, KZG_ERR_INTERNAL,
+                     msg + ": communicator formation abandoned, this group is dead.  RCCL bootstraps over TCP on the interface it "
+                           "picks: on one node set NCCL_SOCKET_IFNAME=lo (and NCCL_RAS_ENABLE=0, NCCL_IB_DISABLE=1) before the first "
+                           "RCCL call; NCCL_DEBUG=INFO NCCL_DEBUG_FILE=<file> shows where it waits");
     }
+    if (e != ncclSuccess) {
+        m->dead = true;  // every rank fails the same way or the peers' own deadlines expire: the group cannot be used
+        return mfail(m, KZG_ERR_HIP, std::string(what) + ": " + r->GetErrorString(e) + " (" + phase_report(m, r) + " ms)");
+    }
+    m->comms = st->comms;
+    hipSetDevice(m->devices[0]);
     return KZG_OK;
 }
 
@@ -348,9 +491,14 @@ extern "C" int kzg_mctx_create(const int *devices, int n, kzg_mctx **out) {
         rc = mctx_comm(m, &r);
     }
     if (rc != KZG_OK) {
+        {
+            std::lock_guard<std::mutex> lk(merr_mu());
+            create_err() = m->err.empty() && !m->ctxs.empty() ? std::string(kzg_last_error(m->ctxs.back())) : m->err;
+        }
         kzg_mctx_destroy(m);
         return rc;
     }
+    create_err().clear();
     *out = m;
     return KZG_OK;
 }
@@ -358,12 +506,36 @@ extern "C" int kzg_mctx_create(const int *devices, int n, kzg_mctx **out) {
 extern "C" int kzg_mctx_unique_id(void *id_out) {
     if (!id_out) return KZG_ERR_SHAPE;
     std::string err;
+    create_err().clear();
     Rccl *r = rccl_load(&err);
-    if (!r) return KZG_ERR_INTERNAL;
-    ncclUniqueId id;
-    if (r->GetUniqueId(&id) != ncclSuccess) return KZG_ERR_HIP;
+    if (!r) {
+        create_err() = err;
+        return KZG_ERR_INTERNAL;
+    }
+    if (g_rccl_wedged) {
+        std::lock_guard<std::mutex> lk(g_wedge_mu);
+        create_err() = "an earlier RCCL communicator call of this process never returned (" + g_wedge_msg + ")";
+        return KZG_ERR_INTERNAL;
+    }
+    auto st = std::make_shared<BoundedState>();
+    ncclResult_t e = ncclSuccess;
+    double ms = 0;
+    const int64_t deadline = default_comm_timeout_ms();
+    if (!run_bounded(deadline, st, [r](BoundedState &s) { return r->GetUniqueId(&s.uid); }, &e, &ms)) {
+        create_err() = "ncclGetUniqueId did not return within " + std::to_string(deadline) + " ms (RCCL " + r->path + ", load=" +
+                       std::to_string(r->load_ms) + " ms): abandoned; on one node set NCCL_SOCKET_IFNAME=lo before the first RCCL call";
+        rccl_mark_wedged(create_err());
+        KZG_DBG("ncclGetUniqueId ABANDONED after %.1f ms", ms);
+        return KZG_ERR_INTERNAL;
+    }
+    r->uid_ms = ms;
+    KZG_DBG("ncclGetUniqueId: %.1f ms", ms);
+    if (e != ncclSuccess) {
+        create_err() = std::string("ncclGetUniqueId: ") + r->GetErrorString(e);
+        return KZG_ERR_HIP;
+    }
     static_assert(sizeof(ncclUniqueId) == KZG_UNIQUE_ID_BYTES, "ncclUniqueId size");
-    memcpy(id_out, &id, sizeof id);
+    memcpy(id_out, &st->uid, sizeof st->uid);
     return KZG_OK;
 }
 
@@ -382,11 +554,29 @@ extern "C" int kzg_mctx_create_rank(int device, int rank, int world, const void 
         rc = mctx_comm(m, &r);  // collective: every rank is inside kzg_mctx_create_rank
     }
     if (rc != KZG_OK) {
+        {
+            std::lock_guard<std::mutex> lk(merr_mu());
+            create_err() = m->err.empty() && !m->ctxs.empty() ? std::string(kzg_last_error(m->ctxs.back())) : m->err;
+        }
         kzg_mctx_destroy(m);
         return rc;
     }
+    create_err().clear();
     *out = m;
     return KZG_OK;
+}
+
+// true when every stream of the context went idle within `ms` (polled: never blocks on a stream an aborted collective still holds)
+static bool ctx_idle_within(kzg_ctx *c, int64_t ms) {
+    const double t0 = now_ms();
+    for (;;) {
+        bool busy = false;
+        for (auto &l : c->lanes)
+            if (l.stream && hipStreamQuery(l.stream) == hipErrorNotReady) busy = true;
+        if (!busy) return true;
+        if (now_ms() - t0 > (double)ms) return false;
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+    }
 }
 
 extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
@@ -394,8 +584,31 @@ extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
     workers_stop(m);
     for (int i = 0; i < (int)m->ctxs.size(); i++) {
         hipSetDevice(m->devices[i]);
-        if (m->ctxs[i]) kzg_sync(m->ctxs[i]);
-        if (i < (int)m->comms.size() && m->comms[i] && g_rccl && !m->dead) g_rccl->CommDestroy(m->comms[i]);
+        bool leak = false;
+        if (m->ctxs[i]) {
+            // A live group drains its streams.  A DEAD one (exchange or formation timed out) may have a stream that an aborted
+            // collective never leaves: synchronising on it -- or destroying it, or freeing the buffers its kernels address -- would
+            // turn "destroy it and form a new one" into the hang the deadline was there to prevent.  Such a context is left behind.
+            if (!m->dead) kzg_sync(m->ctxs[i]);
+            else leak = !ctx_idle_within(m->ctxs[i], 2000);
+        }
+        if (i < (int)m->comms.size() && m->comms[i] && g_rccl && !m->dead && !g_rccl_wedged) {
+            Rccl *r = g_rccl;
+            ncclComm_t c = m->comms[i];
+            auto st = std::make_shared<BoundedState>();
+            ncclResult_t e = ncclSuccess;
+            double ms = 0;
+            const int dev = m->devices[i];
+            if (!run_bounded(m->comm_timeout_ms, st, [r, c, dev](BoundedState &) { hipSetDevice(dev); return r->CommDestroy(c); }, &e, &ms))
+                rccl_mark_wedged("ncclCommDestroy did not return within " + std::to_string(m->comm_timeout_ms) + " ms");
+            m->t_destroy_ms = ms;
+            KZG_DBG("ncclCommDestroy: %.1f ms", ms);
+        }
+        if (leak) {
+            fprintf(stderr, "kzg: device group on GPU %d destroyed while a stream is still held by an aborted collective: its context and "
+                            "exchange buffers are left behind (not freed)\n", m->devices[i]);
+            continue;
+        }
         if (m->d_part[i]) hipFree(m->d_part[i]);
         if (m->d_gath[i]) hipFree(m->d_gath[i]);
         if (m->d_quot[i]) hipFree(m->d_quot[i]);
@@ -428,8 +641,14 @@ extern "C" int kzg_mctx_info(kzg_mctx *m, char *buf, size_t buflen) {
         m->err = err;
         return KZG_ERR_INTERNAL;
     }
-    snprintf(buf, buflen, "rccl=%s version=%d hip=%s world=%d local=%d mode=%s", r->path.c_str(), r->version, r->hip_path.c_str(),
-             m->world, m->nlocal(), m->per_process ? "process-per-gpu" : "one-process");
+    // formation_ms: what forming this group's communicator cost so far (RCCL load + unique id + ncclCommInit*), -1 before a
+    // communicator exists; the phases follow (ms; -1 = has not happened)
+    std::lock_guard<std::mutex> lk(m->mu);
+    const double form = m->t_init_ms < 0 ? -1.0 : r->load_ms + (r->uid_ms > 0 ? r->uid_ms : 0.0) + m->t_init_ms;
+    snprintf(buf, buflen, "rccl=%s version=%d hip=%s world=%d local=%d mode=%s formation_ms=%.1f phases_ms=[%s] comm_timeout_ms=%lld "
+                          "gather_timeout_ms=%lld dead=%d", r->path.c_str(), r->version, r->hip_path.c_str(), m->world, m->nlocal(),
+             m->per_process ? "process-per-gpu" : "one-process", form, phase_report(m, r).c_str(), (long long)m->comm_timeout_ms,
+             (long long)m->gather_timeout_ms, m->dead ? 1 : 0);
     return KZG_OK;
 }
 extern "C" int kzg_mctx_world(const kzg_mctx *m) { return m ? m->world : 0; }
@@ -447,6 +666,11 @@ extern "C" int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value) 
     if (std::string(key) == "gather_timeout_ms") {
         if (value < 0) return mfail(m, KZG_ERR_SHAPE, "gather_timeout_ms must be >= 0 (0 = wait for ever)");
         m->gather_timeout_ms = value;
+        return KZG_OK;
+    }
+    if (std::string(key) == "comm_timeout_ms") {
+        if (value < 0) return mfail(m, KZG_ERR_SHAPE, "comm_timeout_ms must be >= 0 (0 = wait for ever)");
+        m->comm_timeout_ms = value;
         return KZG_OK;
     }
     for (int i = 0; i < m->nlocal(); i++) {
@@ -583,17 +807,29 @@ static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
         if (us > m->gather_timeout_ms * 1000) break;
         if (us > 2000) std::this_thread::sleep_for(std::chrono::microseconds(100));  // a healthy exchange is over long before
     }
-    // a peer never arrived: abort the communicators so that the collective kernels leave the streams, and retire the group
+    // a peer never arrived: abort the communicators so that the collective kernels leave the streams, and retire the group.
+    // ncclCommAbort itself waits for the stream's kernels (measured: behind a 12 s spin kernel it returned after 12 s), so it runs
+    // bounded like every other communicator call; abort + drain together get 5 s, a stream that still hangs is left behind.
     m->dead = true;
-    if (r && r->CommAbort)
-        for (auto &c : m->comms)
-            if (c) r->CommAbort(c);
+    const double t_ab = now_ms();
+    if (r && r->CommAbort && !g_rccl_wedged) {
+        auto st = std::make_shared<BoundedState>();
+        st->comms = m->comms;
+        ncclResult_t e = ncclSuccess;
+        double ms = 0;
+        Rccl *rr = r;
+        if (!run_bounded(5000, st, [rr](BoundedState &s) {
+                for (auto &c : s.comms)
+                    if (c) rr->CommAbort(c);
+                return ncclSuccess;
+            }, &e, &ms))
+            rccl_mark_wedged("ncclCommAbort did not return within 5000 ms");
+        KZG_DBG("ncclCommAbort: %.1f ms", ms);
+    }
     m->comms.clear();
-    for (int j = 0; j < m->nlocal(); j++) {  // bounded: an aborted collective returns promptly; a stream that still hangs is left behind
+    for (int j = 0; j < m->nlocal(); j++) {
         hipSetDevice(m->devices[j]);
-        const auto t1 = std::chrono::steady_clock::now();
-        while (hipStreamQuery(m->ctxs[j]->lanes[0].stream) == hipErrorNotReady &&
-               std::chrono::steady_clock::now() - t1 < std::chrono::seconds(5))
+        while (hipStreamQuery(m->ctxs[j]->lanes[0].stream) == hipErrorNotReady && now_ms() - t_ab < 5000.0)
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
     return mfail(m, KZG_ERR_INTERNAL, std::string(what) + " did not complete within " + std::to_string(m->gather_timeout_ms) +
@@ -627,11 +863,17 @@ static int mctx_agree(kzg_mctx *m, int code, const char *what) {
     uint8_t *mine = (uint8_t *)m->d_stat[0], *all = mine + STATUS_BYTES;
     int32_t *hall = (int32_t *)((uint8_t *)m->h_status[0] + STATUS_ALL_OFF);
     if (hipMemcpyAsync(mine, hs, STATUS_BYTES, hipMemcpyHostToDevice, st) != hipSuccess) return mfail(m, KZG_ERR_HIP, "status upload");
+    const bool first = m->t_first_ms < 0;
+    const double t_x0 = now_ms();
     ncclResult_t e = r->AllGather(mine, all, STATUS_BYTES, ncclUint8, m->comms[0], st);
     if (e != ncclSuccess) return mfail(m, KZG_ERR_HIP, std::string("ncclAllGather(status): ") + r->GetErrorString(e));
     if (hipMemcpyAsync(hall, all, STATUS_BYTES * (size_t)m->world, hipMemcpyDeviceToHost, st) != hipSuccess)
         return mfail(m, KZG_ERR_HIP, "status download");
     KZG_TRY(mctx_wait(m, r, 0, "status agreement"));
+    if (first) {
+        m->t_first_ms = now_ms() - t_x0;
+        KZG_DBG("first exchange (status agreement): %.1f ms", m->t_first_ms);
+    }
     for (int rk = 0; rk < m->world; rk++)
         if (hall[4 * rk] != KZG_OK) {
             if (rk == m->ranks[0]) return code;  // this rank's own failure: its message is already in place
@@ -724,6 +966,10 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
             }
 #endif
         }
+        const bool first = m->t_first_ms < 0;
+        if (first)  // the first exchange is timed on its own (RCCL loads its kernels here): the local phases drain first
+            for (int i = 0; i < m->nlocal(); i++) kzg_sync(m->ctxs[i]);
+        const double t_x0 = now_ms();
         KZG_NCCL(m, r, r->GroupStart());
         for (int i = 0; i < m->nlocal(); i++) {
             ncclResult_t e = r->AllGather(m->d_part[i], m->d_gath[i], rec, ncclUint8, m->comms[i], m->ctxs[i]->lanes[0].stream);
@@ -741,6 +987,10 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
                              (size_t)m->world, hipMemcpyDeviceToHost, m->ctxs[0]->lanes[0].stream) != hipSuccess)
             return mfail(m, KZG_ERR_HIP, "status download");
         for (int i = 0; i < m->nlocal(); i++) KZG_TRY(mctx_wait(m, r, i, "the all-gather of the partial points"));
+        if (first) {
+            m->t_first_ms = now_ms() - t_x0;
+            KZG_DBG("first exchange (all-gather of the partials): %.1f ms", m->t_first_ms);
+        }
         if (upload_rc != KZG_OK) return upload_rc;
         for (int rk = 0; rk < m->world; rk++)
             if (hall[4 * rk] != KZG_OK) {
@@ -926,7 +1176,7 @@ extern "C" int kzg_test_mctx_inject_alloc_failure(kzg_mctx *m) {
     return KZG_OK;
 }
 extern "C" int kzg_test_mctx_inject_stall(kzg_mctx *m, int ms) {
-    if (!m || ms < 0 || ms > 5000) return KZG_ERR_SHAPE;
+    if (!m || ms < 0 || ms > 20000) return KZG_ERR_SHAPE;
     std::lock_guard<std::mutex> lk(m->mu);
     m->inject_stall_ms = ms;
     return KZG_OK;

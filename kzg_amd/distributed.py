@@ -11,8 +11,35 @@ locally (EC addition is not an RCCL reduction op, so "all-reduce" = all-gather +
 (The CPU model of the exchange used by the world-size-2 gloo test lives with the tests: tests/protocol_model.py.)
 """
 import ctypes
+import os
 
 from . import _lib as L
+
+# What a ONE-NODE host exports before the first RCCL call of the process (values the host already exported are kept).  The
+# device group never leaves the node (8 GPUs over xGMI), but RCCL does not know that: it bootstraps every communicator -- a
+# world-1 one included -- over TCP on the first non-loopback interface it finds, starts its RAS thread on that interface, and
+# probes InfiniBand and network plugins.  On a box whose interface swallows packets that cost round 4's driver run five minutes
+# per communicator (VERDICT r4); on loopback the same formation takes well under a second (profiles/r05_rccl_formation_ab.txt).
+SINGLE_NODE_RCCL_ENV = {
+    "NCCL_SOCKET_IFNAME": "lo",     # bootstrap + socket transport on loopback
+    "NCCL_RAS_ENABLE": "0",         # no RAS listener threads / sockets (2.24+)
+    "NCCL_IB_DISABLE": "1",         # no InfiniBand probing: nothing crosses the node
+    "NCCL_NET_PLUGIN": "none",      # no external network plugin search
+}
+
+
+def single_node_rccl_env():
+    """setdefault()s SINGLE_NODE_RCCL_ENV into this process' environment (KZG_RCCL_SINGLE_NODE_ENV=0 leaves it alone).  Called by
+    DeviceGroup before anything loads RCCL; a Rust host does the same with std::env::set_var (INTEGRATION.md section 5b).  Returns
+    the variables it set."""
+    if os.environ.get("KZG_RCCL_SINGLE_NODE_ENV", "1") == "0":
+        return {}
+    done = {}
+    for k, v in SINGLE_NODE_RCCL_ENV.items():
+        if k not in os.environ:
+            os.environ[k] = v       # os.environ assignment calls putenv: the C library sees it
+            done[k] = v
+    return done
 
 
 def shard_range(n, rank, world):

@@ -1,18 +1,11 @@
-"""Shared fixtures for the -m gpu parity tests: one Engine per session, oracle helpers."""
+"""Shared helpers of the -m gpu parity tests: the hooks-build context, oracle helpers.  (The `engine` / `hooks_engine` fixtures
+live in conftest.py: one object each for the whole session.)"""
 import random
 
 import pytest
 
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-
-
-@pytest.fixture(scope="session")
-def engine():
-    import kzg_amd
-    e = kzg_amd.Engine(0)
-    yield e
-    e.close()
 
 
 class HooksEngine:
@@ -48,13 +41,6 @@ class HooksEngine:
         if self.ctx:
             self.lib.kzg_ctx_destroy(self.ctx)
         self.ctx = None
-
-
-@pytest.fixture(scope="session")
-def hooks_engine():
-    e = HooksEngine(0)
-    yield e
-    e.close()
 
 
 def rand_scalars(rng, n, kind="full"):

@@ -6,7 +6,6 @@ import pytest
 
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-from tests.gpu_common import hooks_engine  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 

@@ -11,7 +11,6 @@ import kzg_amd
 from kzg_amd import _lib as L
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-from tests.gpu_common import engine  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 R = M.R

@@ -5,7 +5,6 @@ import pytest
 import kzg_amd
 from kzg_amd import _lib as L
 from tests import golden_util as GU
-from tests.gpu_common import engine  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 

@@ -12,11 +12,23 @@ from kzg_amd import _lib as L
 from kzg_amd.distributed import shard_range
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-from tests.gpu_common import engine, hooks_engine, rand_scalars  # noqa: F401
+from tests.gpu_common import rand_scalars
 
 pytestmark = pytest.mark.gpu
 
 TAU = 0x0BADC0FFEE123457
+
+
+NO_RCCL_NEEDED = ("test_group_rejects_bad_arguments", "test_rccl_load_failure_is_an_error_not_a_crash",
+                  "test_group_commit_matches_single_gpu_and_oracle[0]")
+
+
+@pytest.fixture(autouse=True)
+def _rccl_or_skip(request):
+    """Everything here but NO_RCCL_NEEDED forms an RCCL communicator in this process: skipped (with the probe's diagnostics) on a
+    box where the session's probe child could not form one in time -- conftest.py, need_rccl."""
+    if request.node.name not in NO_RCCL_NEEDED:
+        request.getfixturevalue("need_rccl")
 
 
 @pytest.fixture(scope="module")
@@ -366,7 +378,7 @@ assert rc == -4 and b"cannot load RCCL" in msg, (rc, msg)
 print("ok")
 """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, KZG_TEST_NO_RCCL="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=140)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
 
 
@@ -390,7 +402,7 @@ def test_group_context_leaves_hardware_queues_to_rccl():
     res = {}
     import re
     for name, code, most in (("group", group_code, 14), ("plain", plain_code, 16)):
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_DEBUG="1"), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KZG_DEBUG="1"), capture_output=True, text=True, timeout=70)
         assert r.returncode == 0 and "DONE" in r.stdout, r.stderr[-2000:]
         plans = [tuple(map(int, re.findall(r"(\d+) lanes \+ (\d+) accumulation", ln)[0])) for ln in r.stderr.splitlines() if "pipeline plan" in ln]
         # (inside the whole suite the pytest process holds contexts of its own on this GPU, and a child may find the chip's queues

@@ -32,6 +32,11 @@ TAU = 0x0BADC0FFEE123457
 N, D = 5003, 1 << 11
 
 
+@pytest.fixture(autouse=True)
+def _children_get_the_gpu(released_gpu):
+    """every test here works in child processes: the session's own contexts (and their hardware queues) go first"""
+
+
 def _env():
     env = dict(os.environ)
     env["KZG_TEST_SHM_TRANSPORT"] = "1"
@@ -152,11 +157,12 @@ def _unique_id():
     code = ("import sys, ctypes; sys.path.insert(0, %r); from kzg_amd import _lib as L; "
             "lib = L.load(%r); b = ctypes.create_string_buffer(128); assert lib.kzg_mctx_unique_id(b) == 0; print(b.raw.hex())"
             % (ROOT, os.path.join(ROOT, "kzg_amd", "libkzg_mi355x_hooks.so")))
-    p = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=300)
+    p = subprocess.run([sys.executable, "-c", code], env=_env(), capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-2000:]
     return p.stdout.strip().splitlines()[-1]
 
 
+@pytest.mark.limit(300)
 @pytest.mark.parametrize("world", [2, 3, 8])
 def test_process_per_gpu_group_on_one_gpu(world):
     seed = 100 + world
@@ -168,7 +174,7 @@ def test_process_per_gpu_group_on_one_gpu(world):
     outs = []
     try:
         for p, (fo, fe) in zip(procs, files):
-            p.wait(timeout=600)
+            p.wait(timeout=280)
             fo.seek(0)
             fe.seek(0)
             outs.append((p.returncode, fo.read(), fe.read()))
@@ -191,11 +197,12 @@ def test_process_per_gpu_group_on_one_gpu(world):
             assert f"rank {world - 1}" in res["local_failure"][2] and f"rank {world - 1}" in res["alloc_failure"][2]
 
 
+@pytest.mark.limit(300)
 @pytest.mark.parametrize("world", [2, 4])
 def test_one_process_group_on_one_gpu(world):
     """kzg_mctx_create(devices, n > 1): one process, `world` contexts, the persistent worker threads, the grouped all-gather."""
     seed = 200 + world
-    p = subprocess.run([sys.executable, WORKER, "one", str(world), str(seed)], env=_env(), capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, WORKER, "one", str(world), str(seed)], env=_env(), capture_output=True, text=True, timeout=280)
     assert p.returncode == 0, p.stderr[-3000:]
     res = _result(p.stdout)
     assert res["ranks"] == list(range(world)) and "mode=one-process" in res["info"]

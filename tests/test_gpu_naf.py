@@ -11,7 +11,7 @@ import kzg_amd
 from kzg_amd import _lib as L
 from oracle import c_oracle as C
 from oracle import kzg_model as M
-from tests.gpu_common import engine, rand_scalars  # noqa: F401
+from tests.gpu_common import rand_scalars
 
 pytestmark = pytest.mark.gpu
 R = M.R

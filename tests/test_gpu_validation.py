@@ -11,7 +11,7 @@ from kzg_amd import _lib as L
 from oracle import c_oracle as C
 from oracle import kzg_model as M
 from oracle import pairing_model as PM
-from tests.gpu_common import engine, rand_scalars  # noqa: F401
+from tests.gpu_common import rand_scalars
 
 pytestmark = pytest.mark.gpu
 TAU = 0x77AA55CC33
