@@ -9,6 +9,7 @@
 #include <array>
 #include <cstring>
 #include <stdexcept>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -250,13 +251,27 @@ class KZGVerifier {  // src/coeff_form.rs:114-183; the pairing checks run on the
 
 // ---- multi-GPU: KZGParams.gs sharded over a group of GPUs, KZGProver::commit / create_witness over the group ----
 // (the seam is the multi_exp call, src/coeff_form.rs:61,78; partial points are combined over RCCL inside the library)
+// What a ONE-NODE host exports before the first RCCL call of the process (values already exported are kept): RCCL bootstraps every
+// communicator over TCP on the first non-loopback interface it finds, which stalls formation for minutes on a host whose interface
+// swallows packets; the library bounds formation (KZG_COMM_TIMEOUT_MS / "comm_timeout_ms") but the environment is the host's.
+inline void single_node_rccl_env() {
+    setenv("NCCL_SOCKET_IFNAME", "lo", 0);
+    setenv("NCCL_RAS_ENABLE", "0", 0);
+    setenv("NCCL_IB_DISABLE", "1", 0);
+    setenv("NCCL_NET_PLUGIN", "none", 0);
+}
+
 class DeviceGroup {
   public:
     explicit DeviceGroup(const std::vector<int> &devices) {  // one process drives all GPUs
-        if (int rc = kzg_mctx_create(devices.data(), (int)devices.size(), &m_)) throw EngineError("kzg_mctx_create failed: " + std::to_string(rc));
+        single_node_rccl_env();
+        if (int rc = kzg_mctx_create(devices.data(), (int)devices.size(), &m_))
+            throw EngineError("kzg_mctx_create failed: " + std::to_string(rc) + ": " + kzg_mctx_create_error());
     }
     DeviceGroup(int device, int rank, int world, const void *unique_id) {  // one process per GPU
-        if (int rc = kzg_mctx_create_rank(device, rank, world, unique_id, &m_)) throw EngineError("kzg_mctx_create_rank failed: " + std::to_string(rc));
+        single_node_rccl_env();
+        if (int rc = kzg_mctx_create_rank(device, rank, world, unique_id, &m_))
+            throw EngineError("kzg_mctx_create_rank failed: " + std::to_string(rc) + ": " + kzg_mctx_create_error());
     }
     ~DeviceGroup() { kzg_mctx_destroy(m_); }
     DeviceGroup(const DeviceGroup &) = delete;

@@ -590,7 +590,7 @@ extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
             // collective never leaves: synchronising on it -- or destroying it, or freeing the buffers its kernels address -- would
             // turn "destroy it and form a new one" into the hang the deadline was there to prevent.  Such a context is left behind.
             if (!m->dead) kzg_sync(m->ctxs[i]);
-            else leak = !ctx_idle_within(m->ctxs[i], 2000);
+            else leak = g_rccl_wedged ? true : !ctx_idle_within(m->ctxs[i], 2000);  // (wedged: a call abandoned inside RCCL / HIP may hold the streams' locks)
         }
         if (i < (int)m->comms.size() && m->comms[i] && g_rccl && !m->dead && !g_rccl_wedged) {
             Rccl *r = g_rccl;
@@ -683,6 +683,7 @@ extern "C" int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value) 
 // ---------------------------------------------------------------------------------------------
 // sharded SRS
 // ---------------------------------------------------------------------------------------------
+static bool ctx_idle_within(kzg_ctx *c, int64_t ms);
 template <class F>
 static int msrs_build(kzg_mctx *m, size_t n, kzg_msrs **out, F make_shard) {
     kzg_msrs *s = new kzg_msrs();
@@ -744,8 +745,18 @@ extern "C" const kzg_srs *kzg_msrs_shard(const kzg_msrs *s, int i, size_t *first
 
 extern "C" void kzg_msrs_free(kzg_mctx *m, kzg_msrs *s) {
     if (!s) return;
-    for (size_t i = 0; i < s->shards.size(); i++)
-        if (s->shards[i]) kzg_srs_free(m && i < m->ctxs.size() ? m->ctxs[i] : nullptr, s->shards[i]);
+    for (size_t i = 0; i < s->shards.size(); i++) {
+        if (!s->shards[i]) continue;
+        kzg_ctx *c = m && i < m->ctxs.size() ? m->ctxs[i] : nullptr;
+        // hipFree synchronises the device: on a DEAD group whose stream an aborted collective still holds that is the hang the
+        // deadlines exist to prevent -- the shard's memory is left behind with the context (kzg_mctx_destroy)
+        if (m && m->dead && c && (g_rccl_wedged || !ctx_idle_within(c, 0))) {
+            fprintf(stderr, "kzg: SRS shard of a dead device group on GPU %d is left behind (its stream is still held by an aborted "
+                            "collective; freeing would wait for it)\n", m->devices[i]);
+            continue;
+        }
+        kzg_srs_free(c, s->shards[i]);
+    }
     delete s;
 }
 
@@ -812,26 +823,30 @@ static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
     // bounded like every other communicator call; abort + drain together get 5 s, a stream that still hangs is left behind.
     m->dead = true;
     const double t_ab = now_ms();
+    bool abort_back = true;
+    KZG_DBG("%s: deadline of %lld ms passed, aborting the communicators", what, (long long)m->gather_timeout_ms);
     if (r && r->CommAbort && !g_rccl_wedged) {
         auto st = std::make_shared<BoundedState>();
         st->comms = m->comms;
         ncclResult_t e = ncclSuccess;
         double ms = 0;
         Rccl *rr = r;
-        if (!run_bounded(5000, st, [rr](BoundedState &s) {
+        abort_back = run_bounded(5000, st, [rr](BoundedState &s) {
                 for (auto &c : s.comms)
                     if (c) rr->CommAbort(c);
                 return ncclSuccess;
-            }, &e, &ms))
-            rccl_mark_wedged("ncclCommAbort did not return within 5000 ms");
-        KZG_DBG("ncclCommAbort: %.1f ms", ms);
+            }, &e, &ms);
+        if (!abort_back) rccl_mark_wedged("ncclCommAbort did not return within 5000 ms");
+        KZG_DBG("ncclCommAbort %s after %.1f ms", abort_back ? "returned" : "ABANDONED", ms);
     }
     m->comms.clear();
-    for (int j = 0; j < m->nlocal(); j++) {
+    // (an abandoned ncclCommAbort may sit inside the HIP runtime holding the stream's lock: no further call on those streams)
+    for (int j = 0; j < m->nlocal() && abort_back; j++) {
         hipSetDevice(m->devices[j]);
         while (hipStreamQuery(m->ctxs[j]->lanes[0].stream) == hipErrorNotReady && now_ms() - t_ab < 5000.0)
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
+    KZG_DBG("%s: returning the time-out after %.1f ms of abort + drain", what, now_ms() - t_ab);
     return mfail(m, KZG_ERR_INTERNAL, std::string(what) + " did not complete within " + std::to_string(m->gather_timeout_ms) +
                                           " ms: a peer is dead or stalled.  The communicators were aborted and this group is dead "
                                           "(every further call fails; destroy it and form a new one)");

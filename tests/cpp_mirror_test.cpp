@@ -1,10 +1,14 @@
 // Exercises include/kzg_mi355x.hpp (the C++ host mirror) on the GPU: the reference's test_eval_basic
 // degree-1 edge case (src/coeff_form.rs:332-341) incl. verify_eval, commit/verify_poly (test_basic, :271-285) and
 // a 3-point batched opening with verify_eval_batched (test_eval_batched, :344-376).
+// `cpp_mirror_test group` runs the device-group block as well (it forms an RCCL communicator: tests/test_gpu_mgpu.py, behind the
+// suite's RCCL probe); without the argument only the single-GPU surface runs (tests/test_gpu_kzg.py).
 #include <cstdio>
+#include <cstring>
 #include "../include/kzg_mi355x.hpp"
 using namespace kzg;
-int main() {
+int main(int argc, char **argv) {
+    const bool with_group = argc > 1 && !std::strcmp(argv[1], "group");
     Engine e(0);
     KZGParams params = setup(e, Scalar::from_u64(0x1234567), 13);
     KZGProver prover(params);
@@ -55,7 +59,7 @@ int main() {
         if (!(ws[0] == prover.create_witness(p2, mx[0], my[0]))) return 15;
         if (!verifier.verify_eval(mx[1], my[1], cm2, ws[1])) return 16;
     }
-    {   // the multi-GPU prover over every visible GPU (a group of one on the test box): same commitment / witness as one GPU
+    if (with_group) {   // the multi-GPU prover over every visible GPU (a group of one on the test box): same commitment / witness as one GPU
         int ndev = kzg_device_count();
         if (ndev < 1) return 20;
         std::vector<int> devs;
@@ -74,6 +78,6 @@ int main() {
             if (err.kind != KZGError::PointNotOnPolynomial) return 25;
         }
     }
-    std::printf("cpp mirror ok\n");
+    std::printf(with_group ? "cpp mirror ok (with the device group)\n" : "cpp mirror ok\n");
     return 0;
 }

@@ -54,3 +54,15 @@ def rand_scalars(rng, n, kind="full"):
 def oracle_srs(tau, n):
     """(blob, n) = setup(tau, n).gs as affine-Montgomery bytes, from the C oracle."""
     return C.setup_g1(tau, n)
+
+
+def build_cpp_mirror(tmp_path):
+    """include/kzg_mi355x.hpp: compiles tests/cpp_mirror_test.cpp against the shared library; returns the executable's path."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "cpp_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "cpp_mirror_test.cpp"), "-L" + os.path.join(root, "kzg_amd"),
+                           "-lkzg_mi355x", "-Wl,-rpath," + os.path.join(root, "kzg_amd")])
+    return exe

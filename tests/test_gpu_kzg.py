@@ -318,13 +318,9 @@ def test_compute_lagrange_basis_from_monomial(engine, d):
 
 
 def test_cpp_host_mirror(engine, tmp_path):
-    """include/kzg_mi355x.hpp: compile the C++ mirror test against the shared library and run it."""
-    import os
+    """include/kzg_mi355x.hpp: compile the C++ mirror test against the shared library and run it (the single-GPU surface; the device
+    group part runs in tests/test_gpu_mgpu.py)."""
     import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "cpp_mirror_test")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), "-o", exe,
-                           os.path.join(root, "tests", "cpp_mirror_test.cpp"), "-L" + os.path.join(root, "kzg_amd"),
-                           "-lkzg_mi355x", "-Wl,-rpath," + os.path.join(root, "kzg_amd")])
-    out = subprocess.run([exe], capture_output=True, text=True)
-    assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
+    from tests.gpu_common import build_cpp_mirror
+    out = subprocess.run([build_cpp_mirror(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "cpp mirror ok" in out.stdout, (out.returncode, out.stdout, out.stderr)

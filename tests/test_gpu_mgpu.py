@@ -412,3 +412,12 @@ def test_group_context_leaves_hardware_queues_to_rccl():
             assert all(nl + nas <= 18 for nl, nas in plans), plans
         res[name] = [ln for ln in r.stdout.splitlines() if ln.startswith("DONE")][-1]
     assert res["group"] == res["plain"]        # the same commitment through both
+
+
+def test_cpp_host_mirror_device_group(tmp_path):
+    """include/kzg_mi355x.hpp, DeviceGroup / ShardedKZGProver: the C++ mirror test with its device-group block (RCCL all-gather forced
+    on in a group of one): the sharded commitment and witness equal the single-GPU ones, PointNotOnPolynomial comes through."""
+    import subprocess
+    from tests.gpu_common import build_cpp_mirror
+    out = subprocess.run([build_cpp_mirror(tmp_path), "group"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "with the device group" in out.stdout, (out.returncode, out.stdout, out.stderr)
