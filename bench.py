@@ -294,6 +294,14 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
     res["commit_coeff_ms"] = round(timeit(commit), 3)
     commitment = out.raw
     host_coeffs = coeffs.download()
+    # Every reading below is CHECKED against the oracle (never on the measured path: it runs after each timing, on downloaded
+    # data): p(tau) by its Horner loop over the downloaded coefficients, the expected point by its scalar multiplication of G.
+    from oracle import c_oracle as C
+    G = C.g1_generator()
+    ptau = C.poly_eval_bytes(host_coeffs, n, TAU)
+    checks = {}
+    res["checked_against_oracle"] = checks
+    checks["commit_coeff"] = bool(commitment == C.g1_mul(G, ptau))
 
     def commit_host():
         assert lib.kzg_commit_coeff(ctx, srs.handle, host_coeffs, n, coeffs.sfmt, 0, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
@@ -337,6 +345,12 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
         assert lib.kzg_commit_eval(ctx, lag.handle, ev.ptr, n, ev.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
     res["commit_eval_ms"] = round(timeit(commit_eval), 3)
     res["commit_eval_equals_commit_coeff"] = bool(out.raw == commitment)
+    # configs[2]: the evaluations came from the GPU's NTT of the coefficients; the Lagrange-SRS MSM of them must be [p(tau)]G
+    checks["commit_eval"] = bool(out.raw == C.g1_mul(G, ptau))
+    _, _, omega_n = kzg_amd.compute_omega(n)
+    ev_head = ev.download(2, offset=n - 2)       # ... and two of the NTT's outputs against direct Horner evaluation by the oracle
+    checks["ntt_outputs_sampled"] = all(int.from_bytes(ev_head[32 * i:32 * i + 32], "little") == C.poly_eval_bytes(host_coeffs, n, pow(omega_n, n - 2 + i, R))
+                                        for i in range(2))
     # config 4, single opening and batched k = 256
     x = kzg_amd.splitmix_scalar(99, 0)
     y = engine.poly_eval(coeffs, x)
@@ -345,6 +359,7 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
         rc = lib.kzg_witness_coeff(ctx, srs.handle, coeffs.ptr, n, b32(x), b32(y), coeffs.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
         assert rc == 0, engine.last_error()
     res["witness_coeff_ms"] = round(timeit(witness), 3)
+    checks["witness_coeff"] = bool(y == C.poly_eval_bytes(host_coeffs, n, x) and out.raw == C.g1_mul(G, (ptau - y) * pow(TAU - x, -1, R) % R))
     m = 12345 % n
     xm = pow(kzg_amd.compute_omega(n)[2], m, R)
     ym = engine.poly_eval(coeffs, xm)
@@ -355,6 +370,7 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
         assert lib.kzg_witness_eval(ctx, lag.handle, ev.ptr, n, m, ev.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT) == 0, engine.last_error()
     res["witness_eval_ms"] = round(timeit(witness_eval), 3)
     res["witness_eval_equals_witness_coeff"] = bool(rc == 0 and out.raw == w_coeff)
+    checks["witness_eval"] = bool(out.raw == C.g1_mul(G, (ptau - C.poly_eval_bytes(host_coeffs, n, xm)) * pow(TAU - xm, -1, R) % R))
     k = 256 if n > 512 else 4
     xs = [kzg_amd.splitmix_scalar(7, i) for i in range(k)]
     ys = [engine.poly_eval(coeffs, v) for v in xs]
@@ -366,6 +382,16 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
                                            rbuf, ctypes.byref(rlen))
         assert rc == 0, engine.last_error()
     res["witness_batched_k%d_ms" % k] = round(timeit(batched, reps=2), 3)
+    # configs[3]: w == [(p(tau) - I(tau)) / Z(tau)]G with I = the returned interpolant (it must pass through the k points, two of
+    # whose values the oracle recomputes from the coefficients) and Z = prod (tau - x_i): all oracle / integer arithmetic
+    Icoef = kzg_amd.unpack_scalars(rbuf.raw[:32 * rlen.value])
+    Ztau = 1
+    for v in xs:
+        Ztau = Ztau * (TAU - v) % R
+    checks["witness_batched_k%d" % k] = bool(
+        rlen.value == (k if k > 1 else 2) and all(C.poly_eval(Icoef, xs[i]) == ys[i] for i in range(0, k, max(1, k // 8)))
+        and all(C.poly_eval_bytes(host_coeffs, n, xs[i]) == ys[i] for i in (0, k - 1))
+        and out.raw == C.g1_mul(G, (ptau - C.poly_eval(Icoef, TAU)) * pow(Ztau, -1, R) % R))
     if time.perf_counter() - t_start < budget_s * 0.5:
         outs = ctypes.create_string_buffer(96 * k)
         st = (ctypes.c_int * k)()
@@ -446,8 +472,51 @@ def measure_spots(kzg_amd, L, engine, budget_ok):
             rc = engine.lib.kzg_msm_g1(engine.ctx, p.gs.handle, 0, sc.ptr, m, sc.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
             assert rc == 0, engine.last_error()
         res["commit_2e%d" % log_m]["single_commit_latency_ms"] = round(timeit(single, reps=2), 3)
+        # checked: commitments of the last batch step against [p(tau)]G by the oracle (2^24: the last one -- half a GiB of
+        # coefficients through its Horner loop; BASELINE configs[4]'s polynomial size on one GPU)
+        try:
+            from oracle import c_oracle as C
+            G = C.g1_generator()
+            which = [batch - 1] if log_m == 24 else sorted({0, batch // 2, batch - 1})
+            res["commit_2e%d" % log_m]["checked_against_oracle"] = all(
+                out.raw[96 * b:96 * b + 96] == C.g1_mul(G, C.poly_eval_bytes(view_of(sc, b * m, m).download(), m, TAU)) for b in which)
+            res["commit_2e%d" % log_m]["checked_commitments"] = which
+        except Exception as e:  # noqa: BLE001
+            res["commit_2e%d" % log_m]["checked_against_oracle"] = "check failed to run: %s" % e
         sc.free()
         p.gs.free()
+    return res
+
+
+def view_of(buf, first, n):
+    import kzg_amd
+    return view(kzg_amd, buf, first, n)
+
+
+def measure_u64(kzg_amd, L, engine, srs, n, batch, steps=3):
+    """The reference benches' own distribution (benches/commit_coeff_form.rs:16-21: coefficients are u64 values): the same batched
+    commit on u64-valued scalars resident in HBM -- SURVEY 8(d)'s secondary reading of the headline metric.  Three commitments of
+    the last step are checked against [p(tau)]G by the oracle."""
+    sc = engine.alloc_scalars(n * batch)
+    for b in range(batch):
+        view(kzg_amd, sc, b * n, n).fill_random(SEED + 31000 + 1000 * b, u64_valued=True)
+    out = ctypes.create_string_buffer(96 * batch)
+
+    def step():
+        rc = engine.lib.kzg_msm_g1_batch(engine.ctx, srs.handle, 0, sc.ptr, n, batch, sc.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+        assert rc == 0, engine.last_error()
+    ms = timeit(step, reps=steps, warm=1)
+    res = {"commit_u64_per_s": round(batch / ms * 1e3, 2), "commit_u64_batch": batch,
+           "commit_u64_scalars": "u64-valued Fr (benches/commit_coeff_form.rs:16-21), 4 non-zero 16/17-bit windows per scalar"}
+    try:
+        from oracle import c_oracle as C
+        G = C.g1_generator()
+        which = sorted({0, batch // 2, batch - 1})
+        res["commit_u64_checked_against_oracle"] = all(
+            out.raw[96 * b:96 * b + 96] == C.g1_mul(G, C.poly_eval_bytes(view(kzg_amd, sc, b * n, n).download(), n, TAU)) for b in which)
+    except Exception as e:  # noqa: BLE001
+        res["commit_u64_checked_against_oracle"] = "check failed to run: %s" % e
+    sc.free()
     return res
 
 
@@ -1165,6 +1234,8 @@ def main():
                 res["paths"]["blocking_callers_16_witness_batched_k%d_per_s" % kb] = round(per_s, 2)   # configs[3], primary reading
                 res["paths"]["blocking_callers_16_witness_batched_vs_value"] = round(per_s / value, 4)
                 res["paths"]["blocking_callers_16_witness_batched_match_lone_calls"] = same
+                if not args.u64:
+                    res["paths"].update(measure_u64(kzg_amd, L, engine, srs, n_poly, args.batch))
                 if args.log_n == 20 and not args.u64:
                     res["paths"].update(measure_spots(kzg_amd, L, engine, lambda: time.perf_counter() - t_extra < 45.0))
             except Exception as e:

@@ -142,16 +142,19 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
         __syncthreads();
         s = 1;
     }
-    const uint32_t quarter = 1u << (t - 2);
+    // One radix-4 butterfly per thread and pair (the launches use tile / 4 threads).  Butterfly b of pair s sits at the tile
+    // positions idx_s(b) ^ {0, m, 2m, 3m}, idx_s(b) = ((b >> s) << (s + 2)) | (b & (m - 1)): a bit permutation of b.  From one pair
+    // to the next only bits s, s+1 of b move (from positions s+2, s+3 down to s, s+1), and the swizzle is GF(2)-linear, so the
+    // swizzled position is CARRIED: p0 ^= (bit s ? D1 : 0) ^ (bit s+1 ? D2 : 0) with two wave-uniform constants -- five VALU
+    // instructions per pair instead of the ~45 of a fresh swz() (profiles/r05_isa_inventory_ntt.txt).
+    const uint32_t b = threadIdx.x;
+    const bool active = b < (vec << (t - 2));
+    uint32_t p0 = swz(((b >> s) << (s + 2)) | (b & ((1u << s) - 1u)), sw);
     for (; s + 1 < t; s += 2) {
         const uint32_t m = 1u << s;
-        const uint32_t total = vec << (t - 2);
         const uint32_t d1 = swz(m, sw), d2 = swz(2 * m, sw);  // the swizzle is linear: swz(p ^ m) = swz(p) ^ swz(m)
-        for (uint32_t b = threadIdx.x; b < total; b += blockDim.x) {
-            uint32_t v = b >> (t - 2);
-            uint32_t i = b & (quarter - 1);
-            uint32_t j = i & (m - 1);
-            const uint32_t p0 = swz((v << t) | (((i >> s) << (s + 2)) | j), sw);
+        if (active) {
+            const uint32_t j = b & (m - 1);
             const uint32_t p1 = p0 ^ d1, p2 = p0 ^ d2, p3 = p1 ^ d2;
             Fr29 x0 = lds[p0], x1 = lds[p1], x2 = lds[p2], x3 = lds[p3];
             Fr29 s0, y1, s2, y3, z0, z1, z2, z3;
@@ -182,8 +185,22 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
             lds[p2] = fr29_normalize(z2);
             lds[p3] = fr29_normalize(z3);
         }
+        // the next pair's position: bits s, s+1 of b move from positions s+2, s+3 down to s, s+1
+        const uint32_t D1 = swz(4 * m, sw) ^ d1, D2 = swz(8 * m, sw) ^ d2;
+        p0 ^= (((uint32_t)((int32_t)(b << (31 - s)) >> 31)) & D1) ^ (((uint32_t)((int32_t)(b << (30 - s)) >> 31)) & D2);
         __syncthreads();
     }
+}
+
+// The four tile positions a thread touches in a load / store phase: element e_i = threadIdx.x + i * blockDim.x (the launches use
+// tile / 4 threads, a power of two).  Every position function of these kernels is a bit permutation of e, i.e. GF(2)-linear, and so
+// is the swizzle: phys(e_i) = phys(threadIdx.x) ^ phys(i * blockDim.x), the second term wave-uniform (scalar ALU).  One swz() per
+// thread and phase instead of four.
+template <class IdxFn>
+__device__ __forceinline__ void tile_positions4(IdxFn idx, uint64_t sw, uint32_t (&p)[4]) {
+    p[0] = swz(idx(threadIdx.x), sw);
+#pragma unroll
+    for (uint32_t i = 1; i < 4; i++) p[i] = p[0] ^ swz(idx(i * blockDim.x), sw);
 }
 
 // Whole transform in one tile (log_n <= 12).
@@ -220,11 +237,10 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
             const uint32_t e = threadIdx.x + i * blockDim.x;
             raw[i] = in[((size_t)(e >> vec_log) << k2) + j2_0 + (e & (vec - 1))];  // consecutive threads -> consecutive columns
         }
+        uint32_t pos[4];
+        tile_positions4([&](uint32_t e) { return ((e & (vec - 1)) << k1) | bitrev(e >> vec_log, k1); }, sw, pos);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t e = threadIdx.x + i * blockDim.x;
-            lds_fr29[swz(((e & (vec - 1)) << k1) | bitrev(e >> vec_log, k1), sw)] = fr29_unpack(raw[i]);
-        }
+        for (int i = 0; i < 4; i++) lds_fr29[pos[i]] = fr29_unpack(raw[i]);
     }
     __syncthreads();
     lds_ntt_stages29(lds_fr29, k1, vec, tw1, sw);
@@ -237,12 +253,14 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
             twf[i] = tw_full[((size_t)(e >> vec_log) << k2) + j2_0 + (e & (vec - 1))];
         }
     }
+    uint32_t opos[4];
+    tile_positions4([&](uint32_t e) { return ((e & (vec - 1)) << k1) | (e >> vec_log); }, sw, opos);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t e = threadIdx.x + i * blockDim.x;
         uint32_t v = e & (vec - 1), kk1 = e >> vec_log;
         uint32_t j2 = j2_0 + v;
-        Fr29 x = lds_fr29[swz((v << k1) | kk1, sw)];
+        Fr29 x = lds_fr29[opos[i]];
         if (tw_full) {
             x = mul29r(x, twf[i]);  // Montgomery-29 product: below 1.4 r for x < 64 r
         } else {
@@ -275,11 +293,10 @@ __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint3
             const uint32_t e = threadIdx.x + i * blockDim.x;
             raw[i] = in[((size_t)(r0 + (e >> k2)) << k2) + (e & (n2 - 1))];  // consecutive threads -> consecutive row elements
         }
+        uint32_t pos[4];
+        tile_positions4([&](uint32_t e) { return ((e >> k2) << k2) | bitrev(e & (n2 - 1), k2); }, sw, pos);
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t e = threadIdx.x + i * blockDim.x;
-            lds_fr29[swz(((e >> k2) << k2) | bitrev(e & (n2 - 1), k2), sw)] = fr29_unpack(raw[i]);
-        }
+        for (int i = 0; i < 4; i++) lds_fr29[pos[i]] = fr29_unpack(raw[i]);
     } else {
         const uint32_t lo_mask = (1u << lo_bits) - 1;
 #pragma unroll
@@ -305,11 +322,13 @@ __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint3
     }
     __syncthreads();
     lds_ntt_stages29(lds_fr29, k2, vec, tw2, sw);
+    uint32_t opos[4];
+    tile_positions4([&](uint32_t e) { return ((e & (vec - 1)) << k2) | (e >> vec_log); }, sw, opos);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const uint32_t e = threadIdx.x + i * blockDim.x;
         uint32_t v = e & (vec - 1), kk2 = e >> vec_log;  // consecutive threads -> consecutive k1
-        Fr29 x = lds_fr29[swz((v << k2) | kk2, sw)];
+        Fr29 x = lds_fr29[opos[i]];
         // the scale already sits in the inter-pass table: only canonicalise (x < 64 r) -- no multiplication
         x = scale_folded ? fr29_reduce_below_2r(x) : mulshoup29(x, scale, scale_p);
         out[((size_t)kk2 << k1) + r0 + v] = fr29_pack_canonical(x);
