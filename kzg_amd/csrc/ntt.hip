@@ -119,6 +119,11 @@ __device__ __forceinline__ uint32_t swz(uint32_t idx, uint64_t masks) {
     return x;
 }
 
+// swz(1 << k): a single set bit contributes its own mask (bits >= 5) or nothing -- two scalar instructions for a wave-uniform k
+__device__ __forceinline__ uint32_t swz_bit(uint32_t k, uint64_t masks) {
+    return (1u << k) ^ (k >= 5 ? (uint32_t)(masks >> (5 * (k - 5))) & 31u : 0u);
+}
+
 // DIT stages over `vec` independent 2^t-point vectors held in LDS at lds[swz(v << t | pos)] (36-byte elements),
 // input already in bit-reversed position order.  Stage pairs
 // (s, s+1) are fused: a thread takes the 4 elements {p, p+m, p+2m, p+3m}, m = 2^s, through both stages in
@@ -146,13 +151,14 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
     // positions idx_s(b) ^ {0, m, 2m, 3m}, idx_s(b) = ((b >> s) << (s + 2)) | (b & (m - 1)): a bit permutation of b.  From one pair
     // to the next only bits s, s+1 of b move (from positions s+2, s+3 down to s, s+1), and the swizzle is GF(2)-linear, so the
     // swizzled position is CARRIED: p0 ^= (bit s ? D1 : 0) ^ (bit s+1 ? D2 : 0) with two wave-uniform constants -- five VALU
-    // instructions per pair instead of the ~45 of a fresh swz() (profiles/r05_isa_inventory_ntt.txt).
+    // instructions per pair instead of the ~45 of a fresh swz() (profiles/r05_isa_inventory_ntt.txt).  (Measured: 10 % fewer VALU
+    // instructions per transform and the SAME kernel time -- these kernels are not issue-bound; profiles/r05_ab_ntt.txt.)
     const uint32_t b = threadIdx.x;
     const bool active = b < (vec << (t - 2));
     uint32_t p0 = swz(((b >> s) << (s + 2)) | (b & ((1u << s) - 1u)), sw);
     for (; s + 1 < t; s += 2) {
         const uint32_t m = 1u << s;
-        const uint32_t d1 = swz(m, sw), d2 = swz(2 * m, sw);  // the swizzle is linear: swz(p ^ m) = swz(p) ^ swz(m)
+        const uint32_t d1 = swz_bit(s, sw), d2 = swz_bit(s + 1, sw);  // the swizzle is linear: swz(p ^ m) = swz(p) ^ swz(m)
         if (active) {
             const uint32_t j = b & (m - 1);
             const uint32_t p1 = p0 ^ d1, p2 = p0 ^ d2, p3 = p1 ^ d2;
@@ -186,7 +192,7 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
             lds[p3] = fr29_normalize(z3);
         }
         // the next pair's position: bits s, s+1 of b move from positions s+2, s+3 down to s, s+1
-        const uint32_t D1 = swz(4 * m, sw) ^ d1, D2 = swz(8 * m, sw) ^ d2;
+        const uint32_t D1 = swz_bit(s + 2, sw) ^ d1, D2 = swz_bit(s + 3, sw) ^ d2;
         p0 ^= (((uint32_t)((int32_t)(b << (31 - s)) >> 31)) & D1) ^ (((uint32_t)((int32_t)(b << (30 - s)) >> 31)) & D2);
         __syncthreads();
     }
@@ -199,8 +205,11 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
 template <class IdxFn>
 __device__ __forceinline__ void tile_positions4(IdxFn idx, uint64_t sw, uint32_t (&p)[4]) {
     p[0] = swz(idx(threadIdx.x), sw);
-#pragma unroll
-    for (uint32_t i = 1; i < 4; i++) p[i] = p[0] ^ swz(idx(i * blockDim.x), sw);
+    // idx(blockDim.x) and idx(2 blockDim.x) are single bits (blockDim.x is a power of two and idx permutes bits)
+    const uint32_t q1 = swz_bit(__builtin_ctz(idx(blockDim.x)), sw), q2 = swz_bit(__builtin_ctz(idx(2 * blockDim.x)), sw);
+    p[1] = p[0] ^ q1;
+    p[2] = p[0] ^ q2;
+    p[3] = p[1] ^ q2;
 }
 
 // Whole transform in one tile (log_n <= 12).

@@ -84,8 +84,11 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("-")]
     path = args[0] if args else os.path.join(ROOT, "kzg_amd", "build", "ntt_dev_pp.s")
     fs = functions(open(path).read().split("\n"))
-    for key, label in (("k_ntt_pass1", "k_ntt_pass1"), ("k_ntt_pass2ILb0", "k_ntt_pass2<false>")):
-        name = [n for n in fs if key in n][0]
+    for key, label in (("k_ntt_pass1ILb1", "k_ntt_pass1<DEFER>"), ("k_ntt_pass2ILb0ELb1", "k_ntt_pass2<!SHORT, TWIN>")):
+        cand = [n for n in fs if key in n]
+        if not cand:    # an assembly from before the templates
+            cand = [n for n in fs if key.split("ILb")[0] in n]
+        name = cand[0]
         bl = blocks_of(fs[name])
         print("== %s: %d basic blocks, %d instructions" % (label, len(bl), sum(len(b[1]) for b in bl)))
         for n, ins in bl:
