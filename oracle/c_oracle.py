@@ -100,6 +100,14 @@ def msm_g1_raw(points_blob, scalar_bytes, n):
     return out.raw
 
 
+def msm_g1_fast_raw(points_blob, scalar_bytes, n):
+    """bench.py's cpu_baseline TIMING leg: signed 16-bit windows, batch-affine bucket accumulation, unrolled Montgomery
+    multiplication (orc_msm_g1_fast).  Not a checker: tests compare it with msm_g1_raw."""
+    out = _buf(96)
+    lib().orc_msm_g1_fast(points_blob, scalar_bytes, ctypes.c_size_t(n), out)
+    return out.raw
+
+
 def g1_generator():
     out = _buf(96)
     lib().orc_g1_generator(out)

@@ -246,6 +246,180 @@ void orc_msm_g1(const uint8_t *points, const uint8_t *scalars, size_t n, uint8_t
     g1j_to_affine((g1a *)out, &total);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* TIMING LEG ONLY (bench.py's cpu_baseline): a faster single-threaded Pippenger.  The checker of   */
+/* every test stays orc_msm_g1 above; this one is checked against it (tests/test_oracle_c.py).      */
+/* What a tuned CPU library does that the textbook loop above does not: signed 16-bit window digits  */
+/* (half the buckets), bucket accumulation in AFFINE coordinates with the field inversions of a      */
+/* whole batch of additions shared (Montgomery's trick: ~6 multiplications per addition instead of   */
+/* the 11 of a mixed Jacobian one), and an unrolled no-carry CIOS Montgomery multiplication.         */
+/* ------------------------------------------------------------------------------------------ */
+#define FQ_MAC(hi, lo, a, b, c, d) do { u128 _x = (u128)(a) * (b) + (c) + (d); lo = (u64)_x; hi = (u64)(_x >> 64); } while (0)
+static inline void fq_mulf(fq *r, const fq *a, const fq *b) {
+    /* the modulus' top limb (0x1a01...) leaves spare bits: the carry of a round fits the top word */
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0;
+    const u64 *p = fq_P;
+#define FQ_ROUND(bi) do { u64 A, C, m, _d; \
+        FQ_MAC(A, t0, a->v[0], bi, t0, 0); m = t0 * fq_INV; FQ_MAC(C, _d, m, p[0], t0, 0); (void)_d; \
+        FQ_MAC(A, t1, a->v[1], bi, t1, A); FQ_MAC(C, t0, m, p[1], t1, C); \
+        FQ_MAC(A, t2, a->v[2], bi, t2, A); FQ_MAC(C, t1, m, p[2], t2, C); \
+        FQ_MAC(A, t3, a->v[3], bi, t3, A); FQ_MAC(C, t2, m, p[3], t3, C); \
+        FQ_MAC(A, t4, a->v[4], bi, t4, A); FQ_MAC(C, t3, m, p[4], t4, C); \
+        FQ_MAC(A, t5, a->v[5], bi, t5, A); FQ_MAC(C, t4, m, p[5], t5, C); \
+        t5 = C + A; } while (0)
+    FQ_ROUND(b->v[0]); FQ_ROUND(b->v[1]); FQ_ROUND(b->v[2]); FQ_ROUND(b->v[3]); FQ_ROUND(b->v[4]); FQ_ROUND(b->v[5]);
+#undef FQ_ROUND
+    u64 t[6] = {t0, t1, t2, t3, t4, t5};
+    if (fq_geq_p(t)) fq_sub_p(t);
+    memcpy(r->v, t, sizeof t);
+}
+
+/* Jacobian helpers on the fast multiplication (same formulas as above) */
+static void g1j_add_affine_f(g1j *r, const g1j *p, const g1a *q) {
+    if (g1a_is_inf(q)) { *r = *p; return; }
+    if (fq_is_zero(&p->z)) { r->x = q->x; r->y = q->y; r->z = fq_R1; return; }
+    fq Z1Z1, U2, S2, H, Rr, HH, HHH, V, t;
+    fq_mulf(&Z1Z1, &p->z, &p->z);
+    fq_mulf(&U2, &q->x, &Z1Z1);
+    fq_mulf(&S2, &q->y, &p->z); fq_mulf(&S2, &S2, &Z1Z1);
+    if (fq_eq(&U2, &p->x)) {
+        if (fq_eq(&S2, &p->y)) { g1j_double(r, p); return; }
+        g1j_set_inf(r); return;
+    }
+    fq_sub(&H, &U2, &p->x); fq_sub(&Rr, &S2, &p->y);
+    fq_mulf(&HH, &H, &H); fq_mulf(&HHH, &H, &HH); fq_mulf(&V, &p->x, &HH);
+    fq X3; fq_mulf(&X3, &Rr, &Rr); fq_sub(&X3, &X3, &HHH); fq_sub(&X3, &X3, &V); fq_sub(&X3, &X3, &V);
+    fq Y3; fq_sub(&t, &V, &X3); fq_mulf(&Y3, &Rr, &t); fq_mulf(&t, &p->y, &HHH); fq_sub(&Y3, &Y3, &t);
+    fq Z3; fq_mulf(&Z3, &p->z, &H);
+    r->x = X3; r->y = Y3; r->z = Z3;
+}
+static void g1j_add_f(g1j *r, const g1j *p, const g1j *q) {
+    if (fq_is_zero(&p->z)) { *r = *q; return; }
+    if (fq_is_zero(&q->z)) { *r = *p; return; }
+    fq Z1Z1, Z2Z2, U1, U2, S1, S2, H, Rr, HH, HHH, V, t;
+    fq_mulf(&Z1Z1, &p->z, &p->z); fq_mulf(&Z2Z2, &q->z, &q->z);
+    fq_mulf(&U1, &p->x, &Z2Z2); fq_mulf(&U2, &q->x, &Z1Z1);
+    fq_mulf(&S1, &p->y, &q->z); fq_mulf(&S1, &S1, &Z2Z2);
+    fq_mulf(&S2, &q->y, &p->z); fq_mulf(&S2, &S2, &Z1Z1);
+    if (fq_eq(&U1, &U2)) {
+        if (fq_eq(&S1, &S2)) { g1j_double(r, p); return; }
+        g1j_set_inf(r); return;
+    }
+    fq_sub(&H, &U2, &U1); fq_sub(&Rr, &S2, &S1);
+    fq_mulf(&HH, &H, &H); fq_mulf(&HHH, &H, &HH); fq_mulf(&V, &U1, &HH);
+    fq X3; fq_mulf(&X3, &Rr, &Rr); fq_sub(&X3, &X3, &HHH); fq_sub(&X3, &X3, &V); fq_sub(&X3, &X3, &V);
+    fq Y3; fq_sub(&t, &V, &X3); fq_mulf(&Y3, &Rr, &t); fq_mulf(&t, &S1, &HHH); fq_sub(&Y3, &Y3, &t);
+    fq Z3; fq_mulf(&Z3, &p->z, &q->z); fq_mulf(&Z3, &Z3, &H);
+    r->x = X3; r->y = Y3; r->z = Z3;
+}
+
+#define FAST_C 16                 /* window width: 16 windows cover 255 bits + the carry of the signed recoding */
+#define FAST_NWIN 16
+#define FAST_BATCH 1024           /* affine additions that share one field inversion */
+typedef struct { uint32_t bucket; g1a pt; } fast_job;
+
+/* one batch of affine additions bucket[b] += pt, all to DIFFERENT non-empty buckets: one inversion for all of them */
+static void fast_flush(g1a *buckets, uint8_t *busy, fast_job *jobs, size_t m, fq *den, fq *pre) {
+    if (!m) return;
+    fq acc = fq_R1;
+    for (size_t k = 0; k < m; k++) {          /* denominators: x2 - x1, or 2 y for a doubling, or 1 for P + (-P) */
+        g1a *B = &buckets[jobs[k].bucket];
+        fq_sub(&den[k], &jobs[k].pt.x, &B->x);
+        if (fq_is_zero(&den[k])) {
+            if (fq_eq(&jobs[k].pt.y, &B->y)) fq_add(&den[k], &B->y, &B->y);   /* same point (y != 0 on this curve's prime-order group) */
+            else den[k] = fq_R1;                                                  /* opposite points: the sum is the identity */
+        }
+        pre[k] = acc;
+        fq_mulf(&acc, &acc, &den[k]);
+    }
+    fq inv; fq_inv(&inv, &acc);
+    for (size_t k = m; k-- > 0;) {
+        g1a *B = &buckets[jobs[k].bucket];
+        const g1a *P = &jobs[k].pt;
+        fq dinv; fq_mulf(&dinv, &inv, &pre[k]); fq_mulf(&inv, &inv, &den[k]);
+        fq num, lam, x3, y3, t;
+        fq_sub(&t, &P->x, &B->x);
+        if (fq_is_zero(&t)) {
+            if (!fq_eq(&P->y, &B->y)) { memset(B, 0, sizeof *B); busy[jobs[k].bucket] = 0; continue; }   /* identity: bucket empty again */
+            fq_mulf(&num, &B->x, &B->x); fq_add(&t, &num, &num); fq_add(&num, &t, &num);                  /* 3 x^2 (a = 0) */
+        } else {
+            fq_sub(&num, &P->y, &B->y);
+        }
+        fq_mulf(&lam, &num, &dinv);
+        fq_mulf(&x3, &lam, &lam); fq_sub(&x3, &x3, &B->x); fq_sub(&x3, &x3, &P->x);
+        fq_sub(&t, &B->x, &x3); fq_mulf(&y3, &lam, &t); fq_sub(&y3, &y3, &B->y);
+        B->x = x3; B->y = y3;
+        busy[jobs[k].bucket] = 0;
+    }
+}
+
+void orc_msm_g1_fast(const uint8_t *points, const uint8_t *scalars, size_t n, uint8_t *out) {
+    const g1a *pts = (const g1a *)points;
+    const u64 *sc = (const u64 *)scalars;
+    const size_t nb = (size_t)1 << (FAST_C - 1);
+    int16_t *dig = (int16_t *)malloc(n * FAST_NWIN * sizeof(int16_t) + 16);
+    for (size_t i = 0; i < n; i++) {          /* signed digits in [-2^15, 2^15): d_w - 2^16 and a carry when d_w >= 2^15 */
+        const u64 *s = sc + 4 * i;
+        int carry = 0;
+        for (int w = 0; w < FAST_NWIN; w++) {
+            int d = (int)((s[w / 4] >> (16 * (w % 4))) & 0xffff) + carry;
+            carry = d >= 0x8000;
+            dig[i * FAST_NWIN + w] = (int16_t)(d - (carry << 16));
+        }                                      /* canonical scalars are below 2^255: the last digit never carries */
+    }
+    g1a *buckets = (g1a *)malloc(nb * sizeof(g1a));
+    uint8_t *busy = (uint8_t *)calloc(nb, 1);
+    uint8_t *full = (uint8_t *)malloc(nb);
+    fast_job *jobs = (fast_job *)malloc(FAST_BATCH * sizeof(fast_job));
+    fast_job *defer = (fast_job *)malloc((n + 1) * sizeof(fast_job)), *defer2 = (fast_job *)malloc((n + 1) * sizeof(fast_job));
+    fq *den = (fq *)malloc(FAST_BATCH * sizeof(fq)), *pre = (fq *)malloc(FAST_BATCH * sizeof(fq));
+    g1j total; g1j_set_inf(&total);
+    for (int w = FAST_NWIN - 1; w >= 0; w--) {
+        for (int i = 0; i < FAST_C; i++) g1j_double(&total, &total);
+        memset(full, 0, nb);
+        size_t m = 0, nd = 0;
+        for (size_t i = 0; i < n; i++) {
+            int d = dig[i * FAST_NWIN + w];
+            if (!d || g1a_is_inf(&pts[i])) continue;
+            fast_job j;
+            j.bucket = (uint32_t)((d < 0 ? -d : d) - 1);
+            j.pt = pts[i];
+            if (d < 0) fq_neg(&j.pt.y, &j.pt.y);
+            if (busy[j.bucket]) { defer[nd++] = j; continue; }                                  /* already in this batch: later */
+            if (!full[j.bucket] || g1a_is_inf(&buckets[j.bucket])) {                            /* first point of the bucket (or emptied by P + (-P)) */
+                buckets[j.bucket] = j.pt; full[j.bucket] = 1; continue; }
+            busy[j.bucket] = 1;
+            jobs[m++] = j;
+            if (m == FAST_BATCH) { fast_flush(buckets, busy, jobs, m, den, pre); m = 0; }
+        }
+        fast_flush(buckets, busy, jobs, m, den, pre);
+        m = 0;
+        while (nd) {                             /* the deferred additions, in rounds: each round takes one per bucket */
+            size_t nd2 = 0;
+            for (size_t k = 0; k < nd; k++) {
+                fast_job *j = &defer[k];
+                if (g1a_is_inf(&buckets[j->bucket])) { buckets[j->bucket] = j->pt; continue; }   /* emptied by P + (-P) */
+                if (busy[j->bucket]) { defer2[nd2++] = *j; continue; }
+                busy[j->bucket] = 1;
+                jobs[m++] = *j;
+                if (m == FAST_BATCH) { fast_flush(buckets, busy, jobs, m, den, pre); m = 0; }
+            }
+            fast_flush(buckets, busy, jobs, m, den, pre);
+            m = 0;
+            fast_job *tq = defer; defer = defer2; defer2 = tq;
+            nd = nd2;
+        }
+        g1j run, sum; g1j_set_inf(&run); g1j_set_inf(&sum);
+        for (size_t b = nb; b-- > 0;) {
+            if (full[b] && !g1a_is_inf(&buckets[b])) g1j_add_affine_f(&run, &run, &buckets[b]);
+            g1j_add_f(&sum, &sum, &run);
+        }
+        g1j_add_f(&total, &total, &sum);
+    }
+    free(dig); free(buckets); free(busy); free(full); free(jobs); free(defer); free(defer2); free(den); free(pre);
+    g1j_to_affine((g1a *)out, &total);
+}
+
 /* naive sum_i [s_i]P_i (independent of the bucket method; cross-check for orc_msm_g1) */
 void orc_msm_g1_naive(const uint8_t *points, const uint8_t *scalars, size_t n, uint8_t *out) {
     g1j total; g1j_set_inf(&total);

@@ -96,3 +96,33 @@ def test_poly_helpers_vs_model():
         e = M.EvaluationDomain.from_coeffs(xs)
         e.fft()
         assert C.fft(xs) == e.coeffs
+
+
+def test_fast_msm_of_the_timing_leg_equals_the_checker():
+    """orc_msm_g1_fast (bench.py's cpu_baseline timing leg: signed 16-bit windows, batch-affine buckets, unrolled Montgomery
+    multiplication) against the plain Pippenger the tests check with -- random and u64-valued scalars, the extremes, and the cases
+    the affine formulas special-case: a bucket receiving the same point twice (doubling), a point and its negative (the bucket
+    empties), identity points, n = 0 and 1."""
+    rng = random.Random(77)
+    n = 700
+    blob_all = C.setup_g1(0x1234567, n)
+    pts = [blob_all[96 * i:96 * i + 96] for i in range(n)]
+
+    def neg(p):
+        return p[:48] + ((M.Q - int.from_bytes(p[48:], "little")) % M.Q).to_bytes(48, "little")
+
+    def same(ptsl, scal):
+        pb, sb = b"".join(ptsl), C.scalars_to_bytes([s % M.R for s in scal])
+        assert C.msm_g1_fast_raw(pb, sb, len(scal)) == C.msm_g1_raw(pb, sb, len(scal))
+
+    same(pts, [rng.randrange(M.R) for _ in range(n)])
+    same(pts, [rng.getrandbits(64) for _ in range(n)])
+    same(pts[:200], [M.R - 1] * 200)
+    same(pts[:50], [0] * 50)
+    same([pts[5]] * 300, [rng.randrange(M.R) for _ in range(300)])
+    same([pts[5]] * 300, [12345] * 300)
+    same([pts[7], neg(pts[7])] * 60 + pts[:40], [999] * 120 + [rng.randrange(M.R) for _ in range(40)])
+    same([pts[7], neg(pts[7]), pts[7], pts[7], neg(pts[7])] * 30, [999] * 150)
+    same([bytes(96)] * 10 + pts[:10], [rng.randrange(M.R) for _ in range(20)])
+    same(pts[:1], [1])
+    same([], [])
