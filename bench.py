@@ -135,6 +135,7 @@ class CpuBaseline:
         from oracle import c_oracle as C
         C.build()
         self.native = C.build_native()
+        self.native_build = C.NATIVE_BUILD
         try:
             ncpu = len(os.sched_getaffinity(0))
         except Exception:
@@ -157,7 +158,7 @@ class CpuBaseline:
             t_med = statistics.median(t for t, _ in r1)
             ok1 = all(o == gpu_result for _, o in r1)
             single = {"value": round(scale / t_med, 5), "unit": "commitments/s", "cores": 1, "kind": "port",
-                      "build": "gcc -O3 -march=native" if self.native else "gcc -O2 (portable)",
+                      "build": (self.native_build or "native") if self.native else "gcc -O2 (portable)",
                       "algorithm": "Pippenger, signed 16-bit windows, batch-affine bucket accumulation (one inversion per 1024 additions), "
                                    "64-bit no-carry CIOS Montgomery multiplication in C (oracle/kzg_oracle.c: orc_msm_g1_fast); no precomputed tables",
                       "samples_s": [round(t, 2) for t, _ in r1],

@@ -317,7 +317,12 @@ int kzg_witness_coeff_many(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs,
 /* KZGProver::create_witness_batched (:83-111): w = [(p - I)/Z]_1 and r = I (the interpolant through
  * (xs, ys)).  xs, ys: k host scalars.  out_r receives *out_r_len scalars (host, sfmt): k normally,
  * 2 for k == 1 (the reference returns X + (y - x), src/polynomial.rs:244-247).
- * KZG_ERR_POINT_NOT_ON_POLY iff some p(xs[i]) != ys[i]. */
+ * KZG_ERR_POINT_NOT_ON_POLY iff some p(xs[i]) != ys[i].
+ * Opening-point sets are remembered per context: what depends on xs alone (Z, the barycentric weights, the coset shift, 1 / Z on the
+ * coset: N x 32 bytes) is kept in one of "witness_cache_slots" equal slots (kzg_ctx_set_option, default 16, 0 = off; the pool is
+ * allocated by the first call, sized for that call), so that opening many polynomials at ONE point set -- the way batched openings are
+ * used -- pays for the point set once.  Results are identical with and without the cache.  kzg_prof_get(ctx, "point_set_cache",
+ * &hits, &misses_as_double) reports its use. */
 int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const void *coeffs, size_t n,
                               const void *xs, const void *ys, size_t k, int sfmt, int flags, void *out_w,
                               int ofmt, void *out_r, size_t *out_r_len);

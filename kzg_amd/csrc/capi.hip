@@ -343,6 +343,7 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
     ntt_plans_free(ctx);
     eval_tabs_free(ctx);
     fixed_base_free(ctx);
+    point_sets_free(ctx);
     delete ctx;
 }
 
@@ -429,6 +430,10 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
         ctx->opt_naf_window = (int)value;
     } else if (k == "trusted_points") {
         ctx->opt_trusted_points = value != 0;
+    } else if (k == "witness_cache_slots") {
+        if (value < 0 || value > 256) return fail(ctx, KZG_ERR_SHAPE, "witness_cache_slots must be 0..256");
+        if (ctx->point_sets) return fail(ctx, KZG_ERR_SHAPE, "witness_cache_slots: the cache already exists (set the option before the first create_witness_batched)");
+        ctx->opt_witness_cache_slots = (int)value;
     } else if (k == "ntt_vec_log") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_vec_log must be 0..2");
         ctx->opt_ntt_vec_log = (int)value;
@@ -488,6 +493,13 @@ extern "C" int kzg_prof_reset(kzg_ctx *ctx) {
 }
 extern "C" int kzg_prof_get(kzg_ctx *ctx, const char *kernel, uint64_t *launches, double *total_ms) {
     if (!ctx || !kernel) return KZG_ERR_SHAPE;
+    if (!strcmp(kernel, "point_set_cache")) {  // create_witness_batched's opening-point-set cache: launches = hits, total_ms = misses
+        uint64_t h = 0, m = 0;
+        point_set_stats(ctx, &h, &m);
+        if (launches) *launches = h;
+        if (total_ms) *total_ms = (double)m;
+        return KZG_OK;
+    }
     Guard g(ctx);
     prof_collect(ctx);
     auto it = ctx->prof_map.find(kernel);

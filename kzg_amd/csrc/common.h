@@ -98,6 +98,12 @@ constexpr int KZG_MAX_LANES = 24;  // lanes.reserve(): leased lanes are indexed 
 
 }  // namespace kzg
 
+struct kzg_ctx;
+namespace kzg {
+struct PointSetCache;
+void point_sets_free(kzg_ctx *ctx);  // witness.hip
+void point_set_stats(kzg_ctx *ctx, uint64_t *hits, uint64_t *misses);
+}
 struct kzg_ctx {
     int device = 0;
     kzg::CtxGate mu;
@@ -166,6 +172,11 @@ struct kzg_ctx {
     kzg::FixedBaseTable *fixed_base = nullptr;
     // distribute_powers (coset NTTs): per coset generator g two device tables g^j and g^(1024 j), j < 1024 (witness.hip)
     std::vector<std::pair<std::array<uint32_t, 8>, void *>> coset_tabs;
+    // create_witness_batched: what depends on the opening POINTS only (Z, 1 / Z'(x_i), the coset shift, 1 / Z on the coset), kept
+    // per point set for callers that open many polynomials at the same points (witness.hip, PointSetCache).  One pool of equal slots,
+    // allocated by the first call that can use it; option "witness_cache_slots" (default 16, 0 = off; read before the pool exists).
+    kzg::PointSetCache *point_sets = nullptr;
+    int opt_witness_cache_slots = 16;
     // Oversized sort bins (msm_wide.hip).  A level-2 block that finds its bin oversized writes the MSM's sequence number (per lane,
     // Lane::heavy_seq) into the lane's word of d_lane_heavy; the host picks the words up with the results (finish_point,
     // batch_end) and notes the context's MSM count at that moment in heavy_last.  The three slice kernels are only enqueued for

@@ -199,12 +199,12 @@ __global__ __launch_bounds__(256) void k_bary_rows(const Fr *xs, const Fr *ys, c
     }
 }
 
-// I_j = sum_i rows[j][i]
-__global__ __launch_bounds__(256) void k_bary_colsum(const Fr *rows, uint32_t k, Fr *out) {
+// I_j = sum_i rows[j][i]   (ys given: sum_i ys[i] rows[j][i] -- rows = a point set's kept basis matrix)
+__global__ __launch_bounds__(256) void k_bary_colsum(const Fr *rows, uint32_t k, Fr *out, const Fr *ys) {
     __shared__ Fr sh[256];
     uint32_t j = blockIdx.x;
     Fr acc = Fr::zero();
-    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) acc = add(acc, rows[(size_t)j * k + i]);
+    for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) acc = add(acc, ys ? mul(ys[i], rows[(size_t)j * k + i]) : rows[(size_t)j * k + i]);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_bary_rows_chunked(const Fr *xs, const F
     __shared__ Fr B[256];
     const uint32_t i = blockIdx.x, c = threadIdx.x;
     const Fr xi = xs[i];
-    const Fr ci = mul(ys[i], den_inv[i]);
+    const Fr ci = ys ? mul(ys[i], den_inv[i]) : den_inv[i];  // (no ys: the basis matrix of a point set, kept by PointSetCache)
     const uint32_t lo = c * CH, hi = lo + CH < k + 1 ? lo + CH : k + 1;  // coefficients z[lo, hi) of this chunk
     Fr bv = Fr::zero();
     if (c < nch)
@@ -402,6 +402,127 @@ extern "C" int kzg_witness_coeff_batched(kzg_ctx *ctx, const kzg_srs *srs, const
     return witness_coeff_batched_run(ctx, sink, coeffs, n, xs, ys, k, sfmt, flags, out_w, ofmt, out_r, out_r_len);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Opening-point sets.  Everything create_witness_batched derives from the opening POINTS alone -- Z = prod (X - x_i), the
+// barycentric weights 1 / Z'(x_i), the coset shift on which Z has no root, and 1 / Z on that coset (N values: the batch inversion of
+// the division) -- is the same for every polynomial opened at those points, which is how batched openings are used (one point set,
+// many polynomials).  A call that finds its point set here skips the coset test with its host round trip, the two product trees,
+// the small iNTT, the k inversions, Z's transform and the batch inversion: ~0.35 of the ~1.1 ms a k = 256 opening at 2^20 costs
+// over a commit (profiles/r05_prof_witness.txt).  Entries are published by the call that built them after its stream is
+// synchronised, are immutable, and are pinned (users) while a call reads them; eviction is LRU over unpinned slots.
+// ---------------------------------------------------------------------------------------------
+namespace kzg {
+struct PointSetEntry {
+    std::vector<uint8_t> key;  // the k x 32 bytes of xs as the caller passed them
+    int sfmt = 0;
+    uint32_t log_N = 0;
+    size_t k = 0;
+    Fr gsh;                    // the coset shift
+    uint8_t *slot = nullptr;   // dx[k] | z0[k + 1] | deni[k] | zinv[N] | basis[k x k] (k <= POINT_SET_BASIS_MAX)   (Montgomery form)
+    size_t N = 0;
+    int users = 0;
+    uint64_t stamp = 0;
+    bool valid = false;
+    Fr *dx() const { return (Fr *)slot; }
+    Fr *z0() const { return dx() + k; }
+    Fr *deni() const { return z0() + k + 1; }
+    Fr *zinv() const { return deni() + k; }
+    Fr *basis() const { return zinv() + N; }  // rows[j * k + i] = coefficient j of L_i = Z / ((X - x_i) Z'(x_i)): I = sum_i y_i L_i
+};
+constexpr size_t POINT_SET_BASIS_MAX = 1024;  // 32 MB of basis matrix at most
+struct PointSetCache {
+    uint8_t *pool = nullptr;
+    size_t slot_bytes = 0;
+    std::vector<PointSetEntry> slots;
+    uint64_t clock = 0, hits = 0, misses = 0;
+};
+static size_t point_set_bytes(size_t k, size_t N) {
+    return ((3 * k + 1 + N + (k <= POINT_SET_BASIS_MAX ? k * k : 0)) * 32 + 255) & ~(size_t)255;
+}
+
+// a published entry for (xs, sfmt, log_N), pinned; nullptr on a miss
+static PointSetEntry *point_set_lookup(kzg_ctx *ctx, const void *xs, size_t k, int sfmt, uint32_t log_N) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    PointSetCache *c = ctx->point_sets;
+    if (!c) return nullptr;
+    for (auto &e : c->slots)
+        if (e.valid && e.k == k && e.sfmt == sfmt && e.log_N == log_N && !memcmp(e.key.data(), xs, k * 32)) {
+            e.users++;
+            e.stamp = ++c->clock;
+            c->hits++;
+            return &e;
+        }
+    c->misses++;
+    return nullptr;
+}
+static void point_set_release(kzg_ctx *ctx, PointSetEntry *e) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    e->users--;
+}
+// A slot for a new entry (pinned, not yet valid), or nullptr: cache off, entry larger than a slot, every slot pinned, or the pool
+// cannot be allocated.  The pool comes into being here, sized for the first entry: `slots` equal slots.
+static PointSetEntry *point_set_reserve(kzg_ctx *ctx, size_t k, size_t N) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    if (ctx->opt_witness_cache_slots <= 0) return nullptr;
+    PointSetCache *c = ctx->point_sets;
+    const size_t need = point_set_bytes(k, N);
+    if (!c) {
+        if (need * (size_t)ctx->opt_witness_cache_slots > ((size_t)8 << 30)) return nullptr;  // (2^24-coefficient polynomials: not cached)
+        c = new PointSetCache();
+        if (hipMalloc((void **)&c->pool, need * (size_t)ctx->opt_witness_cache_slots) != hipSuccess) {
+            hipGetLastError();
+            delete c;
+            ctx->opt_witness_cache_slots = 0;
+            return nullptr;
+        }
+        c->slot_bytes = need;
+        c->slots.resize(ctx->opt_witness_cache_slots);
+        for (size_t i = 0; i < c->slots.size(); i++) c->slots[i].slot = c->pool + i * need;
+        ctx->point_sets = c;
+    }
+    if (need > c->slot_bytes) return nullptr;
+    PointSetEntry *best = nullptr;
+    for (auto &e : c->slots) {
+        if (e.users) continue;
+        if (!e.valid) {
+            best = &e;
+            break;
+        }
+        if (!best || e.stamp < best->stamp) best = &e;
+    }
+    if (!best) return nullptr;
+    best->valid = false;
+    best->users = 1;
+    best->k = k;  // the slot's layout (dx | z0 | deni | zinv | basis) is the new occupant's from here on
+    best->N = N;
+    return best;
+}
+static void point_set_publish(kzg_ctx *ctx, PointSetEntry *e, const void *xs, size_t k, int sfmt, uint32_t log_N, const Fr &gsh, bool ok) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    e->users--;
+    if (!ok) return;
+    e->key.assign((const uint8_t *)xs, (const uint8_t *)xs + k * 32);
+    e->k = k;
+    e->sfmt = sfmt;
+    e->log_N = log_N;
+    e->gsh = gsh;
+    e->stamp = ++ctx->point_sets->clock;
+    e->valid = true;
+}
+void point_set_stats(kzg_ctx *ctx, uint64_t *hits, uint64_t *misses) {
+    std::lock_guard<std::mutex> lk(ctx->cache_mu);
+    *hits = ctx->point_sets ? ctx->point_sets->hits : 0;
+    *misses = ctx->point_sets ? ctx->point_sets->misses : 0;
+}
+void point_sets_free(kzg_ctx *ctx) {
+    if (!ctx->point_sets) return;
+    if (ctx->point_sets->pool) hipFree(ctx->point_sets->pool);
+    delete ctx->point_sets;
+    ctx->point_sets = nullptr;
+}
+}  // namespace kzg
+
 // KZGProver::create_witness_batched (src/coeff_form.rs:83-111).  `sink` says where the quotient MSM goes: the whole SRS of this
 // GPU and the witness to the caller (above), or one shard [first, first + len) of a group's SRS and the 144-byte partial into
 // the group's exchange buffer (mgpu.hip: the quotient is replicated on every GPU, the MSM is sharded -- SURVEY 8e).
@@ -488,18 +609,43 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     if (!dx || !dy || !z0 || !z1 || !den || !deni || !rows || !I || !A || !Bv || !Cv || !Ci || !pin || !flag)
         return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_HIP_CHECK(ctx, hipMemsetAsync(flag, 0, sizeof(int), st));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(dx, xs, k * 32, hipMemcpyHostToDevice, st));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(dy, ys, k * 32, hipMemcpyHostToDevice, st));
-    if (to_m) {
-        KZG_TRY(fr_convert(ctx, st, dx, k, 1));
-        KZG_TRY(fr_convert(ctx, st, dy, k, 1));
+    // the point set: known (everything that depends on xs alone is taken from the cache), or new and to be kept, or neither
+    struct PointSetGuard {
+        kzg_ctx *ctx;
+        PointSetEntry *hit = nullptr, *fill = nullptr;
+        const void *xs = nullptr;
+        size_t k = 0;
+        int sfmt = 0;
+        uint32_t log_N = 0;
+        Fr gsh;
+        bool ok = false;
+        ~PointSetGuard() {
+            if (hit) point_set_release(ctx, hit);
+            if (fill) point_set_publish(ctx, fill, xs, k, sfmt, log_N, gsh, ok);
+        }
+    } ps{ctx};
+    ps.xs = xs, ps.k = k, ps.sfmt = sfmt, ps.log_N = log_N;
+    if (!small_poly) {
+        ps.hit = point_set_lookup(ctx, xs, k, sfmt, log_N);
+        if (!ps.hit) ps.fill = point_set_reserve(ctx, k, N);
     }
+    if (ps.hit) {
+        dx = ps.hit->dx();
+        z0 = ps.hit->z0();
+        deni = ps.hit->deni();
+    } else {
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(dx, xs, k * 32, hipMemcpyHostToDevice, st));
+        if (to_m) KZG_TRY(fr_convert(ctx, st, dx, k, 1));
+    }
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(dy, ys, k * 32, hipMemcpyHostToDevice, st));
+    if (to_m) KZG_TRY(fr_convert(ctx, st, dy, k, 1));
     // pick a shift g on whose coset g*H Z has no root: g = 1 first -- H itself, no scaling passes at all (two passes over N elements
     // saved whenever no opening point is an N-th root of unity) --, then 7, 7^2, ...  An opening point inside g*H (x = 1 or a power of
     // omega for H, x = 7 for 7*H) would make Z vanish there; the cosets 7^j*H are pairwise distinct, so at most k + 1 candidates fail.
     // This is the one host round trip of the call, so it comes first, while the stream holds nothing but the upload of the points.
     Fr g1 = from_u64<FrParams>(FR_MULT_GENERATOR), gsh = Fr::one();
-    if (!small_poly) {
+    if (ps.hit) gsh = ps.hit->gsh;
+    if (!small_poly && !ps.hit) {
         int *cflag = (int *)lane_alloc(ctx, lane, 256);
         if (!cflag) return fail(ctx, KZG_ERR_ALLOC, "workspace");
         for (size_t attempt = 0;; attempt++) {
@@ -516,7 +662,7 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     // interpolant
     // Z = prod (X - x_i): its values on the M-th roots of unity (M = 2^m > k), one tree product per value, then one small iNTT;
     // Z'(x_i) the same way; the interpolant by chunked synthetic divisions.  Everything here is log- or sqrt-depth in k.
-    {
+    if (!ps.hit) {
         const uint32_t log_M = (uint32_t)ilog2_ceil(k + 1);
         const size_t Mz = (size_t)1 << log_M;
         Fr *zev = (Fr *)lane_alloc(ctx, lane, Mz * 32), *wpow = (Fr *)lane_alloc(ctx, lane, Mz * 32);
@@ -526,18 +672,30 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         KZG_TRY(ntt_run(ctx, lane, zev, log_M, 1));
         KZG_HIP_CHECK(ctx, hipMemcpyAsync(z0, zev, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
     }
-    KZG_LAUNCH(ctx, st, "k_prod_diff", k_prod_diff, (unsigned)k, 256, 0, dx, dx, (uint32_t)k, 1, den);
-    KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(k), 256, 0, den, k, flag);  // duplicate x_i
-    KZG_LAUNCH(ctx, st, "k_inverse_each", k_inverse_each, gridfor(k), 256, 0, den, deni, k);
-    {
+    if (!ps.hit) {
+        KZG_LAUNCH(ctx, st, "k_prod_diff", k_prod_diff, (unsigned)k, 256, 0, dx, dx, (uint32_t)k, 1, den);
+        KZG_LAUNCH(ctx, st, "k_any_zero", k_any_zero, gridfor(k), 256, 0, den, k, flag);  // duplicate x_i
+        KZG_LAUNCH(ctx, st, "k_inverse_each", k_inverse_each, gridfor(k), 256, 0, den, deni, k);
+        if (ps.fill) {  // (a point set with duplicates fails the call and is not published)
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(ps.fill->dx(), dx, k * 32, hipMemcpyDeviceToDevice, st));
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(ps.fill->z0(), z0, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
+            KZG_HIP_CHECK(ctx, hipMemcpyAsync(ps.fill->deni(), deni, k * 32, hipMemcpyDeviceToDevice, st));
+        }
+    }
+    if (ps.hit && k <= POINT_SET_BASIS_MAX) {
+        KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, ps.hit->basis(), (uint32_t)k, I, dy);  // I = sum_i y_i L_i
+    } else {
         uint32_t CH = 1;
         while ((uint64_t)CH * CH * 4 <= k) CH *= 2;             // CH = 2^floor(log2(k) / 2): 16 at k = 256, 64 at 4096
         const uint32_t nch = (uint32_t)((k + 1 + CH - 1) / CH);  // <= 256 for k <= 16384 (k = 16383: CH = 64, nch = 256)
         if (nch > 256) return fail(ctx, KZG_ERR_INTERNAL, "interpolation chunk count exceeds the kernel's LDS array (B[256])");
-        KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, nch <= 64 ? 64 : (nch <= 128 ? 128 : 256), 0, dx, dy, deni, z0,
-                   (uint32_t)k, CH, nch, rows);
+        const unsigned bt = nch <= 64 ? 64 : (nch <= 128 ? 128 : 256);
+        KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, bt, 0, dx, dy, deni, z0, (uint32_t)k, CH, nch, rows);
+        KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, rows, (uint32_t)k, I, (const Fr *)nullptr);
+        if (ps.fill && k <= POINT_SET_BASIS_MAX)  // the basis matrix of the point set, for the calls that find it
+            KZG_LAUNCH(ctx, st, "k_bary_rows", k_bary_rows_chunked, (unsigned)k, bt, 0, dx, (const Fr *)nullptr, deni, z0, (uint32_t)k, CH, nch,
+                       ps.fill->basis());
     }
-    KZG_LAUNCH(ctx, st, "k_bary_colsum", k_bary_colsum, (unsigned)k, 256, 0, rows, (uint32_t)k, I);
     // numerator and divisor on the coset g*H
     const Fr *psrc = (const Fr *)coeffs;  // device-resident coefficients are read where they are
     if (!(flags & KZG_IN_DEVICE)) {
@@ -555,14 +713,24 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     } else {
         // Z on the coset: its k + 1 coefficients times g^j, then a transform whose input is short -- when the k + 1 values fit the
         // first row of the four-step matrix the column pass is skipped and nothing beyond them is read (no zero padding)
-        if (ntt_short_input_ok(log_N, k + 1)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(Cv, z0, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
-        else KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
-        KZG_TRY(coset_ntt_run(ctx, lane, Cv, log_N, 0, gsh, k + 1));
+        if (!ps.hit) {
+            if (ntt_short_input_ok(log_N, k + 1)) KZG_HIP_CHECK(ctx, hipMemcpyAsync(Cv, z0, (k + 1) * 32, hipMemcpyDeviceToDevice, st));
+            else KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(N), 256, 0, z0, k + 1, Cv, N, 0);
+            KZG_TRY(coset_ntt_run(ctx, lane, Cv, log_N, 0, gsh, k + 1));
+        }
         // (p - I) g^i in one pass over p, then its transform; the pointwise division by Z's values (one batch inversion; a zero
-        // among them would be an opening point on the coset, excluded above) inside the inversion's second sweep
+        // among them would be an opening point on the coset, excluded above) inside the inversion's second sweep -- or, for a known
+        // point set, one multiplication by the kept 1 / Z
         KZG_TRY(numerator_on_coset(ctx, st, psrc, n, I, k, A, N, to_m, gsh));
         KZG_TRY(ntt_run(ctx, lane, A, log_N, 0));
-        KZG_TRY(batch_inverse_mul(ctx, st, Cv, A, Ci, N, flag));
+        if (ps.hit) {
+            KZG_LAUNCH(ctx, st, "k_mul_inplace", k_mul_inplace, gridfor(N), 256, 0, A, ps.hit->zinv(), N);
+        } else if (ps.fill) {
+            KZG_TRY(batch_inverse(ctx, st, Cv, ps.fill->zinv(), N));  // the inverses are kept: one more pass than the fused division
+            KZG_LAUNCH(ctx, st, "k_mul_inplace", k_mul_inplace, gridfor(N), 256, 0, A, ps.fill->zinv(), N);
+        } else {
+            KZG_TRY(batch_inverse_mul(ctx, st, Cv, A, Ci, N, flag));
+        }
         KZG_TRY(coset_ntt_run(ctx, lane, A, log_N, 1, gsh));
         // exact division <=> deg q <= N-1-k <=> the top k coefficients vanish
         KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);
@@ -572,6 +740,8 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
     if (to_m) KZG_TRY(fr_convert(ctx, st, I, k, 0));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(out_r, I, k * 32, hipMemcpyDeviceToHost, st));
     KZG_TRY(sink_finish(res));
+    ps.gsh = gsh;
+    ps.ok = !(hflag & 1);  // the stream is synchronised: the slot's contents are complete (a wrong y leaves the point set usable)
     if (ctx->prof) prof_collect(ctx);
     if (hflag & 1) {
         // a zero denominator: duplicate opening points (the reference unwrap()s an invert() of zero)

@@ -21,20 +21,34 @@ def build(force=False):
     return _SO
 
 
+NATIVE_BUILD = None   # the command line build_native() used (bench.py quotes it)
+
+
 def build_native():
     """bench.py's cpu_baseline leg only: the same source compiled for the host it runs on (-O3 -march=native, mulx/adx),
-    into a temp directory (the committed recipe builds the portable -O2 library, which must run on any box).  Returns the
-    path, or None when no compiler is available."""
+    into a temp directory (the committed recipe builds the portable -O2 library, which must run on any box).  ROCm's clang
+    is preferred when present (its code for the unrolled Montgomery multiplication is ~25 % faster than gcc 11's: 40 ns
+    against 46 ns per multiplication on the build box), gcc otherwise.  Returns the path, or None when no compiler works."""
+    global NATIVE_BUILD
     import tempfile
     out = os.path.join(tempfile.gettempdir(), "libkzg_oracle_native_%d.so" % os.getuid())
     src = os.path.join(_HERE, "kzg_oracle.c")
-    try:
-        if not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-            subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-shared", "-Wno-unused-function", "-o", out + ".tmp", src])
-            os.replace(out + ".tmp", out)
-        return out
-    except Exception:
-        return None
+    compilers = [c for c in ("/opt/rocm/lib/llvm/bin/clang", "gcc") if c == "gcc" or os.path.exists(c)]
+    for cc in compilers:
+        try:
+            stamp = out + ".cc"
+            if (not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src) or not os.path.exists(stamp)
+                    or open(stamp).read() != cc):
+                subprocess.check_call([cc, "-O3", "-march=native", "-fPIC", "-shared", "-Wno-unused-function", "-o", out + ".tmp", src],
+                                      stderr=subprocess.DEVNULL)
+                os.replace(out + ".tmp", out)
+                with open(stamp, "w") as f:
+                    f.write(cc)
+            NATIVE_BUILD = "%s -O3 -march=native" % os.path.basename(cc)
+            return out
+        except Exception:
+            continue
+    return None
 
 
 def use_library(path):

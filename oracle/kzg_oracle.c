@@ -316,17 +316,19 @@ static void g1j_add_f(g1j *r, const g1j *p, const g1j *q) {
 #define FAST_C 16                 /* window width: 16 windows cover 255 bits + the carry of the signed recoding */
 #define FAST_NWIN 16
 #define FAST_BATCH 1024           /* affine additions that share one field inversion */
-typedef struct { uint32_t bucket; g1a pt; } fast_job;
+typedef struct { uint32_t bucket; uint32_t idx; } fast_job;   /* idx: point index, top bit = negated */
 
 /* one batch of affine additions bucket[b] += pt, all to DIFFERENT non-empty buckets: one inversion for all of them */
-static void fast_flush(g1a *buckets, uint8_t *busy, fast_job *jobs, size_t m, fq *den, fq *pre) {
+static void fast_flush(g1a *buckets, uint8_t *busy, const g1a *pts, fast_job *jobs, size_t m, fq *den, fq *pre, g1a *tmp) {
     if (!m) return;
     fq acc = fq_R1;
     for (size_t k = 0; k < m; k++) {          /* denominators: x2 - x1, or 2 y for a doubling, or 1 for P + (-P) */
         g1a *B = &buckets[jobs[k].bucket];
-        fq_sub(&den[k], &jobs[k].pt.x, &B->x);
+        tmp[k] = pts[jobs[k].idx & 0x7fffffffu];
+        if (jobs[k].idx >> 31) fq_neg(&tmp[k].y, &tmp[k].y);
+        fq_sub(&den[k], &tmp[k].x, &B->x);
         if (fq_is_zero(&den[k])) {
-            if (fq_eq(&jobs[k].pt.y, &B->y)) fq_add(&den[k], &B->y, &B->y);   /* same point (y != 0 on this curve's prime-order group) */
+            if (fq_eq(&tmp[k].y, &B->y)) fq_add(&den[k], &B->y, &B->y);   /* same point (y != 0 on this curve's prime-order group) */
             else den[k] = fq_R1;                                                  /* opposite points: the sum is the identity */
         }
         pre[k] = acc;
@@ -335,7 +337,7 @@ static void fast_flush(g1a *buckets, uint8_t *busy, fast_job *jobs, size_t m, fq
     fq inv; fq_inv(&inv, &acc);
     for (size_t k = m; k-- > 0;) {
         g1a *B = &buckets[jobs[k].bucket];
-        const g1a *P = &jobs[k].pt;
+        const g1a *P = &tmp[k];
         fq dinv; fq_mulf(&dinv, &inv, &pre[k]); fq_mulf(&inv, &inv, &den[k]);
         fq num, lam, x3, y3, t;
         fq_sub(&t, &P->x, &B->x);
@@ -373,6 +375,7 @@ void orc_msm_g1_fast(const uint8_t *points, const uint8_t *scalars, size_t n, ui
     fast_job *jobs = (fast_job *)malloc(FAST_BATCH * sizeof(fast_job));
     fast_job *defer = (fast_job *)malloc((n + 1) * sizeof(fast_job)), *defer2 = (fast_job *)malloc((n + 1) * sizeof(fast_job));
     fq *den = (fq *)malloc(FAST_BATCH * sizeof(fq)), *pre = (fq *)malloc(FAST_BATCH * sizeof(fq));
+    g1a *tmp = (g1a *)malloc(FAST_BATCH * sizeof(g1a));
     g1j total; g1j_set_inf(&total);
     for (int w = FAST_NWIN - 1; w >= 0; w--) {
         for (int i = 0; i < FAST_C; i++) g1j_double(&total, &total);
@@ -383,28 +386,33 @@ void orc_msm_g1_fast(const uint8_t *points, const uint8_t *scalars, size_t n, ui
             if (!d || g1a_is_inf(&pts[i])) continue;
             fast_job j;
             j.bucket = (uint32_t)((d < 0 ? -d : d) - 1);
-            j.pt = pts[i];
-            if (d < 0) fq_neg(&j.pt.y, &j.pt.y);
+            j.idx = (uint32_t)i | (d < 0 ? 0x80000000u : 0u);
             if (busy[j.bucket]) { defer[nd++] = j; continue; }                                  /* already in this batch: later */
             if (!full[j.bucket] || g1a_is_inf(&buckets[j.bucket])) {                            /* first point of the bucket (or emptied by P + (-P)) */
-                buckets[j.bucket] = j.pt; full[j.bucket] = 1; continue; }
+                buckets[j.bucket] = pts[i];
+                if (d < 0) fq_neg(&buckets[j.bucket].y, &buckets[j.bucket].y);
+                full[j.bucket] = 1; continue; }
+            __builtin_prefetch(&buckets[j.bucket]);                                             /* the flush finds it in cache */
             busy[j.bucket] = 1;
             jobs[m++] = j;
-            if (m == FAST_BATCH) { fast_flush(buckets, busy, jobs, m, den, pre); m = 0; }
+            if (m == FAST_BATCH) { fast_flush(buckets, busy, pts, jobs, m, den, pre, tmp); m = 0; }
         }
-        fast_flush(buckets, busy, jobs, m, den, pre);
+        fast_flush(buckets, busy, pts, jobs, m, den, pre, tmp);
         m = 0;
         while (nd) {                             /* the deferred additions, in rounds: each round takes one per bucket */
             size_t nd2 = 0;
             for (size_t k = 0; k < nd; k++) {
                 fast_job *j = &defer[k];
-                if (g1a_is_inf(&buckets[j->bucket])) { buckets[j->bucket] = j->pt; continue; }   /* emptied by P + (-P) */
                 if (busy[j->bucket]) { defer2[nd2++] = *j; continue; }
+                if (g1a_is_inf(&buckets[j->bucket])) {                                           /* emptied by P + (-P) */
+                    buckets[j->bucket] = pts[j->idx & 0x7fffffffu];
+                    if (j->idx >> 31) fq_neg(&buckets[j->bucket].y, &buckets[j->bucket].y);
+                    continue; }
                 busy[j->bucket] = 1;
                 jobs[m++] = *j;
-                if (m == FAST_BATCH) { fast_flush(buckets, busy, jobs, m, den, pre); m = 0; }
+                if (m == FAST_BATCH) { fast_flush(buckets, busy, pts, jobs, m, den, pre, tmp); m = 0; }
             }
-            fast_flush(buckets, busy, jobs, m, den, pre);
+            fast_flush(buckets, busy, pts, jobs, m, den, pre, tmp);
             m = 0;
             fast_job *tq = defer; defer = defer2; defer2 = tq;
             nd = nd2;
@@ -416,7 +424,7 @@ void orc_msm_g1_fast(const uint8_t *points, const uint8_t *scalars, size_t n, ui
         }
         g1j_add_f(&total, &total, &sum);
     }
-    free(dig); free(buckets); free(busy); free(full); free(jobs); free(defer); free(defer2); free(den); free(pre);
+    free(dig); free(buckets); free(busy); free(full); free(jobs); free(defer); free(defer2); free(den); free(pre); free(tmp);
     g1j_to_affine((g1a *)out, &total);
 }
 

@@ -324,3 +324,69 @@ def test_cpp_host_mirror(engine, tmp_path):
     from tests.gpu_common import build_cpp_mirror
     out = subprocess.run([build_cpp_mirror(tmp_path)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "cpp mirror ok" in out.stdout, (out.returncode, out.stdout, out.stderr)
+
+
+def test_create_witness_batched_point_set_cache():
+    """create_witness_batched keeps what depends on the opening POINTS alone (Z, weights, coset shift, 1 / Z on the coset) per point set
+    (witness.hip, PointSetCache).  In a context of its own with TWO slots: many polynomials at one point set (hits) give the oracle's
+    [(p(tau) - I(tau)) / Z(tau)]G each; a wrong value is still refused on a hit; a point set with duplicates fails every time and is
+    never kept; a third point set evicts the least recently used one; results with the cache switched off are identical."""
+    import ctypes
+    tau = 0x5EED1234
+    n, k = 1 << 12, 16
+    rng = random.Random(4242)
+    G = C.g1_generator()
+
+    def want(coeffs, xs, ys, icoef):
+        z = 1
+        for x in xs:
+            z = z * (tau - x) % M.R
+        return C.g1_mul(G, (C.poly_eval(coeffs, tau) - C.poly_eval(icoef, tau)) * pow(z, -1, M.R) % M.R)
+
+    def stats(e):
+        h, m = ctypes.c_uint64(), ctypes.c_double()
+        assert e.lib.kzg_prof_get(e.ctx, b"point_set_cache", ctypes.byref(h), ctypes.byref(m)) == 0
+        return h.value, int(m.value)
+
+    results = {}
+    for slots in (2, 0):
+        e = kzg_amd.Engine(0)
+        e.set_option("witness_cache_slots", slots)
+        params = kzg_amd.setup(e, tau, n, g2_len=0)
+        prover = kzg_amd.KZGProver(params)
+        rng = random.Random(4242)
+        sets = [[rng.randrange(M.R) for _ in range(k)] for _ in range(3)]
+        got = []
+        for rnd in range(3):                      # A A A B A C B ... : hits, a miss, an eviction
+            for xs in (sets[0], sets[0], sets[1], sets[0], sets[2], sets[1]):
+                coeffs = [rng.randrange(M.R) for _ in range(n)]
+                ys = [C.poly_eval(coeffs, x) for x in xs]
+                wit = prover.create_witness_batched(kzg_amd.Polynomial(coeffs), xs, ys)
+                icoef = wit.r.slice_coeffs()
+                assert all(C.poly_eval(icoef, x) == y for x, y in zip(xs, ys))
+                assert wit.w == want(coeffs, xs, ys, icoef)
+                got.append(wit.w)
+        # a wrong value on a cached point set
+        coeffs = [rng.randrange(M.R) for _ in range(n)]
+        ys = [C.poly_eval(coeffs, x) for x in sets[0]]
+        ys[3] = (ys[3] + 1) % M.R
+        with pytest.raises(kzg_amd.PointNotOnPolynomial):
+            prover.create_witness_batched(kzg_amd.Polynomial(coeffs), sets[0], ys)
+        # duplicates: refused twice (the failing point set is not kept), and the good ones still work afterwards
+        dup = list(sets[1])
+        dup[5] = dup[2]
+        for _ in range(2):
+            with pytest.raises(kzg_amd.ReferencePanic):
+                prover.create_witness_batched(kzg_amd.Polynomial(coeffs), dup, [C.poly_eval(coeffs, x) for x in dup])
+        ys = [C.poly_eval(coeffs, x) for x in sets[1]]
+        wit = prover.create_witness_batched(kzg_amd.Polynomial(coeffs), sets[1], ys)
+        assert wit.w == want(coeffs, sets[1], ys, wit.r.slice_coeffs())
+        hits, misses = stats(e)
+        if slots:
+            assert hits >= 6 and misses >= 3, (hits, misses)      # A twice in a row per round at least; B / C alternate through two slots
+        else:
+            assert hits == 0
+        results[slots] = got
+        params.gs.free()
+        e.close()
+    assert results[2] == results[0]
