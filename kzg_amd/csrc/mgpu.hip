@@ -375,12 +375,8 @@ static int mctx_make_ctxs(kzg_mctx *m) {
         int rc = kzg_ctx_create(m->devices[i], &c);
         if (rc != KZG_OK) return rc;
         m->ctxs.push_back(c);
-        // A group's context shares the process' hardware-queue pool with the RCCL communicator: with 16 lanes + 4 accumulation
-        // streams the exchange's kernels end up behind the pipeline's on shared queues (measured at world 1, all-gather forced on:
-        // 400 against 482 commitments/s); 14 + 4 costs the plain pipeline <= 1 % and leaves RCCL its queues
-        // (profiles/r04_group_queues_ab.txt).  kzg_mctx_set_option(m, "streams", ...) overrides.
-        rc = kzg_ctx_set_option(c, "streams", 14);
-        if (rc != KZG_OK) return rc;
+        // (every context plans 14 lanes + 4 accumulation streams from the process' shared pool: an RCCL communicator needs about six
+        // of the pool's 24 hardware queues -- capi.hip, StreamPool; kzg_mctx_set_option(m, "streams", ...) overrides)
     }
     // the exchange buffers of ordinary calls (up to 64 polynomials per call) and the status-only agreement buffer exist from the
     // start: a group that formed can always exchange statuses, whatever fails later
@@ -649,6 +645,11 @@ extern "C" int kzg_mctx_info(kzg_mctx *m, char *buf, size_t buflen) {
                           "gather_timeout_ms=%lld dead=%d", r->path.c_str(), r->version, r->hip_path.c_str(), m->world, m->nlocal(),
              m->per_process ? "process-per-gpu" : "one-process", form, phase_report(m, r).c_str(), (long long)m->comm_timeout_ms,
              (long long)m->gather_timeout_ms, m->dead ? 1 : 0);
+    for (int i = 0; i < m->nlocal(); i++) {  // each local context's pipeline plan (narrowed_from != none: the queue pool is short)
+        char ci[256];
+        const size_t used = strlen(buf);
+        if (kzg_ctx_info(m->ctxs[i], ci, sizeof ci) == KZG_OK && used + strlen(ci) + 16 < buflen) snprintf(buf + used, buflen - used, " ctx%d=[%s]", i, ci);
+    }
     return KZG_OK;
 }
 extern "C" int kzg_mctx_world(const kzg_mctx *m) { return m ? m->world : 0; }
