@@ -519,6 +519,26 @@ int orc_compute_omega(u64 d, u64 *m_out, uint32_t *exp_out, uint8_t *omega_out) 
 static uint32_t bitreverse(uint32_t n, uint32_t l) {
     uint32_t r = 0; for (uint32_t i = 0; i < l; i++) { r = (r << 1) | (n & 1); n >>= 1; } return r; }
 
+/* fr_mul unrolled (no-carry CIOS: r's top limb 0x73ed... leaves a spare bit): the same product, ~2x faster -- the full-size NTT
+ * parity tests spend their time in the two multiplications per butterfly below */
+static inline void fr_mulf(fr *r, const fr *a, const fr *b) {
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    const u64 *p = fr_P;
+#define FR_MAC(hi, lo, x, y, c, d) do { u128 _x = (u128)(x) * (y) + (c) + (d); lo = (u64)_x; hi = (u64)(_x >> 64); } while (0)
+#define FR_ROUND(bi) do { u64 A, C, m, _d; \
+        FR_MAC(A, t0, a->v[0], bi, t0, 0); m = t0 * fr_INV; FR_MAC(C, _d, m, p[0], t0, 0); (void)_d; \
+        FR_MAC(A, t1, a->v[1], bi, t1, A); FR_MAC(C, t0, m, p[1], t1, C); \
+        FR_MAC(A, t2, a->v[2], bi, t2, A); FR_MAC(C, t1, m, p[2], t2, C); \
+        FR_MAC(A, t3, a->v[3], bi, t3, A); FR_MAC(C, t2, m, p[3], t3, C); \
+        t3 = C + A; } while (0)
+    FR_ROUND(b->v[0]); FR_ROUND(b->v[1]); FR_ROUND(b->v[2]); FR_ROUND(b->v[3]);
+#undef FR_ROUND
+#undef FR_MAC
+    u64 t[4] = {t0, t1, t2, t3};
+    if (fr_geq_p(t)) fr_sub_p(t);
+    memcpy(r->v, t, sizeof t);
+}
+
 /* serial_fft (src/ft.rs:291-333) on Montgomery-form data */
 static void serial_fft_mont(fr *a, const fr *omega, uint32_t log_n) {
     uint32_t n = 1u << log_n;
@@ -530,10 +550,10 @@ static void serial_fft_mont(fr *a, const fr *omega, uint32_t log_n) {
         for (uint32_t k = 0; k < n; k += 2 * m) {
             fr w = fr_R1;
             for (uint32_t j = 0; j < m; j++) {
-                fr t; fr_mul(&t, &a[k + j + m], &w);
+                fr t; fr_mulf(&t, &a[k + j + m], &w);
                 fr tmp; fr_sub(&tmp, &a[k + j], &t); a[k + j + m] = tmp;
                 fr_add(&a[k + j], &a[k + j], &t);
-                fr_mul(&w, &w, &w_m);
+                fr_mulf(&w, &w, &w_m);
             }
         }
         m *= 2;
