@@ -797,13 +797,6 @@ def sharded_child_main(args):
     os.close(real_stdout)
 
 
-def _free_port():
-    import socket
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
-        so.bind(("127.0.0.1", 0))
-        return so.getsockname()[1]
-
-
 def _tail(path_or_text, n=1500, is_path=False):
     try:
         t = open(path_or_text, errors="replace").read() if is_path else (path_or_text or "")
@@ -812,16 +805,20 @@ def _tail(path_or_text, n=1500, is_path=False):
     return t[-n:]
 
 
-def run_sharded_block_in_children(job, args, rank, local_rank, world):
-    """The `sharded` block in a FRESH child process per rank.  The parent holds this run's number and has touched the GPU: whatever
-    goes wrong while a device group forms over RCCL -- a bootstrap that stalls for minutes on a hostile network stack (round 4's
-    driver box), a crash inside the communicator, a dead peer -- happens in a process that can be killed, the parent's line and exit
-    status stay truthful, and the block says what happened: the library's per-phase formation times (KZG_DEBUG), the child's exit
-    code, and the tail of RCCL's own log (NCCL_DEBUG=INFO into NCCL_DEBUG_FILE from the start)."""
+def run_sharded_block_in_children(args, rank, local_rank, world):
+    """The `sharded` block in a FRESH child process per rank, run BEFORE this process touches the GPU.  Whatever goes wrong while a
+    device group forms over RCCL -- a bootstrap that stalls for minutes on a hostile network stack (round 4's driver box), a crash
+    inside the communicator, a dead peer -- happens in a process that can be killed; this process' line and exit status stay
+    truthful, and the block says what happened: the library's per-phase formation times (KZG_DEBUG), the child's exit code, and the
+    tail of RCCL's own log (NCCL_DEBUG=INFO into NCCL_DEBUG_FILE from the start).  Before, not after: a process that has used the
+    GPU slows every OTHER process on it by its mere presence (its hardware queues stay mapped; measured from a parent that had run
+    one batch and closed its engine: 43 instead of 460 commitments/s in the child, and hipDeviceReset does not give them back)."""
     import glob
     import signal
     import subprocess
-    port = job.broadcast_object(_free_port)
+    # the children's own rendezvous: a port every rank can derive without talking (this runs before the ranks have a process group)
+    base = int(os.environ.get("MASTER_PORT", "29531"))
+    port = base + 29 if base + 29 < 65536 else base - 29
     log_prefix = os.path.join(tempfile.gettempdir(), "kzg_rccl_%d_r%d" % (os.getpid(), rank))
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}   # (the agent-store flag would make the child look
     #                                                                                     for torchrun's store on the new port)
@@ -858,7 +855,7 @@ def run_sharded_block_in_children(job, args, rank, local_rank, world):
             except ValueError:
                 pass
     child = {"rc": p.returncode, "wall_s": round(wall, 2), "timed_out": timed_out, "process": "fresh child per rank"}
-    healthy = job.all_agree(not timed_out and p.returncode == 0)
+    healthy = not timed_out and p.returncode == 0     # (rank 0's child has agreed every check with the other ranks' children)
     if rank != 0:
         for f in glob.glob(log_prefix + "*"):
             try:
@@ -871,10 +868,9 @@ def run_sharded_block_in_children(job, args, rank, local_rank, world):
                  else "the sharded block's process ended with code %s and no result" % p.returncode}
     block["child"] = child
     slow = isinstance(block.get("formation"), dict) and block["formation"].get("formation_ms", 0) > 10000
-    if timed_out or p.returncode != 0 or not healthy or slow or "error" in block or "note" in block:
+    if not healthy or slow or "error" in block or "note" in block:
         logs = sorted(glob.glob(log_prefix + "*"))
         block["diagnostics"] = {"stderr_tail": _tail(err, 2500), "rccl_log_tail": _tail(logs[0], 2500, is_path=True) if logs else "",
-                                "every_rank_healthy": healthy,
                                 "env": {k: v for k, v in env.items() if k.startswith(("NCCL_", "RCCL_", "KZG_", "GPU_MAX"))}}
     for f in glob.glob(log_prefix + "*"):
         try:
@@ -943,6 +939,10 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    # The sharded-SRS + RCCL modes (north_star's design; at N > 1 part of the default run), measured by the ranks' CHILD processes
+    # before this process initialises HIP (run_sharded_block_in_children); the result joins the line at the end.
+    sharded_res = run_sharded_block_in_children(args, rank, local_rank, world) if want_block else None
 
     cpu = None
     if rank == 0 and world == 1 and not sharded and not args.no_cpu_baseline:
@@ -1286,25 +1286,12 @@ def main():
     if cpu is not None:
         cpu.close()
     main_closed = False
-    if want_block:
-        # The sharded-SRS + RCCL modes, measured by every rank together after everything else (collective) -- in a fresh child process
-        # per rank (run_sharded_block_in_children): `value` above is already final and this process keeps it whatever the device
-        # group does.  (Inside the library every exchange and the communicator's formation have their own deadlines:
-        # gather_timeout_ms, comm_timeout_ms.)  The main engine goes first: the child's group context needs the chip's hardware
-        # queues to itself (two contexts' streams on one queue pool: the second one narrows its pipeline, -12 % at world 1).
-        job.engines.remove(engine)
-        scal.free()
-        if params is not None:
-            params.gs.free()     # 2 GiB at 2^20: the child's group sets up its own shards
-        engine.close()
-        main_closed = True
-        sharded_res = run_sharded_block_in_children(job, args, rank, local_rank, world)
-        if rank == 0:
-            res["sharded"] = sharded_res
-            res["headline"] = ("value = data-parallel replicas (the throughput answer for independent degree-2^20 commitments: a 2 GiB SRS "
-                               "fits every GPU); sharded.strong / sharded.config5 = the sharded-SRS + RCCL design north_star names, "
-                               "measured by the same ranks in fresh child processes right after the timed region")
-            line = json.dumps(res)
+    if want_block and rank == 0:
+        res["sharded"] = sharded_res
+        res["headline"] = ("value = data-parallel replicas (the throughput answer for independent degree-2^20 commitments: a 2 GiB SRS "
+                           "fits every GPU); sharded.strong / sharded.config5 = the sharded-SRS + RCCL design north_star names, "
+                           "measured by the same ranks in fresh child processes before the timed region")
+        line = json.dumps(res)
     # RCCL writes a version banner through C stdio, which is block-buffered on a pipe and would surface after Python's own
     # output when a process exits: every rank flushes it before the last barrier, so that rank 0's JSON line ends the output
     sys.stdout.flush()

@@ -31,7 +31,7 @@ int lane_reserve(kzg_ctx *ctx, int lane, size_t bytes) {
 void *lane_alloc(kzg_ctx *ctx, int lane, size_t bytes) {
     Lane &l = ctx->lanes[lane];
     size_t off = align_up(l.arena_used, 256);
-    if (off + bytes > l.arena_bytes) return nullptr;
+    if (off + bytes > (l.arena_limit ? std::min(l.arena_limit, l.arena_bytes) : l.arena_bytes)) return nullptr;
     l.arena_used = off + bytes;
     return l.arena + off;
 }
@@ -315,7 +315,10 @@ extern "C" int kzg_device_count(void) {
 // 471.1 against 473.5 alone, both committing at once 512-517 in total (profiles/r05_engine_and_group.txt).  Not isolated: a
 // collective that never leaves the group's exchange stream (lane 0; after a failed ncclCommAbort) blocks that pool stream for the
 // device's other contexts too -- by then the process has lost its RCCL anyway (mgpu.hip, rccl_mark_wedged).
-// The pool lives as long as the process (streams are not returned).
+// The pool's streams live as long as some context of the device does: when the last one is destroyed they are returned (a process that
+// has used many streams costs OTHER processes on the GPU dearly even when idle: a child process measured 43 instead of 460
+// commitments/s beside a parent that had run one batch and closed its engine, 317 beside one that had only created a context --
+// and hipDeviceReset in the parent does not give the queues back; bench.py therefore runs its child BEFORE it touches the GPU).
 namespace kzg {
 struct StreamPool {
     std::mutex mu;
@@ -323,6 +326,7 @@ struct StreamPool {
     hipStream_t accum[4] = {nullptr, nullptr, nullptr, nullptr};
     // the last queue measurement over pool streams: class (= hardware queue) of each measured stream
     std::map<hipStream_t, int> cls;
+    int refs = 0;  // contexts of this device alive in the process
 };
 static std::mutex g_pools_mu;
 static std::map<int, StreamPool *> g_pools;
@@ -333,6 +337,22 @@ static StreamPool *pool_for(int device) {
     StreamPool *p = new StreamPool();
     g_pools[device] = p;
     return p;
+}
+static void pool_ref(StreamPool *p) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    p->refs++;
+}
+static void pool_unref(StreamPool *p) {  // the caller has synchronised its streams and set the device
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (--p->refs > 0) return;
+    for (auto st : p->lanes) hipStreamDestroy(st);
+    for (auto &st : p->accum)
+        if (st) {
+            hipStreamDestroy(st);
+            st = nullptr;
+        }
+    p->lanes.clear();
+    p->cls.clear();
 }
 static hipError_t pool_lane(StreamPool *p, int i, hipStream_t *out) {
     std::lock_guard<std::mutex> lk(p->mu);
@@ -368,13 +388,16 @@ extern "C" int kzg_ctx_create(int device, kzg_ctx **out) {
     ctx->lanes.reserve(KZG_MAX_LANES);  // never reallocated: leased lanes are indexed while an exclusive caller appends
     ctx->lanes.resize(1);
     ctx->pool = pool_for(device);
+    pool_ref(ctx->pool);
     if (pool_lane(ctx->pool, 0, &ctx->lanes[0].stream) != hipSuccess) {
+        pool_unref(ctx->pool);
         delete ctx;
         return KZG_ERR_HIP;
     }
     if (hipMalloc((void **)&ctx->d_lane_heavy, KZG_MAX_LANES * 4) != hipSuccess ||
         hipMemset(ctx->d_lane_heavy, 0, KZG_MAX_LANES * 4) != hipSuccess) {
         if (ctx->d_lane_heavy) hipFree(ctx->d_lane_heavy);
+        pool_unref(ctx->pool);
         delete ctx;
         return KZG_ERR_ALLOC;
     }
@@ -412,6 +435,9 @@ extern "C" void kzg_ctx_destroy(kzg_ctx *ctx) {
     eval_tabs_free(ctx);
     fixed_base_free(ctx);
     point_sets_free(ctx);
+    for (auto st : ctx->accum_streams)
+        if (st) hipStreamSynchronize(st);
+    pool_unref(ctx->pool);  // the last context of the device returns the pool's streams
     delete ctx;
 }
 
@@ -1002,6 +1028,8 @@ int msm_batch_strided(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const voi
         int l = (int)(b % bp.nl);
         const size_t half = defer ? ((b / (size_t)bp.nl) & 1) : 0;
         ctx->lanes[l].arena_used = half * per;  // stream order makes re-use of the lane arena (of this half) safe
+        ctx->lanes[l].arena_limit = defer ? (half + 1) * per : 0;  // an under-estimated workspace fails (KZG_ERR_ALLOC) instead of running
+                                                                   // into the other half, which belongs to the lane's other MSM in flight
         const void *d_sc = nullptr;
         rc = stage_in(ctx, l, (const uint8_t *)scalars + b * stride_bytes, n * 32, flags, &d_sc);
         MsmPoint *res = nullptr;
@@ -1017,6 +1045,7 @@ int msm_batch_strided(kzg_ctx *ctx, const kzg_srs *srs, size_t offset, const voi
     }
     if (defer)
         for (size_t b = batch > (size_t)bp.nl ? batch - bp.nl : 0; b < batch && rc == KZG_OK; b++) rc = finish(b);
+    for (int l = 0; l < bp.nl; l++) ctx->lanes[l].arena_limit = 0;
     return batch_end(ctx, bp, rc, out, batch * psz);
 }
 }  // namespace kzg

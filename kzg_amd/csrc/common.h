@@ -51,6 +51,7 @@ struct Lane {
     char *arena = nullptr;
     size_t arena_bytes = 0;
     size_t arena_used = 0;
+    size_t arena_limit = 0;  // 0 = the whole arena; else lane_alloc fails beyond this offset (two MSMs in flight share the arena as halves)
     uint32_t heavy_seq = 0, heavy_seen = 0;  // MSMs sorted on this lane / the one last looked at (kzg_ctx::d_lane_heavy)
     char *pinned = nullptr;  // small pinned host staging buffer for results
     size_t pinned_bytes = 0;
