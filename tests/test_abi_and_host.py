@@ -88,3 +88,30 @@ def test_host_only_helpers_shard_range_and_footprint():
     h = ctypes.c_void_p()
     arr = (ctypes.c_int * 2)(0, 0)
     assert lib.kzg_mctx_create(arr, 2, ctypes.byref(h)) == 3 and lib.kzg_mctx_create(arr, 0, ctypes.byref(h)) == 3
+
+
+def test_single_node_rccl_env_sets_defaults_and_keeps_the_hosts_values(monkeypatch):
+    """kzg_amd.distributed.single_node_rccl_env (what DeviceGroup calls before anything loads RCCL): the one-node knobs go into the
+    process environment with setdefault semantics -- a value the host's operator exported is kept -- and KZG_RCCL_SINGLE_NODE_ENV=0
+    switches the whole thing off.  (RCCL bootstrapping over a non-loopback interface cost the driver's box five minutes
+    per communicator.)"""
+    import os
+    from kzg_amd.distributed import SINGLE_NODE_RCCL_ENV, single_node_rccl_env
+    for k in SINGLE_NODE_RCCL_ENV:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.delenv("KZG_RCCL_SINGLE_NODE_ENV", raising=False)
+    monkeypatch.setenv("NCCL_SOCKET_IFNAME", "eth7")
+    done = single_node_rccl_env()
+    assert os.environ["NCCL_SOCKET_IFNAME"] == "eth7" and "NCCL_SOCKET_IFNAME" not in done
+    assert os.environ["NCCL_RAS_ENABLE"] == "0" and os.environ["NCCL_IB_DISABLE"] == "1" and os.environ["NCCL_NET_PLUGIN"] == "none"
+    assert set(done) == set(SINGLE_NODE_RCCL_ENV) - {"NCCL_SOCKET_IFNAME"}
+    for k in SINGLE_NODE_RCCL_ENV:
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("KZG_RCCL_SINGLE_NODE_ENV", "0")
+    assert single_node_rccl_env() == {} and "NCCL_RAS_ENABLE" not in os.environ
+    # the C++ and Rust hosts set the same four variables
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hpp = open(os.path.join(root, "include", "kzg_mi355x.hpp")).read()
+    rs = open(os.path.join(root, "integration", "mi355x.rs")).read()
+    for k, v in SINGLE_NODE_RCCL_ENV.items():
+        assert 'setenv("%s", "%s", 0)' % (k, v) in hpp and '("%s", "%s")' % (k, v) in rs, k

@@ -263,3 +263,28 @@ def test_srs_of_another_gpu_is_refused():
     assert lib.kzg_msm_g1(h.ctx, srs, 0, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw[:96] == want
     lib.kzg_srs_free(h.ctx, srs)
     h.close()
+
+
+def test_pipeline_narrowing_is_reported_not_silent():
+    """a batched pipeline that finds fewer hardware queues than it wants narrows itself -- and now says so:
+    kzg_ctx_info reports the plan (`narrowed_from=14+4`), and the context prints one line on stderr.  Forced here with option
+    hw_queues = 4 (what a process whose host never asked for queues gets), in a child process so that the line can be read."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import kzg_amd\n"
+            "e = kzg_amd.Engine(0); print('BEFORE', e.info())\n"
+            "n = 1 << 12; p = kzg_amd.setup(e, 77, n, g2_len=0); buf = e.alloc_scalars(n * 24).fill_random(3)\n"
+            "a = e.msm_batch(p.gs, buf, n, 24); print('FULL', e.info())\n"
+            "e.set_option('hw_queues', 4); b = e.msm_batch(p.gs, buf, n, 24); print('NARROW', e.info()); assert a == b\n"
+            "e.set_option('hw_queues', 0); c = e.msm_batch(p.gs, buf, n, 24); print('AGAIN', e.info()); assert a == c\n" % root)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = {ln.split(" ", 1)[0]: ln for ln in r.stdout.splitlines() if ln.split(" ", 1)[0] in ("BEFORE", "FULL", "NARROW", "AGAIN")}
+    assert "lanes=0 accum_streams=0" in lines["BEFORE"] and "narrowed_from=none" in lines["BEFORE"]
+    assert "lanes=14 accum_streams=4" in lines["FULL"] and "narrowed_from=none" in lines["FULL"]
+    assert "lanes=3 accum_streams=1 hw_queues_found=4 narrowed_from=14+4" in lines["NARROW"], lines["NARROW"]
+    assert "narrowed_from=none" in lines["AGAIN"]
+    warn = [ln for ln in r.stderr.splitlines() if ln.startswith("kzg: device 0: this context's 14 + 4 streams found only 4 hardware queues")]
+    assert len(warn) == 1, r.stderr[-1500:]          # once per context, not once per call
