@@ -231,12 +231,19 @@ __global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const
     for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) data[i] = fr29_pack_canonical(mulshoup29(lds_fr29[swz(i, sw)], scale, scale_p));
 }
 
-// pass 1: columns j2 = blockIdx.x*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b + 8 share one, MI355X_MICROARCH.md), each with its own L2.  The tile
+// a block takes is therefore chosen so that the blocks of ONE XCD take ADJACENT tiles: in pass 1 their 128-byte column segments then
+// make up runs of a row in one L2 (4 KB per row and XCD at 2^20 instead of 128 B in each of eight L2s): pass 1 -6 % at 2^20, -13 % at
+// 2^21, -8 % at 2^24 (profiles/r05_ntt_xcd_probe.txt).  In pass 2 the same order concentrates an XCD's transposed 64-byte stores on
+// one 2 KB column range of every 32 KB row (+5 % at 2^20-2^22: channel camping), so pass 2 keeps the plain order except at 2^24.
+__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t g, int on) { return (!on || (g & 7u)) ? b : (b & 7u) * (g >> 3) + (b >> 3); }
+
+// pass 1: columns j2 = tile*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
 __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
                                                     const Tw29 tw1, const Tw29 tw_lo, const Tw29 tw_hi, uint32_t lo_bits,
-                                                    const Fr29 *tw_full, uint64_t sw) {
+                                                    const Fr29 *tw_full, uint64_t sw, int xcd) {
     const uint32_t vec = 1u << vec_log;
-    const uint32_t j2_0 = blockIdx.x << vec_log;
+    const uint32_t j2_0 = xcd_tile(blockIdx.x, gridDim.x, xcd) << vec_log;
     // every thread moves exactly four elements (the launch uses total / 4 threads): all four loads are issued before the first
     // is unpacked, so a wave waits for HBM once, not four times
     {
@@ -292,9 +299,9 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
 template <bool SHORT>
 __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint32_t k1, uint32_t k2, uint32_t vec_log,
                                                     const Tw29 tw2, Fr29 scale, Fr29 scale_p, int scale_folded, uint64_t sw,
-                                                    uint32_t nnz, const Fr29 *tw_full, const Tw29 tw_lo, const Tw29 tw_hi, uint32_t lo_bits) {
+                                                    uint32_t nnz, const Fr29 *tw_full, const Tw29 tw_lo, const Tw29 tw_hi, uint32_t lo_bits, int xcd) {
     const uint32_t n2 = 1u << k2, vec = 1u << vec_log;
-    const uint32_t r0 = blockIdx.x << vec_log;
+    const uint32_t r0 = xcd_tile(blockIdx.x, gridDim.x, xcd) << vec_log;
     if (!SHORT) {
         Fr raw[4];
 #pragma unroll
@@ -558,16 +565,19 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, siz
     unsigned g1 = 1u << (p->k2 - vec1), g2 = 1u << (p->k1 - vec2);
     // one radix-4 butterfly per thread and stage; smaller tiles leave room for a second block per CU
     unsigned th1 = std::min(1024u, 1u << (p->k1 + vec1 - 2)), th2 = std::min(1024u, 1u << (p->k2 + vec2 - 2));
+    // XCD-aware tile order (xcd_tile): pass 1 always; pass 2 only at 2^24, the one size where it measured a gain (option ntt_xcd: 0 off,
+    // 1 this rule, 2 pass 2 only, 3 both; profiles/r05_ntt_xcd_probe.txt)
+    const int xcd1 = ctx->opt_ntt_xcd & 1, xcd2 = ctx->opt_ntt_xcd == 1 ? (log_n >= 24) : (ctx->opt_ntt_xcd >> 1 & 1);
     if (nnz <= ((size_t)1 << p->k2)) {
         if (nnz) KZG_HIP_CHECK(ctx, hipMemcpyAsync(scratch, d_data, nnz * sizeof(Fr), hipMemcpyDeviceToDevice, st));  // pass 2 writes d_data
         KZG_LAUNCH(ctx, st, "k_ntt_pass2_short", k_ntt_pass2<true>, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
-                   p->scale_p, p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2], (uint32_t)nnz, p->tw_full, p->tw_lo, p->tw_hi, p->lo_bits);
+                   p->scale_p, p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2], (uint32_t)nnz, p->tw_full, p->tw_lo, p->tw_hi, p->lo_bits, xcd2);
         return KZG_OK;
     }
     KZG_LAUNCH(ctx, st, "k_ntt_pass1", k_ntt_pass1, g1, th1, lds1, d_data, scratch, p->k1, p->k2, vec1, p->tw1, p->tw_lo,
-               p->tw_hi, p->lo_bits, p->tw_full, LDS_SWIZZLE[p->k1][vec1]);
+               p->tw_hi, p->lo_bits, p->tw_full, LDS_SWIZZLE[p->k1][vec1], xcd1);
     KZG_LAUNCH(ctx, st, "k_ntt_pass2", k_ntt_pass2<false>, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale, p->scale_p,
-               p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2], 0u, (const Fr29 *)nullptr, Tw29(), Tw29(), 0u);
+               p->tw_full ? 1 : 0, LDS_SWIZZLE[p->k2][vec2], 0u, (const Fr29 *)nullptr, Tw29(), Tw29(), 0u, xcd2);
     return KZG_OK;
 }
 
