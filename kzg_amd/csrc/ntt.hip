@@ -235,7 +235,8 @@ __global__ __launch_bounds__(1024) void k_ntt_single(Fr *data, uint32_t t, const
 // a block takes is therefore chosen so that the blocks of ONE XCD take ADJACENT tiles: in pass 1 their 128-byte column segments then
 // make up runs of a row in one L2 (4 KB per row and XCD at 2^20 instead of 128 B in each of eight L2s): pass 1 -6 % at 2^20, -13 % at
 // 2^21, -8 % at 2^24 (profiles/r05_ntt_xcd_probe.txt).  In pass 2 the same order concentrates an XCD's transposed 64-byte stores on
-// one 2 KB column range of every 32 KB row (+5 % at 2^20-2^22: channel camping), so pass 2 keeps the plain order except at 2^24.
+// one 2 KB column range of every 32 KB row (+5 % at 2^20-2^22: channel camping), so pass 2 keeps the plain order except at 2^24
+// (keeping only the PAIRS of tiles whose 64-byte halves make up a line on one XCD was measured too: no better than the plain order).
 __device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t g, int on) { return (!on || (g & 7u)) ? b : (b & 7u) * (g >> 3) + (b >> 3); }
 
 // pass 1: columns j2 = tile*vec .. +vec-1; element (j1, j2) at in[j1*n2 + j2]
