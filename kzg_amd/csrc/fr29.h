@@ -139,8 +139,24 @@ KZG_HD Fr29 mulshoup29_inline(const Fr29 &x, const Fr29 &w, const Fr29 &wp) {
 
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(KZG_C_MUL29R) && !defined(KZG_OOL_MUL29R)
 KZG_HD Fr29 mulshoup29(const Fr29 &x, const Fr29 &w, const Fr29 &wp) { return mulshoup29_asm(x, w, wp); }
+// two independent products as one instruction stream, the two accumulator chains interleaved multiply-add by multiply-add (tools/gen_mul30.py)
+KZG_HD void mulshoup29x2(Fr29 &x, const Fr29 &w, const Fr29 &wp, Fr29 &y, const Fr29 &w2, const Fr29 &wp2) {
+#ifdef KZG_NTT_SINGLE_CHAIN
+    x = mulshoup29_asm(x, w, wp);
+    y = mulshoup29_asm(y, w2, wp2);
+#else
+    Fr29 rx, ry;
+    mulshoup29x2_asm(x, w, wp, y, w2, wp2, rx, ry);
+    x = rx;
+    y = ry;
+#endif
+}
 #else
 KZG_HD Fr29 mulshoup29(const Fr29 &x, const Fr29 &w, const Fr29 &wp) { return mulshoup29_inline(x, w, wp); }
+KZG_HD void mulshoup29x2(Fr29 &x, const Fr29 &w, const Fr29 &wp, Fr29 &y, const Fr29 &w2, const Fr29 &wp2) {
+    x = mulshoup29_inline(x, w, wp);
+    y = mulshoup29_inline(y, w2, wp2);
+}
 #endif
 
 // low 261 bits of a * b (table construction only)

@@ -168,12 +168,12 @@ __device__ __forceinline__ void lds_ntt_stages29(Fr29 *lds, uint32_t t, uint32_t
                 // stage s: twiddle w_{2m}^j on the odd halves; stage s+1: w_{4m}^j and w_{4m}^(j+m)
                 const uint32_t ia = j << (t - 1 - s), ib = j << (t - 2 - s), ic = (j + m) << (t - 2 - s);
                 const Fr29 a = tw.w[ia], ap = tw.wp[ia];
-                x1 = mulshoup29(x1, a, ap);
-                x3 = mulshoup29(x3, a, ap);
+                mulshoup29x2(x1, a, ap, x3, a, ap);   // the two products that share a twiddle as ONE instruction stream, chains interleaved:
+                                                      // two independent dependency chains in flight per wave (-2 % at every size)
                 fr29_butterfly_lazy(x0, x1, s0, y1);
                 fr29_butterfly_lazy(x2, x3, s2, y3);
-                s2 = mulshoup29(s2, tw.w[ib], tw.wp[ib]);
-                y3 = mulshoup29(y3, tw.w[ic], tw.wp[ic]);
+                s2 = mulshoup29(s2, tw.w[ib], tw.wp[ib]);   // (these two as an interleaved pair as well: 94 live registers for the pair alone,
+                y3 = mulshoup29(y3, tw.w[ic], tw.wp[ic]);   // the kernels spill at their 128 and lose 14 %: profiles/r05_ab_ntt.txt)
                 fr29_butterfly_lazy(s0, s2, z0, z2);
                 fr29_butterfly_lazy(y1, y3, z1, z3);
             } else {
@@ -279,7 +279,7 @@ __global__ __launch_bounds__(1024) void k_ntt_pass1(const Fr *in, Fr *out, uint3
         uint32_t j2 = j2_0 + v;
         Fr29 x = lds_fr29[opos[i]];
         if (tw_full) {
-            x = mul29r(x, twf[i]);  // Montgomery-29 product: below 1.4 r for x < 64 r
+            x = mul29r(x, twf[i]);  // Montgomery-29 product: below 1.4 r for x < 64 r (as two interleaved pairs: no gain, measured)
         } else {
             const uint64_t ex = (uint64_t)j2 * kk1;  // < n
             const size_t ih = ex >> lo_bits, il = ex & lo_mask;

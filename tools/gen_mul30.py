@@ -203,6 +203,81 @@ def gen_shoup29():
     return s
 
 
+def block2(products, mnem):
+    """two interleaved accumulator chains in one asm statement: products = list of (chain, x, xc, y, yc); chain 0 -> acc (%0), chain 1 -> acc2 (%1)"""
+    ops, lines = [], []
+
+    def ref(cons, expr):
+        for i, (c, e) in enumerate(ops):
+            if e == expr and c == cons:
+                return i + 2
+        ops.append((cons, expr))
+        return len(ops) + 1
+    for ch, x, xc, y, yc in products:
+        xtxt = f"%{ref(xc, x)}"
+        ytxt = y if yc == "i" else f"%{ref(yc, y)}"
+        lines.append(f"{mnem} %{ch}, vcc, {xtxt}, {ytxt}, %{ch}")
+    assert len(ops) + 2 <= MAX_OPS, len(ops)
+    body = "\\n\\t".join(lines)
+    ins = ", ".join(f'"{c}"({e})' for c, e in ops)
+    return f'    asm("{body}" : "+v"(acc), "+v"(acc2) : {ins} : "vcc");\n'
+
+
+def emit_products2(pa, pb, mnem):
+    """columns of two independent products, multiply-add by multiply-add alternating between the two chains; split into blocks that
+    respect the operand limit"""
+    seq = []
+    for i in range(max(len(pa), len(pb))):
+        if i < len(pa):
+            seq.append((0,) + pa[i])
+        if i < len(pb):
+            seq.append((1,) + pb[i])
+    out, cur, names = "", [], set()
+    for pr in seq:
+        new = {(pr[2], pr[1])} | ({(pr[4], pr[3])} if pr[4] != "i" else set())
+        if len(names | new) + 2 > MAX_OPS:
+            out += block2(cur, mnem)
+            cur, names = [], set()
+        cur.append(pr)
+        names |= new
+    if cur:
+        out += block2(cur, mnem)
+    return out
+
+
+def gen_shoup29_dual():
+    """Two Shoup products (x * w, y * w2) as ONE instruction stream with the two accumulator chains interleaved multiply-add by
+    multiply-add: a wave then has two independent dependency chains in flight (a dependent v_mad_u64_u32 issues every 5.3 cycles, an
+    independent one every 4.3: profiles/r03_issue_cost.txt) -- for the NTT's stage pairs, whose four products per butterfly come in
+    two independent pairs."""
+    n = 9
+    s = ("__device__ __forceinline__ void mulshoup29x2_asm(const Fr29 &x, const Fr29 &w, const Fr29 &wp, const Fr29 &y, const Fr29 &w2, const Fr29 &wp2,\n"
+         "                                                 Fr29 &rx, Fr29 &ry) {\n    uint32_t q[R29_N], q2[R29_N];\n    Fr29 r, r2;\n"
+         "    uint64_t acc = 0, acc2 = 0;\n")
+    for k in range(7, 2 * n - 1):
+        rng = range(max(0, k - n + 1), min(n - 1, k) + 1)
+        pa = [(f"x.v[{i}]", "v", f"wp.v[{k - i}]", "v") for i in rng]
+        pb = [(f"y.v[{i}]", "v", f"wp2.v[{k - i}]", "v") for i in rng]
+        s += emit_products2(pa, pb, "v_mad_u64_u32")
+        if k >= n:
+            s += f"    q[{k - n}] = (uint32_t)acc & F29_MASK;\n    q2[{k - n}] = (uint32_t)acc2 & F29_MASK;\n"
+        s += "    acc >>= 29;\n    acc2 >>= 29;\n"
+    s += f"    q[{n - 1}] = (uint32_t)acc;\n    q2[{n - 1}] = (uint32_t)acc2;\n    acc = 0;\n    acc2 = 0;\n"
+    for k in range(n):
+        def col(xn, wn, qn):
+            prods = [(f"{xn}.v[{i}]", "v", f"{wn}.v[{k - i}]", "v") for i in range(k + 1)]
+            for i in range(k + 1):
+                j = k - i
+                prods.append((f"{qn}[{i}]", "v", "-1", "i") if j == 0 else (f"{qn}[{i}]", "v", f"(int32_t)(0u - Fr29Consts::mod({j}))", "s"))
+            return prods
+        s += emit_products2(col("x", "w", "q"), col("y", "w2", "q2"), "v_mad_i64_i32")
+        s += f"    r.v[{k}] = (uint32_t)acc & F29_MASK;\n    r2.v[{k}] = (uint32_t)acc2 & F29_MASK;\n"
+        if k < n - 1:
+            s += "    acc = (uint64_t)((int64_t)acc >> 29);\n    acc2 = (uint64_t)((int64_t)acc2 >> 29);\n"
+    s += "    rx = r;\n    ry = r2;\n}\n"
+    return s
+
+
 def main(dst):
     out = ("// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_mul() + gen_sqr() + gen_muladd() +
            gen_mul("mul30_sub_asm", (("c", -1),)) + gen_sqr("sqr30_sub2_asm", (("c", -1), ("e", -2))) +
@@ -210,7 +285,7 @@ def main(dst):
     open(dst, "w").write(out)
     print("wrote", dst)
     if len(sys.argv) > 2:
-        open(sys.argv[2], "w").write("// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_fr29() + gen_shoup29())
+        open(sys.argv[2], "w").write("// GENERATED by tools/gen_mul30.py -- do not edit.\n" + gen_fr29() + gen_shoup29() + gen_shoup29_dual())
         print("wrote", sys.argv[2])
 
 
