@@ -460,8 +460,8 @@ static void point_set_release(kzg_ctx *ctx, PointSetEntry *e) {
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     e->users--;
 }
-// A slot for a new entry (pinned, not yet valid), or nullptr: cache off, entry larger than a slot, every slot pinned, or the pool
-// cannot be allocated.  The pool comes into being here, sized for the first entry: `slots` equal slots.
+// A slot for a new entry (pinned, not yet valid), or nullptr: cache off, every slot pinned, or the pool cannot be allocated.  The pool
+// comes into being here, sized for the first entry (`slots` equal slots), and is rebuilt with larger slots when a larger entry comes.
 static PointSetEntry *point_set_reserve(kzg_ctx *ctx, size_t k, size_t N) {
     std::lock_guard<std::mutex> lk(ctx->cache_mu);
     if (ctx->opt_witness_cache_slots <= 0) return nullptr;
@@ -481,7 +481,25 @@ static PointSetEntry *point_set_reserve(kzg_ctx *ctx, size_t k, size_t N) {
         for (size_t i = 0; i < c->slots.size(); i++) c->slots[i].slot = c->pool + i * need;
         ctx->point_sets = c;
     }
-    if (need > c->slot_bytes) return nullptr;
+    if (need > c->slot_bytes) {
+        // a larger point set than the pool was sized for (a context that opened small polynomials first): the pool is rebuilt with
+        // larger slots -- once per growth, and only while nobody reads an entry (hipFree waits for the device: a one-time stall)
+        for (auto &e : c->slots)
+            if (e.users) return nullptr;
+        if (need * c->slots.size() > ((size_t)8 << 30)) return nullptr;
+        uint8_t *np = nullptr;
+        if (hipMalloc((void **)&np, need * c->slots.size()) != hipSuccess) {
+            hipGetLastError();
+            return nullptr;
+        }
+        hipFree(c->pool);
+        c->pool = np;
+        c->slot_bytes = need;
+        for (size_t i = 0; i < c->slots.size(); i++) {
+            c->slots[i] = PointSetEntry();
+            c->slots[i].slot = c->pool + i * need;
+        }
+    }
     PointSetEntry *best = nullptr;
     for (auto &e : c->slots) {
         if (e.users) continue;

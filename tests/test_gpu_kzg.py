@@ -390,3 +390,17 @@ def test_create_witness_batched_point_set_cache():
         params.gs.free()
         e.close()
     assert results[2] == results[0]
+    # a context that opened small polynomials first: the pool grows when a larger point set arrives, and the larger set is then hit
+    e = kzg_amd.Engine(0)
+    params = kzg_amd.setup(e, tau, 1 << 14, g2_len=0)
+    prover = kzg_amd.KZGProver(params)
+    for n2, k2 in ((1 << 10, 4), (1 << 14, 8), (1 << 14, 8), (1 << 10, 4)):
+        xs = [rng.randrange(M.R) for _ in range(k2)] if n2 == 1 << 10 else list(range(100, 100 + k2))
+        coeffs = [rng.randrange(M.R) for _ in range(n2)]
+        ys = [C.poly_eval(coeffs, x) for x in xs]
+        wit = prover.create_witness_batched(kzg_amd.Polynomial(coeffs), xs, ys)
+        assert wit.w == want(coeffs, xs, ys, wit.r.slice_coeffs())
+    hits, _ = stats(e)
+    assert hits >= 1            # the second 2^14 opening found the entry the grown pool holds
+    params.gs.free()
+    e.close()
