@@ -301,12 +301,12 @@ extern "C" int kzg_device_count(void) {
 }
 
 // ---- one pool of streams per device and PROCESS ----------------------------------------------------------------------------
-// Every context used to create its own 16 lanes + 4 accumulation streams, and the runtime multiplexes all streams of a process onto
+// Every context used to create its own lanes (16, or 14 in a device group) + 4 accumulation streams, and the runtime multiplexes all streams of a process onto
 // ONE pool of hardware queues (GPU_MAX_HW_QUEUES).  A second context -- a device group's beside a plain prover's, what INTEGRATION.md
 // section 5b describes -- then found most of its streams sharing queues with the first one's, narrowed its pipeline to what was
 // left and lost 19 % of its batched rate (384.8 against 475.6 commitments/s; profiles/r05_engine_and_group.txt).  Streams are only
 // ordered queues: contexts of one device now take THE SAME streams from this pool (lane i of every context is pool lane i), so a
-// process holds 20 streams however many contexts it has, each on a queue of its own.  Work of two contexts interleaves on a
+// process holds 18 streams however many contexts it has, each on a queue of its own.  Work of two contexts interleaves on a
 // stream in submission order; every wait is on an event that the same host thread submitted EARLIER in real time, so the streams'
 // FIFO order cannot close a cycle.  An RCCL communicator needs about six queues of the same pool (24 by default): with 16 lanes + 4
 // accumulation streams beside one the exchange's kernels queue behind the pipeline's (336.6 against 469.9 commitments/s), which is
