@@ -234,3 +234,41 @@ def test_concurrent_2_20_every_leased_call(engine):
         for w in work_bufs:
             w.free()
         params.gs.free()
+
+
+def test_concurrent_batched_openings_share_and_churn_point_sets():
+    """create_witness_batched from 16 threads on one context whose point-set cache has FOUR slots: threads 0-7 all open their own
+    polynomials at ONE shared point set (concurrent hits on one entry, pinned by several readers), threads 8-15 each cycle through three
+    point sets of their own (misses, fills and evictions while the others read).  Every witness is the oracle's
+    [(p(tau) - I(tau)) / Z(tau)]G and every interpolant passes through its points."""
+    import random
+    n, k, rounds = 1 << 12, 8, 6
+    e = kzg_amd.Engine(0)
+    e.set_option("witness_cache_slots", 4)
+    params = kzg_amd.setup(e, TAU, n, g2_len=0)
+    prover = kzg_amd.KZGProver(params)
+    G = C.g1_generator()
+    rng99 = random.Random(99)
+    shared = [rng99.randrange(R) for _ in range(k)]
+
+    def work(t):
+        rng = random.Random(1000 + t)
+        own = [[rng.randrange(R) for _ in range(k)] for _ in range(3)]
+        for rnd in range(rounds):
+            xs = shared if t < 8 else own[rnd % 3]
+            coeffs = [rng.randrange(R) for _ in range(n)]
+            ys = [C.poly_eval(coeffs, x) for x in xs]
+            wit = prover.create_witness_batched(kzg_amd.Polynomial(coeffs), xs, ys)
+            icoef = wit.r.slice_coeffs()
+            assert all(C.poly_eval(icoef, x) == y for x, y in zip(xs, ys))
+            z = 1
+            for x in xs:
+                z = z * (TAU - x) % R
+            assert wit.w == C.g1_mul(G, (C.poly_eval(coeffs, TAU) - C.poly_eval(icoef, TAU)) * pow(z, -1, R) % R), (t, rnd)
+
+    _run_threads(16, work)
+    h, m = ctypes.c_uint64(), ctypes.c_double()
+    assert e.lib.kzg_prof_get(e.ctx, b"point_set_cache", ctypes.byref(h), ctypes.byref(m)) == 0
+    assert h.value >= 8 and m.value >= 8, (h.value, m.value)      # both paths were exercised
+    params.gs.free()
+    e.close()
