@@ -11,8 +11,10 @@ N = 1 : workload = BASELINE configs[1] "degree-2^20 coeff_form commit (G1 Pippen
 N > 1 : one process per GPU.  Commitments are independent objects and a degree-2^20 SRS is 2 GiB, so the metric shards by
         commitment: every rank holds the full SRS and commits its own polynomials, NO data-path collective ("scaling": "weak";
         torch.distributed -- a gloo process group: control plane only -- carries the barriers and the max-over-ranks time).  That
-        is `value`.  The same run then measures, in the same processes, the sharded-SRS + RCCL design through the library's device
-        group and reports it beside `value` as `sharded.strong` / `sharded.config5` (measure_sharded_block).  Where one commitment
+        is `value`.  The same run also measures the sharded-SRS + RCCL design through the library's device group and reports it
+        beside `value` as `sharded.strong` / `sharded.config5` (measure_sharded_block) -- by the same ranks, in a fresh child
+        process each, BEFORE this process touches the GPU (run_sharded_block_in_children: killable, and a process that has used
+        the GPU slows every other process on it).  Where one commitment
         does not fit or its latency matters, the C ABI's device group shards the commitment itself (kzg_mctx_create_rank /
         kzg_commit_coeff_sharded_batch, kzg_amd/csrc/mgpu.hip: SRS sharded contiguously, one partial point per rank and
         polynomial, ONE ncclAllGather of the 144-byte partials inside the library, local sums):
