@@ -541,26 +541,49 @@ static inline void fr_mulf(fr *r, const fr *a, const fr *b) {
 
 /* serial_fft (src/ft.rs:291-333) on Montgomery-form data */
 static void serial_fft_mont(fr *a, const fr *omega, uint32_t log_n) {
+    /* The reference's loop nest, butterfly for butterfly.  With OpenMP (the Makefile asks for it when the compiler has it) the
+     * independent butterflies of a stage are spread over the host's cores -- whole groups while there are many, chunks of one
+     * group's j-range (each chunk starting from w_m^j0 instead of reaching it by repeated multiplication) once there are few.
+     * Field elements are canonical, so the results are the same bits; tests/test_oracle_c.py compares with the python model. */
     uint32_t n = 1u << log_n;
+#pragma omp parallel for schedule(static) if (log_n >= 16)
     for (uint32_t k = 0; k < n; k++) { uint32_t rk = bitreverse(k, log_n);
         if (k < rk) { fr t = a[rk]; a[rk] = a[k]; a[k] = t; } }
     uint32_t m = 1;
     for (uint32_t s = 0; s < log_n; s++) {
         u64 e[1] = {n / (2 * m)}; fr w_m; fr_pow(&w_m, omega, e, 1);
-        for (uint32_t k = 0; k < n; k += 2 * m) {
-            fr w = fr_R1;
-            for (uint32_t j = 0; j < m; j++) {
-                fr t; fr_mulf(&t, &a[k + j + m], &w);
-                fr tmp; fr_sub(&tmp, &a[k + j], &t); a[k + j + m] = tmp;
-                fr_add(&a[k + j], &a[k + j], &t);
-                fr_mulf(&w, &w, &w_m);
+        const uint32_t groups = n / (2 * m);
+        if (groups >= 256 || log_n < 16) {
+#pragma omp parallel for schedule(static) if (log_n >= 16)
+            for (uint32_t g = 0; g < groups; g++) {
+                const uint32_t k = g * 2 * m;
+                fr w = fr_R1;
+                for (uint32_t j = 0; j < m; j++) {
+                    fr t; fr_mulf(&t, &a[k + j + m], &w);
+                    fr tmp; fr_sub(&tmp, &a[k + j], &t); a[k + j + m] = tmp;
+                    fr_add(&a[k + j], &a[k + j], &t);
+                    fr_mulf(&w, &w, &w_m);
+                }
+            }
+        } else {
+            const uint32_t chunk = m >= 4096 ? 4096 : m;   /* m / chunk chunks per group */
+            const uint32_t per = m / chunk;
+#pragma omp parallel for schedule(static)
+            for (uint32_t c = 0; c < groups * per; c++) {
+                const uint32_t k = (c / per) * 2 * m, j0 = (c % per) * chunk;
+                u64 ej[1] = {j0}; fr w; fr_pow(&w, &w_m, ej, 1);
+                for (uint32_t j = j0; j < j0 + chunk; j++) {
+                    fr t; fr_mulf(&t, &a[k + j + m], &w);
+                    fr tmp; fr_sub(&tmp, &a[k + j], &t); a[k + j + m] = tmp;
+                    fr_add(&a[k + j], &a[k + j], &t);
+                    fr_mulf(&w, &w, &w_m);
+                }
             }
         }
         m *= 2;
     }
 }
 
-/* EvaluationDomain::fft / ifft (src/ft.rs:111-140).  data: 2^log_n canonical scalars, in place. */
 void orc_fft(uint8_t *data, uint32_t log_n, int inverse) {
     size_t n = (size_t)1 << log_n;
     u64 m; uint32_t exp; uint8_t wb[32];
