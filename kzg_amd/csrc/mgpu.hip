@@ -17,6 +17,7 @@
 #include <chrono>
 #include <functional>
 #include <memory>
+#include <system_error>
 #include <thread>
 
 #include "common.h"
@@ -89,13 +90,20 @@ static bool run_bounded(int64_t timeout_ms, const std::shared_ptr<BoundedState> 
         *ms = now_ms() - t0;
         return true;
     }
-    std::thread th([st, f]() {
-        ncclResult_t r = f(*st);
-        std::lock_guard<std::mutex> lk(st->mu);
-        st->res = r;
-        st->done = true;
-        st->cv.notify_all();
-    });
+    std::thread th;
+    try {
+        th = std::thread([st, f]() {
+            ncclResult_t r = f(*st);
+            std::lock_guard<std::mutex> lk(st->mu);
+            st->res = r;
+            st->done = true;
+            st->cv.notify_all();
+        });
+    } catch (const std::system_error &) {  // no thread to be had: the call runs here, unbounded (no exception crosses the C ABI)
+        *res = f(*st);
+        *ms = now_ms() - t0;
+        return true;
+    }
     std::unique_lock<std::mutex> lk(st->mu);
     const bool ok = st->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return st->done; });
     lk.unlock();
