@@ -918,7 +918,7 @@ def main():
                     help="N>1: backend of the torch process group that carries barriers and timing reductions (the data-path collective is the "
                          "library's own RCCL communicator either way)")
     ap.add_argument("--no-traffic", action="store_true", help="skip the two rocprofv3 --pmc passes that fill roofline.traffic")
-    ap.add_argument("--sharded-timeout", type=int, default=180, help="seconds the sharded block's child process may take before it is killed and the line printed without it")
+    ap.add_argument("--sharded-timeout", type=int, default=240, help="seconds the sharded block's child process may take before it is killed and the line printed without it")
     ap.add_argument("--sharded-child", action="store_true", help=argparse.SUPPRESS)   # internal: the block alone (run_sharded_block_in_children)
     args = ap.parse_args()
     if args.pmc_child:
