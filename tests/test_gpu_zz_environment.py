@@ -69,7 +69,9 @@ os._exit(0)      # (a helper thread may still sit inside the abandoned ncclCommI
     r = _child(code, {"KZG_AMD_LIBRARY": HOOKS, "KZG_TEST_FORMATION_STALL_MS": "6000"})
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert "did not return within 1500 ms" in out["first"] and "init=15" in out["first"] and "load=" in out["first"], out["first"]
+    import re
+    assert "did not return within 1500 ms" in out["first"] and "load=" in out["first"], out["first"]
+    assert 1500 <= float(re.search(r"init=([0-9.]+)", out["first"]).group(1)) < 5000, out["first"]     # the phase that consumed the time, named
     assert "NCCL_SOCKET_IFNAME=lo" in out["first"]
     assert out["first_s"] < 12
     assert "dead" in out["second"] and out["second_s"] < 0.5
