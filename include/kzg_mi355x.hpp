@@ -53,6 +53,12 @@ class Engine {
     Engine(const Engine &) = delete;
     Engine &operator=(const Engine &) = delete;
     kzg_ctx *ctx() const { return ctx_; }
+    // the batched pipeline's plan and whether the process' hardware-queue pool narrowed it (kzg_ctx_info)
+    std::string info() const {
+        char buf[512];
+        check(kzg_ctx_info(ctx_, buf, sizeof buf));
+        return buf;
+    }
     void check(int rc) const {
         if (rc == KZG_OK) return;
         std::string msg = kzg_last_error(ctx_);
@@ -278,6 +284,12 @@ class DeviceGroup {
     DeviceGroup &operator=(const DeviceGroup &) = delete;
     kzg_mctx *handle() const { return m_; }
     int world() const { return kzg_mctx_world(m_); }
+    // which RCCL the group runs on, what forming its communicator cost per phase, each local context's pipeline plan (kzg_mctx_info)
+    std::string info() const {
+        char buf[2048];
+        check(kzg_mctx_info(m_, buf, sizeof buf));
+        return buf;
+    }
     void check(int rc) const {
         if (rc == KZG_OK) return;
         std::string msg = kzg_mctx_last_error(m_);

@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
         ShardedParams sp = setup_sharded(group, Scalar::from_u64(0x1234567), 13);
         ShardedKZGProver sprover(sp);
         if (!(sprover.commit(p2) == cm2)) return 22;
+        if (group.info().find("formation_ms=") == std::string::npos) return 26;
         Scalar x5 = Scalar::from_u64(5), y5 = p2.eval(e, x5);
         if (!(sprover.create_witness(p2, x5, y5) == prover.create_witness(p2, x5, y5))) return 23;
         try {
@@ -78,6 +79,7 @@ int main(int argc, char **argv) {
             if (err.kind != KZGError::PointNotOnPolynomial) return 25;
         }
     }
+    if (e.info().find("device=0") == std::string::npos) return 30;
     std::printf(with_group ? "cpp mirror ok (with the device group)\n" : "cpp mirror ok\n");
     return 0;
 }
