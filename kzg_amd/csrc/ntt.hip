@@ -555,13 +555,19 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, siz
     size_t n = (size_t)1 << log_n;
     Fr *scratch = (Fr *)lane_alloc(ctx, lane, n * sizeof(Fr));
     if (!scratch) return fail(ctx, KZG_ERR_ALLOC, "NTT workspace not reserved");
-    // vec adjacent columns/rows per block: as many as fit the LDS (4096 elements x 36 B = 144 KiB), at most 4
+    // vec adjacent columns/rows per block: as many as fit the LDS (4096 elements x 36 B = 144 KiB), at most 4 -- but never so many
+    // that fewer than 256 blocks are left for the 256 CUs (2^19: 128 blocks of 4096 -> 256 of 2048, pass 1 54.4 -> 38.8 us; 2^18:
+    // 35.0 -> 28.1 us; profiles/r05_ntt_tile_probe.txt)
     const uint32_t vmax = (uint32_t)ctx->opt_ntt_vec_log;
     uint32_t vec1 = 12 - p->k1 < vmax ? 12 - p->k1 : vmax;
+    while (vec1 && (1u << (p->k2 - vec1)) < 256u) vec1--;
     // rows are contiguous, so narrower pass-2 tiles cost no coalescing and two blocks share a CU: one loads / stores while the
-    // other computes (same-box at 2^20: 58.2 -> 54.2 us); pass 1 needs its 128-byte column segments
+    // other computes (same-box at 2^20: 58.2 -> 54.2 us; 2^22: 2048-element tiles 224.7 -> 205.2 us); pass 1 needs its 128-byte
+    // column segments
     const uint32_t vmax2 = vmax < 1 ? vmax : 1;
     uint32_t vec2 = 12 - p->k2 < vmax2 ? 12 - p->k2 : vmax2;
+    if (p->k2 <= 11 && p->k2 + vec2 > 11) vec2 = 11 - p->k2;
+    while (vec2 && (1u << (p->k1 - vec2)) < 256u) vec2--;
     size_t lds1 = ((size_t)1 << (p->k1 + vec1)) * sizeof(Fr29), lds2 = ((size_t)1 << (p->k2 + vec2)) * sizeof(Fr29);
     unsigned g1 = 1u << (p->k2 - vec1), g2 = 1u << (p->k1 - vec2);
     // one radix-4 butterfly per thread and stage; smaller tiles leave room for a second block per CU
