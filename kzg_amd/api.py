@@ -510,8 +510,18 @@ class DeviceGroup:
                 raise EngineError(f"kzg_mctx_create({list(devices)}) failed with {rc}: {self._create_error(self.lib)} "
                                   "(kzg_amd has no CPU fallback)")
             _handle = h
+            self._flush_c_stdio()
         self.handle = _handle
         self._engines = {}
+
+    @staticmethod
+    def _flush_c_stdio():
+        """RCCL prints its version banner (NCCL_DEBUG=VERSION, exported on some images) with printf: into a pipe or file that is
+        block-buffered and would surface at process exit, after whatever the host printed last.  Flush it where it was caused."""
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except (OSError, AttributeError):
+            pass
 
     @staticmethod
     def _host_env():
@@ -542,6 +552,7 @@ class DeviceGroup:
         if rc:
             raise EngineError(f"kzg_mctx_create_rank(device={device}, rank={rank}/{world}) failed with {rc}: "
                               f"{DeviceGroup._create_error(lib)}")
+        DeviceGroup._flush_c_stdio()
         return DeviceGroup(_handle=h)
 
     def last_error(self):

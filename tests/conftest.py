@@ -112,6 +112,11 @@ def pytest_sessionfinish(session, exitstatus):
         _release()
     except Exception:
         pass
+    try:    # RCCL's printf banner (NCCL_DEBUG=VERSION on some images) belongs before pytest's summary line, not after it
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
 
 
 # ---------------------------------------------------------------------------------------------------------------------
