@@ -559,6 +559,7 @@ class DeviceGroup:
         return (self.lib.kzg_mctx_last_error(self.handle) or b"").decode()
 
     def _check(self, rc):
+        self._flush_c_stdio()     # the communicator is formed inside the first call that needs it
         if rc:
             _raise(self, rc)
 
