@@ -352,6 +352,228 @@ __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint3
     }
 }
 
+// ---- round 6: the same transform with the tile load fused into the first stage pair and the store into the last ----------------
+// k_ntt_pass1 / k_ntt_pass2 above move a tile in three lock-stepped phases: load -> LDS, barrier, five stage pairs (LDS -> registers ->
+// LDS, a barrier each), barrier, LDS -> store.  A thread of the load phase already holds exactly the four inputs of one first-pair
+// butterfly (rows r, r + n/4, r + n/2, r + 3n/4 of its column), and a thread of the store phase writes exactly the four outputs of one
+// last-pair butterfly (k, k + n/4, k + n/2, k + 3n/4): so the first pair runs on the loaded registers and the last pair's results go
+// straight to global memory.  Two LDS round trips and two barriers fewer per pass (4 instead of 6 at 2^10 points), and the memory
+// phases stop being block-wide: a wave starts its first butterfly when ITS loads have landed and stores while others still compute.
+// BPT = 2: two butterflies per thread at half the threads (two waves per SIMD, 256 VGPRs): the middle pairs' twiddles are shared by
+// the two butterflies (half the twiddle loads) and every product has an independent partner for the interleaved two-chain stream.
+struct NttTile {
+    uint32_t t;        // log2 of the transform length of this pass (k1 or k2)
+    uint32_t kother;   // the other pass's log length
+    uint32_t vec_log;  // 2^vec_log columns (pass 1) / rows (pass 2) per tile
+    uint32_t lo_bits, nnz;
+    int xcd, scale_folded;
+    uint64_t sw;
+    Tw29 tw, tw_lo, tw_hi;
+    const Fr29 *tw_full;
+    Fr29 scale, scale_p;
+};
+
+template <int PASS, bool SHORT>
+__device__ __forceinline__ Fr29 ntt_tile_input(const Fr *in, const NttTile &a, uint32_t tile0, uint32_t vv, uint32_t pos) {
+    // pos: index along the transform (row j1 in pass 1, element j2 of the row in pass 2); vv: column / row inside the tile
+    if (PASS == 1) return fr29_unpack(in[((size_t)pos << a.kother) + tile0 + vv]);
+    if (!SHORT) return fr29_unpack(in[((size_t)(tile0 + vv) << a.t) + pos]);
+    Fr29 x;
+#pragma unroll
+    for (int l = 0; l < R29_N; l++) x.v[l] = 0;
+    if (pos < a.nnz) {  // zero-padded short input: pass 1 collapsed to the inter-pass twiddle (see k_ntt_pass2<SHORT>)
+        const uint32_t row = tile0 + vv;
+        x = fr29_unpack(in[pos]);
+        if (a.tw_full) {
+            x = mul29r(x, a.tw_full[((size_t)row << a.t) + pos]);
+        } else {
+            const uint64_t ex = (uint64_t)pos * row;
+            const size_t ih = ex >> a.lo_bits, il = ex & ((1u << a.lo_bits) - 1);
+            x = mulshoup29(x, a.tw_hi.w[ih], a.tw_hi.wp[ih]);
+            x = mulshoup29(x, a.tw_lo.w[il], a.tw_lo.wp[il]);
+        }
+    }
+    return x;
+}
+
+template <int PASS, int BPT, bool SHORT>
+__global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, const NttTile a) {
+    Fr29 *lds = lds_fr29;
+    const uint32_t t = a.t, vl = a.vec_log, vec = 1u << vl, Q = 1u << (t - 2);
+    const uint32_t nthreads = blockDim.x;  // = (vec << t) / (4 BPT)
+    const uint32_t tile0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd) << vl;
+    const uint64_t sw = a.sw;
+    const Tw29 tw = a.tw;
+    // ---- first pair (or the radix-2 stage of an odd length), on the loaded registers --------------------------------------------
+    {
+        Fr29 e[BPT][4];
+        uint32_t p[BPT];
+#pragma unroll
+        for (int u = 0; u < BPT; u++) {
+            const uint32_t g = threadIdx.x + u * nthreads;
+            // pass 1: consecutive threads -> consecutive columns, then rows; pass 2: consecutive threads -> consecutive row elements
+            const uint32_t vv = PASS == 1 ? (g & (vec - 1)) : (g >> (t - 2)), q = PASS == 1 ? (g >> vl) : (g & (Q - 1));
+            if (PASS == 1 || !SHORT) {  // all loads of a thread in flight before the first unpack
+                Fr raw[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+                    raw[i] = PASS == 1 ? in[((size_t)(q + i * Q) << a.kother) + tile0 + vv] : in[((size_t)(tile0 + vv) << t) + q + i * Q];
+#pragma unroll
+                for (int i = 0; i < 4; i++) e[u][i] = fr29_unpack(raw[i]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) e[u][i] = ntt_tile_input<PASS, SHORT>(in, a, tile0, vv, q + i * Q);
+            }
+            p[u] = swz((vv << t) | (bitrev(q, t - 2) << 2), sw);  // positions p ^ {0,1,2,3} hold rows q, q + 2Q, q + Q, q + 3Q
+        }
+        if (t & 1) {
+#pragma unroll
+            for (int u = 0; u < BPT; u++) {
+                Fr29 s0, d0, s1, d1;
+                fr29_butterfly_lazy(e[u][0], e[u][2], s0, d0);
+                fr29_butterfly_lazy(e[u][1], e[u][3], s1, d1);
+                lds[p[u]] = fr29_normalize(s0);
+                lds[p[u] ^ 1] = fr29_normalize(d0);
+                lds[p[u] ^ 2] = fr29_normalize(s1);
+                lds[p[u] ^ 3] = fr29_normalize(d1);
+            }
+        } else {
+            const uint32_t ic = 1u << (t - 2);
+            const Fr29 c = tw.w[ic], cp = tw.wp[ic];
+            Fr29 s0[BPT], y1[BPT], s2[BPT], y3[BPT];
+#pragma unroll
+            for (int u = 0; u < BPT; u++) {
+                fr29_butterfly_lazy(e[u][0], e[u][2], s0[u], y1[u]);
+                fr29_butterfly_lazy(e[u][1], e[u][3], s2[u], y3[u]);
+                s2[u] = fr29_normalize(s2[u]);
+            }
+            if constexpr (BPT == 2) mulshoup29x2(y3[0], c, cp, y3[1], c, cp);
+            else y3[0] = mulshoup29(y3[0], c, cp);
+#pragma unroll
+            for (int u = 0; u < BPT; u++) {
+                Fr29 z0, z1, z2, z3;
+                fr29_butterfly_lazy8(s0[u], s2[u], z0, z2);
+                fr29_butterfly_lazy(y1[u], y3[u], z1, z3);
+                lds[p[u]] = fr29_normalize(z0);
+                lds[p[u] ^ 1] = fr29_normalize(z1);
+                lds[p[u] ^ 2] = fr29_normalize(z2);
+                lds[p[u] ^ 3] = fr29_normalize(z3);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- middle pairs: LDS -> registers -> LDS (lds_ntt_stages29's pair; two butterflies of a thread differ in bit h of b, above s) ----
+    uint32_t s = (t & 1) ? 1 : 2;
+    const uint32_t b = threadIdx.x;
+    const uint32_t h = __builtin_ctz(nthreads);
+    uint32_t p0 = swz(((b >> s) << (s + 2)) | (b & ((1u << s) - 1u)), sw);
+    for (; s + 2 < t; s += 2) {
+        const uint32_t m = 1u << s;
+        const uint32_t d1 = swz_bit(s, sw), d2 = swz_bit(s + 1, sw), dh = swz_bit(h + 2, sw);
+        const uint32_t j = b & (m - 1);
+        const uint32_t ia = j << (t - 1 - s), ib = j << (t - 2 - s), ic = (j + m) << (t - 2 - s);
+        const Fr29 wa = tw.w[ia], wap = tw.wp[ia];
+        Fr29 x0[BPT], x1[BPT], x2[BPT], x3[BPT];
+#pragma unroll
+        for (int u = 0; u < BPT; u++) {
+            const uint32_t pu = p0 ^ (u ? dh : 0u);
+            x0[u] = lds[pu];
+            x1[u] = lds[pu ^ d1];
+            x2[u] = lds[pu ^ d2];
+            x3[u] = lds[pu ^ d1 ^ d2];
+        }
+        const Fr29 wb = tw.w[ib], wbp = tw.wp[ib], wc = tw.w[ic], wcp = tw.wp[ic];
+        if constexpr (BPT == 2) {
+            mulshoup29x2(x1[0], wa, wap, x1[1], wa, wap);
+            mulshoup29x2(x3[0], wa, wap, x3[1], wa, wap);
+        } else {
+            mulshoup29x2(x1[0], wa, wap, x3[0], wa, wap);
+        }
+        Fr29 s0[BPT], y1[BPT], s2[BPT], y3[BPT];
+#pragma unroll
+        for (int u = 0; u < BPT; u++) {
+            fr29_butterfly_lazy(x0[u], x1[u], s0[u], y1[u]);
+            fr29_butterfly_lazy(x2[u], x3[u], s2[u], y3[u]);
+        }
+        if constexpr (BPT == 2) {
+            mulshoup29x2(s2[0], wb, wbp, s2[1], wb, wbp);
+            mulshoup29x2(y3[0], wc, wcp, y3[1], wc, wcp);
+        } else {
+            s2[0] = mulshoup29(s2[0], wb, wbp);
+            y3[0] = mulshoup29(y3[0], wc, wcp);
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; u++) {
+            const uint32_t pu = p0 ^ (u ? dh : 0u);
+            Fr29 z0, z1, z2, z3;
+            fr29_butterfly_lazy(s0[u], s2[u], z0, z2);
+            fr29_butterfly_lazy(y1[u], y3[u], z1, z3);
+            lds[pu] = fr29_normalize(z0);
+            lds[pu ^ d1] = fr29_normalize(z1);
+            lds[pu ^ d2] = fr29_normalize(z2);
+            lds[pu ^ d1 ^ d2] = fr29_normalize(z3);
+        }
+        const uint32_t D1 = swz_bit(s + 2, sw) ^ d1, D2 = swz_bit(s + 3, sw) ^ d2;
+        p0 ^= (((uint32_t)((int32_t)(b << (31 - s)) >> 31)) & D1) ^ (((uint32_t)((int32_t)(b << (30 - s)) >> 31)) & D2);
+        __syncthreads();
+    }
+    // ---- last pair (s = t - 2): results multiplied / reduced and stored from the registers ------------------------------------------
+    {
+        const uint32_t d1 = swz_bit(t - 2, sw), d2 = swz_bit(t - 1, sw);
+        const uint32_t lo_mask = (1u << a.lo_bits) - 1;
+#pragma unroll
+        for (int u = 0; u < BPT; u++) {
+            const uint32_t g = threadIdx.x + u * nthreads;
+            const uint32_t vv = g & (vec - 1), j = g >> vl;  // consecutive threads -> consecutive columns (pass 1) / rows (pass 2)
+            const uint32_t pu = swz((vv << t) | j, sw);
+            // the four inter-pass table entries of this butterfly: requested before the LDS reads where the registers allow it (BPT = 2,
+            // 256 VGPRs), one at a time behind the butterflies at four waves per SIMD (128 VGPRs: requested together they spill 8-21 registers)
+            Fr29 twf[4];
+            if (BPT == 2 && PASS == 1 && a.tw_full) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) twf[i] = a.tw_full[((size_t)(j + i * Q) << a.kother) + tile0 + vv];
+            }
+            Fr29 x0 = lds[pu], x1 = lds[pu ^ d1], x2 = lds[pu ^ d2], x3 = lds[pu ^ d1 ^ d2];
+            Fr29 s0, y1, s2, y3, z[4];
+            {
+                const uint32_t ia = j << 1, ib = j, ic = j + Q;
+                const Fr29 wa = tw.w[ia], wap = tw.wp[ia];
+                mulshoup29x2(x1, wa, wap, x3, wa, wap);
+                fr29_butterfly_lazy(x0, x1, s0, y1);
+                fr29_butterfly_lazy(x2, x3, s2, y3);
+                if constexpr (BPT == 2) {
+                    mulshoup29x2(s2, tw.w[ib], tw.wp[ib], y3, tw.w[ic], tw.wp[ic]);
+                } else {
+                    s2 = mulshoup29(s2, tw.w[ib], tw.wp[ib]);
+                    y3 = mulshoup29(y3, tw.w[ic], tw.wp[ic]);
+                }
+                fr29_butterfly_lazy(s0, s2, z[0], z[2]);
+                fr29_butterfly_lazy(y1, y3, z[1], z[3]);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t kk = j + i * Q;
+                Fr29 x = fr29_normalize(z[i]);
+                if (PASS == 1) {
+                    const uint32_t j2 = tile0 + vv;
+                    if (a.tw_full) {
+                        x = mul29r(x, BPT == 2 ? twf[i] : a.tw_full[((size_t)kk << a.kother) + j2]);
+                    } else {
+                        const uint64_t ex = (uint64_t)j2 * kk;
+                        const size_t ih = ex >> a.lo_bits, il = ex & lo_mask;
+                        x = mulshoup29(x, a.tw_hi.w[ih], a.tw_hi.wp[ih]);
+                        x = mulshoup29(x, a.tw_lo.w[il], a.tw_lo.wp[il]);
+                    }
+                    out[((size_t)kk << a.kother) + j2] = fr29_pack_raw(x);
+                } else {
+                    x = a.scale_folded ? fr29_reduce_below_2r(x) : mulshoup29(x, a.scale, a.scale_p);
+                    out[((size_t)kk << a.kother) + tile0 + vv] = fr29_pack_canonical(x);
+                }
+            }
+        }
+    }
+}
+
 static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t count, Tw29 *out) {
     if (!count) count = 1;
     KZG_HIP_CHECK(ctx, hipMalloc((void **)&out->w, count * sizeof(Fr29)));
@@ -413,6 +635,9 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass1, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass2<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_ntt_pass2<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        for (const void *k : {(const void *)k_ntt_tile<1, 1, false>, (const void *)k_ntt_tile<1, 2, false>, (const void *)k_ntt_tile<2, 1, false>,
+                              (const void *)k_ntt_tile<2, 2, false>, (const void *)k_ntt_tile<2, 1, true>, (const void *)k_ntt_tile<2, 2, true>})
+            KZG_HIP_CHECK(ctx, hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         ctx->attr_ntt_set = true;
     }
     NttPlan *p = new NttPlan();
@@ -575,6 +800,31 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, siz
     // XCD-aware tile order (xcd_tile): pass 1 always; pass 2 only at 2^24, the one size where it measured a gain (option ntt_xcd: 0 off,
     // 1 this rule, 2 pass 2 only, 3 both; profiles/r05_ntt_xcd_probe.txt)
     const int xcd1 = ctx->opt_ntt_xcd & 1, xcd2 = ctx->opt_ntt_xcd == 1 ? (log_n >= 24) : (ctx->opt_ntt_xcd >> 1 & 1);
+    if (ctx->opt_ntt_kernel) {  // round 6: load / store fused into the first / last stage pair (k_ntt_tile)
+        NttTile a1, a2;
+        a1.t = p->k1; a1.kother = p->k2; a1.vec_log = vec1; a1.lo_bits = p->lo_bits; a1.nnz = 0; a1.xcd = xcd1; a1.scale_folded = 0;
+        a1.sw = LDS_SWIZZLE[p->k1][vec1]; a1.tw = p->tw1; a1.tw_lo = p->tw_lo; a1.tw_hi = p->tw_hi; a1.tw_full = p->tw_full;
+        a1.scale = p->scale; a1.scale_p = p->scale_p;
+        a2 = a1;
+        a2.t = p->k2; a2.kother = p->k1; a2.vec_log = vec2; a2.xcd = xcd2; a2.scale_folded = p->tw_full ? 1 : 0;
+        a2.sw = LDS_SWIZZLE[p->k2][vec2]; a2.tw = p->tw2;
+        const unsigned nb1 = 1u << (p->k1 + vec1 - 2), nb2 = 1u << (p->k2 + vec2 - 2);  // radix-4 butterflies per tile
+        const bool two1 = ctx->opt_ntt_kernel == 2 && nb1 >= 512, two2 = ctx->opt_ntt_kernel == 2 && nb2 >= 512;
+        const bool is_short = nnz <= ((size_t)1 << p->k2);
+        if (is_short) {
+            if (nnz) KZG_HIP_CHECK(ctx, hipMemcpyAsync(scratch, d_data, nnz * sizeof(Fr), hipMemcpyDeviceToDevice, st));  // pass 2 writes d_data
+            a2.nnz = (uint32_t)nnz;
+            if (two2) KZG_LAUNCH(ctx, st, "k_ntt_pass2_short", (k_ntt_tile<2, 2, true>), g2, nb2 / 2, lds2, scratch, d_data, a2);
+            else KZG_LAUNCH(ctx, st, "k_ntt_pass2_short", (k_ntt_tile<2, 1, true>), g2, nb2, lds2, scratch, d_data, a2);
+            return KZG_OK;
+        }
+        a2.tw_full = nullptr;
+        if (two1) KZG_LAUNCH(ctx, st, "k_ntt_pass1", (k_ntt_tile<1, 2, false>), g1, nb1 / 2, lds1, d_data, scratch, a1);
+        else KZG_LAUNCH(ctx, st, "k_ntt_pass1", (k_ntt_tile<1, 1, false>), g1, nb1, lds1, d_data, scratch, a1);
+        if (two2) KZG_LAUNCH(ctx, st, "k_ntt_pass2", (k_ntt_tile<2, 2, false>), g2, nb2 / 2, lds2, scratch, d_data, a2);
+        else KZG_LAUNCH(ctx, st, "k_ntt_pass2", (k_ntt_tile<2, 1, false>), g2, nb2, lds2, scratch, d_data, a2);
+        return KZG_OK;
+    }
     if (nnz <= ((size_t)1 << p->k2)) {
         if (nnz) KZG_HIP_CHECK(ctx, hipMemcpyAsync(scratch, d_data, nnz * sizeof(Fr), hipMemcpyDeviceToDevice, st));  // pass 2 writes d_data
         KZG_LAUNCH(ctx, st, "k_ntt_pass2_short", k_ntt_pass2<true>, g2, th2, lds2, scratch, d_data, p->k1, p->k2, vec2, p->tw2, p->scale,
