@@ -2,7 +2,7 @@
 // translation units of libkzg_mi355x.so.
 #pragma once
 #ifndef KZG_NTT_KERNEL_DEFAULT
-#define KZG_NTT_KERNEL_DEFAULT 0
+#define KZG_NTT_KERNEL_DEFAULT 1
 #endif
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -141,6 +141,7 @@ struct kzg_ctx {
     int opt_trusted_points = 0;        // 1: caller vouches for its points (skip the subgroup check of uploads / verifier inputs)
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
     int opt_ntt_kernel = KZG_NTT_KERNEL_DEFAULT;  // 0: three-phase passes (k_ntt_pass1/2); 1: load/store fused into the first/last stage pair (k_ntt_tile); 2: 1 + two butterflies per thread
+    int opt_ntt_vec2_log = 1;          // pass 2: at most 2^v rows per tile (rows are contiguous: narrow tiles cost no coalescing on the load side)
     int opt_ntt_xcd = 1;               // XCD-aware tile order: bit 0 = pass 1, bit 1 = pass 2 (ntt.hip, xcd_tile)
     int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort
                                        // kernels of the neighbouring MSMs in flight (measured +6 % throughput)

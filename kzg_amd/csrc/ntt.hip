@@ -789,9 +789,9 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, siz
     // rows are contiguous, so narrower pass-2 tiles cost no coalescing and two blocks share a CU: one loads / stores while the
     // other computes (same-box at 2^20: 58.2 -> 54.2 us; 2^22: 2048-element tiles 224.7 -> 205.2 us); pass 1 needs its 128-byte
     // column segments
-    const uint32_t vmax2 = vmax < 1 ? vmax : 1;
+    const uint32_t vmax2 = vmax < (uint32_t)ctx->opt_ntt_vec2_log ? vmax : (uint32_t)ctx->opt_ntt_vec2_log;
     uint32_t vec2 = 12 - p->k2 < vmax2 ? 12 - p->k2 : vmax2;
-    if (p->k2 <= 11 && p->k2 + vec2 > 11) vec2 = 11 - p->k2;
+    if (ctx->opt_ntt_vec2_log <= 1 && p->k2 <= 11 && p->k2 + vec2 > 11) vec2 = 11 - p->k2;
     while (vec2 && (1u << (p->k1 - vec2)) < 256u) vec2--;
     size_t lds1 = ((size_t)1 << (p->k1 + vec1)) * sizeof(Fr29), lds2 = ((size_t)1 << (p->k2 + vec2)) * sizeof(Fr29);
     unsigned g1 = 1u << (p->k2 - vec1), g2 = 1u << (p->k1 - vec2);
