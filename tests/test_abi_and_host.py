@@ -3,6 +3,7 @@ the host-only helpers work, and there is no CPU fallback (context creation fails
 import ctypes
 import os
 import re
+import sys
 
 import pytest
 
@@ -54,6 +55,52 @@ def test_product_does_not_import_oracle():
     so = os.path.join(ROOT, "kzg_amd", "libkzg_mi355x.so")
     out = os.popen(f"ldd {so}").read()
     assert "kzg_oracle" not in out
+
+
+def test_bench_timed_region_does_not_import_oracle_or_torch():
+    """bench.py's parts (tools/benchlib): only `checks` (the after-the-timer checkers) and `cpu_pool` (the CPU baseline's workers) may
+    touch oracle/; the module that holds the timed region (headline), the other readings, the rank control plane and bench.py itself
+    import neither the oracle nor torch; the control plane is standard-library sockets."""
+    import ast
+    lib_dir = os.path.join(ROOT, "tools", "benchlib")
+    files = {f: os.path.join(lib_dir, f) for f in os.listdir(lib_dir) if f.endswith(".py")}
+    files["bench.py"] = os.path.join(ROOT, "bench.py")
+    assert {"headline.py", "paths.py", "control.py", "traffic.py", "sharded.py", "checks.py", "cpu_pool.py", "common.py"} <= set(files)
+    for name, path in files.items():
+        mods = set()
+        for node in ast.walk(ast.parse(open(path).read())):
+            if isinstance(node, ast.Import):
+                mods |= {a.name.split(".")[0] for a in node.names}
+            elif isinstance(node, ast.ImportFrom) and node.module and node.level == 0:
+                mods.add(node.module.split(".")[0])
+        assert "torch" not in mods, name
+        if name not in ("checks.py", "cpu_pool.py"):
+            assert "oracle" not in mods, name
+    assert len(open(files["bench.py"]).read().splitlines()) <= 300
+
+
+def test_bench_control_plane_star_of_three_ranks():
+    """tools/benchlib/control.py: barrier, max-over-ranks, agreement, gather and broadcast over the TCP star, three ranks as threads."""
+    import threading
+    sys.path.insert(0, ROOT)
+    from tools.benchlib.control import TcpStar
+    port, world, out = 29911, 3, {}
+
+    def rank_main(r):
+        s = TcpStar(r, world, "127.0.0.1", port, timeout_s=30)
+        got = [s.all_gather(None), max(s.all_gather(1.5 * (r + 1))), all(s.all_gather(r != 1)), s.all_gather({"rank": r, "blob": bytes([r]) * 200000}),
+               s.all_gather(b"id-from-0" if r == 0 else None)[0]]
+        s.close()
+        out[r] = got
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in reversed(th):      # the hub starts last: the others retry until it listens
+        t.start()
+    for t in th:
+        t.join(60)
+    for r in range(world):
+        g = out[r]
+        assert g[0] == [None] * 3 and g[1] == 4.5 and g[2] is False and g[4] == b"id-from-0"
+        assert [d["rank"] for d in g[3]] == [0, 1, 2] and g[3][2]["blob"] == bytes([2]) * 200000
 
 
 def test_polynomial_and_domain_host_mirror():
