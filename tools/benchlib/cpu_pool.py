@@ -35,11 +35,12 @@ def _cpu_worker_msm(args):
     """One CPU Pippenger over terms [lo, hi) of the shared sample file -- the oracle library's TIMING leg (orc_msm_g1_fast: signed
     16-bit windows, batch-affine bucket accumulation, unrolled Montgomery multiplication; checked against the plain Pippenger in
     tests/test_oracle_c.py and, by the caller, against the GPU's result); returns (seconds, 96-byte result)."""
-    path, n, lo, hi = args
+    path, n, lo, hi = args[:4]
+    plain = len(args) > 4 and args[4] == "plain"    # the textbook Pippenger (orc_msm_g1: window by size): faster below ~2^15 terms
     from oracle import c_oracle as C
     pts, sc = _read_sample(path, n, lo, hi)
     t0 = time.perf_counter()
-    out = C.msm_g1_fast_raw(pts, sc, hi - lo)
+    out = C.msm_g1_raw(pts, sc, hi - lo) if plain else C.msm_g1_fast_raw(pts, sc, hi - lo)
     return time.perf_counter() - t0, out
 
 
@@ -140,10 +141,15 @@ class CpuBaseline:
                                                   "matches_gpu": bool(not nz and ow == gpu["witness"][2])}
             for log_m in sorted(k for k in gpu["msm"] if k != log_top):     # the smaller sizes BASELINE.md lists: prefixes of the same sample
                 m = 1 << log_m
-                rs = list(self.pool.map(_cpu_worker_msm, [(path, n, 0, m)] * 3))
-                tm = statistics.median(t for t, _ in rs)
+                # both of the oracle's Pippengers, the faster one is the baseline: the 16-bit windows of orc_msm_g1_fast cost 2^20 bucket
+                # operations whatever n is, the textbook loop picks its window by size
+                rs = list(self.pool.map(_cpu_worker_msm, [(path, n, 0, m)] * 3 + [(path, n, 0, m, "plain")] * 3))
+                tf, tp = statistics.median(t for t, _ in rs[:3]), statistics.median(t for t, _ in rs[3:])
+                tm = min(tf, tp)
                 legs["msm_2e%d" % log_m] = {"value": round(1 / tm, 4), "unit": "commitments/s", "seconds": round(tm, 5), "cores": 1,
-                                            "terms_per_s": round(m / tm, 1), "matches_gpu": all(o == gpu["msm"][log_m] for _, o in rs)}
+                                            "terms_per_s": round(m / tm, 1), "matches_gpu": all(o == gpu["msm"][log_m] for _, o in rs),
+                                            "algorithm": "orc_msm_g1_fast" if tf <= tp else "orc_msm_g1 (textbook Pippenger, window by size)",
+                                            "seconds_by_algorithm": {"orc_msm_g1_fast": round(tf, 5), "orc_msm_g1": round(tp, 5)}}
             single.update(legs)
             single["all_match_gpu"] = all(v["matches_gpu"] for v in legs.values())
             # (ii) all cores.  The box may grant far fewer cores than os.cpu_count() reports (cgroup quota), so the usable
