@@ -1384,11 +1384,17 @@ extern "C" int kzg_witness_coeff(kzg_ctx *ctx, const kzg_srs *srs, const void *c
     Fr *dpx = (Fr *)lane_alloc(ctx, lane, 256);
     if (!dq || !dpx) return fail(ctx, KZG_ERR_ALLOC, "workspace");
     KZG_TRY(quotient_linear_run(ctx, lane, (const Fr *)d, n, xm, dq, dpx));
-    Fr px;
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
+    // p(x) goes to the lane's PINNED staging buffer (behind the 144 bytes finish_point uses): a device-to-host copy into pageable
+    // memory -- the stack variable this used to be -- makes hipMemcpyAsync wait for the stream, so the host sat out the three quotient
+    // kernels before it could enqueue the MSM's fourteen, and the GPU then idled between those short kernels (0.4-0.5 ms of a lone
+    // create_witness; profiles/r06_prof_witness_coeff.txt)
+    KZG_TRY(lane_pinned(ctx, lane, 4096));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned + 1024, dpx, 32, hipMemcpyDeviceToHost, st));
     MsmPoint *res = nullptr;
     KZG_TRY(lease_msm(ctx, ls, srs, 0, dq, n - 1, sfmt, &res));
     KZG_TRY(finish_point(ctx, lane, res, out, ofmt, flags));  // synchronises the stream
+    Fr px;
+    memcpy(px.v, ctx->lanes[lane].pinned + 1024, 32);
     // remainder of (p - y)/(X - x) is p(x) - y: Some(_) => Err(PointNotOnPolynomial)
     if (memcmp(px.v, y, 32) != 0) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
     return KZG_OK;

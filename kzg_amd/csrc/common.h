@@ -174,7 +174,7 @@ struct kzg_ctx {
     int accum_blocks_single() const { return opt_accum_blocks ? opt_accum_blocks : 256 * KZG_ACCUM_WAVES; }
     int accum_blocks_batch() const { return opt_accum_blocks_batch ? opt_accum_blocks_batch : 240 * KZG_ACCUM_WAVES; }
     int num_cus = 256;
-    std::atomic<bool> attr_msm_set{false}, attr_ntt_set{false}, attr_wide_set{false}, attr_sort20_set{false};  // > 64 KiB dynamic-LDS opt-in done for this device
+    std::atomic<bool> attr_msm_set{false}, attr_ntt_set{false}, attr_wide_set{false}, attr_sort20_set{false}, attr_horner_set{false};  // > 64 KiB dynamic-LDS opt-in done for this device
     // profiling
     bool prof = false;
     bool prof_only_accum = false;  // events around k_accum_affine only (bench.py's timed region: two events per kernel launch cost 1.4 % there)

@@ -120,36 +120,76 @@ __device__ __forceinline__ Fr horner8(const Fr a[HE], const Fr &x) {
     return v;
 }
 
-__device__ __forceinline__ void load8(const Fr *coeffs, size_t n, size_t i0, Fr a[HE]) {
+// The block's 2048 coefficients (64 KiB) move between global memory and the threads' registers through LDS: a thread owns EIGHT
+// CONSECUTIVE coefficients (256 bytes), so direct loads / stores put the 64 lanes of an instruction 256 bytes apart -- every
+// instruction touched 64 lines for 16 bytes each (k_quotient_apply moved 64 MB in 59 us, k_horner_partials 32 MB in 38 us: 1.1 and
+// 0.9 TB/s).  Now lane l of an instruction moves the 16-byte chunk l of a 4 KiB run (whole lines), and the
+// thread's own 16 chunks sit in LDS at chunk index 17 t + j: the 272-byte stride spreads 16 lanes of a ds_read_b128 over all 64 banks.
+constexpr int H_CHUNKS = HB * 2;                         // 16-byte chunks per block
+constexpr int H_LDS_BYTES = (H_CHUNKS + HT) * 16;        // one pad chunk per thread segment
+typedef uint32_t __attribute__((ext_vector_type(4))) hchunk;
+
+__device__ __forceinline__ uint32_t h_slot(uint32_t c) { return c + (c >> 4); }
+
+// a[k] = coeffs[block start + 8 t + k] (zero beyond n), through the LDS tile `lds` (H_LDS_BYTES)
+__device__ __forceinline__ void load8_tile(const Fr *coeffs, size_t n, hchunk *lds, Fr a[HE]) {
+    const int t = threadIdx.x;
+    const size_t c0 = (size_t)blockIdx.x * H_CHUNKS, cn = n * 2;     // chunk indices; the array holds cn chunks
+    const hchunk *g = (const hchunk *)coeffs;
+    hchunk v[16];
 #pragma unroll
-    for (int k = 0; k < HE; k++) a[k] = (i0 + k < n) ? coeffs[i0 + k] : Fr::zero();
+    for (int j = 0; j < 16; j++) {
+        const size_t c = c0 + (size_t)(t + j * HT);
+        v[j] = c < cn ? g[c] : hchunk{0u, 0u, 0u, 0u};
+    }
+#pragma unroll
+    for (int j = 0; j < 16; j++) lds[h_slot(t + j * HT)] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HE; k++) {
+        const hchunk lo = lds[17 * t + 2 * k], hi = lds[17 * t + 2 * k + 1];
+        a[k].v[0] = lo.x; a[k].v[1] = lo.y; a[k].v[2] = lo.z; a[k].v[3] = lo.w;
+        a[k].v[4] = hi.x; a[k].v[5] = hi.y; a[k].v[6] = hi.z; a[k].v[7] = hi.w;
+    }
 }
 
+// x8^(2^k), k < 8: the multipliers of the eight steps of a 256-thread tree / scan.  Computed once on the host -- every thread used to
+// square its own copy eight times (8 of a thread's 23-31 multiplications).
+struct HornerPowers {
+    Fr p[8];
+};
+
 // S[b] = sum_{i in block b} a_i x^(i - start_b)
-__global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t n, Fr x, Fr x8, Fr *S) {
-    __shared__ Fr sh[HT];
+__global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t n, Fr x, HornerPowers pw, Fr *S) {
+    extern __shared__ __attribute__((aligned(16))) hchunk h_lds[];
     int t = threadIdx.x;
-    size_t i0 = (size_t)blockIdx.x * HB + (size_t)t * HE;
     Fr a[HE];
-    load8(coeffs, n, i0, a);
+    load8_tile(coeffs, n, h_lds, a);
     Fr v = horner8(a, x);
-    Fr m = x8;
+    __syncthreads();                 // the tile is consumed: its memory carries the tree
+    Fr *sh = (Fr *)h_lds;
     sh[t] = v;
     __syncthreads();
-    for (int off = 1; off < HT; off <<= 1) {
+#pragma unroll
+    for (int st = 0; st < 8; st++) {
+        const int off = 1 << st;
         bool active = (t & (2 * off - 1)) == 0;
-        if (active) v = add(v, mul(sh[t + off], m));
+        if (active) v = add(v, mul(sh[t + off], pw.p[st]));
         __syncthreads();
         if (active) sh[t] = v;
         __syncthreads();
-        m = sqr(m);
     }
     if (t == 0) S[blockIdx.x] = v;
 }
 
-// H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block.
+// H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block.  The multipliers of the ten scan
+// steps, (X^g)^(2^k), come from the host: every thread used to raise X to the g-th power by a 64-step square-and-multiply loop of its
+// own and to square the result ten times -- 64 us for a kernel that moves 32 KB (profiles/r06_prof_witness_coeff.txt).
 constexpr int HS_T = 1024;
-__global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk, Fr X, Fr *H, Fr *px) {
+struct ScanPowers {
+    Fr p[10];
+};
+__global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk, Fr X, ScanPowers pw, Fr *H, Fr *px) {
     __shared__ Fr sh[HS_T];
     int t = threadIdx.x;
     uint32_t g = (nblk + HS_T - 1) / HS_T;  // blocks per thread
@@ -158,19 +198,19 @@ __global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk
     Fr v = Fr::zero();
     for (uint32_t k = g; k-- > 0;) {
         Fr s = (b0 + k < nblk) ? S[b0 + k] : Fr::zero();
-        v = add(mul(v, X), s);
+        v = g == 1 ? s : add(mul(v, X), s);
     }
-    Fr M = pow_u64(X, (uint64_t)g);
-    // inclusive suffix scan A_t = v_t + M A_{t+1}
+    // inclusive suffix scan A_t = v_t + M A_{t+1}, M = X^g
     sh[t] = v;
     __syncthreads();
-    for (int off = 1; off < HS_T; off <<= 1) {
+#pragma unroll
+    for (int st = 0; st < 10; st++) {
+        const int off = 1 << st;
         Fr o = (t + off < HS_T) ? sh[t + off] : Fr::zero();
         __syncthreads();
-        v = add(v, mul(o, M));
+        v = add(v, mul(o, pw.p[st]));
         sh[t] = v;
         __syncthreads();
-        M = sqr(M);
     }
     Fr carry = (t + 1 < HS_T) ? sh[t + 1] : Fr::zero();
     for (uint32_t k = g; k-- > 0;) {
@@ -182,36 +222,49 @@ __global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk
     if (t == 0) *px = carry;
 }
 
-// q_i = sum_{j > i} a_j x^(j-i-1) for i < n - 1.  coeffs may alias q.
-__global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t n, Fr x, Fr x8, const Fr *H, Fr *q) {
-    __shared__ Fr sh[HT];
+// q_i = sum_{j > i} a_j x^(j-i-1) for i < n - 1.  coeffs may alias q (a block reads its whole tile before it writes).
+__global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t n, Fr x, HornerPowers pw, const Fr *H, Fr *q) {
+    extern __shared__ __attribute__((aligned(16))) hchunk h_lds[];
     int t = threadIdx.x;
-    size_t i0 = (size_t)blockIdx.x * HB + (size_t)t * HE;
     Fr a[HE];
-    load8(coeffs, n, i0, a);
+    load8_tile(coeffs, n, h_lds, a);
     Fr v = horner8(a, x);
-    if (t == HT - 1) v = add(v, mul(x8, H[blockIdx.x]));  // fold the carry from higher blocks in
-    Fr M = x8;
+    const Fr Hb = H[blockIdx.x];
+    if (t == HT - 1) v = add(v, mul(pw.p[0], Hb));  // fold the carry from higher blocks in
+    __syncthreads();                 // every thread has read its coefficients: the tile's memory carries the scan
+    Fr *sh = (Fr *)h_lds;
     sh[t] = v;
     __syncthreads();
-    for (int off = 1; off < HT; off <<= 1) {
+#pragma unroll
+    for (int st = 0; st < 8; st++) {
+        const int off = 1 << st;
         Fr o = (t + off < HT) ? sh[t + off] : Fr::zero();
         __syncthreads();
-        v = add(v, mul(o, M));
+        v = add(v, mul(o, pw.p[st]));
         sh[t] = v;
         __syncthreads();
-        M = sqr(M);
     }
-    Fr carry = (t + 1 < HT) ? sh[t + 1] : H[blockIdx.x];
+    Fr carry = (t + 1 < HT) ? sh[t + 1] : Hb;
+    __syncthreads();
+    // the eight quotient coefficients of this thread go back through the tile: whole-line stores
 #pragma unroll
     for (int k = HE - 1; k >= 0; k--) {
-        if (i0 + k + 1 < n) q[i0 + k] = carry;
+        h_lds[17 * t + 2 * k] = hchunk{carry.v[0], carry.v[1], carry.v[2], carry.v[3]};
+        h_lds[17 * t + 2 * k + 1] = hchunk{carry.v[4], carry.v[5], carry.v[6], carry.v[7]};
         carry = add(a[k], mul(carry, x));
+    }
+    __syncthreads();
+    const size_t c0 = (size_t)blockIdx.x * H_CHUNKS, cq = (n - 1) * 2;     // q has n - 1 coefficients
+    hchunk *g = (hchunk *)q;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const size_t c = c0 + (size_t)(t + j * HT);
+        if (c < cq) g[c] = h_lds[h_slot(t + j * HT)];
     }
 }
 
 static int horner_common(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x, Fr **S, Fr **H, Fr **px,
-                         uint32_t *nblk_out, Fr *x8_out) {
+                         uint32_t *nblk_out, HornerPowers *pw_out) {
     hipStream_t st = ctx->lanes[lane].stream;
     uint32_t nblk = (uint32_t)((n + HB - 1) / HB);
     *S = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
@@ -220,19 +273,31 @@ static int horner_common(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, c
     if (!*S || !*H || !*px) return fail(ctx, KZG_ERR_ALLOC, "Horner workspace not reserved");
     Fr x8 = pow_u64(x, HE);
     Fr X = pow_u64(x, HB);
-    KZG_LAUNCH(ctx, st, "k_horner_partials", k_horner_partials, nblk, HT, 0, d_coeffs, n, x, x8, *S);
-    KZG_LAUNCH(ctx, st, "k_horner_scan", k_horner_scan, 1, HS_T, 0, *S, nblk, X, *H, *px);
+    HornerPowers pw;
+    pw.p[0] = x8;
+    for (int k = 1; k < 8; k++) pw.p[k] = sqr(pw.p[k - 1]);
+    if (!ctx->attr_horner_set) {
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_horner_partials, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES));
+        KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_quotient_apply, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES));
+        ctx->attr_horner_set = true;
+    }
+    KZG_LAUNCH(ctx, st, "k_horner_partials", k_horner_partials, nblk, HT, H_LDS_BYTES, d_coeffs, n, x, pw, *S);
+    ScanPowers spw;
+    spw.p[0] = pow_u64(X, (uint64_t)((nblk + HS_T - 1) / HS_T));
+    for (int k = 1; k < 10; k++) spw.p[k] = sqr(spw.p[k - 1]);
+    KZG_LAUNCH(ctx, st, "k_horner_scan", k_horner_scan, 1, HS_T, 0, *S, nblk, X, spw, *H, *px);
     *nblk_out = nblk;
-    *x8_out = x8;
+    *pw_out = pw;
     return KZG_OK;
 }
 
 int poly_eval_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x_mont, Fr *d_y_out) {
     hipStream_t st = ctx->lanes[lane].stream;
     if (n == 0) return fail(ctx, KZG_ERR_SHAPE, "empty polynomial");
-    Fr *S, *H, *px, x8;
+    Fr *S, *H, *px;
+    HornerPowers pw;
     uint32_t nblk;
-    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &x8));
+    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &pw));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_y_out, px, sizeof(Fr), hipMemcpyDeviceToDevice, st));
     return KZG_OK;
 }
@@ -241,10 +306,11 @@ int quotient_linear_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, co
                         Fr *d_px_out) {
     hipStream_t st = ctx->lanes[lane].stream;
     if (n == 0) return fail(ctx, KZG_ERR_SHAPE, "empty polynomial");
-    Fr *S, *H, *px, x8;
+    Fr *S, *H, *px;
+    HornerPowers pw;
     uint32_t nblk;
-    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &x8));
-    if (n > 1) KZG_LAUNCH(ctx, st, "k_quotient_apply", k_quotient_apply, nblk, HT, 0, d_coeffs, n, x_mont, x8, H, d_q_out);
+    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &pw));
+    if (n > 1) KZG_LAUNCH(ctx, st, "k_quotient_apply", k_quotient_apply, nblk, HT, H_LDS_BYTES, d_coeffs, n, x_mont, pw, H, d_q_out);
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_px_out, px, sizeof(Fr), hipMemcpyDeviceToDevice, st));
     return KZG_OK;
 }

@@ -588,11 +588,15 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         KZG_LAUNCH(ctx, st, "k_load_padded", k_load_padded, gridfor(n2), 256, 0, pin, n, p, n2, to_m);
         KZG_LAUNCH(ctx, st, "k_sub_linear", k_sub_linear, gridfor(n2), 256, 0, p, n2, p, n2, sub(ym, xm));
         KZG_TRY(quotient_linear_run(ctx, lane, p, n2, xm, q, dpx));
-        Fr px;
-        KZG_HIP_CHECK(ctx, hipMemcpyAsync(px.v, dpx, 32, hipMemcpyDeviceToHost, st));
+        // (to the lane's pinned staging buffer: a copy into pageable host memory would make the host wait for the stream here, before
+        // the MSM is enqueued -- see kzg_witness_coeff)
+        KZG_TRY(lane_pinned(ctx, lane, 4096));
+        KZG_HIP_CHECK(ctx, hipMemcpyAsync(ctx->lanes[lane].pinned + 1024, dpx, 32, hipMemcpyDeviceToHost, st));
         MsmPoint *res = nullptr;
         KZG_TRY(sink_msm(q, n2 - 1, &res));
         KZG_TRY(sink_finish(res));
+        Fr px;
+        memcpy(px.v, ctx->lanes[lane].pinned + 1024, 32);
         if (ctx->prof) prof_collect(ctx);
         if (!px.is_zero()) return fail(ctx, KZG_ERR_POINT_NOT_ON_POLY, "point not on polynomial!");
         Fr r0 = sub(ym, xm), r1 = Fr::one();
@@ -754,10 +758,17 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         KZG_LAUNCH(ctx, st, "k_any_nonzero", k_any_nonzero, gridfor(k), 256, 0, A + (N - k), k, flag);
         KZG_TRY(sink_msm(A, nq, &res));
     }
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(&hflag, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    // flag and interpolant leave through the lane's pinned staging buffer (flag at +1024, coefficients from +4096): copies into the
+    // caller's pageable memory would block the host until the MSM in front of them has finished, and the conversion kernel and the
+    // second copy would only be enqueued then
+    KZG_TRY(lane_pinned(ctx, lane, 8192 + k * 32));
+    char *pin_host = ctx->lanes[lane].pinned;
     if (to_m) KZG_TRY(fr_convert(ctx, st, I, k, 0));
-    KZG_HIP_CHECK(ctx, hipMemcpyAsync(out_r, I, k * 32, hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin_host + 1024, flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    KZG_HIP_CHECK(ctx, hipMemcpyAsync(pin_host + 4096, I, k * 32, hipMemcpyDeviceToHost, st));
     KZG_TRY(sink_finish(res));
+    memcpy(&hflag, pin_host + 1024, sizeof(int));
+    memcpy(out_r, pin_host + 4096, k * 32);
     ps.gsh = gsh;
     ps.ok = !(hflag & 1);  // the stream is synchronised: the slot's contents are complete (a wrong y leaves the point set usable)
     if (ctx->prof) prof_collect(ctx);

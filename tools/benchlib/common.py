@@ -57,7 +57,10 @@ def view(kzg_amd, buf, first, n):
     return v
 
 
-def timeit(f, reps=3, warm=1):
+def timeit(f, reps=5, warm=4):
+    """ms per call.  Four untimed calls first: every reading of `paths` follows seconds of host-side checking (the oracle's Horner
+    loops) during which the GPU idles and drops its clocks -- one warm-up call read a lone create_witness 0.3-0.5 ms slower inside the
+    bench than the same call in a loop (profiles/r06_prof_witness_coeff.txt)."""
     for _ in range(warm):
         f()
     t0 = time.perf_counter()

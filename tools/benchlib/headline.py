@@ -282,7 +282,7 @@ def run(args):
                 rc = engine.lib.kzg_msm_g1(engine.ctx, srs.handle, 0, scal.ptr, n_poly, scal.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT)
                 if rc:
                     raise RuntimeError(engine.last_error())
-            latency_ms = timeit(single, reps=4, warm=1)
+            latency_ms = timeit(single, reps=5, warm=4)
             if roofline is not None:
                 engine.prof_enable(True)
                 engine.prof_reset()

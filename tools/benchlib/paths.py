@@ -113,8 +113,8 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
     ev.upload(host_coeffs)
     def ntt():
         assert lib.kzg_ntt_fr(ctx, ev.ptr, log_n, 0, L.IN_DEVICE) == 0, engine.last_error()
-    reps = 5
-    ntt_ms = timeit(ntt, reps=20, warm=2)       # wall time of the blocking call, profiling off
+    reps = 20
+    ntt_ms = timeit(ntt, reps=20, warm=20)       # wall time of the blocking call, profiling off
     engine.prof_enable(True)                    # kernel times: HIP events on the engine's stream (their recording costs wall time)
     engine.prof_reset()
     timeit(ntt, reps=reps, warm=1)
