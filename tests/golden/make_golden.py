@@ -49,13 +49,25 @@ def main():
                     "result": pt(M.g1_multi_exp(gs[:16], s))})
     json.dump({"tau": sc(tau), "cases": msm}, open(os.path.join(HERE, "msm.json"), "w"), indent=0)
 
-    # (iii) NTT vectors log n = 0..8
+    # (iii) NTT vectors log n = 0..8 (9, 10 below)
     ntt = []
     for log_n in range(0, 9):
         xs = [rng.randrange(M.R) for _ in range(1 << log_n)]
         e = M.EvaluationDomain.from_coeffs(xs)
         e.fft()
         ntt.append({"log_n": log_n, "omega": sc(e.omega), "input": [sc(x) for x in xs], "fft": [sc(x) for x in e.coeffs]})
+    # round 6: log n = 9, 10 (0..10) from a generator of their own, so that the vectors behind them keep their values, and
+    # EvaluationDomain::ifft of every input (src/ft.rs:115-140) beside its fft
+    rng2 = random.Random(20261004)
+    for log_n in (9, 10):
+        xs = [rng2.randrange(M.R) for _ in range(1 << log_n)]
+        e = M.EvaluationDomain.from_coeffs(xs)
+        e.fft()
+        ntt.append({"log_n": log_n, "omega": sc(e.omega), "input": [sc(x) for x in xs], "fft": [sc(x) for x in e.coeffs]})
+    for case in ntt:
+        e = M.EvaluationDomain.from_coeffs([int.from_bytes(bytes.fromhex(h), "little") for h in case["input"]])
+        e.ifft()
+        case["ifft"] = [sc(x) for x in e.coeffs]
     json.dump({"cases": ntt}, open(os.path.join(HERE, "ntt.json"), "w"), indent=0)
 
     # (iv)+(v) KZG vectors: commit / create_witness (incl. degree-1 edge, wrong y) / batched / eval form

@@ -25,6 +25,7 @@ def test_golden_ntt(engine, case):
     want = [GU.sc(h) for h in case["fft"]]
     assert engine.ntt(xs, case["log_n"]) == want
     assert engine.ntt(want, case["log_n"], inverse=True) == xs
+    assert engine.ntt(xs, case["log_n"], inverse=True) == [GU.sc(h) for h in case["ifft"]]     # EvaluationDomain::ifft of the input itself (src/ft.rs:115-140)
     assert kzg_amd.compute_omega(len(xs))[2] == GU.sc(case["omega"])
 
 

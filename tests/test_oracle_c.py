@@ -52,6 +52,7 @@ def test_golden_ntt(case):
     want = [GU.sc(h) for h in case["fft"]]
     assert C.fft(xs) == want
     assert C.fft(want, inverse=True) == xs
+    assert C.fft(xs, inverse=True) == [GU.sc(h) for h in case["ifft"]]     # EvaluationDomain::ifft of the input itself (src/ft.rs:115-140)
     assert C.compute_omega(len(xs))[2] == GU.sc(case["omega"])
 
 

@@ -130,3 +130,41 @@ def test_splices_call_the_abi_with_the_right_arity():
         assert fn in src[src.index("multi-GPU"):] if "multi-GPU" in src else fn in src, fn
     for cite in ("src/coeff_form.rs:59-64", "src/coeff_form.rs:66-81", "src/coeff_form.rs:83-111", "src/eval_form.rs:114-140", "src/ft.rs:111-140"):
         assert cite in open(os.path.join(ROOT, "integration", "mi355x.rs")).read(), cite
+
+
+def test_pin_test_reads_only_keys_the_fixtures_hold():
+    """INTEGRATION.md's `mi355x_pin` (the one test a maintainer runs on the reference side, the only road from "parity: partial" to
+    green): every fixture file it includes exists under tests/golden/, and every JSON key it indexes exists in that file -- so the
+    paste cannot fail on a renamed field.  It must cover all four fixture groups: coefficient form (incl. the degree-1 edge case),
+    evaluation form, the NTT (fft and ifft, log n = 0..10) and multi_exp."""
+    import json
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"```rust\n(#\[cfg\(test\)\]\nmod mi355x_pin \{.*?)\n```", text, re.S)
+    assert m, "mi355x_pin block not found"
+    block = m.group(1)
+    fns = re.split(r"\n    #\[test\]\n", block)[1:]
+    names = [re.match(r"\s*fn ([a-z_0-9]+)", f).group(1) for f in fns]
+    assert names == ["layouts", "golden_commit_and_witness", "golden_eval_form", "golden_ntt", "golden_msm"]
+
+    def keys_of(obj, acc):
+        if isinstance(obj, dict):
+            for k, v in obj.items():
+                acc.add(k)
+                keys_of(v, acc)
+        elif isinstance(obj, list):
+            for v in obj:
+                keys_of(v, acc)
+        return acc
+    for name, body in zip(names, fns):
+        files = re.findall(r'include_str!\("\.\./tests/golden/([a-z_]+\.json)"\)', body)
+        if name == "layouts":
+            assert not files
+            continue
+        assert len(files) == 1, name
+        have = keys_of(json.load(open(os.path.join(ROOT, "tests", "golden", files[0]))), set())
+        used = set(re.findall(r'\["([a-z_0-9]+)"\]', body))
+        assert used and used <= have, (name, sorted(used - have))
+    kz = json.load(open(os.path.join(ROOT, "tests", "golden", "kzg.json")))
+    assert {"coeff", "degree1", "batched", "eval"} <= set(kz)
+    ntt = json.load(open(os.path.join(ROOT, "tests", "golden", "ntt.json")))["cases"]
+    assert [c["log_n"] for c in ntt] == list(range(11)) and all({"input", "fft", "ifft", "omega"} <= set(c) for c in ntt)
