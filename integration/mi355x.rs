@@ -196,21 +196,24 @@ pub fn single_node_rccl_env() {
     }
 }
 
-/// An SRS (monomial `gs` or a Lagrange basis) sharded contiguously over the group's GPUs; freed with the group that made it.
-pub struct ShardedSrs {
+/// An SRS (monomial `gs` or a Lagrange basis) sharded contiguously over the group's GPUs.  It BORROWS the group that made it:
+/// kzg_msrs_free reads the group's state (its devices, contexts and whether it is dead), so the borrow checker -- not a comment --
+/// keeps the group alive until every one of its SRSs has been dropped (with a raw pointer, safe code could drop or move
+/// the group first).
+pub struct ShardedSrs<'g> {
     s: *mut sys::kzg_msrs,
-    m: *mut sys::kzg_mctx,
+    group: &'g Mi355xGroup,
 }
-unsafe impl Send for ShardedSrs {}
-unsafe impl Sync for ShardedSrs {}
-impl ShardedSrs {
+unsafe impl<'g> Send for ShardedSrs<'g> {}
+unsafe impl<'g> Sync for ShardedSrs<'g> {}
+impl<'g> ShardedSrs<'g> {
     pub fn len(&self) -> usize {
         unsafe { sys::kzg_msrs_len(self.s) }
     }
 }
-impl Drop for ShardedSrs {
+impl<'g> Drop for ShardedSrs<'g> {
     fn drop(&mut self) {
-        unsafe { sys::kzg_msrs_free(self.m, self.s) } // (drop it before the group)
+        unsafe { sys::kzg_msrs_free(self.group.m, self.s) }
     }
 }
 
@@ -235,16 +238,23 @@ impl Mi355xGroup {
         }
     }
     /// One process per GPU: rank 0 draws the id, the host carries the 128 bytes to the other ranks by its own means.
-    pub fn unique_id() -> Result<[u8; 128], String> {
-        single_node_rccl_env();
+    pub fn unique_id(single_node: bool) -> Result<[u8; 128], String> {
+        if single_node {
+            single_node_rccl_env();
+        }
         let mut id = [0u8; 128];
         match unsafe { sys::kzg_mctx_unique_id(id.as_mut_ptr() as *mut c_void) } {
             0 => Ok(id),
             e => Err(format!("kzg_mctx_unique_id failed with {}: {}", e, Self::create_error())),
         }
     }
-    pub fn for_rank(device: i32, rank: i32, world: i32, id: &[u8; 128]) -> Result<Self, String> {
-        single_node_rccl_env();
+    /// `single_node`: the whole world lives on this node (the xGMI case) -- the loopback bootstrap knobs of single_node_rccl_env()
+    /// are applied; a world that spans nodes passes false and brings its own NCCL_* environment (with the loopback knobs it could
+    /// not form its communicator at all).
+    pub fn for_rank(device: i32, rank: i32, world: i32, id: &[u8; 128], single_node: bool) -> Result<Self, String> {
+        if single_node {
+            single_node_rccl_env();
+        }
         let mut m = std::ptr::null_mut();
         match unsafe { sys::kzg_mctx_create_rank(device, rank, world, id.as_ptr() as *const c_void, &mut m) } {
             0 => Ok(Mi355xGroup { m }),
@@ -268,13 +278,13 @@ impl Mi355xGroup {
         unsafe { CStr::from_ptr(buf.as_ptr() as *const std::os::raw::c_char) }.to_string_lossy().into_owned()
     }
     /// `KZGParams.gs` (or `lagrange_basis_g`) sharded over the group: rank r uploads its contiguous range of the caller's vector.
-    pub fn upload(&self, gs: &[blstrs::G1Projective]) -> ShardedSrs {
+    pub fn upload<'g>(&'g self, gs: &[blstrs::G1Projective]) -> ShardedSrs<'g> {
         let mut s = std::ptr::null_mut();
         let rc = unsafe { sys::kzg_srs_upload_g1_sharded(self.m, gs.as_ptr() as *const c_void, gs.len(), KZG_G1_JACOBIAN_MONT_144, &mut s) };
         if rc != 0 {
             self.fail(rc)
         }
-        ShardedSrs { s, m: self.m }
+        ShardedSrs { s, group: self }
     }
     /// KZGProver::commit over the group (src/coeff_form.rs:59-64).
     pub fn commit(&self, srs: &ShardedSrs, coeffs: &[Scalar]) -> G1Affine {

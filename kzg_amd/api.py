@@ -11,6 +11,7 @@ G1 points as 96-byte affine-Montgomery blobs (`bytes`), identity = 96 zero bytes
 happens on the GPU in libkzg_mi355x.so; nothing here computes field or curve operations.
 """
 import ctypes
+import os
 
 from . import _lib as L
 
@@ -513,6 +514,7 @@ class DeviceGroup:
             self._flush_c_stdio()
         self.handle = _handle
         self._engines = {}
+        self._flushed = False
 
     @staticmethod
     def _flush_c_stdio():
@@ -534,9 +536,21 @@ class DeviceGroup:
         return (lib.kzg_mctx_create_error() or b"").decode()
 
     @staticmethod
-    def unique_id():
+    def _node_local(single_node):
+        """single_node=None (default): the world is taken to live on this node unless the launcher says otherwise -- MASTER_ADDR set and
+        not a loopback address.  A world that spans nodes must NOT get the loopback bootstrap knobs (NCCL_SOCKET_IFNAME=lo,
+        NCCL_IB_DISABLE=1, NCCL_NET_PLUGIN=none): with them it cannot form its communicator and just meets the formation deadline
+        (ADVICE r5).  Pass single_node=False (or export KZG_RCCL_SINGLE_NODE_ENV=0) there and bring your own NCCL_* environment."""
+        if single_node is not None:
+            return bool(single_node)
+        addr = os.environ.get("MASTER_ADDR", "")
+        return addr in ("", "localhost") or addr.startswith("127.") or addr == "::1"
+
+    @staticmethod
+    def unique_id(single_node=None):
         lib = L.load()
-        DeviceGroup._host_env()
+        if DeviceGroup._node_local(single_node):
+            DeviceGroup._host_env()
         buf = ctypes.create_string_buffer(128)
         rc = lib.kzg_mctx_unique_id(buf)
         if rc:
@@ -544,9 +558,11 @@ class DeviceGroup:
         return buf.raw
 
     @staticmethod
-    def for_rank(device, rank, world, unique_id):
+    def for_rank(device, rank, world, unique_id, single_node=None):
+        """One process per GPU.  The one-node RCCL environment is applied only when the world is node-local (_node_local)."""
         lib = L.load()
-        DeviceGroup._host_env()
+        if DeviceGroup._node_local(single_node):
+            DeviceGroup._host_env()
         h = ctypes.c_void_p()
         rc = lib.kzg_mctx_create_rank(device, rank, world, unique_id, ctypes.byref(h))
         if rc:
@@ -559,7 +575,12 @@ class DeviceGroup:
         return (self.lib.kzg_mctx_last_error(self.handle) or b"").decode()
 
     def _check(self, rc):
-        self._flush_c_stdio()     # the communicator is formed inside the first call that needs it
+        # the communicator is formed inside the first call that needs it: RCCL's banner is flushed ONCE, after the first call that
+        # succeeded -- not a dlopen and a flush of all the host's stdio on every group call
+        if not self._flushed:
+            if rc == 0:
+                self._flushed = True
+            self._flush_c_stdio()
         if rc:
             _raise(self, rc)
 

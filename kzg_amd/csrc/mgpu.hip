@@ -277,6 +277,13 @@ struct kzg_mctx {
     std::vector<void *> d_quot;      // create_witness: the quotient polynomial on each GPU
     std::vector<size_t> cap_quot;
     std::vector<void *> h_status;    // pinned: the status words of all ranks after the exchange, per local GPU
+    // The exchange has a stream of ITS OWN per local GPU -- not a lane of the device's shared stream pool (capi.hip, StreamPool): the
+    // group's deadlines decide "exchange done / stream stuck" from this stream alone, so a plain Engine of the same device that is busy
+    // on pool lane 0 cannot make a healthy exchange read as NotReady (and get the communicators aborted), and a collective that never
+    // leaves its stream cannot hang another prover's hipStreamSynchronize.  x_ready orders the exchange behind the local
+    // phase on the context's lane 0; x_done, recorded right behind the collective and its status download, is what the wait polls.
+    std::vector<hipStream_t> xstream;
+    std::vector<hipEvent_t> x_ready, x_done;
     int inject_fail = 0;             // KZG_TEST_HOOKS: the next local phase fails with this code on local GPU 0
     int nlocal() const { return (int)devices.size(); }
     // one persistent host thread per local GPU (groups of several GPUs in one process): a sharded call hands each of them its
@@ -383,6 +390,16 @@ static int mctx_make_ctxs(kzg_mctx *m) {
         int rc = kzg_ctx_create(m->devices[i], &c);
         if (rc != KZG_OK) return rc;
         m->ctxs.push_back(c);
+        hipStream_t xs = nullptr;
+        hipEvent_t e1 = nullptr, e2 = nullptr;
+        hipSetDevice(m->devices[i]);
+        const bool made = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking) == hipSuccess &&
+                          hipEventCreateWithFlags(&e1, hipEventDisableTiming) == hipSuccess &&
+                          hipEventCreateWithFlags(&e2, hipEventDisableTiming) == hipSuccess;
+        m->xstream.push_back(xs);
+        m->x_ready.push_back(e1);
+        m->x_done.push_back(e2);
+        if (!made) return mfail(m, KZG_ERR_HIP, "hipStreamCreate / hipEventCreate (the group's exchange stream)");
         // (every context plans 14 lanes + 4 accumulation streams from the process' shared pool: an RCCL communicator needs about six
         // of the pool's 24 hardware queues -- capi.hip, StreamPool; kzg_mctx_set_option(m, "streams", ...) overrides)
     }
@@ -570,14 +587,14 @@ extern "C" int kzg_mctx_create_rank(int device, int rank, int world, const void 
     return KZG_OK;
 }
 
-// true when every stream of the context went idle within `ms` (polled: never blocks on a stream an aborted collective still holds)
-static bool ctx_idle_within(kzg_ctx *c, int64_t ms) {
+// true when local GPU i's exchange stream went idle within `ms` (polled: never blocks on a stream an aborted collective still
+// holds).  Collectives run on that stream only, so a dead group's context, shards and buffers are safe to release exactly when it is
+// idle -- what other contexts of the device keep on the shared pool lanes is finite work and no concern of this group.
+static bool exchange_idle_within(kzg_mctx *m, int i, int64_t ms) {
+    if (i >= (int)m->xstream.size() || !m->xstream[i]) return true;
     const double t0 = now_ms();
     for (;;) {
-        bool busy = false;
-        for (auto &l : c->lanes)
-            if (l.stream && hipStreamQuery(l.stream) == hipErrorNotReady) busy = true;
-        if (!busy) return true;
+        if (hipStreamQuery(m->xstream[i]) != hipErrorNotReady) return true;
         if (now_ms() - t0 > (double)ms) return false;
         std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
@@ -593,8 +610,12 @@ extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
             // A live group drains its streams.  A DEAD one (exchange or formation timed out) may have a stream that an aborted
             // collective never leaves: synchronising on it -- or destroying it, or freeing the buffers its kernels address -- would
             // turn "destroy it and form a new one" into the hang the deadline was there to prevent.  Such a context is left behind.
-            if (!m->dead) kzg_sync(m->ctxs[i]);
-            else leak = g_rccl_wedged ? true : !ctx_idle_within(m->ctxs[i], 2000);  // (wedged: a call abandoned inside RCCL / HIP may hold the streams' locks)
+            if (!m->dead) {
+                kzg_sync(m->ctxs[i]);
+                if (i < (int)m->xstream.size() && m->xstream[i]) hipStreamSynchronize(m->xstream[i]);
+            } else {
+                leak = g_rccl_wedged ? true : !exchange_idle_within(m, i, 2000);  // (wedged: a call abandoned inside RCCL / HIP may hold the streams' locks)
+            }
         }
         if (i < (int)m->comms.size() && m->comms[i] && g_rccl && !m->dead && !g_rccl_wedged) {
             Rccl *r = g_rccl;
@@ -618,6 +639,11 @@ extern "C" void kzg_mctx_destroy(kzg_mctx *m) {
         if (m->d_quot[i]) hipFree(m->d_quot[i]);
         if (m->h_status[i]) hipHostFree(m->h_status[i]);
         if (i < (int)m->d_stat.size() && m->d_stat[i]) hipFree(m->d_stat[i]);
+        if (i < (int)m->xstream.size()) {
+            if (m->x_ready[i]) hipEventDestroy(m->x_ready[i]);
+            if (m->x_done[i]) hipEventDestroy(m->x_done[i]);
+            if (m->xstream[i]) hipStreamDestroy(m->xstream[i]);
+        }
         if (m->ctxs[i]) kzg_ctx_destroy(m->ctxs[i]);
     }
     delete m;
@@ -692,7 +718,7 @@ extern "C" int kzg_mctx_set_option(kzg_mctx *m, const char *key, int64_t value) 
 // ---------------------------------------------------------------------------------------------
 // sharded SRS
 // ---------------------------------------------------------------------------------------------
-static bool ctx_idle_within(kzg_ctx *c, int64_t ms);
+static bool exchange_idle_within(kzg_mctx *m, int i, int64_t ms);
 template <class F>
 static int msrs_build(kzg_mctx *m, size_t n, kzg_msrs **out, F make_shard) {
     kzg_msrs *s = new kzg_msrs();
@@ -759,7 +785,7 @@ extern "C" void kzg_msrs_free(kzg_mctx *m, kzg_msrs *s) {
         kzg_ctx *c = m && i < m->ctxs.size() ? m->ctxs[i] : nullptr;
         // hipFree synchronises the device: on a DEAD group whose stream an aborted collective still holds that is the hang the
         // deadlines exist to prevent -- the shard's memory is left behind with the context (kzg_mctx_destroy)
-        if (m && m->dead && c && (g_rccl_wedged || !ctx_idle_within(c, 0))) {
+        if (m && m->dead && c && (g_rccl_wedged || !exchange_idle_within(m, (int)i, 0))) {
             fprintf(stderr, "kzg: SRS shard of a dead device group on GPU %d is left behind (its stream is still held by an aborted "
                             "collective; freeing would wait for it)\n", m->devices[i]);
             continue;
@@ -812,15 +838,21 @@ static int mctx_buffers_grow(kzg_mctx *m, size_t batch) {
 
 // Wait for local GPU i's exchange stream, with the group's deadline.  KZG_OK, or the group is aborted and dead.
 static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
-    hipStream_t st = m->ctxs[i]->lanes[0].stream;
     hipSetDevice(m->devices[i]);
+    // completion = the event recorded on the group's exchange stream right behind the collective and its status download; nothing
+    // but the exchange ever runs on that stream
+    if (hipEventRecord(m->x_done[i], m->xstream[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + ": hipEventRecord");
+    // The local phase in front of the exchange (x_ready: recorded on the context's lane 0, a stream of the device's shared pool) is
+    // this rank's own, finite work -- possibly queued behind another context's kernels on that lane: it is waited for WITHOUT a
+    // deadline.  The deadline below is the collective's alone.
+    if (hipEventSynchronize(m->x_ready[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + ": the local phase failed");
     if (m->gather_timeout_ms <= 0) {
-        if (hipStreamSynchronize(st) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + " failed");
+        if (hipEventSynchronize(m->x_done[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + " failed");
         return KZG_OK;
     }
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
-        hipError_t e = hipStreamQuery(st);
+        hipError_t e = hipEventQuery(m->x_done[i]);
         if (e == hipSuccess) return KZG_OK;
         if (e != hipErrorNotReady) return mfail(m, KZG_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
         const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
@@ -852,7 +884,7 @@ static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
     // (an abandoned ncclCommAbort may sit inside the HIP runtime holding the stream's lock: no further call on those streams)
     for (int j = 0; j < m->nlocal() && abort_back; j++) {
         hipSetDevice(m->devices[j]);
-        while (hipStreamQuery(m->ctxs[j]->lanes[0].stream) == hipErrorNotReady && now_ms() - t_ab < 5000.0)
+        while (hipStreamQuery(m->xstream[j]) == hipErrorNotReady && now_ms() - t_ab < 5000.0)
             std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
     KZG_DBG("%s: returning the time-out after %.1f ms of abort + drain", what, now_ms() - t_ab);
@@ -878,7 +910,7 @@ static int mctx_agree(kzg_mctx *m, int code, const char *what) {
     Rccl *r = nullptr;
     int crc = mctx_comm(m, &r);
     if (crc != KZG_OK) return crc;  // no communicator: nothing can be exchanged (the peers' wait has its deadline)
-    hipStream_t st = m->ctxs[0]->lanes[0].stream;
+    hipStream_t st = m->xstream[0];  // the group's own exchange stream: the agreement depends on nothing the lanes hold
     hipSetDevice(m->devices[0]);
     int32_t *hs = (int32_t *)m->h_status[0];
     hs[0] = code;
@@ -983,9 +1015,12 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
             if (hipMemsetAsync(slot, 0xff, STATUS_BYTES, st) != hipSuccess ||
                 hipMemcpyAsync(slot, hs, STATUS_BYTES, hipMemcpyHostToDevice, st) != hipSuccess)
                 upload_rc = mfail(m, KZG_ERR_HIP, "status upload");
+            // the exchange stream takes over behind everything lane 0 holds for this call: the partials and the status slot
+            if (hipEventRecord(m->x_ready[i], st) != hipSuccess || hipStreamWaitEvent(m->xstream[i], m->x_ready[i], 0) != hipSuccess)
+                upload_rc = mfail(m, KZG_ERR_HIP, "ordering the exchange stream behind the local phase");
 #ifdef KZG_TEST_HOOKS
             if (m->inject_stall_ms && i == 0) {  // a late peer: the exchange sits behind a spin kernel
-                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, st, (unsigned long long)m->inject_stall_ms * 100000ull);  // wall_clock64: 100 MHz
+                hipLaunchKernelGGL(k_test_stall, dim3(1), dim3(1), 0, m->xstream[i], (unsigned long long)m->inject_stall_ms * 100000ull);  // wall_clock64: 100 MHz
                 m->inject_stall_ms = 0;
             }
 #endif
@@ -996,7 +1031,7 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
         const double t_x0 = now_ms();
         KZG_NCCL(m, r, r->GroupStart());
         for (int i = 0; i < m->nlocal(); i++) {
-            ncclResult_t e = r->AllGather(m->d_part[i], m->d_gath[i], rec, ncclUint8, m->comms[i], m->ctxs[i]->lanes[0].stream);
+            ncclResult_t e = r->AllGather(m->d_part[i], m->d_gath[i], rec, ncclUint8, m->comms[i], m->xstream[i]);
             if (e != ncclSuccess) {
                 r->GroupEnd();
                 return mfail(m, KZG_ERR_HIP, std::string("ncclAllGather: ") + r->GetErrorString(e));
@@ -1008,7 +1043,7 @@ static int mctx_combine(kzg_mctx *m, size_t batch, const std::vector<int> &local
         hipSetDevice(m->devices[0]);
         int32_t *hall = (int32_t *)((uint8_t *)m->h_status[0] + STATUS_ALL_OFF);
         if (hipMemcpy2DAsync(hall, STATUS_BYTES, (const uint8_t *)m->d_gath[0] + batch * PARTIAL_BYTES, rec, STATUS_BYTES,
-                             (size_t)m->world, hipMemcpyDeviceToHost, m->ctxs[0]->lanes[0].stream) != hipSuccess)
+                             (size_t)m->world, hipMemcpyDeviceToHost, m->xstream[0]) != hipSuccess)
             return mfail(m, KZG_ERR_HIP, "status download");
         for (int i = 0; i < m->nlocal(); i++) KZG_TRY(mctx_wait(m, r, i, "the all-gather of the partial points"));
         if (first) {

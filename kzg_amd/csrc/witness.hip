@@ -641,11 +641,17 @@ int kzg::witness_coeff_batched_run(kzg_ctx *ctx, const WitnessSink &sink, const 
         uint32_t log_N = 0;
         Fr gsh;
         bool ok = false;
+        hipStream_t stream = nullptr;
         ~PointSetGuard() {
             if (hit) point_set_release(ctx, hit);
+            // An early return (a failed launch, a failed check) leaves `ok` false with copies and kernels that write the reserved slot
+            // possibly still in flight on this lane's stream: the slot must not be handed to another lane before they have drained
+            // (a second filler's entry could otherwise be overwritten by the stale writes).
+            if (fill && !ok && stream) hipStreamSynchronize(stream);
             if (fill) point_set_publish(ctx, fill, xs, k, sfmt, log_N, gsh, ok);
         }
     } ps{ctx};
+    ps.stream = st;
     ps.xs = xs, ps.k = k, ps.sfmt = sfmt, ps.log_N = log_N;
     if (!small_poly) {
         ps.hit = point_set_lookup(ctx, xs, k, sfmt, log_N);
