@@ -312,54 +312,52 @@ def test_exchange_deadline_kills_the_group_instead_of_hanging(hooks_engine):
     lib.kzg_mctx_destroy(h)
 
 
-def test_exchange_deadline_ignores_another_contexts_work_on_the_shared_lanes(hooks_engine):
+def test_exchange_deadline_ignores_another_contexts_work_on_the_shared_lanes(engine, need_rccl):
     """every context of a device draws its lanes from one shared stream pool, so a plain Engine busy on pool lane 0 used to
     sit in front of the group's all-gather and a short gather_timeout_ms read a healthy exchange as a dead peer.  The exchange now has
     a stream of its own, completion is an event behind the collective, and the group's local phase is waited for without a deadline:
-    with an engine of the same device saturating the lanes from another thread, twenty commits under a 40 ms deadline all succeed and
-    the group stays alive."""
+    with an engine of the same device (same library, same pool) saturating the lanes from another thread, twenty commits under a
+    40 ms deadline all succeed and the group stays alive."""
     import threading
-    lib = hooks_engine.lib
-    h = _hooks_group(hooks_engine, True)
-    assert lib.kzg_mctx_set_option(h, b"always_gather", 1) == 0
+    group = kzg_amd.DeviceGroup([0])
+    group.set_option("always_gather", 1)
     n = 300
-    srs = ctypes.c_void_p()
-    assert lib.kzg_srs_setup_g1_sharded(h, (TAU % M.R).to_bytes(32, "little"), L.FR_CANONICAL, n, ctypes.byref(srs)) == 0
+    srs = group.setup(TAU, n)
     rng = random.Random(24)
     coeffs = rand_scalars(rng, n)
-    blob = kzg_amd.pack_scalars(coeffs)
-    out = ctypes.create_string_buffer(96)
     want = C.g1_mul(C.g1_generator(), C.poly_eval(coeffs, TAU))
-    assert lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT) == 0 and out.raw == want   # communicator formed
+    assert group.commit(srs, coeffs) == want       # the communicator is formed
     # the neighbour: batches of 32 commitments of 2^16 terms over all of the pool's lanes (about 10 ms each), back to back
     m, batch = 1 << 16, 32
-    params = kzg_amd.setup(hooks_engine, TAU, m, g2_len=0)
-    sc = hooks_engine.alloc_scalars(m * batch).fill_random(77)
+    params = kzg_amd.setup(engine, TAU, m, g2_len=0)
+    sc = engine.alloc_scalars(m * batch).fill_random(77)
     bout = ctypes.create_string_buffer(96 * batch)
-    stop, steps = threading.Event(), [0]
+    stop, steps, bad = threading.Event(), [0], []
 
     def neighbour():
         while not stop.is_set():
-            assert lib.kzg_msm_g1_batch(hooks_engine.ctx, params.gs.handle, 0, sc.ptr, m, batch, sc.sfmt, L.IN_DEVICE, bout, L.G1_AFFINE_MONT) == 0
+            rc = engine.lib.kzg_msm_g1_batch(engine.ctx, params.gs.handle, 0, sc.ptr, m, batch, sc.sfmt, L.IN_DEVICE, bout, L.G1_AFFINE_MONT)
+            if rc:
+                bad.append(rc)
+                return
             steps[0] += 1
     th = threading.Thread(target=neighbour)
     th.start()
     try:
-        while steps[0] < 2:
+        while steps[0] < 2 and not bad:
             pass
-        assert lib.kzg_mctx_set_option(h, b"gather_timeout_ms", 40) == 0
+        group.set_option("gather_timeout_ms", 40)
         for _ in range(20):
-            rc = lib.kzg_commit_coeff_sharded(h, srs, blob, n, L.FR_CANONICAL, 0, out, L.G1_AFFINE_MONT)
-            assert rc == 0, lib.kzg_mctx_last_error(h)
-            assert out.raw == want
+            assert group.commit(srs, coeffs) == want
+        assert "dead=0" in group.info()
     finally:
         stop.set()
         th.join()
-    assert steps[0] >= 2
+    assert steps[0] >= 2 and not bad
     sc.free()
     params.gs.free()
-    lib.kzg_msrs_free(h, srs)
-    lib.kzg_mctx_destroy(h)
+    srs.free()
+    group.close()
 
 
 def test_witness_eval_sharded(engine):
