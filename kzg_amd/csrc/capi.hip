@@ -534,6 +534,9 @@ extern "C" int kzg_ctx_set_option(kzg_ctx *ctx, const char *key, int64_t value) 
     } else if (k == "ntt_kernel") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_kernel must be 0..2");
         ctx->opt_ntt_kernel = (int)value;
+    } else if (k == "ntt_three_from") {
+        if (value != 0 && (value < 20 || value > 24)) return fail(ctx, KZG_ERR_SHAPE, "ntt_three_from must be 0 (never) or 20..24");
+        ctx->opt_ntt_three_from = (int)value;
     } else if (k == "ntt_vec2_log") {
         if (value < 0 || value > 2) return fail(ctx, KZG_ERR_SHAPE, "ntt_vec2_log must be 0..2");
         ctx->opt_ntt_vec2_log = (int)value;

@@ -141,6 +141,7 @@ struct kzg_ctx {
     int opt_trusted_points = 0;        // 1: caller vouches for its points (skip the subgroup check of uploads / verifier inputs)
     int opt_ntt_vec_log = 2;           // NTT passes: 2^v adjacent columns / rows per LDS tile
     int opt_ntt_kernel = KZG_NTT_KERNEL_DEFAULT;  // 0: three-phase passes (k_ntt_pass1/2); 1: load/store fused into the first/last stage pair (k_ntt_tile); 2: 1 + two butterflies per thread
+    int opt_ntt_three_from = 23;       // NTT sizes from 2^this on take three passes of <= 2^8 points (ntt_run3); 0 = never
     int opt_ntt_vec2_log = 1;          // pass 2: at most 2^v rows per tile (rows are contiguous: narrow tiles cost no coalescing on the load side)
     int opt_ntt_xcd = 1;               // XCD-aware tile order: bit 0 = pass 1, bit 1 = pass 2 (ntt.hip, xcd_tile)
     int opt_accum_blocks_batch = 0;    // batched MSMs (0 = auto): leave 1/16 of the wave slots to the latency-bound tail and sort

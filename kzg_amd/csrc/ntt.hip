@@ -38,6 +38,11 @@ struct NttPlan {
     // HBM, and the (w, wp) pair would double what it reads there (same-box: 63 -> 68 us for pass 1 at 2^20 with the pair)
     Fr29 *tw_full = nullptr;
     Fr29 scale, scale_p;  // d^-1 for the inverse, one otherwise (pair)
+    // three-pass plans (ntt_run3): k1 = 8 outer columns, then a (k2 x k3)-point inner transform per outer index; tw1 / tw2 / tw3 the
+    // stage twiddles of the three passes, tw_lo / tw_hi the two-level table of w_n (inter-pass product of pass A), tw_full the inner
+    // inter-pass table w'^(j3 k2) * scale of 2^(k2 + k3) entries (w' = w_n^(2^k1))
+    uint32_t k3 = 0;
+    Tw29 tw3;
 };
 
 Fr host_omega(uint32_t exp) {
@@ -92,21 +97,22 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 // lds[idx] those sets alias on 4..32 lanes per bank (rocprofv3: 80 % of LDS cycles were conflict replays).
 // Elements are 9 dwords (odd), so 32 lanes are conflict-free iff their indices differ mod 32; the linear map
 // phys = idx ^ XOR_{b>=5, idx bit b set} MASK[b] with the per-shape masks below (tools/find_lds_swizzle.py
-// checks every pattern's GF(2) rank) makes that hold for every phase.  Index [t][vec_log], 5 bits per mask.
-static const uint64_t LDS_SWIZZLE[13][3] = {
-    {0x0ull, 0x0ull, 0x0ull},  // t = 0
-    {0x0ull, 0x0ull, 0x0ull},  // t = 1
-    {0x0ull, 0x0ull, 0x0ull},  // t = 2
-    {0x0ull, 0x0ull, 0x0ull},  // t = 3
-    {0x0ull, 0x0ull, 0x0ull},  // t = 4
-    {0x0ull, 0x1full, 0x36dull},  // t = 5
-    {0x7ull, 0x33full, 0x3355ull},  // t = 6
-    {0x36dull, 0x4acbull, 0xfb36dull},  // t = 7
-    {0xb3full, 0xf0b3full, 0x1c7076dull},  // t = 8
-    {0x94d9bull, 0x1c7076dull, 0x2d9f8dbbull},  // t = 9
-    {0x1c7076dull, 0x306fb36dull, 0x6997f0f6dull},  // t = 10
-    {0x306fb36dull, 0x4966d065dull, 0x0ull},  // t = 11
-    {0x6997f0f6dull, 0x0ull, 0x0ull},  // t = 12
+// checks every pattern's GF(2) rank) makes that hold for every phase.  Index [t][vec_log], 5 bits per mask (vec_log 3..5: the wide
+// tiles of the three-pass transforms, 16 or 32 short vectors side by side).
+static const uint64_t LDS_SWIZZLE[13][6] = {
+    {0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 0
+    {0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 1
+    {0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 2
+    {0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 3
+    {0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 4
+    {0x0ull, 0x1full, 0x36dull, 0x4acbull, 0x7728bull, 0x1c7076dull},  // t = 5
+    {0x7ull, 0x33full, 0x3355ull, 0xfb36dull, 0x6fb36dull, 0x306fb36dull},  // t = 6
+    {0x36dull, 0x4acbull, 0xfb36dull, 0x6fb36dull, 0x2d9f8dbbull, 0x4966d065dull},  // t = 7
+    {0xb3full, 0xf0b3full, 0x1c7076dull, 0x14cb46bbull, 0x5fc518b6dull, 0x0ull},  // t = 8
+    {0x94d9bull, 0x1c7076dull, 0x2d9f8dbbull, 0x4966d065dull, 0x0ull, 0x0ull},  // t = 9
+    {0x1c7076dull, 0x306fb36dull, 0x6997f0f6dull, 0x0ull, 0x0ull, 0x0ull},  // t = 10
+    {0x306fb36dull, 0x4966d065dull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 11
+    {0x6997f0f6dull, 0x0ull, 0x0ull, 0x0ull, 0x0ull, 0x0ull},  // t = 12
 };
 
 __device__ __forceinline__ uint32_t swz(uint32_t idx, uint64_t masks) {
@@ -362,9 +368,15 @@ __global__ __launch_bounds__(1024) void k_ntt_pass2(const Fr *in, Fr *out, uint3
 // BPT = 2: two butterflies per thread at half the threads (two waves per SIMD, 256 VGPRs): the middle pairs' twiddles are shared by
 // the two butterflies (half the twiddle loads) and every product has an independent partner for the interleaved two-chain stream.
 struct NttTile {
-    uint32_t t;        // log2 of the transform length of this pass (k1 or k2)
-    uint32_t kother;   // the other pass's log length
+    uint32_t t;        // log2 of the transform length of this pass
+    uint32_t kother;   // column pass (PASS 1): log2 of the column stride = of the columns per batch; row pass (PASS 2): log2 of the
+                       // output stride of the transform index (k1 bits, plus the middle bits of a three-pass transform)
     uint32_t vec_log;  // 2^vec_log columns (pass 1) / rows (pass 2) per tile
+    // Three-pass transforms (n = n1 n2 n3, log n >= 22; ntt_run3).  Column pass over a BATCH of matrices: tile -> (batch = tile >>
+    // tpb_log, column group = the low bits), batch b starts at b << (t + kother).  Row pass over gathered rows: tile -> (k2 = tile >>
+    // g1_log, k1 group = the low bits), row (k1, k2) is read at ((k1 << mid_log) + k2) << t and written at
+    // (k3 << kother) + (k2 << (kother - mid_log)) + k1.  Two-pass transforms: tpb_log = g1_log = 31, mid_log = 0.
+    uint32_t tpb_log = 31, g1_log = 31, mid_log = 0;
     uint32_t lo_bits, nnz;
     int xcd, scale_folded;
     uint64_t sw;
@@ -401,7 +413,13 @@ __global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, 
     Fr29 *lds = lds_fr29;
     const uint32_t t = a.t, vl = a.vec_log, vec = 1u << vl, Q = 1u << (t - 2);
     const uint32_t nthreads = blockDim.x;  // = (vec << t) / (4 BPT)
-    const uint32_t tile0 = xcd_tile(blockIdx.x, gridDim.x, a.xcd) << vl;
+    const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x, a.xcd);
+    // column pass: first column of the tile inside its batch, and the batch's base; row pass: first row (k1) of the tile and its k2
+    const uint32_t tile0 = (PASS == 1 ? (tile & ((1u << a.tpb_log) - 1u)) : (tile & ((1u << a.g1_log) - 1u))) << vl;
+    const uint32_t hi_id = PASS == 1 ? (tile >> a.tpb_log) : (tile >> a.g1_log);   // batch (pass 1) / k2 (pass 2); 0 for two-pass transforms
+    const size_t in_base = PASS == 1 ? ((size_t)hi_id << (t + a.kother)) : ((size_t)hi_id << t);
+    const size_t out_base = PASS == 1 ? in_base : ((size_t)hi_id << (a.kother - a.mid_log));
+    const uint32_t row_shift = t + a.mid_log;   // row pass: rows of a tile are 2^row_shift elements apart
     const uint64_t sw = a.sw;
     const Tw29 tw = a.tw;
     // ---- first pair (or the radix-2 stage of an odd length), on the loaded registers --------------------------------------------
@@ -417,7 +435,8 @@ __global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, 
                 Fr raw[4];
 #pragma unroll
                 for (int i = 0; i < 4; i++)
-                    raw[i] = PASS == 1 ? in[((size_t)(q + i * Q) << a.kother) + tile0 + vv] : in[((size_t)(tile0 + vv) << t) + q + i * Q];
+                    raw[i] = PASS == 1 ? in[in_base + ((size_t)(q + i * Q) << a.kother) + tile0 + vv]
+                                       : in[in_base + ((size_t)(tile0 + vv) << row_shift) + q + i * Q];
 #pragma unroll
                 for (int i = 0; i < 4; i++) e[u][i] = fr29_unpack(raw[i]);
             } else {
@@ -564,10 +583,10 @@ __global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, 
                         x = mulshoup29(x, a.tw_hi.w[ih], a.tw_hi.wp[ih]);
                         x = mulshoup29(x, a.tw_lo.w[il], a.tw_lo.wp[il]);
                     }
-                    out[((size_t)kk << a.kother) + j2] = fr29_pack_raw(x);
+                    out[out_base + ((size_t)kk << a.kother) + j2] = fr29_pack_raw(x);
                 } else {
                     x = a.scale_folded ? fr29_reduce_below_2r(x) : mulshoup29(x, a.scale, a.scale_p);
-                    out[((size_t)kk << a.kother) + tile0 + vv] = fr29_pack_canonical(x);
+                    out[out_base + ((size_t)kk << a.kother) + tile0 + vv] = fr29_pack_canonical(x);
                 }
             }
         }
@@ -583,7 +602,7 @@ static int pow_table29(kzg_ctx *ctx, hipStream_t st, const Fr &base, size_t coun
 }
 
 static void plan_free(NttPlan *p) {
-    for (Tw29 *t : {&p->tw1, &p->tw2, &p->tw_lo, &p->tw_hi}) {
+    for (Tw29 *t : {&p->tw1, &p->tw2, &p->tw3, &p->tw_lo, &p->tw_hi}) {
         if (t->w) hipFree(t->w);
         if (t->wp) hipFree(t->wp);
     }
@@ -620,8 +639,9 @@ static int ntt_plan_build(kzg_ctx *ctx, hipStream_t st, NttPlan *p) {
     return KZG_OK;
 }
 
-static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, NttPlan **out) {
-    uint32_t key = log_n * 2 + (inverse ? 1 : 0);
+static int ntt_plan3_build(kzg_ctx *ctx, hipStream_t st, NttPlan *p);
+static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, NttPlan **out, bool three = false) {
+    uint32_t key = log_n * 2 + (inverse ? 1 : 0) + (three ? 1000 : 0);
     // leased lanes (concurrent fft / create_witness_batched / verify_poly callers) share the plans: one builder at a time, and a
     // plan is published only after the stream that filled its tables has been synchronised
     std::lock_guard<std::mutex> clk(ctx->cache_mu);
@@ -643,7 +663,7 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
     NttPlan *p = new NttPlan();
     p->log_n = log_n;
     p->inverse = inverse;
-    int rc = ntt_plan_build(ctx, st, p);
+    int rc = three ? ntt_plan3_build(ctx, st, p) : ntt_plan_build(ctx, st, p);
     if (rc == KZG_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "NTT twiddle tables");
     if (rc != KZG_OK) {  // nothing half-built stays behind
         hipStreamSynchronize(st);
@@ -652,6 +672,79 @@ static int ntt_plan(kzg_ctx *ctx, hipStream_t st, uint32_t log_n, int inverse, N
     }
     ctx->ntt_plans[key] = p;
     *out = p;
+    return KZG_OK;
+}
+
+// ---- three-pass transforms (round 6): n = 2^8 * n2 * n3 ------------------------------------------------------------------------
+// At 2^22 .. 2^24 the two-pass split leaves pass 1 with tiles of 2, 1 and 1 columns of 2^11 / 2^12 points: 64- and 32-byte segments
+// 64 KB / 128 KB apart in both its loads and its stores (pass 1 1.14 ms against pass 2's 0.89 at 2^24), and above 2^21 the inter-pass
+// twiddle is a two-level product (two multiplications).  Three passes of at most 2^8 points have 16 or 32 vectors per tile (512- / 1024-
+// byte segments everywhere), the same number of multiplications per element (three passes of 4 - 1 stage products, two + one inter-pass
+// products: 12, as the two-pass transform with its two-level product), and pay one more trip through HBM and one more unpack / pack:
+//   A  for every column c = (j2, j3) of the 2^8 x 2^(k2 + k3) matrix: 2^8-point transform over stride-2^(k2 + k3) elements, times
+//      w_n^(c k1) (two-level table), data -> scratch in the same layout              (k_ntt_tile<1>, 16 columns per tile)
+//   B  for every k1 and every column j3 of its 2^k2 x 2^k3 matrix: 2^k2-point transform over stride-2^k3 elements, times
+//      w'^(j3 k2) * scale (one full table of 2^(k2 + k3) entries, w' = w_n^(2^8)), in place in scratch   (k_ntt_tile<1>, batched)
+//   C  for every (k1, k2): 2^k3-point transform of the contiguous row, written to X[k1 + 2^8 k2 + 2^(8 + k2) k3]: a tile takes 16 / 32
+//      consecutive k1 of one k2, so its stores are 512- / 1024-byte segments           (k_ntt_tile<2>, gathered rows)
+static int ntt_plan3_build(kzg_ctx *ctx, hipStream_t st, NttPlan *p) {
+    const uint32_t log_n = p->log_n;
+    Fr w = host_omega(log_n);
+    if (p->inverse) w = inv(w);
+    const size_t n = (size_t)1 << log_n;
+    const Fr scale = p->inverse ? inv(from_u64<FrParams>((uint64_t)n)) : Fr::one();
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(scale), p->scale, p->scale_p);
+    p->k1 = 8;
+    const uint32_t inner = log_n - 8;
+    p->k2 = (inner + 1) / 2;
+    p->k3 = inner - p->k2;
+    const size_t n1 = 256, n2 = (size_t)1 << p->k2, n3 = (size_t)1 << p->k3, ni = (size_t)1 << inner;
+    p->lo_bits = 12;
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)ni), n1 >> 1, &p->tw1));        // w_{n1} = w^(n / n1)
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)(n1 * n3)), n2 >> 1, &p->tw2));  // w_{n2} = w'^(n3)
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, (uint64_t)(n1 * n2)), n3 >> 1, &p->tw3));  // w_{n3} = w'^(n2)
+    KZG_TRY(pow_table29(ctx, st, w, (size_t)1 << p->lo_bits, &p->tw_lo));
+    KZG_TRY(pow_table29(ctx, st, pow_u64(w, 1ull << p->lo_bits), n >> p->lo_bits, &p->tw_hi));
+    // the inner inter-pass table from a two-level table of w' of its own (freed below)
+    Tw29 ilo, ihi;
+    const Fr wi = pow_u64(w, (uint64_t)n1);
+    const uint32_t ilo_bits = p->k2;
+    int rc = pow_table29(ctx, st, wi, (size_t)1 << ilo_bits, &ilo);
+    if (rc == KZG_OK) rc = pow_table29(ctx, st, pow_u64(wi, 1ull << ilo_bits), ni >> ilo_bits, &ihi);
+    if (rc == KZG_OK && hipMalloc((void **)&p->tw_full, ni * sizeof(Fr29)) != hipSuccess) rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(NTT inter-pass table)");
+    if (rc == KZG_OK) {
+        KZG_LAUNCH(ctx, st, "k_twiddle_full", k_twiddle_full, (unsigned)((ni + 255) / 256), 256, 0, ilo, ihi, ilo_bits, p->k3, scale, ni, p->tw_full);
+        if (hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "NTT twiddle tables");
+    }
+    for (Tw29 *t : {&ilo, &ihi}) {
+        if (t->w) hipFree(t->w);
+        if (t->wp) hipFree(t->wp);
+    }
+    return rc;
+}
+
+static int ntt_run3(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse) {
+    hipStream_t st = ctx->lanes[lane].stream;
+    NttPlan *p = nullptr;
+    KZG_TRY(ntt_plan(ctx, st, log_n, inverse, &p, true));
+    const size_t n = (size_t)1 << log_n;
+    Fr *scratch = (Fr *)lane_alloc(ctx, lane, n * sizeof(Fr));
+    if (!scratch) return fail(ctx, KZG_ERR_ALLOC, "NTT workspace not reserved");
+    const uint32_t inner = p->k2 + p->k3;
+    NttTile a, b, c;
+    a.t = 8; a.kother = inner; a.vec_log = 4; a.lo_bits = p->lo_bits; a.nnz = 0; a.xcd = ctx->opt_ntt_xcd & 1; a.scale_folded = 0;
+    a.sw = LDS_SWIZZLE[8][4]; a.tw = p->tw1; a.tw_lo = p->tw_lo; a.tw_hi = p->tw_hi; a.tw_full = nullptr; a.scale = p->scale; a.scale_p = p->scale_p;
+    b = a;
+    b.t = p->k2; b.kother = p->k3; b.vec_log = 12 - p->k2; b.tpb_log = p->k3 - b.vec_log; b.xcd = 0; b.sw = LDS_SWIZZLE[p->k2][b.vec_log];
+    b.tw = p->tw2; b.tw_full = p->tw_full;
+    c = a;
+    c.t = p->k3; c.vec_log = 12 - p->k3; c.g1_log = 8 - c.vec_log; c.mid_log = p->k2; c.kother = 8 + p->k2; c.xcd = 0;
+    c.sw = LDS_SWIZZLE[p->k3][c.vec_log]; c.tw = p->tw3; c.tw_full = nullptr; c.scale_folded = 1;
+    const size_t lds = (size_t)4096 * sizeof(Fr29);
+    const unsigned grid = (unsigned)(n >> 12);
+    KZG_LAUNCH(ctx, st, "k_ntt_pass1", (k_ntt_tile<1, 1, false>), grid, 1024, lds, d_data, scratch, a);
+    KZG_LAUNCH(ctx, st, "k_ntt_pass1b", (k_ntt_tile<1, 1, false>), grid, 1024, lds, scratch, scratch, b);
+    KZG_LAUNCH(ctx, st, "k_ntt_pass2", (k_ntt_tile<2, 1, false>), grid, 1024, lds, scratch, d_data, c);
     return KZG_OK;
 }
 
@@ -767,6 +860,11 @@ int ntt_run(kzg_ctx *ctx, int lane, Fr *d_data, uint32_t log_n, int inverse, siz
     if (log_n >= FR_TWO_ADICITY) return fail(ctx, KZG_ERR_DEGREE_TOO_LARGE, "polynomial degree too large");
     if (log_n > 28) return fail(ctx, KZG_ERR_SHAPE, "NTT sizes above 2^28 are not supported (2^24-point two-pass transforms under one 16-point outer level)");
     if (log_n > 24) return ntt_run_large(ctx, lane, d_data, log_n, inverse);
+    // three passes from 2^ntt_three_from on (default 23: profiles/r06_ab_ntt.txt), unless the input is short enough for the two-pass transform's short-input
+    // path (one pass) or the round-5 kernels are selected
+    if (ctx->opt_ntt_kernel && ctx->opt_ntt_three_from && log_n >= (uint32_t)ctx->opt_ntt_three_from && log_n >= 20 &&
+        !(nnz <= ((size_t)1 << (log_n - (log_n + 1) / 2))))
+        return ntt_run3(ctx, lane, d_data, log_n, inverse);
     hipStream_t st = ctx->lanes[lane].stream;
     NttPlan *p = nullptr;
     KZG_TRY(ntt_plan(ctx, st, log_n, inverse, &p));

@@ -9,7 +9,18 @@ sys.path.insert(0, ROOT)
 import kzg_amd
 from kzg_amd import _lib as L
 
-KERNELS = [int(k) for k in os.environ.get("NTT_KERNELS", "0,1,2").split(",")]
+# variants: NTT_VARIANTS="label:opt=value,opt=value;label:..." (default: the three kernels, two-pass everywhere)
+_V = os.environ.get("NTT_VARIANTS", "0:ntt_kernel=0,ntt_three_from=0;1:ntt_kernel=1,ntt_three_from=0;2:ntt_kernel=2,ntt_three_from=0")
+VARIANTS = {}
+for item in _V.split(";"):
+    label, opts = item.split(":")
+    VARIANTS[label] = [(kv.split("=")[0], int(kv.split("=")[1])) for kv in opts.split(",")]
+KERNELS = list(VARIANTS)
+
+
+def select(e, label):
+    for k, v in VARIANTS[label]:
+        e.set_option(k, v)
 e = kzg_amd.Engine(0)
 for log_n in [int(a) for a in sys.argv[1:]] or [20]:
     n = 1 << log_n
@@ -18,7 +29,7 @@ for log_n in [int(a) for a in sys.argv[1:]] or [20]:
     buf = e.alloc_scalars(n)
     digests = {}
     for kern in KERNELS:
-        e.set_option("ntt_kernel", kern)
+        select(e, kern)
         d = []
         for inv in (0, 1):
             buf.upload(raw)
@@ -30,14 +41,14 @@ for log_n in [int(a) for a in sys.argv[1:]] or [20]:
     res = {k: {"p1": [], "p2": [], "wall": []} for k in KERNELS}
     for rnd in range(6):
         for kern in KERNELS:
-            e.set_option("ntt_kernel", kern)
+            select(e, kern)
             reps = 30 if log_n <= 22 else 8
             e.prof_enable(True); e.prof_reset()
             for _ in range(reps):
                 assert e.lib.kzg_ntt_fr(e.ctx, buf.ptr, log_n, rnd & 1, L.IN_DEVICE) == 0
             prof = e.prof_all()
             e.prof_enable(False)
-            res[kern]["p1"].append(prof.get("k_ntt_pass1", (0, 0))[1] / reps)
+            res[kern]["p1"].append((prof.get("k_ntt_pass1", (0, 0))[1] + prof.get("k_ntt_pass1b", (0, 0))[1]) / reps)
             res[kern]["p2"].append(prof.get("k_ntt_pass2", (0, 0))[1] / reps)
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -47,5 +58,5 @@ for log_n in [int(a) for a in sys.argv[1:]] or [20]:
     med = lambda v: sorted(v)[len(v) // 2]
     for kern in KERNELS:
         r = res[kern]
-        print("  ntt_kernel=%d 2^%d  pass1 %.4f  pass2 %.4f  sum %.4f ms   wall %.4f ms" % (kern, log_n, med(r["p1"]), med(r["p2"]), med(r["p1"]) + med(r["p2"]), med(r["wall"])), flush=True)
+        print("  variant %-6s 2^%d  pass1(+1b) %.4f  pass2 %.4f  sum %.4f ms   wall %.4f ms" % (kern, log_n, med(r["p1"]), med(r["p2"]), med(r["p1"]) + med(r["p2"]), med(r["wall"])), flush=True)
     src.free(); buf.free()
