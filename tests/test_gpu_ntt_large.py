@@ -24,7 +24,8 @@ def _coset_scale(blob, n, g):
     return bytes(out)
 
 
-@pytest.mark.parametrize("log_n", [15, 16, 17, 18, 19, 20, 21, 22])
+@pytest.mark.limit(300)
+@pytest.mark.parametrize("log_n", [15, 16, 17, 18, 19, 20, 21, 22, 23])   # 23: the smallest size that takes three passes (ntt_run3)
 def test_ntt_bit_exact_vs_oracle(engine, log_n):
     n = 1 << log_n
     buf = engine.alloc_scalars(n).fill_random(500 + log_n)
@@ -41,6 +42,33 @@ def test_ntt_bit_exact_vs_oracle(engine, log_n):
     for i in (1, n - 3):
         assert int.from_bytes(want[32 * i:32 * i + 32], "little") == C.poly_eval_bytes(a0, n, pow(omega, i, R))
     buf.free()
+
+
+@pytest.mark.limit(300)
+@pytest.mark.parametrize("opts", [{"ntt_kernel": 0, "ntt_three_from": 0}, {"ntt_kernel": 1, "ntt_three_from": 0}, {"ntt_kernel": 2, "ntt_three_from": 0},
+                                  {"ntt_kernel": 1, "ntt_three_from": 20}, {"ntt_kernel": 2, "ntt_three_from": 22}],
+                         ids=["r5-kernels", "fused", "fused-two-butterflies", "three-pass-from-2^20", "three-pass-two-butterflies"])
+def test_ntt_kernel_variants_bit_exact_vs_oracle(engine, opts):
+    """Every selectable form of the pass kernels (option ntt_kernel: round 5's three-phase passes, the fused k_ntt_tile, two butterflies
+    per thread) and of the decomposition (two passes / three passes of <= 2^8 points) against the oracle's serial_fft, forward and
+    inverse: even and odd sub-transform lengths, the full inter-pass table (<= 2^21) and the two-level product, 2^13 (the smallest
+    two-pass size) up to 2^22; the defaults are restored afterwards."""
+    defaults = {"ntt_kernel": 1, "ntt_three_from": 23}
+    try:
+        for k, v in opts.items():
+            engine.set_option(k, v)
+        for log_n in (13, 14, 17, 20, 21, 22):
+            n = 1 << log_n
+            buf = engine.alloc_scalars(n).fill_random(700 + log_n)
+            a0 = buf.download()
+            engine.ntt(buf, log_n)
+            assert buf.download() == C.fft_bytes(a0, log_n), (opts, log_n)
+            engine.ntt(buf, log_n, inverse=True)
+            assert buf.download() == a0, (opts, log_n)
+            buf.free()
+    finally:
+        for k, v in defaults.items():
+            engine.set_option(k, v)
 
 
 @pytest.mark.parametrize("log_n", [15, 18, 20, 22])
