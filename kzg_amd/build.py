@@ -15,8 +15,8 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libkzg_mi355x.so")
 # the same library with the unit-test hooks of include/kzg_mi355x_test.h compiled in (-DKZG_TEST_HOOKS): loaded by tests/ only
 OUT_HOOKS = os.path.join(HERE, "libkzg_mi355x_hooks.so")
-HOOK_SOURCES = ["capi.hip", "mgpu.hip"]  # the translation units that hold hooks
-SOURCES = ["capi.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip", "msm_wide.hip", "msm_tail.hip", "mgpu.hip", "gfft.hip"]
+HOOK_SOURCES = ["capi.hip", "mgpu.hip"]  # the translation units that hold hooks (runtime.hip holds none)
+SOURCES = ["capi.hip", "runtime.hip", "msm.hip", "srs.hip", "ntt.hip", "poly.hip", "witness.hip", "pairing.hip", "msm_wide.hip", "msm_tail.hip", "mgpu.hip", "gfft.hip"]
 # per-file extra flags (none at present; out-of-line multiplies for the tail kernels were measured: no gain)
 EXTRA_FLAGS = {}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]

@@ -104,7 +104,7 @@ constexpr int KZG_MAX_LANES = 24;  // lanes.reserve(): leased lanes are indexed 
 
 struct kzg_ctx;
 namespace kzg {
-struct StreamPool;                     // capi.hip: the process' streams of one device, shared by its contexts
+struct StreamPool;                     // runtime.hip: the process' streams of one device, shared by its contexts
 struct PointSetCache;
 void point_sets_free(kzg_ctx *ctx);  // witness.hip
 void point_set_stats(kzg_ctx *ctx, uint64_t *hits, uint64_t *misses);
@@ -126,12 +126,12 @@ struct kzg_ctx {
     int pipe_lanes = 1, pipe_accum = 0;
     std::string err;
     std::vector<kzg::Lane> lanes;
-    kzg::StreamPool *pool = nullptr;   // where the lanes' and accumulation streams come from (capi.hip)
+    kzg::StreamPool *pool = nullptr;   // where the lanes' and accumulation streams come from (runtime.hip)
     int opt_window_bits = 0;  // 0 = auto
     int opt_streams = 14;  // lanes: depth of the batched pipeline and of the pool concurrent blocking callers lease from (14 + 4
-                           // accumulation streams leave an RCCL communicator its ~6 hardware queues of the 24: capi.hip, StreamPool)
+                           // accumulation streams leave an RCCL communicator its ~6 hardware queues of the 24: runtime.hip, StreamPool)
     int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
-    int opt_hw_queues = 0;             // hardware queues to plan the batched pipeline for (0 = measure: probe_queues in capi.hip)
+    int opt_hw_queues = 0;             // hardware queues to plan the batched pipeline for (0 = measure: probe_queues in runtime.hip)
     int probed_queues = 0;             // hardware queues the probed streams were found on (0 = not measured yet)
     int probed_lanes = 0, probed_accum = 0;  // which streams that measurement covered: lanes [0, probed_lanes), accumulation streams
     std::vector<hipStream_t> probed_order;  // the probed streams, one per queue first
@@ -233,7 +233,7 @@ struct Guard {  // exclusive use of the context for the scope
 };
 
 // Shared use of the context for the scope: one leased lane (stream + arena).  Every blocking prover / verifier / transform call
-// that works on ONE lane takes a Lease instead of a Guard (capi.hip: lease_lane), so N host threads inside create_witness_batched,
+// that works on ONE lane takes a Lease instead of a Guard (runtime.hip: lease_lane), so N host threads inside create_witness_batched,
 // commit, fft, verify_poly ... run side by side on one context, as the reference's `&self` methods do (src/coeff_form.rs:59-111).
 struct Lease {
     kzg_ctx *ctx = nullptr;
@@ -287,6 +287,11 @@ inline int fail(kzg_ctx *ctx, int code, const std::string &msg) {
 int lane_reserve(kzg_ctx *ctx, int lane, size_t bytes);  // ensure arena >= bytes and reset it
 void *lane_alloc(kzg_ctx *ctx, int lane, size_t bytes);  // 256-B aligned bump allocation (nullptr if exhausted)
 int lane_pinned(kzg_ctx *ctx, int lane, size_t bytes);   // ensure pinned staging >= bytes
+// runtime.hip: the pipeline plan of a context (lanes + accumulation streams on hardware queues of their own) and the shape of a lane
+int ensure_lanes(kzg_ctx *ctx, int want);                                     // exclusive callers only
+int plan_pipeline(kzg_ctx *ctx, int want, int *nl_out, int *nas_out);
+void set_lane_mode(kzg_ctx *ctx, int lane, bool pipelined, bool deep);
+int accum_streams_for(kzg_ctx *ctx, int planned, const kzg_srs *srs, size_t n);  // accumulation streams MSMs of this size are spread over
 
 // ---- profiling -----------------------------------------------------------------------------
 struct ProfScope {
@@ -346,7 +351,7 @@ int msm_run(kzg_ctx *ctx, int lane, const kzg_srs *srs, size_t offset, const voi
             MsmPoint **d_result, hipStream_t accum_stream = nullptr, hipEvent_t sorted_ev = nullptr, hipEvent_t accum_ev = nullptr,
             MsmPending *defer = nullptr);
 int msm_finish(kzg_ctx *ctx, MsmPending &pd, MsmPoint **d_result);  // the deferred part of an MSM (its result if it was not deferred)
-// capi.hip: one MSM on a leased lane (its accumulation kernel on the lease's FIFO stream when other calls are in flight)
+// runtime.hip: one MSM on a leased lane (its accumulation kernel on the lease's FIFO stream when other calls are in flight)
 int lease_msm(kzg_ctx *ctx, const Lease &ls, const kzg_srs *srs, size_t offset, const void *d_sc, size_t n, int sfmt, MsmPoint **res);
 // d_points: count points -> one point (plain sum)
 int sum_points_run(kzg_ctx *ctx, int lane, MsmPoint *d_points, size_t count, MsmPoint *d_scratch, MsmPoint **d_result);

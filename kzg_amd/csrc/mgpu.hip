@@ -277,7 +277,7 @@ struct kzg_mctx {
     std::vector<void *> d_quot;      // create_witness: the quotient polynomial on each GPU
     std::vector<size_t> cap_quot;
     std::vector<void *> h_status;    // pinned: the status words of all ranks after the exchange, per local GPU
-    // The exchange has a stream of ITS OWN per local GPU -- not a lane of the device's shared stream pool (capi.hip, StreamPool): the
+    // The exchange has a stream of ITS OWN per local GPU -- not a lane of the device's shared stream pool (runtime.hip, StreamPool): the
     // group's deadlines decide "exchange done / stream stuck" from this stream alone, so a plain Engine of the same device that is busy
     // on pool lane 0 cannot make a healthy exchange read as NotReady (and get the communicators aborted), and a collective that never
     // leaves its stream cannot hang another prover's hipStreamSynchronize.  x_ready orders the exchange behind the local
@@ -401,7 +401,7 @@ static int mctx_make_ctxs(kzg_mctx *m) {
         m->x_done.push_back(e2);
         if (!made) return mfail(m, KZG_ERR_HIP, "hipStreamCreate / hipEventCreate (the group's exchange stream)");
         // (every context plans 14 lanes + 4 accumulation streams from the process' shared pool: an RCCL communicator needs about six
-        // of the pool's 24 hardware queues -- capi.hip, StreamPool; kzg_mctx_set_option(m, "streams", ...) overrides)
+        // of the pool's 24 hardware queues -- runtime.hip, StreamPool; kzg_mctx_set_option(m, "streams", ...) overrides)
     }
     // the exchange buffers of ordinary calls (up to 64 polynomials per call) and the status-only agreement buffer exist from the
     // start: a group that formed can always exchange statuses, whatever fails later

@@ -1,5 +1,5 @@
 """The reference's call shape: KZGProver is Clone + &self (src/coeff_form.rs:37-64), so many host threads call commit() /
-create_witness() at once.  On one kzg_ctx each blocking call leases a lane (capi.hip, CtxGate in common.h); these tests drive
+create_witness() at once.  On one kzg_ctx each blocking call leases a lane (runtime.hip, CtxGate in common.h); these tests drive
 one context from 16 threads with mixed calls and check every result against the oracle, and share one resident SRS between
 contexts."""
 import ctypes

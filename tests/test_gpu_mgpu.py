@@ -433,7 +433,7 @@ print("ok")
 @pytest.mark.limit(300)
 def test_prover_context_and_device_group_share_one_stream_pool():
     """VERDICT r4 weak #13 (the silent hardware-queue cliff): a plain prover context and a device group alive in ONE process -- what
-    INTEGRATION.md section 5b describes.  All contexts of a device take their streams from one pool per process (capi.hip, StreamPool),
+    INTEGRATION.md section 5b describes.  All contexts of a device take their streams from one pool per process (runtime.hip, StreamPool),
     14 lanes + 4 accumulation streams, which leaves the RCCL communicator its queues: neither plan is narrowed (kzg_ctx_info /
     kzg_mctx_info say so, and no warning is printed) and both paths give the same commitments, alone, one after the other and
     committing at once from two threads.  (Same-box rates: the group beside a live context 471 against 473 commitments/s alone; it
