@@ -10,6 +10,7 @@ from kzg_amd import _lib as L
 from tools.benchlib.common import view, timeit, TAU, SEED
 
 e = kzg_amd.Engine(0)
+U64 = os.environ.get("PROBE_FULL_WIDTH", "") == ""      # PROBE_FULL_WIDTH=1: uniform full-width scalars instead (the headline's distribution)
 for kv in sys.argv[1:]:
     k, v = kv.split("=")
     e.set_option(k, int(v))
@@ -17,7 +18,7 @@ n, batch = 1 << 20, 64
 params = kzg_amd.setup(e, TAU, n, g2_len=0)
 sc = e.alloc_scalars(n * batch)
 for b in range(batch):
-    view(kzg_amd, sc, b * n, n).fill_random(SEED + 31000 + 1000 * b, u64_valued=True)
+    view(kzg_amd, sc, b * n, n).fill_random(SEED + 31000 + 1000 * b, u64_valued=U64)
 out = ctypes.create_string_buffer(96 * batch)
 
 
@@ -27,7 +28,7 @@ def step():
 
 
 ms = timeit(step, reps=5, warm=3)
-print("options %s: u64 batch of %d: %.3f ms per step = %.1f commitments/s" % (sys.argv[1:], batch, ms, batch / ms * 1e3))
+print("options %s: %s batch of %d: %.3f ms per step = %.1f commitments/s" % (sys.argv[1:], "u64" if U64 else "full-width", batch, ms, batch / ms * 1e3))
 e.prof_enable(True); e.prof_reset()
 step()
 pr = e.prof_all(); e.prof_enable(False)
@@ -38,4 +39,4 @@ for k, v in sorted(pr.items(), key=lambda kv: -kv[1][1]):
 one = ctypes.create_string_buffer(96)
 def single():
     assert e.lib.kzg_msm_g1(e.ctx, params.gs.handle, 0, sc.ptr, n, sc.sfmt, L.IN_DEVICE, one, L.G1_AFFINE_MONT) == 0
-print("lone u64 commit: %.3f ms" % timeit(single))
+print("lone commit: %.3f ms" % timeit(single))
