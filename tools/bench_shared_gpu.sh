@@ -1,5 +1,5 @@
 #!/bin/bash
-# The driver's N > 1 launch of bench.py with all N ranks on the ONE GPU of a test box: gloo control plane, and the device group over
+# The driver's N > 1 launch of bench.py with all N ranks on the ONE GPU of a test box: the bench's TCP-star control plane (no torch in the ranks), and the device group over
 # the hooks build's test transport (kzg_amd/csrc/test_transport.h; RCCL refuses two ranks on one GPU).  Numbers from this are not
 # scaling numbers -- the ranks share a GPU -- it shows that the N > 1 line is produced and checked.
 #   bash tools/bench_shared_gpu.sh N [bench.py arguments...]
