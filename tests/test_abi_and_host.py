@@ -162,3 +162,41 @@ def test_single_node_rccl_env_sets_defaults_and_keeps_the_hosts_values(monkeypat
     rs = open(os.path.join(root, "integration", "mi355x.rs")).read()
     for k, v in SINGLE_NODE_RCCL_ENV.items():
         assert 'setenv("%s", "%s", 0)' % (k, v) in hpp and '("%s", "%s")' % (k, v) in rs, k
+
+
+def test_bench_cpu_baseline_legs_on_a_small_sample():
+    """tools/benchlib/cpu_pool.py without a GPU: the worker pool, the MSM legs at the requested sizes (both of the oracle's Pippengers for
+    the small ones), the NTT and create_witness legs, the all-cores pass -- on a 2^10 sample whose "GPU side" is produced by the oracle's
+    plain functions here, so every `matches_gpu` must come out true and a corrupted expected value must come out false."""
+    import hashlib
+    import random
+    sys.path.insert(0, ROOT)
+    from oracle import c_oracle as C
+    from oracle import kzg_model as M
+    from tools.benchlib.cpu_pool import CpuBaseline
+    n, log_n, tau = 1 << 10, 10, 0x1234567
+    rng = random.Random(9)
+    coeffs = [rng.randrange(M.R) for _ in range(n)]
+    sc = C.scalars_to_bytes(coeffs)
+    pts = C.setup_g1(tau, n)
+    x = rng.randrange(M.R)
+    y = C.poly_eval(coeffs, x)
+    G = C.g1_generator()
+    ptau = C.poly_eval(coeffs, tau)
+    gpu = {"msm": {10: C.msm_g1_raw(pts, sc, n), 6: C.msm_g1_raw(pts[:96 * 64], sc[:32 * 64], 64)},
+           "ntt_sha256": hashlib.sha256(C.fft_bytes(sc, log_n)).hexdigest(),
+           "witness": (x, y, C.g1_mul(G, (ptau - y) * pow(tau - x, -1, M.R) % M.R))}
+    cpu = CpuBaseline()
+    cpu.start()
+    try:
+        single, allc = cpu.run(pts, sc, n, log_n, gpu)
+        assert single["kind"] == "port" and single["cores"] == 1 and single["unit"] == "commitments/s" and single["value"] > 0
+        assert set(k for k in single if k.startswith(("msm_", "ntt_", "witness_"))) == {"msm_2e10", "msm_2e6", "ntt_2e10", "witness_2e10"}
+        assert single["all_match_gpu"] is True and all(single[k]["matches_gpu"] for k in ("msm_2e10", "msm_2e6", "ntt_2e10", "witness_2e10"))
+        assert single["msm_2e6"]["algorithm"].startswith("orc_msm_g1") and set(single["msm_2e6"]["seconds_by_algorithm"]) == {"orc_msm_g1_fast", "orc_msm_g1"}
+        assert allc["cores"] >= 1 and allc["matches_gpu"] is True and allc["ntt_2e10"]["matches_gpu"] is True
+        bad = dict(gpu, msm={10: gpu["msm"][10], 6: gpu["msm"][10]}, ntt_sha256="00" * 32)
+        single, _ = cpu.run(pts, sc, n, log_n, bad)
+        assert single["msm_2e6"]["matches_gpu"] is False and single["ntt_2e10"]["matches_gpu"] is False and single["all_match_gpu"] is False
+    finally:
+        cpu.close()
