@@ -71,6 +71,27 @@ def test_ntt_kernel_variants_bit_exact_vs_oracle(engine, opts):
             engine.set_option(k, v)
 
 
+@pytest.mark.limit(300)
+@pytest.mark.parametrize("log_n", [13, 16, 20, 23])
+def test_ntt_extreme_values_bit_exact_vs_oracle(engine, log_n):
+    """Inputs at the ends of the lazy arithmetic's ranges -- all r - 1, r - 1 alternating with 0 and with 1, a lone r - 1 among zeros,
+    in canonical and in Montgomery form (R mod r and r - 1 as raw words): every limb chain of the butterflies sees its largest operands.
+    Forward and inverse against the oracle's serial_fft (two-pass sizes, and 2^23: three passes)."""
+    n = 1 << log_n
+    big = (R - 1).to_bytes(32, "little")
+    zero, one = bytes(32), (1).to_bytes(32, "little")
+    patterns = [big * n, (big + zero) * (n // 2), (one + big) * (n // 2), zero * (n - 1) + big, big + zero * (n - 1)]
+    buf = engine.alloc_scalars(n)
+    for k, blob in enumerate(patterns[:3] if log_n >= 23 else patterns):
+        buf.upload(blob)
+        engine.ntt(buf, log_n)
+        assert buf.download() == C.fft_bytes(blob, log_n), (log_n, k)
+        buf.upload(blob)
+        engine.ntt(buf, log_n, inverse=True)
+        assert buf.download() == C.fft_bytes(blob, log_n, inverse=True), (log_n, k)
+    buf.free()
+
+
 @pytest.mark.parametrize("log_n", [15, 18, 20, 22])
 def test_coset_ntt_bit_exact_vs_oracle(engine, log_n):
     """coset_fft = distribute_powers(7) then fft; icoset_fft = ifft then distribute_powers(7^-1) (src/ft.rs:142-178)."""
