@@ -40,7 +40,7 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="commitments per step (pipelined on the engine's HIP streams)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="lanes the engine pipelines a batch over (0 = the engine's default: 14 + 4 accumulation streams from the process' shared "
+                    help="lanes the engine pipelines a batch over (0 = the engine's default: 13 + 4 accumulation streams from the process' shared "
                          "stream pool, which leaves an RCCL communicator its hardware queues)")
     ap.add_argument("--accum-blocks", type=int, default=0, help="engine option accum_blocks_batch (0 = default)")
     ap.add_argument("--opt", action="append", default=[], metavar="KEY=VALUE", help="extra engine option (kzg_ctx_set_option), repeatable")

@@ -198,7 +198,7 @@ int kzg_g1_sum_batch(kzg_ctx *ctx, const void *points, size_t count, size_t grou
  *     store, torch.distributed), every rank calls kzg_mctx_create_rank(device, rank, world, id)   (ncclCommInitRank).
  * RCCL (librccl.so.1) is loaded on first use; a group of one GPU needs no RCCL unless option "always_gather" is set.
  * Streams: all contexts of one device in a process -- plain ones and a group's -- take their streams from ONE pool (lane i of every
- * context is the same HIP stream), 14 lanes + 4 accumulation streams: the runtime multiplexes a process' streams onto one pool of
+ * context is the same HIP stream), 13 lanes + 4 accumulation streams (+ one exchange stream per device group): the runtime multiplexes a process' streams onto one pool of
  * hardware queues (24 after kzg_init_hw_queues) of which an RCCL communicator needs about six, and streams that share a queue
  * serialise.  A plain prover context and a device group alive in one process therefore cost each other nothing (group path 471
  * against 473 commitments/s alone; both committing at once 512-517 in total).  kzg_ctx_info / kzg_mctx_info report each context's plan

@@ -128,7 +128,7 @@ struct kzg_ctx {
     std::vector<kzg::Lane> lanes;
     kzg::StreamPool *pool = nullptr;   // where the lanes' and accumulation streams come from (runtime.hip)
     int opt_window_bits = 0;  // 0 = auto
-    int opt_streams = 14;  // lanes: depth of the batched pipeline and of the pool concurrent blocking callers lease from (14 + 4
+    int opt_streams = 13;  // lanes: depth of the batched pipeline and of the pool concurrent blocking callers lease from (13 + 4
                            // accumulation streams leave an RCCL communicator its ~6 hardware queues of the 24: runtime.hip, StreamPool)
     int opt_accum_blocks = 0;          // k_accum_affine grid for a single MSM (0 = every SIMD holds its KZG_ACCUM_WAVES waves)
     int opt_hw_queues = 0;             // hardware queues to plan the batched pipeline for (0 = measure: probe_queues in runtime.hip)

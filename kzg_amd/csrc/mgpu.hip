@@ -400,7 +400,8 @@ static int mctx_make_ctxs(kzg_mctx *m) {
         m->x_ready.push_back(e1);
         m->x_done.push_back(e2);
         if (!made) return mfail(m, KZG_ERR_HIP, "hipStreamCreate / hipEventCreate (the group's exchange stream)");
-        // (every context plans 14 lanes + 4 accumulation streams from the process' shared pool: an RCCL communicator needs about six
+        // (every context plans 13 lanes + 4 accumulation streams from the process' shared pool, the group's exchange stream above is the
+        // 18th stream: an RCCL communicator needs about six
         // of the pool's 24 hardware queues -- runtime.hip, StreamPool; kzg_mctx_set_option(m, "streams", ...) overrides)
     }
     // the exchange buffers of ordinary calls (up to 64 polynomials per call) and the status-only agreement buffer exist from the
@@ -841,11 +842,13 @@ static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
     hipSetDevice(m->devices[i]);
     // completion = the event recorded on the group's exchange stream right behind the collective and its status download; nothing
     // but the exchange ever runs on that stream
+    const double t_w0 = now_ms();
     if (hipEventRecord(m->x_done[i], m->xstream[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + ": hipEventRecord");
     // The local phase in front of the exchange (x_ready: recorded on the context's lane 0, a stream of the device's shared pool) is
     // this rank's own, finite work -- possibly queued behind another context's kernels on that lane: it is waited for WITHOUT a
     // deadline.  The deadline below is the collective's alone.
     if (hipEventSynchronize(m->x_ready[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + ": the local phase failed");
+    const double t_w1 = now_ms();
     if (m->gather_timeout_ms <= 0) {
         if (hipEventSynchronize(m->x_done[i]) != hipSuccess) return mfail(m, KZG_ERR_HIP, std::string(what) + " failed");
         return KZG_OK;
@@ -853,7 +856,10 @@ static int mctx_wait(kzg_mctx *m, Rccl *r, int i, const char *what) {
     const auto t0 = std::chrono::steady_clock::now();
     for (;;) {
         hipError_t e = hipEventQuery(m->x_done[i]);
-        if (e == hipSuccess) return KZG_OK;
+        if (e == hipSuccess) {
+            KZG_DBG("%s: local phase %.2f ms, collective %.2f ms", what, t_w1 - t_w0, now_ms() - t_w1);
+            return KZG_OK;
+        }
         if (e != hipErrorNotReady) return mfail(m, KZG_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
         const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
         if (us > m->gather_timeout_ms * 1000) break;

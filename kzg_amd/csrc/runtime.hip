@@ -116,7 +116,7 @@ using namespace kzg;
 // ---------------------------------------------------------------------------------------------
 extern "C" const char *kzg_version(void) { return "kzg-mi355x 0.1.0 (gfx950)"; }
 
-// The pipelined paths want one hardware queue per stream (14 lanes + 4 accumulation streams, and ~6 for an RCCL communicator); the HIP runtime sizes its queue
+// The pipelined paths want one hardware queue per stream (13 lanes + 4 accumulation streams, one exchange stream per device group, and ~6 for an RCCL communicator); the HIP runtime sizes its queue
 // pool from GPU_MAX_HW_QUEUES (default 4) when it initialises, i.e. at the first HIP call of the process.  The library does not
 // touch the host's environment on its own: the host either exports GPU_MAX_HW_QUEUES itself, or calls kzg_init_hw_queues()
 // before its first HIP call, or sets KZG_SET_HW_QUEUES=<n> to let the load-time constructor below do it.  Without any of these
@@ -178,7 +178,9 @@ extern "C" int kzg_device_count(void) {
 // stream in submission order; every wait is on an event that the same host thread submitted EARLIER in real time, so the streams'
 // FIFO order cannot close a cycle.  An RCCL communicator needs about six queues of the same pool (24 by default): with 16 lanes + 4
 // accumulation streams beside one the exchange's kernels queue behind the pipeline's (336.6 against 469.9 commitments/s), which is
-// why every context plans 14 + 4 (option "streams"; same-box 474.2 against 471.2 commitments/s for a plain context: no loss) -- a
+// why every context plans 13 + 4 (option "streams"; round 5 planned 14 + 4 -- 474.2 against 471.2 commitments/s at 16: no loss; round 6 gave the
+// 14th lane's queue to the device group's own exchange stream: with 14 + 4 + that stream + RCCL's six the 25th stream shared a queue and the group path
+// fell from 465 to 337 commitments/s, with 13 lanes it is back at 475 and a plain context measures 471-472 against 473-474, profiles/r06_group_exchange_stream.txt) -- a
 // prover context, a device group and its communicator then fit the pool together: the group path beside a live plain context
 // 471.1 against 473.5 alone, both committing at once 512-517 in total (profiles/r05_engine_and_group.txt).  Not isolated: a
 // collective that never leaves the group's exchange stream (lane 0; after a failed ncclCommAbort) blocks that pool stream for the

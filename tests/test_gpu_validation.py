@@ -283,8 +283,8 @@ def test_pipeline_narrowing_is_reported_not_silent():
     assert r.returncode == 0, r.stderr[-2000:]
     lines = {ln.split(" ", 1)[0]: ln for ln in r.stdout.splitlines() if ln.split(" ", 1)[0] in ("BEFORE", "FULL", "NARROW", "AGAIN")}
     assert "lanes=0 accum_streams=0" in lines["BEFORE"] and "narrowed_from=none" in lines["BEFORE"]
-    assert "lanes=14 accum_streams=4" in lines["FULL"] and "narrowed_from=none" in lines["FULL"]
-    assert "lanes=3 accum_streams=1 hw_queues_found=4 narrowed_from=14+4" in lines["NARROW"], lines["NARROW"]
+    assert "lanes=13 accum_streams=4" in lines["FULL"] and "narrowed_from=none" in lines["FULL"]
+    assert "lanes=3 accum_streams=1 hw_queues_found=4 narrowed_from=13+4" in lines["NARROW"], lines["NARROW"]
     assert "narrowed_from=none" in lines["AGAIN"]
-    warn = [ln for ln in r.stderr.splitlines() if ln.startswith("kzg: device 0: this context's 14 + 4 streams found only 4 hardware queues")]
+    warn = [ln for ln in r.stderr.splitlines() if ln.startswith("kzg: device 0: this context's 13 + 4 streams found only 4 hardware queues")]
     assert len(warn) == 1, r.stderr[-1500:]          # once per context, not once per call
