@@ -126,8 +126,10 @@ void kzg_ctx_destroy(kzg_ctx *ctx);
 const char *kzg_last_error(kzg_ctx *ctx);
 int kzg_sync(kzg_ctx *ctx);
 /* tunables: "window_bits" (0 = auto, 4..20), "window_rows" (0 = one table row per window; applies to SRSs created afterwards),
- * "trusted_points" (0 / 1), "streams" (1..16: batch pipelining depth), "accum_streams" (0..4), "accum_blocks[_batch]",
- * "sort_threads[_batch]", "ntt_vec_log", "hw_queues" (0 = measure), "tail_quads" (0 / 1: latency-mode tail kernels of a
+ * "trusted_points" (0 / 1), "streams" (1..16: batch pipelining depth, default 13), "accum_streams" (0..4), "accum_blocks[_batch]",
+ * "sort_threads[_batch]", "ntt_vec_log" / "ntt_vec2_log" (tile widths of the NTT passes), "ntt_kernel" (1 = default: tile load / store fused
+ * into the first / last stage pair; 0 = the round-5 three-phase passes, 2 = two butterflies per thread: A/B only), "ntt_three_from" (sizes from
+ * 2^this on take three passes of <= 2^8 points, default 23; 0 = never), "hw_queues" (0 = measure), "tail_quads" (0 / 1: latency-mode tail kernels of a
  * lone MSM), "host_affine" (1 / 0: a lone result bound for host memory is converted to affine and serialised by the calling
  * thread -- the same field code compiled for the host -- instead of one GPU lane; same bytes, ~90 us less latency),
  * "sort_single_pass" (0 / 1: 17-bit windows sorted in one pass instead of two levels; A/B only),
