@@ -51,6 +51,8 @@ def main():
         if isinstance(uid, dict):
             raise kzg_amd.EngineError(uid["error"])
         group = DeviceGroup.for_rank(rank, rank, world, uid)          # device = rank: one process per GPU
+        if world == 1:
+            group.set_option("always_gather", 1)      # a group of one still forms its communicator and runs the all-gather
         out = {"rank": rank, "world": group.world, "info": group.info(), "torch_imported": "torch" in sys.modules}
         srs = group.setup(TAU, N)
         shard, first = srs.shard(0)
