@@ -360,49 +360,6 @@ def test_exchange_deadline_ignores_another_contexts_work_on_the_shared_lanes(eng
     group.close()
 
 
-@pytest.mark.limit(300)
-def test_group_batch_rate_is_the_plain_batch_rate(engine, need_rccl):
-    """A guard for the process' hardware-queue budget (profiles/r06_group_exchange_stream.txt): the device group's batched commit at world 1
-    (RCCL all-gather forced on) runs at the rate of the plain kzg_msm_g1_batch on the same polynomials -- when the group's exchange stream
-    became the 25th stream of a 24-queue process, two streams shared a queue and the group path dropped to 0.72 of it.  Threshold 0.85."""
-    import time
-    n, batch = 1 << 18, 28
-    group = kzg_amd.DeviceGroup([0])
-    group.set_option("always_gather", 1)
-    eng = group.engine(0)
-    sc = eng.alloc_scalars(n * batch).fill_random(4242)
-    msrs = group.setup(TAU, n)
-    out = ctypes.create_string_buffer(96 * batch)
-    ptrs = (ctypes.c_void_p * 1)(sc.ptr.value)
-
-    def group_step():
-        rc = group.lib.kzg_commit_coeff_sharded_batch(group.handle, msrs.handle, ptrs, n, batch, sc.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
-        assert rc == 0, group.last_error()
-    shard, _ = msrs.shard(0)
-    out2 = ctypes.create_string_buffer(96 * batch)
-
-    def plain_step():
-        rc = eng.lib.kzg_msm_g1_batch(eng.ctx, shard.handle, 0, sc.ptr, n, batch, sc.sfmt, L.IN_DEVICE, out2, L.G1_AFFINE_MONT)
-        assert rc == 0, eng.last_error()
-
-    def rate(f):
-        for _ in range(3):
-            f()
-        best = 1e9
-        for _ in range(3):
-            t0 = time.perf_counter()
-            for _ in range(4):
-                f()
-            best = min(best, (time.perf_counter() - t0) / 4)
-        return batch / best
-    r_plain, r_group = rate(plain_step), rate(group_step)
-    assert out.raw == out2.raw
-    assert r_group > 0.85 * r_plain, (r_group, r_plain, group.info())
-    sc.free()
-    msrs.free()
-    group.close()
-
-
 def test_witness_eval_sharded(engine):
     """KZGProverEvalForm::create_witness over the device group (src/eval_form.rs:124-140): Lagrange-basis SRS sharded, quotient
     replicated, MSM sharded; equal to the oracle's [(p(tau) - y) / (tau - w^m)]G, to the single-GPU kzg_witness_eval, host- and
