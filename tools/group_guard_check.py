@@ -2,7 +2,8 @@
 """The device group's batched commit at world 1 (RCCL all-gather forced on) against the plain kzg_msm_g1_batch on the same polynomials, in a
 process of its own: the ratio of the two rates for each lane count given (default: the engine's default).  A guard for the process'
 hardware-queue budget (profiles/r06_group_exchange_stream.txt): 0.997 at 13 lanes, 0.634 at 14, where the group's exchange stream is the
-25th stream of a 24-queue process.  tests/test_gpu_bench_multi.py::test_group_batch_rate_is_the_plain_batch_rate runs it.
+25th stream of a 24-queue process.  Run it ALONE on the box (not from the test session: a pytest process that has used the GPU -- its
+contexts released or not -- skews the two rates differently, which is why this is a tool and not a test).
    python tools/group_guard_check.py [lanes ...]"""
 import ctypes, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
