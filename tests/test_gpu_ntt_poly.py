@@ -227,3 +227,35 @@ def test_evaluation_domain_remaining_ops(engine):
     assert rc == 0
     assert kzg_amd.unpack_scalars(da.download()) == [x * y % M.R * Rm % M.R for x, y in zip(xs, ys)]
     da.free(); db.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.limit(300)
+@pytest.mark.parametrize("n", [1, 2, 7, 2047, 2048, 2049, 100003, (1 << 21) + 1, (1 << 22) + 12345])
+def test_horner_scan_every_shape(engine, n):
+    """kzg_poly_eval and kzg_witness_coeff through the Horner scan kernels of poly.hip (LDS-staged tiles of 2048 coefficients, block
+    carries scanned by one block with host-computed step multipliers) at sizes that exercise every shape: below one tile, ragged last
+    tiles, one block carry per scan thread (<= 2^21) and several (above): p(x) by the oracle's Horner loop, the witness against
+    [(p(tau) - y) / (tau - x)]G (src/polynomial.rs:193-227, src/coeff_form.rs:66-81)."""
+    import ctypes
+    from oracle import c_oracle as C
+    R = kzg_amd.api.R_MODULUS
+    tau = 0x5EED5EED
+    buf = engine.alloc_scalars(n).fill_random(900 + n % 97)
+    host = buf.download()
+    x = kzg_amd.splitmix_scalar(31, n % 1000)
+    y = engine.poly_eval(buf, x)
+    assert y == C.poly_eval_bytes(host, n, x)
+    if n >= 2:
+        params = kzg_amd.setup(engine, tau, n, g2_len=0)
+        out = ctypes.create_string_buffer(96)
+        rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, (x % R).to_bytes(32, "little"), (y % R).to_bytes(32, "little"),
+                                          buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+        assert rc == 0, engine.last_error()
+        ptau = C.poly_eval_bytes(host, n, tau)
+        assert out.raw == C.g1_mul(C.g1_generator(), (ptau - y) * pow(tau - x, -1, R) % R)
+        rc = engine.lib.kzg_witness_coeff(engine.ctx, params.gs.handle, buf.ptr, n, (x % R).to_bytes(32, "little"), ((y + 1) % R).to_bytes(32, "little"),
+                                          buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
+        assert rc == L.KZG_ERR_POINT_NOT_ON_POLY
+        params.gs.free()
+    buf.free()
