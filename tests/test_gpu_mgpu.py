@@ -317,7 +317,7 @@ def test_exchange_deadline_ignores_another_contexts_work_on_the_shared_lanes(eng
     sit in front of the group's all-gather and a short gather_timeout_ms read a healthy exchange as a dead peer.  The exchange now has
     a stream of its own, completion is an event behind the collective, and the group's local phase is waited for without a deadline:
     with an engine of the same device (same library, same pool) saturating the lanes from another thread, twenty commits under a
-    40 ms deadline all succeed and the group stays alive."""
+    100 ms deadline all succeed and the group stays alive."""
     import threading
     group = kzg_amd.DeviceGroup([0])
     group.set_option("always_gather", 1)
@@ -346,7 +346,7 @@ def test_exchange_deadline_ignores_another_contexts_work_on_the_shared_lanes(eng
     try:
         while steps[0] < 2 and not bad:
             pass
-        group.set_option("gather_timeout_ms", 40)
+        group.set_option("gather_timeout_ms", 100)
         for _ in range(20):
             assert group.commit(srs, coeffs) == want
         assert "dead=0" in group.info()
