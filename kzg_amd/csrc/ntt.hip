@@ -546,7 +546,7 @@ __global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, 
             const uint32_t vv = g & (vec - 1), j = g >> vl;  // consecutive threads -> consecutive columns (pass 1) / rows (pass 2)
             const uint32_t pu = swz((vv << t) | j, sw);
             // the four inter-pass table entries of this butterfly: requested before the LDS reads where the registers allow it (BPT = 2,
-            // 256 VGPRs), one at a time behind the butterflies at four waves per SIMD (128 VGPRs: requested together they spill 8-21 registers)
+            // 256 VGPRs), one ahead of its use behind the butterflies at four waves per SIMD (128 VGPRs: requested together they spill 8-21 registers)
             Fr29 twf[4];
             if (BPT == 2 && PASS == 1 && a.tw_full) {
 #pragma unroll
@@ -569,6 +569,10 @@ __global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, 
                 fr29_butterfly_lazy(s0, s2, z[0], z[2]);
                 fr29_butterfly_lazy(y1, y3, z[1], z[3]);
             }
+            // BPT = 1: the table entry of element i + 1 is requested before the product of element i (one entry in flight beside the one in
+            // use: 126 VGPRs, no spill; pass 1 -1..2 % at 2^20 / 2^21, profiles/r06_ab_ntt.txt)
+            Fr29 twn;
+            if (BPT == 1 && PASS == 1 && a.tw_full) twn = a.tw_full[((size_t)j << a.kother) + tile0 + vv];
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t kk = j + i * Q;
@@ -576,7 +580,9 @@ __global__ __launch_bounds__(1024 / BPT) void k_ntt_tile(const Fr *in, Fr *out, 
                 if (PASS == 1) {
                     const uint32_t j2 = tile0 + vv;
                     if (a.tw_full) {
-                        x = mul29r(x, BPT == 2 ? twf[i] : a.tw_full[((size_t)kk << a.kother) + j2]);
+                        const Fr29 twc = twn;
+                        if (BPT == 1 && i < 3) twn = a.tw_full[((size_t)(kk + Q) << a.kother) + j2];
+                        x = mul29r(x, BPT == 2 ? twf[i] : twc);
                     } else {
                         const uint64_t ex = (uint64_t)j2 * kk;
                         const size_t ih = ex >> a.lo_bits, il = ex & lo_mask;
