@@ -8,6 +8,7 @@
 //   * batch inversion, format conversion, Polynomial::eval (src/polynomial.rs:156-165), and the
 //     counter-based synthetic input generator used by bench.py.
 #include "common.h"
+#include "fr29.h"
 
 namespace kzg {
 
@@ -113,10 +114,54 @@ constexpr int HT = 256;          // threads per block
 constexpr int HE = 8;            // coefficients per thread
 constexpr int HB = HT * HE;      // coefficients per block
 
-__device__ __forceinline__ Fr horner8(const Fr a[HE], const Fr &x) {
-    Fr v = a[HE - 1];
+// Every multiplication of the three kernels is by a constant of the launch (x, a power of x), so it is the NTT's Shoup product on
+// 9 x 29-bit limbs (fr29.h: 143 multiply-adds and 37 shifts / masks, no carry folds) instead of the saturated Montgomery product
+// (128 multiply-adds + 156 carry folds + moves: ~380 instructions, out of line).  The data keeps whatever form it has (the product
+// with the plain integer x is the product of the residues), sums stay unreduced between products (a product accepts any value
+// below 2^261 with limbs below 1.5 * 2^30 and returns one below 2r), and what leaves a kernel is canonical.
+struct ShoupConst {
+    Fr29 w, wp;                   // the constant as a plain residue and floor(w 2^261 / r)
+};
+static ShoupConst shoup_const(const Fr &c_mont) {
+    ShoupConst c;
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(c_mont), c.w, c.wp);
+    return c;
+}
+__device__ __forceinline__ Fr29 mul_const(const Fr29 &v, const ShoupConst &c) { return mulshoup29(v, c.w, c.wp); }
+__device__ __forceinline__ Fr29 add29(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
 #pragma unroll
-    for (int k = HE - 2; k >= 0; k--) v = add(mul(v, x), a[k]);
+    for (int i = 0; i < R29_N; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+__device__ __forceinline__ Fr29 zero29() {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) r.v[i] = 0u;
+    return r;
+}
+// any normalised value below 64 r -> the canonical residue in 8 x 32-bit words
+__device__ __forceinline__ Fr canonical29(const Fr29 &v) { return fr29_pack_canonical(fr29_reduce_below_2r(v)); }
+// nine-limb values of a block in LDS, limb-major (conflict-free 32-bit accesses)
+template <int T>
+__device__ __forceinline__ void sh_put(uint32_t *sh, int t, const Fr29 &v) {
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) sh[i * T + t] = v.v[i];
+}
+template <int T>
+__device__ __forceinline__ Fr29 sh_get(const uint32_t *sh, int t) {
+    Fr29 v;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) v.v[i] = sh[i * T + t];
+    return v;
+}
+
+// a_0 + x (a_1 + x (... a_7)): limbs below 2^30, value below 2^256 + 2r; not normalised.  (Splitting it into an even and an odd chain
+// by x^2 issued as one interleaved stream -- four products deep instead of seven -- changed nothing: DESIGN.md section 3.4.)
+__device__ __forceinline__ Fr29 horner8(const Fr a[HE], const ShoupConst &x) {
+    Fr29 v = fr29_unpack(a[HE - 1]);
+#pragma unroll
+    for (int k = HE - 2; k >= 0; k--) v = add29(mul_const(v, x), fr29_unpack(a[k]));
     return v;
 }
 
@@ -153,141 +198,174 @@ __device__ __forceinline__ void load8_tile(const Fr *coeffs, size_t n, hchunk *l
     }
 }
 
-// x8^(2^k), k < 8: the multipliers of the eight steps of a 256-thread tree / scan.  Computed once on the host -- every thread used to
-// square its own copy eight times (8 of a thread's 23-31 multiplications).
-struct HornerPowers {
-    Fr p[8];
+// the constants of a launch: x, and x^8 squared k times (k < 8) -- the multipliers of the block tree / scan steps.  They come from
+// the host: every thread used to square its own copy eight times.
+struct HornerConsts {
+    ShoupConst x;
+    ShoupConst p[8];
 };
 
 // S[b] = sum_{i in block b} a_i x^(i - start_b)
-__global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t n, Fr x, HornerPowers pw, Fr *S) {
+__global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t n, HornerConsts c, Fr *S) {
     extern __shared__ __attribute__((aligned(16))) hchunk h_lds[];
     int t = threadIdx.x;
     Fr a[HE];
     load8_tile(coeffs, n, h_lds, a);
-    Fr v = horner8(a, x);
+    Fr29 v = fr29_normalize(horner8(a, c.x));
     __syncthreads();                 // the tile is consumed: its memory carries the tree
-    Fr *sh = (Fr *)h_lds;
-    sh[t] = v;
+    uint32_t *sh = (uint32_t *)h_lds;
+    sh_put<HT>(sh, t, v);
     __syncthreads();
 #pragma unroll
-    for (int st = 0; st < 8; st++) {
+    for (int st = 0; st < 8; st++) {     // v grows by less than 2r per step: below 21 r at the end
         const int off = 1 << st;
         bool active = (t & (2 * off - 1)) == 0;
-        if (active) v = add(v, mul(sh[t + off], pw.p[st]));
+        if (active) v = fr29_normalize(add29(v, mul_const(sh_get<HT>(sh, t + off), c.p[st])));
         __syncthreads();
-        if (active) sh[t] = v;
+        if (active) sh_put<HT>(sh, t, v);
         __syncthreads();
     }
-    if (t == 0) S[blockIdx.x] = v;
+    if (t == 0) S[blockIdx.x] = canonical29(v);
 }
 
-// H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block.  The multipliers of the ten scan
-// steps, (X^g)^(2^k), come from the host: every thread used to raise X to the g-th power by a 64-step square-and-multiply loop of its
-// own and to square the result ten times -- 64 us for a kernel that moves 32 KB (profiles/r06_prof_witness_coeff.txt).
+// H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block of T = blockDim.x threads, T the
+// power of two that covers nblk (64 <= T <= 1024): a 2^20 polynomial has 512 partial sums, and 1024 threads scanned them in ten
+// steps with half of the block multiplying zeros.  The multipliers of the scan steps, (X^g)^(2^k), come from the host: every thread
+// used to raise X to the g-th power by a 64-step square-and-multiply loop of its own and to square the result ten times -- 64 us
+// for a kernel that moves 32 KB (profiles/r06_prof_witness_coeff.txt).
 constexpr int HS_T = 1024;
-struct ScanPowers {
-    Fr p[10];
+struct ScanConsts {
+    ShoupConst X;
+    ShoupConst p[10];
 };
-__global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk, Fr X, ScanPowers pw, Fr *H, Fr *px) {
-    __shared__ Fr sh[HS_T];
-    int t = threadIdx.x;
-    uint32_t g = (nblk + HS_T - 1) / HS_T;  // blocks per thread
+__global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk, ScanConsts c, Fr *H, Fr *px) {
+    __shared__ uint32_t sh[R29_N * HS_T];
+    const int t = threadIdx.x, T = blockDim.x;
+    uint32_t g = (nblk + T - 1) / T;  // blocks per thread
     uint32_t b0 = t * g;
     // segment value v_t = sum_k S[b0+k] X^k
-    Fr v = Fr::zero();
+    Fr29 v = zero29();
     for (uint32_t k = g; k-- > 0;) {
-        Fr s = (b0 + k < nblk) ? S[b0 + k] : Fr::zero();
-        v = g == 1 ? s : add(mul(v, X), s);
+        Fr29 s = (b0 + k < nblk) ? fr29_unpack(S[b0 + k]) : zero29();
+        v = g == 1 ? s : add29(mul_const(v, c.X), s);
     }
-    // inclusive suffix scan A_t = v_t + M A_{t+1}, M = X^g
-    sh[t] = v;
+    v = fr29_normalize(v);
+    // inclusive suffix scan A_t = v_t + M A_{t+1}, M = X^g; v grows by less than 2r per step: below 25 r at the end
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) sh[i * T + t] = v.v[i];
     __syncthreads();
 #pragma unroll
     for (int st = 0; st < 10; st++) {
         const int off = 1 << st;
-        Fr o = (t + off < HS_T) ? sh[t + off] : Fr::zero();
-        __syncthreads();
-        v = add(v, mul(o, pw.p[st]));
-        sh[t] = v;
-        __syncthreads();
-    }
-    Fr carry = (t + 1 < HS_T) ? sh[t + 1] : Fr::zero();
-    for (uint32_t k = g; k-- > 0;) {
-        if (b0 + k < nblk) {
-            H[b0 + k] = carry;
-            carry = add(S[b0 + k], mul(carry, X));
+        if (off < T) {               // uniform
+            Fr29 o = zero29();
+            if (t + off < T) {
+#pragma unroll
+                for (int i = 0; i < R29_N; i++) o.v[i] = sh[i * T + t + off];
+            }
+            __syncthreads();
+            v = fr29_normalize(add29(v, mul_const(o, c.p[st])));
+#pragma unroll
+            for (int i = 0; i < R29_N; i++) sh[i * T + t] = v.v[i];
+            __syncthreads();
         }
     }
-    if (t == 0) *px = carry;
+    Fr29 carry = zero29();
+    if (t + 1 < T) {
+#pragma unroll
+        for (int i = 0; i < R29_N; i++) carry.v[i] = sh[i * T + t + 1];
+    }
+    for (uint32_t k = g; k-- > 0;) {
+        if (b0 + k < nblk) {
+            H[b0 + k] = canonical29(carry);
+            carry = fr29_normalize(add29(fr29_unpack(S[b0 + k]), mul_const(carry, c.X)));
+        }
+    }
+    if (t == 0) *px = canonical29(carry);
 }
 
 // q_i = sum_{j > i} a_j x^(j-i-1) for i < n - 1.  coeffs may alias q (a block reads its whole tile before it writes).
-__global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t n, Fr x, HornerPowers pw, const Fr *H, Fr *q) {
+__global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t n, HornerConsts c, const Fr *H, Fr *q) {
     extern __shared__ __attribute__((aligned(16))) hchunk h_lds[];
     int t = threadIdx.x;
     Fr a[HE];
     load8_tile(coeffs, n, h_lds, a);
-    Fr v = horner8(a, x);
-    const Fr Hb = H[blockIdx.x];
-    if (t == HT - 1) v = add(v, mul(pw.p[0], Hb));  // fold the carry from higher blocks in
+    Fr29 v = horner8(a, c.x);
+    const Fr29 Hb = fr29_unpack(H[blockIdx.x]);
+    if (t == HT - 1) v = add29(v, mul_const(Hb, c.p[0]));  // fold the carry from higher blocks in
+    v = fr29_normalize(v);
     __syncthreads();                 // every thread has read its coefficients: the tile's memory carries the scan
-    Fr *sh = (Fr *)h_lds;
-    sh[t] = v;
+    uint32_t *sh = (uint32_t *)h_lds;
+    sh_put<HT>(sh, t, v);
     __syncthreads();
 #pragma unroll
-    for (int st = 0; st < 8; st++) {
+    for (int st = 0; st < 8; st++) {     // v grows by less than 2r per step: below 23 r at the end
         const int off = 1 << st;
-        Fr o = (t + off < HT) ? sh[t + off] : Fr::zero();
+        Fr29 o = (t + off < HT) ? sh_get<HT>(sh, t + off) : zero29();
         __syncthreads();
-        v = add(v, mul(o, pw.p[st]));
-        sh[t] = v;
+        v = fr29_normalize(add29(v, mul_const(o, c.p[st])));
+        sh_put<HT>(sh, t, v);
         __syncthreads();
     }
-    Fr carry = (t + 1 < HT) ? sh[t + 1] : Hb;
+    Fr29 carry = (t + 1 < HT) ? sh_get<HT>(sh, t + 1) : Hb;
     __syncthreads();
-    // the eight quotient coefficients of this thread go back through the tile: whole-line stores
+    // the eight quotient coefficients of this thread go back through the tile: whole-line stores.  q_(8t+7) is the carry; each of the
+    // others is a coefficient (canonical: the caller's scalars are) plus a Shoup product made canonical -- one modular addition, and
+    // the next product starts from the sum's limbs.
+    Fr out = canonical29(carry);
 #pragma unroll
     for (int k = HE - 1; k >= 0; k--) {
-        h_lds[17 * t + 2 * k] = hchunk{carry.v[0], carry.v[1], carry.v[2], carry.v[3]};
-        h_lds[17 * t + 2 * k + 1] = hchunk{carry.v[4], carry.v[5], carry.v[6], carry.v[7]};
-        carry = add(a[k], mul(carry, x));
+        h_lds[17 * t + 2 * k] = hchunk{out.v[0], out.v[1], out.v[2], out.v[3]};
+        h_lds[17 * t + 2 * k + 1] = hchunk{out.v[4], out.v[5], out.v[6], out.v[7]};
+        if (k) {
+            out = add(a[k], fr29_pack_canonical(mul_const(carry, c.x)));
+            carry = fr29_unpack(out);
+        }
     }
     __syncthreads();
     const size_t c0 = (size_t)blockIdx.x * H_CHUNKS, cq = (n - 1) * 2;     // q has n - 1 coefficients
     hchunk *g = (hchunk *)q;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
-        const size_t c = c0 + (size_t)(t + j * HT);
-        if (c < cq) g[c] = h_lds[h_slot(t + j * HT)];
+        const size_t cc = c0 + (size_t)(t + j * HT);
+        if (cc < cq) g[cc] = h_lds[h_slot(t + j * HT)];
     }
 }
 
 static int horner_common(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr &x, Fr **S, Fr **H, Fr **px,
-                         uint32_t *nblk_out, HornerPowers *pw_out) {
+                         uint32_t *nblk_out, HornerConsts *hc_out) {
     hipStream_t st = ctx->lanes[lane].stream;
     uint32_t nblk = (uint32_t)((n + HB - 1) / HB);
     *S = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
     *H = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
     *px = (Fr *)lane_alloc(ctx, lane, sizeof(Fr));
     if (!*S || !*H || !*px) return fail(ctx, KZG_ERR_ALLOC, "Horner workspace not reserved");
-    Fr x8 = pow_u64(x, HE);
-    Fr X = pow_u64(x, HB);
-    HornerPowers pw;
-    pw.p[0] = x8;
-    for (int k = 1; k < 8; k++) pw.p[k] = sqr(pw.p[k - 1]);
+    Fr pk = pow_u64(x, HE);
+    HornerConsts hc;
+    hc.x = shoup_const(x);
+    for (int k = 0; k < 8; k++) {
+        hc.p[k] = shoup_const(pk);
+        pk = sqr(pk);
+    }
+    const Fr X = pk;                 // x^(8 * 2^8) = x^HB
     if (!ctx->attr_horner_set) {
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_horner_partials, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES));
         KZG_HIP_CHECK(ctx, hipFuncSetAttribute((const void *)k_quotient_apply, hipFuncAttributeMaxDynamicSharedMemorySize, H_LDS_BYTES));
         ctx->attr_horner_set = true;
     }
-    KZG_LAUNCH(ctx, st, "k_horner_partials", k_horner_partials, nblk, HT, H_LDS_BYTES, d_coeffs, n, x, pw, *S);
-    ScanPowers spw;
-    spw.p[0] = pow_u64(X, (uint64_t)((nblk + HS_T - 1) / HS_T));
-    for (int k = 1; k < 10; k++) spw.p[k] = sqr(spw.p[k - 1]);
-    KZG_LAUNCH(ctx, st, "k_horner_scan", k_horner_scan, 1, HS_T, 0, *S, nblk, X, spw, *H, *px);
+    KZG_LAUNCH(ctx, st, "k_horner_partials", k_horner_partials, nblk, HT, H_LDS_BYTES, d_coeffs, n, hc, *S);
+    uint32_t T = 64;                 // scan width: the power of two that covers the partial sums
+    while (T < (uint32_t)HS_T && T < nblk) T *= 2;
+    ScanConsts sc;
+    sc.X = shoup_const(X);
+    pk = pow_u64(X, (uint64_t)((nblk + T - 1) / T));
+    for (int k = 0; k < 10; k++) {
+        sc.p[k] = shoup_const(pk);
+        pk = sqr(pk);
+    }
+    KZG_LAUNCH(ctx, st, "k_horner_scan", k_horner_scan, 1, T, 0, *S, nblk, sc, *H, *px);
     *nblk_out = nblk;
-    *pw_out = pw;
+    *hc_out = hc;
     return KZG_OK;
 }
 
@@ -295,9 +373,9 @@ int poly_eval_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, const Fr
     hipStream_t st = ctx->lanes[lane].stream;
     if (n == 0) return fail(ctx, KZG_ERR_SHAPE, "empty polynomial");
     Fr *S, *H, *px;
-    HornerPowers pw;
+    HornerConsts hc;
     uint32_t nblk;
-    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &pw));
+    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &hc));
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_y_out, px, sizeof(Fr), hipMemcpyDeviceToDevice, st));
     return KZG_OK;
 }
@@ -307,10 +385,10 @@ int quotient_linear_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, co
     hipStream_t st = ctx->lanes[lane].stream;
     if (n == 0) return fail(ctx, KZG_ERR_SHAPE, "empty polynomial");
     Fr *S, *H, *px;
-    HornerPowers pw;
+    HornerConsts hc;
     uint32_t nblk;
-    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &pw));
-    if (n > 1) KZG_LAUNCH(ctx, st, "k_quotient_apply", k_quotient_apply, nblk, HT, H_LDS_BYTES, d_coeffs, n, x_mont, pw, H, d_q_out);
+    KZG_TRY(horner_common(ctx, lane, d_coeffs, n, x_mont, &S, &H, &px, &nblk, &hc));
+    if (n > 1) KZG_LAUNCH(ctx, st, "k_quotient_apply", k_quotient_apply, nblk, HT, H_LDS_BYTES, d_coeffs, n, hc, H, d_q_out);
     KZG_HIP_CHECK(ctx, hipMemcpyAsync(d_px_out, px, sizeof(Fr), hipMemcpyDeviceToDevice, st));
     return KZG_OK;
 }

@@ -231,11 +231,11 @@ def test_evaluation_domain_remaining_ops(engine):
 
 @pytest.mark.gpu
 @pytest.mark.limit(300)
-@pytest.mark.parametrize("n", [1, 2, 7, 2047, 2048, 2049, 100003, (1 << 21) + 1, (1 << 22) + 12345])
+@pytest.mark.parametrize("n", [1, 2, 7, 2047, 2048, 2049, 100003, 150001, (1 << 18) + 5, 1 << 20, (1 << 21) + 1, (1 << 22) + 12345])
 def test_horner_scan_every_shape(engine, n):
     """kzg_poly_eval and kzg_witness_coeff through the Horner scan kernels of poly.hip (LDS-staged tiles of 2048 coefficients, block
     carries scanned by one block with host-computed step multipliers) at sizes that exercise every shape: below one tile, ragged last
-    tiles, one block carry per scan thread (<= 2^21) and several (above): p(x) by the oracle's Horner loop, the witness against
+    tiles, every width of the carry scan (64 to 1024 threads), one block carry per scan thread (<= 2^21) and several (above): p(x) by the oracle's Horner loop, the witness against
     [(p(tau) - y) / (tau - x)]G (src/polynomial.rs:193-227, src/coeff_form.rs:66-81)."""
     import ctypes
     from oracle import c_oracle as C
@@ -258,4 +258,29 @@ def test_horner_scan_every_shape(engine, n):
                                           buf.sfmt, L.IN_DEVICE, out, L.G1_AFFINE_MONT)
         assert rc == L.KZG_ERR_POINT_NOT_ON_POLY
         params.gs.free()
+    buf.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2048, 70001, (1 << 18) + 3])
+def test_horner_extreme_values(engine, n):
+    """The Horner kernels keep unreduced sums of Shoup products in 29-bit limbs (poly.hip: below 25 r before a value is reduced): the
+    largest operands -- every coefficient r - 1, x = r - 1 (and x = 1, x = 0, all-zero coefficients) -- against the oracle's serial
+    loop, in both scalar formats (src/polynomial.rs:156-165, 193-227)."""
+    big = (M.R - 1).to_bytes(32, "little")
+    rng = random.Random(n)
+    cases = [("max", big * n), ("zero", bytes(32 * n)),
+             ("mixed", b"".join(big if rng.random() < 0.5 else bytes(32) for _ in range(n)))]
+    for name, blob in cases:
+        coeffs = C.bytes_to_scalars(blob)
+        for x in (M.R - 1, 1, 0, M.R - 2, 2):
+            y = C.poly_eval_bytes(blob, n, x)
+            assert engine.poly_eval(coeffs, x) == y, (name, x)
+            q = engine.quotient_linear(coeffs, x, y)
+            qb, nz = C.witness_quotient_bytes(blob, n, x, y)
+            assert not nz and q == C.bytes_to_scalars(qb), (name, x)
+    # Montgomery-form scalars resident on the device take the same kernels (the product with the plain x keeps the form)
+    buf = engine.alloc_scalars(n, sfmt=L.FR_MONT).upload(b"".join(((M.R - 1) * (1 << 256) % M.R).to_bytes(32, "little") for _ in range(n)))
+    for x in (M.R - 1, 3):
+        assert engine.poly_eval(buf, x) == C.poly_eval_bytes(big * n, n, x)
     buf.free()
