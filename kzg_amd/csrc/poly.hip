@@ -398,14 +398,12 @@ int quotient_linear_run(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, co
 // ---------------------------------------------------------------------------------------------
 struct EvalDomainTables {
     size_t d = 0;
-    Fr *pw = nullptr;    // w^t
-    Fr *inv1 = nullptr;  // 1/(w^t - 1), inv1[0] = 0
+    Fr *inv1 = nullptr;  // 1/(w^t - 1), inv1[0] = 0.  (w^t itself is not kept: w^t / (w^t - 1) = 1 + inv1[t], see k_eval_quotient)
 };
 
 void eval_tabs_free(kzg_ctx *ctx) {
     for (auto &kv : ctx->eval_tabs) {
-        if (kv.second->pw) hipFree(kv.second->pw);
-        if (kv.second->inv1) hipFree(kv.second->inv1);
+        if (kv.second->inv1) (void)hipFree(kv.second->inv1);
         delete kv.second;
     }
     ctx->eval_tabs.clear();
@@ -429,21 +427,21 @@ static int eval_tables(kzg_ctx *ctx, hipStream_t st, uint32_t log_d, EvalDomainT
     size_t d = (size_t)1 << log_d;
     EvalDomainTables *t = new EvalDomainTables();
     t->d = d;
-    Fr *tmp = nullptr;
+    Fr *pw = nullptr, *tmp = nullptr;        // w^t and w^t - 1: needed while the table is built
     int rc = KZG_OK;
-    if (hipMalloc((void **)&t->pw, d * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&t->inv1, d * sizeof(Fr)) != hipSuccess ||
+    if (hipMalloc((void **)&pw, d * sizeof(Fr)) != hipSuccess || hipMalloc((void **)&t->inv1, d * sizeof(Fr)) != hipSuccess ||
         hipMalloc((void **)&tmp, d * sizeof(Fr)) != hipSuccess)
         rc = fail(ctx, KZG_ERR_ALLOC, "hipMalloc(evaluation-domain tables)");
-    if (rc == KZG_OK) rc = pow_table(ctx, st, host_omega(log_d), Fr::one(), d, t->pw);
+    if (rc == KZG_OK) rc = pow_table(ctx, st, host_omega(log_d), Fr::one(), d, pw);
     if (rc == KZG_OK) {
-        KZG_LAUNCH(ctx, st, "k_sub_one", k_sub_one, (unsigned)((d + 255) / 256), 256, 0, t->pw, tmp, d);
+        KZG_LAUNCH(ctx, st, "k_sub_one", k_sub_one, (unsigned)((d + 255) / 256), 256, 0, pw, tmp, d);
         rc = batch_inverse(ctx, st, tmp, t->inv1, d);
     }
     if (rc == KZG_OK && hipStreamSynchronize(st) != hipSuccess) rc = fail(ctx, KZG_ERR_HIP, "evaluation-domain tables");
-    if (tmp) hipFree(tmp);
+    if (tmp) (void)hipFree(tmp);
+    if (pw) (void)hipFree(pw);
     if (rc != KZG_OK) {  // nothing half-built stays behind
-        if (t->pw) hipFree(t->pw);
-        if (t->inv1) hipFree(t->inv1);
+        if (t->inv1) (void)hipFree(t->inv1);
         delete t;
         return rc;
     }
@@ -466,17 +464,20 @@ __device__ __forceinline__ Fr block_sum_fr(Fr v, Fr *sh) {
 }
 
 // q_j = (f_j - y) / (w^j - w^m) for j != m; partial[b] = sum_{j in block} q_j w^((j-m) mod d)
-__global__ __launch_bounds__(256) void k_eval_quotient(const Fr *evals, size_t d, size_t m, Fr wm_inv, const Fr *pw,
-                                                       const Fr *inv1, Fr *q, Fr *partial) {
+__global__ __launch_bounds__(256) void k_eval_quotient(const Fr *evals, size_t d, size_t m, Fr wm_inv, const Fr *inv1, Fr *q,
+                                                       Fr *partial) {
     __shared__ Fr sh[256];
     size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     Fr contrib = Fr::zero();
     if (j < d && j != m) {
         Fr y = evals[m];
         size_t t = (j + d - m) & (d - 1);
-        Fr qj = mul(sub(evals[j], y), mul(wm_inv, inv1[t]));
+        // q_j = g_j / (w^t - 1) with g_j = (f_j - y) w^-m, and its term of q_m: q_j w^t = g_j (1 + 1 / (w^t - 1)) = g_j + q_j --
+        // two products per element and no read of the w^t table (it used to be three and 128 B per element)
+        Fr g = mul(sub(evals[j], y), wm_inv);
+        Fr qj = mul(g, inv1[t]);
         q[j] = qj;
-        contrib = mul(qj, pw[t]);
+        contrib = add(g, qj);
     }
     Fr s = block_sum_fr(contrib, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -510,9 +511,8 @@ int quotient_eval_run(kzg_ctx *ctx, int lane, const Fr *d_evals, uint32_t log_d,
     Fr *partial = (Fr *)lane_alloc(ctx, lane, (size_t)nblk * sizeof(Fr));
     if (!partial) return fail(ctx, KZG_ERR_ALLOC, "eval quotient workspace not reserved");
     Fr omega = host_omega(log_d);
-    Fr wm_inv = inv(pow_u64(omega, (uint64_t)m));
-    KZG_LAUNCH(ctx, st, "k_eval_quotient", k_eval_quotient, nblk, 256, 0, d_evals, d, m, wm_inv, tab->pw, tab->inv1,
-               d_q_out, partial);
+    Fr wm_inv = pow_u64(omega, (uint64_t)((d - m) & (d - 1)));  // w^-m = w^(d-m): no field inversion on the host (~25 us per call)
+    KZG_LAUNCH(ctx, st, "k_eval_quotient", k_eval_quotient, nblk, 256, 0, d_evals, d, m, wm_inv, tab->inv1, d_q_out, partial);
     KZG_LAUNCH(ctx, st, "k_eval_quotient_fix", k_eval_quotient_fix, 1, 256, 0, partial, nblk, m, d_q_out);
     return KZG_OK;
 }
