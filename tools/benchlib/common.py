@@ -57,16 +57,23 @@ def view(kzg_amd, buf, first, n):
     return v
 
 
-def timeit(f, reps=5, warm=4):
-    """ms per call.  Four untimed calls first: every reading of `paths` follows seconds of host-side checking (the oracle's Horner
-    loops) during which the GPU idles and drops its clocks -- one warm-up call read a lone create_witness 0.3-0.5 ms slower inside the
-    bench than the same call in a loop (profiles/r06_prof_witness_coeff.txt)."""
-    for _ in range(warm):
+def timeit(f, reps=10, warm=4, warm_ms=40.0):
+    """ms per call: the median of `reps` blocking calls, each timed by itself.  Untimed calls first -- at least `warm` of them and at
+    least `warm_ms` of them: every reading of `paths` follows seconds of host-side checking (the oracle's Horner loops) during which
+    the GPU idles and drops its clocks -- one warm-up call read a lone create_witness 0.3-0.5 ms slower inside the bench than the
+    same call in a loop, four still 0.2-0.3 ms slower (profiles/r06_prof_witness_coeff.txt: commit 2.41 but create_witness 2.74 ms in
+    one line, 0.04-0.10 ms apart in a loop)."""
+    t0, i = time.perf_counter(), 0
+    while i < warm or ((time.perf_counter() - t0) * 1e3 < warm_ms and i < 200):
         f()
-    t0 = time.perf_counter()
+        i += 1
+    ts = []
     for _ in range(reps):
+        t0 = time.perf_counter()
         f()
-    return (time.perf_counter() - t0) / reps * 1e3
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    return (ts[len(ts) // 2] if len(ts) % 2 else 0.5 * (ts[len(ts) // 2 - 1] + ts[len(ts) // 2])) * 1e3
 
 
 def view_of(buf, first, n):
