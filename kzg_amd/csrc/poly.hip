@@ -229,14 +229,18 @@ __global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t
 }
 
 // H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block of T = blockDim.x threads, T the
-// power of two that covers nblk (64 <= T <= 1024): a 2^20 polynomial has 512 partial sums, and 1024 threads scanned them in ten
-// steps with half of the block multiplying zeros.  The multipliers of the scan steps, (X^g)^(2^k), come from the host: every thread
-// used to raise X to the g-th power by a 64-step square-and-multiply loop of its own and to square the result ten times -- 64 us
-// for a kernel that moves 32 KB (profiles/r06_prof_witness_coeff.txt).
-constexpr int HS_T = 1024;
+// power of two that covers nblk, 64 <= T <= 512.  The block runs on ONE CU, so what counts is the number of products a SIMD goes
+// through in sequence: 2 g + log2 T with g = nblk / T sums per thread, times half the waves per SIMD (a lone wave's dependent
+// multiply-add chain leaves room for a second one; from there on waves share the issue slots).  Measured, same box
+// (profiles/r06_ab_horner.txt): 512 partial sums of a 2^20 polynomial -- 1024 threads (half of them multiplying zeros) 0.037 ms,
+// 512 threads 0.0206, 256 threads 0.0195; 8192 of a 2^24 polynomial -- 1024 threads 0.0606, 512 threads 0.0584, 256 threads 0.0684 ms.  The
+// multipliers of the scan steps, (X^g)^(2^k), come from the host: every thread used to raise X to the g-th power by a 64-step
+// square-and-multiply loop of its own and to square the result ten times -- 64 us for a kernel that moves 32 KB
+// (profiles/r06_prof_witness_coeff.txt).
+constexpr int HS_T = 512;
 struct ScanConsts {
     ShoupConst X;
-    ShoupConst p[10];
+    ShoupConst p[9];
 };
 __global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk, ScanConsts c, Fr *H, Fr *px) {
     __shared__ uint32_t sh[R29_N * HS_T];
@@ -255,7 +259,7 @@ __global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk
     for (int i = 0; i < R29_N; i++) sh[i * T + t] = v.v[i];
     __syncthreads();
 #pragma unroll
-    for (int st = 0; st < 10; st++) {
+    for (int st = 0; st < 9; st++) {
         const int off = 1 << st;
         if (off < T) {               // uniform
             Fr29 o = zero29();
@@ -359,7 +363,7 @@ static int horner_common(kzg_ctx *ctx, int lane, const Fr *d_coeffs, size_t n, c
     ScanConsts sc;
     sc.X = shoup_const(X);
     pk = pow_u64(X, (uint64_t)((nblk + T - 1) / T));
-    for (int k = 0; k < 10; k++) {
+    for (int k = 0; k < 9; k++) {
         sc.p[k] = shoup_const(pk);
         pk = sqr(pk);
     }
