@@ -275,6 +275,22 @@ KZG_HD Fr29 fr29_reduce_below_2r(const Fr29 &x) {
     return r;
 }
 
+// limb-wise sum, not normalised (the caller keeps the limbs below the bound of the next operation)
+KZG_HD Fr29 fr29_add_lazy(const Fr29 &a, const Fr29 &b) {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+}
+KZG_HD Fr29 fr29_zero() {
+    Fr29 r;
+#pragma unroll
+    for (int i = 0; i < R29_N; i++) r.v[i] = 0u;
+    return r;
+}
+// any normalised value below 64 r -> the canonical residue in 8 x 32-bit words
+KZG_HD Fr fr29_canonical(const Fr29 &v) { return fr29_pack_canonical(fr29_reduce_below_2r(v)); }
+
 // (w, wp) of a twiddle from its Montgomery-29 form t = w 2^261 mod r (canonical limbs: what fr29_twiddle_from_mont returns):
 // w = t / 2^261 mod r (a Montgomery product with the integer 1), and since w 2^261 = wp r + t, wp = (-t) r^-1 mod 2^261.
 KZG_HD void fr29_shoup_from_twiddle(const Fr29 &t, Fr29 &w, Fr29 &wp) {

@@ -127,21 +127,7 @@ static ShoupConst shoup_const(const Fr &c_mont) {
     fr29_shoup_from_twiddle(fr29_twiddle_from_mont(c_mont), c.w, c.wp);
     return c;
 }
-__device__ __forceinline__ Fr29 mul_const(const Fr29 &v, const ShoupConst &c) { return mulshoup29(v, c.w, c.wp); }
-__device__ __forceinline__ Fr29 add29(const Fr29 &a, const Fr29 &b) {
-    Fr29 r;
-#pragma unroll
-    for (int i = 0; i < R29_N; i++) r.v[i] = a.v[i] + b.v[i];
-    return r;
-}
-__device__ __forceinline__ Fr29 zero29() {
-    Fr29 r;
-#pragma unroll
-    for (int i = 0; i < R29_N; i++) r.v[i] = 0u;
-    return r;
-}
-// any normalised value below 64 r -> the canonical residue in 8 x 32-bit words
-__device__ __forceinline__ Fr canonical29(const Fr29 &v) { return fr29_pack_canonical(fr29_reduce_below_2r(v)); }
+KZG_HD Fr29 mul_const(const Fr29 &v, const ShoupConst &c) { return mulshoup29(v, c.w, c.wp); }
 // nine-limb values of a block in LDS, limb-major (conflict-free 32-bit accesses)
 template <int T>
 __device__ __forceinline__ void sh_put(uint32_t *sh, int t, const Fr29 &v) {
@@ -158,10 +144,10 @@ __device__ __forceinline__ Fr29 sh_get(const uint32_t *sh, int t) {
 
 // a_0 + x (a_1 + x (... a_7)): limbs below 2^30, value below 2^256 + 2r; not normalised.  (Splitting it into an even and an odd chain
 // by x^2 issued as one interleaved stream -- four products deep instead of seven -- changed nothing: DESIGN.md section 3.4.)
-__device__ __forceinline__ Fr29 horner8(const Fr a[HE], const ShoupConst &x) {
+KZG_HD Fr29 horner8(const Fr a[HE], const ShoupConst &x) {
     Fr29 v = fr29_unpack(a[HE - 1]);
 #pragma unroll
-    for (int k = HE - 2; k >= 0; k--) v = add29(mul_const(v, x), fr29_unpack(a[k]));
+    for (int k = HE - 2; k >= 0; k--) v = fr29_add_lazy(mul_const(v, x), fr29_unpack(a[k]));
     return v;
 }
 
@@ -220,12 +206,12 @@ __global__ __launch_bounds__(HT) void k_horner_partials(const Fr *coeffs, size_t
     for (int st = 0; st < 8; st++) {     // v grows by less than 2r per step: below 21 r at the end
         const int off = 1 << st;
         bool active = (t & (2 * off - 1)) == 0;
-        if (active) v = fr29_normalize(add29(v, mul_const(sh_get<HT>(sh, t + off), c.p[st])));
+        if (active) v = fr29_normalize(fr29_add_lazy(v, mul_const(sh_get<HT>(sh, t + off), c.p[st])));
         __syncthreads();
         if (active) sh_put<HT>(sh, t, v);
         __syncthreads();
     }
-    if (t == 0) S[blockIdx.x] = canonical29(v);
+    if (t == 0) S[blockIdx.x] = fr29_canonical(v);
 }
 
 // H[b] = sum_{b' > b} S[b'] X^(b'-b-1) with X = x^HB; px = S[0] + X H[0] = p(x).  Single block of T = blockDim.x threads, T the
@@ -248,10 +234,10 @@ __global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk
     uint32_t g = (nblk + T - 1) / T;  // blocks per thread
     uint32_t b0 = t * g;
     // segment value v_t = sum_k S[b0+k] X^k
-    Fr29 v = zero29();
+    Fr29 v = fr29_zero();
     for (uint32_t k = g; k-- > 0;) {
-        Fr29 s = (b0 + k < nblk) ? fr29_unpack(S[b0 + k]) : zero29();
-        v = g == 1 ? s : add29(mul_const(v, c.X), s);
+        Fr29 s = (b0 + k < nblk) ? fr29_unpack(S[b0 + k]) : fr29_zero();
+        v = g == 1 ? s : fr29_add_lazy(mul_const(v, c.X), s);
     }
     v = fr29_normalize(v);
     // inclusive suffix scan A_t = v_t + M A_{t+1}, M = X^g; v grows by less than 2r per step: below 25 r at the end
@@ -262,30 +248,30 @@ __global__ __launch_bounds__(HS_T) void k_horner_scan(const Fr *S, uint32_t nblk
     for (int st = 0; st < 9; st++) {
         const int off = 1 << st;
         if (off < T) {               // uniform
-            Fr29 o = zero29();
+            Fr29 o = fr29_zero();
             if (t + off < T) {
 #pragma unroll
                 for (int i = 0; i < R29_N; i++) o.v[i] = sh[i * T + t + off];
             }
             __syncthreads();
-            v = fr29_normalize(add29(v, mul_const(o, c.p[st])));
+            v = fr29_normalize(fr29_add_lazy(v, mul_const(o, c.p[st])));
 #pragma unroll
             for (int i = 0; i < R29_N; i++) sh[i * T + t] = v.v[i];
             __syncthreads();
         }
     }
-    Fr29 carry = zero29();
+    Fr29 carry = fr29_zero();
     if (t + 1 < T) {
 #pragma unroll
         for (int i = 0; i < R29_N; i++) carry.v[i] = sh[i * T + t + 1];
     }
     for (uint32_t k = g; k-- > 0;) {
         if (b0 + k < nblk) {
-            H[b0 + k] = canonical29(carry);
-            carry = fr29_normalize(add29(fr29_unpack(S[b0 + k]), mul_const(carry, c.X)));
+            H[b0 + k] = fr29_canonical(carry);
+            carry = fr29_normalize(fr29_add_lazy(fr29_unpack(S[b0 + k]), mul_const(carry, c.X)));
         }
     }
-    if (t == 0) *px = canonical29(carry);
+    if (t == 0) *px = fr29_canonical(carry);
 }
 
 // q_i = sum_{j > i} a_j x^(j-i-1) for i < n - 1.  coeffs may alias q (a block reads its whole tile before it writes).
@@ -296,7 +282,7 @@ __global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t 
     load8_tile(coeffs, n, h_lds, a);
     Fr29 v = horner8(a, c.x);
     const Fr29 Hb = fr29_unpack(H[blockIdx.x]);
-    if (t == HT - 1) v = add29(v, mul_const(Hb, c.p[0]));  // fold the carry from higher blocks in
+    if (t == HT - 1) v = fr29_add_lazy(v, mul_const(Hb, c.p[0]));  // fold the carry from higher blocks in
     v = fr29_normalize(v);
     __syncthreads();                 // every thread has read its coefficients: the tile's memory carries the scan
     uint32_t *sh = (uint32_t *)h_lds;
@@ -305,9 +291,9 @@ __global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t 
 #pragma unroll
     for (int st = 0; st < 8; st++) {     // v grows by less than 2r per step: below 23 r at the end
         const int off = 1 << st;
-        Fr29 o = (t + off < HT) ? sh_get<HT>(sh, t + off) : zero29();
+        Fr29 o = (t + off < HT) ? sh_get<HT>(sh, t + off) : fr29_zero();
         __syncthreads();
-        v = fr29_normalize(add29(v, mul_const(o, c.p[st])));
+        v = fr29_normalize(fr29_add_lazy(v, mul_const(o, c.p[st])));
         sh_put<HT>(sh, t, v);
         __syncthreads();
     }
@@ -316,7 +302,7 @@ __global__ __launch_bounds__(HT) void k_quotient_apply(const Fr *coeffs, size_t 
     // the eight quotient coefficients of this thread go back through the tile: whole-line stores.  q_(8t+7) is the carry; each of the
     // others is a coefficient (canonical: the caller's scalars are) plus a Shoup product made canonical -- one modular addition, and
     // the next product starts from the sum's limbs.
-    Fr out = canonical29(carry);
+    Fr out = fr29_canonical(carry);
 #pragma unroll
     for (int k = HE - 1; k >= 0; k--) {
         h_lds[17 * t + 2 * k] = hchunk{out.v[0], out.v[1], out.v[2], out.v[3]};

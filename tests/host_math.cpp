@@ -151,6 +151,29 @@ void hm_fr29_radix4_chain(const uint32_t *x0, const uint32_t *xs, const uint32_t
         X0 = fr29_normalize(which == 0 ? z0 : which == 1 ? z1 : which == 2 ? z2 : z3);
     }
     Fr z = fr29_pack_canonical(fr29_reduce_below_2r(X0)); memcpy(o, z.v, 32); }
+// The arithmetic of one thread of the quotient kernels (poly.hip: k_horner_partials / k_horner_scan / k_quotient_apply), same
+// primitives in the same order: Horner of eight raw 256-bit coefficients by Shoup products with lazy sums, `m` scan steps each adding
+// the product of a neighbour's value (nine raw limbs as read from LDS: normalised, up to 25 r) with a step constant, the canonical
+// value written out, then one output step of k_quotient_apply: coefficient + canonical(product) by the saturated modular addition.
+// a: 8 x 8 words; x_mont, p_mont: Montgomery form; nb: m x 9 limbs.  o_scan: canonical value after the scan; o_next: the next output.
+void hm_fr29_quotient_thread(const uint32_t *a, const uint32_t *x_mont, const uint32_t *p_mont, const uint32_t *nb, int m, const uint32_t *a_next,
+                             uint32_t *o_scan, uint32_t *o_next, uint32_t *top_limb) {
+    Fr xm, pm; memcpy(xm.v, x_mont, 32); memcpy(pm.v, p_mont, 32);
+    Fr29 X, XP, P, PP;
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(xm), X, XP);
+    fr29_shoup_from_twiddle(fr29_twiddle_from_mont(pm), P, PP);
+    Fr c[8]; memcpy(c, a, 256);
+    Fr29 v = fr29_unpack(c[7]);
+    for (int k = 6; k >= 0; k--) v = fr29_add_lazy(mulshoup29(v, X, XP), fr29_unpack(c[k]));
+    v = fr29_normalize(v);
+    for (int i = 0; i < m; i++) {
+        Fr29 o; memcpy(o.v, nb + 9 * i, 36);
+        v = fr29_normalize(fr29_add_lazy(v, mulshoup29(o, P, PP)));
+    }
+    *top_limb = v.v[8];
+    Fr out = fr29_canonical(v); memcpy(o_scan, out.v, 32);
+    Fr an; memcpy(an.v, a_next, 32);
+    Fr nx = add(an, fr29_pack_canonical(mulshoup29(fr29_unpack(out), X, XP))); memcpy(o_next, nx.v, 32); }
 }
 #include "../kzg_amd/csrc/emit.h"
 extern "C" {

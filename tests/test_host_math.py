@@ -326,6 +326,35 @@ def test_fr29_ntt_arithmetic(L):
             assert int.from_bytes(ou.raw, "little") == U and int.from_bytes(ov.raw, "little") == V
 
 
+def test_fr29_quotient_kernel_thread(L):
+    """poly.hip's quotient kernels keep unreduced sums of Shoup products in 29-bit limbs (kzg_amd/csrc/fr29.h primitives; the
+    reference's long_division, src/polynomial.rs:193-227, reduces after every step): one thread's sequence -- Horner of eight raw
+    256-bit coefficients, up to ten scan steps adding products of neighbours' values as large as the kernels can hold (25 r), the
+    canonical value, one output step -- against big-integer arithmetic, at random and at the largest operands."""
+    rng = random.Random(291)
+    R, R256 = M.R, 1 << 256
+    MASK = (1 << 29) - 1
+    for it in range(300):
+        big = it < 6
+        a = [R256 - 1 if big else rng.randrange(R256) for _ in range(8)]
+        x = [R - 1, 1, 0, R - 2, 2, R - 1][it] if big else rng.randrange(R)
+        p = R - 1 if big else rng.randrange(R)
+        m = 10 if big else rng.randrange(0, 11)
+        nbv = [25 * R - 1 - i if big else rng.randrange(25 * R) for i in range(m)]
+        nb = (ctypes.c_uint32 * (9 * max(m, 1)))()
+        for i, v in enumerate(nbv):         # normalised: limbs below 2^29, the excess in the top limb
+            for j in range(9):
+                nb[9 * i + j] = (v >> (29 * j)) & MASK if j < 8 else v >> 232
+        a_next = rng.randrange(R) if not big else R - 1
+        o_scan, o_next, top = ctypes.create_string_buffer(32), ctypes.create_string_buffer(32), ctypes.c_uint32()
+        L.hm_fr29_quotient_thread(b"".join(b(v, 32) for v in a), b(x * R256 % R, 32), b(p * R256 % R, 32), nb, m, b(a_next, 32), o_scan, o_next,
+                                  ctypes.byref(top))
+        want = (sum(c * pow(x, k, R) for k, c in enumerate(a)) + p * sum(nbv)) % R
+        assert int.from_bytes(o_scan.raw, "little") == want, it
+        assert int.from_bytes(o_next.raw, "little") == (a_next + want * x) % R, it
+        assert top.value < 64 * (R >> 232), it      # what fr29_reduce_below_2r accepts
+
+
 def test_fr29_shoup_multiply_and_lazy_radix4(L):
     """fr29.h, the NTT's multiplication by constants (Shoup: w with wp = floor(w 2^261 / r)) and the lazy radix-4 butterflies:
     (w, wp) from the table builder against big-integer arithmetic; the product exact mod r and below 2r for normalised inputs,
