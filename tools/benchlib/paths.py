@@ -117,7 +117,8 @@ def measure_paths(kzg_amd, L, engine, params, scal, n, log_n, budget_s=60.0, mad
     ntt_ms = timeit(ntt, reps=20, warm=20)       # wall time of the blocking call, profiling off
     engine.prof_enable(True)                    # kernel times: HIP events on the engine's stream (their recording costs wall time)
     engine.prof_reset()
-    timeit(ntt, reps=reps, warm=1)
+    for _ in range(reps + 1):                   # exactly reps + 1 profiled calls (timeit warms up by time)
+        ntt()
     prof = engine.prof_all()
     engine.prof_enable(False)
     kern_ms = sum(v[1] for k, v in prof.items() if k.startswith("k_ntt")) / (reps + 1)
