@@ -33,7 +33,7 @@ os.environ.setdefault("KZG_COMM_TIMEOUT_MS", "30000")
 
 DEFAULT_LIMIT_S = 150
 ORDER = ["test_gpu_arith", "test_gpu_golden", "test_gpu_msm", "test_gpu_naf", "test_gpu_kzg", "test_gpu_ntt_poly", "test_gpu_ntt_large",
-         "test_gpu_fullsize", "test_gpu_verify", "test_gpu_validation", "test_gpu_concurrent",
+         "test_gpu_fullsize", "test_gpu_verify", "test_gpu_validation", "test_gpu_concurrent", "test_gpu_bench_paths",
          "test_gpu_mgpu", "test_gpu_mgpu_world", "test_gpu_bench_multi", "test_gpu_rccl_world", "test_gpu_zz_environment"]
 
 
